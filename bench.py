@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- rendered frames/sec (fwd+bwd) of the GoMAvatar hot path on MI355X.
+
+One "step" = one frame through the whole hot path, forward AND backward:
+FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused
+unpack+L1(rgb)+L1(mask) loss fwd/bwd -> splat backward -> face backward ->
+vertex gather + LBS backward, producing gradients for vertices / so3 / scale /
+appearance.  Workload (BASELINE.json metric): 512x512, 55 104 Gaussians
+(SMPL-topology body, one midpoint subdivision), synthetic poses/cameras/targets
+already resident in HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run): frame-parallel data parallelism, one
+frame per GPU per step, plus ONE RCCL all-reduce of the flat fp32 gradient
+buffer (951 023 floats = the reference model's full parameter count) inside
+the timed step.  Weak scaling: per-GPU work is fixed.
+
+Prints one JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (dominant kernel, HIP-event timed on its own stream) and, at N=1,
+`cpu_baseline` (the CPU oracle timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--img", type=int, default=512)
+    ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(P, D, HW, C):
+    """SURVEY.md section 8(d) byte model, per kernel, per frame."""
+    return {
+        "preprocess": P * (12 + 24 + 4 * C + 4) + P * (8 + 4 + 16 + 4 + 4),
+        "scan_tiles": 0,
+        "emit": 12 * D,
+        "render_fwd": D * (4 + 8 + 16 + 4 * C) + HW * (4 * C + 4 + 4),
+        "render_bwd": HW * (4 * C + 4 + 4) + D * (4 + 8 + 16 + 4 * C) + P * (8 + 12 + 4 + 4 * C),
+        "preprocess_bwd": P * (12 + 24 + 4 + 12 + 8) + P * (12 + 24),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from __graft_entry__ import build
+    from gomavatar_amd import build as hip_build
+    if rank == 0 and hip_build.needs_build():
+        build()
+    if world > 1:
+        dist.barrier()
+    from gomavatar_amd import _lib, synthetic as syn
+    from gomavatar_amd.pipeline import RenderStep
+
+    # ---------------- workload (synthetic, seeded; resident in HBM) ----------------
+    img = args.img
+    body = syn.make_body(args.subdiv)
+    N, F = body["canonical_vertex"].shape[0], body["faces"].shape[0]
+    w = torch.from_numpy(body["canonical_lbs_weights"]).T
+    w25 = torch.cat([w, torch.zeros(1, N)], 0).contiguous()
+    faces = torch.from_numpy(body["faces"])
+    step = RenderStep(faces, N, (img, img), w25, device=dev)
+
+    def dev_params(seed):
+        gp = syn.make_gaussian_params(F, seed)
+        return dict(vertices=torch.from_numpy(body["canonical_vertex"]).T.contiguous().to(dev), so3=torch.from_numpy(gp["so3"]).to(dev),
+                    scale=torch.from_numpy(gp["scale"]).to(dev), appearance=torch.from_numpy(gp["appearance"]).to(dev))
+
+    # flat fp32 gradient buffer = the all-reduce payload; the hot path's gradients are views into it
+    n_own = 3 * N + 9 * F
+    flat = torch.zeros(max(n_own, MODEL_PARAMS_M if args.subdiv == 1 else n_own), dtype=torch.float32, device=dev)
+    off = 0
+    for k, shape in (("vertices", (3, N)), ("so3", (3, F)), ("scale", (3, F)), ("appearance", (3, F))):
+        n = shape[0] * shape[1]
+        step.grads[k] = flat[off:off + n].view(shape)
+        off += n
+    params = dev_params(1)
+    target_params = dev_params(2)
+    frames = []
+    for i in range(args.frames):
+        fr = syn.make_frame(rank * 1000 + i, img)  # each rank renders different frames
+        d = {k: torch.from_numpy(fr[k][0]).contiguous().to(dev) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+        d["K"], d["E"], d["bg"] = fr["K"][0], fr["E"][0], torch.from_numpy(fr["bgcolor"][0]).to(dev)
+        # target = render of a different parameter set (so gradients are non-zero), produced by the HIP path itself
+        step.set_camera(d["K"], d["E"])
+        dummy_rgb = torch.zeros((img, img, 3), device=dev)
+        dummy_m = torch.zeros((img, img), device=dev)
+        step.forward_backward(target_params, d, dummy_rgb, dummy_m, d["bg"], backward=False)
+        rgb, mask = step.rgb_mask()
+        d["gt_rgb"] = (rgb[0] * mask[0, ..., None] + d["bg"] * (1 - mask[0, ..., None])).contiguous().clone()
+        d["gt_mask"] = mask[0].contiguous().clone()
+        d["cam"] = step.cam
+        frames.append(d)
+    torch.cuda.synchronize()
+
+    def run_step(i):
+        d = frames[i % len(frames)]
+        step.cam = d["cam"]
+        step.forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
+        if world > 1:
+            dist.all_reduce(flat)
+
+    for i in range(args.warmup):
+        run_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_pairs, overflow = step.state.poll()
+    assert not overflow, "pair buffer overflow during the benchmark"
+    assert all(torch.isfinite(g).all() for g in step.grads.values()), "non-finite gradients"
+
+    # ---------------- per-kernel times (HIP events on the launch stream) ----------------
+    step.state.set_option(_lib.OPT_PROFILE, 1)
+    acc = {}
+    n_prof = 24
+    for i in range(n_prof):
+        d = frames[i % len(frames)]
+        step.cam = d["cam"]
+        step.forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
+        for k, v in step.state.kernel_times_ms().items():
+            acc[k] = acc.get(k, 0.0) + v
+        nd, _ = step.state.poll()
+        acc["D"] = acc.get("D", 0) + nd
+    step.state.set_option(_lib.OPT_PROFILE, 0)
+    kt = {k: acc[k] / n_prof for k in _lib.KERNEL_NAMES}
+    D_avg = acc["D"] / n_prof
+    abytes = algorithmic_bytes(F, D_avg, img * img, 4)
+    dom = max(kt, key=kt.get)
+    achieved = abytes[dom] / (kt[dom] * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_us": round(kt[dom] * 1e3, 2),
+                "algorithmic_bytes": int(abytes[dom]),
+                "all_kernels_us": {k: round(v * 1e3, 2) for k, v in kt.items()}, "pairs_D": int(D_avg)}
+
+    out = {
+        "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians",
+        "value": round(world * args.steps / elapsed, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, 1 frame per GPU per step"
+                               + (", + RCCL all-reduce of the flat grad buffer" if world > 1 else ""),
+                   "gaussians": F, "image": [img, img], "frames_per_step": world, "parallelism": f"frame-dp{world}",
+                   "allreduce_floats": int(flat.numel()) if world > 1 else 0},
+        "roofline": roofline,
+    }
+
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only) ----------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import geometry as og, raster as orast
+        cores = os.cpu_count() or 1
+        threads = max(1, min(cores, 64))
+        torch.set_num_threads(threads)
+        orast.set_threads(threads)
+        pc = {k: v.detach().cpu() for k, v in params.items()}
+        times = []
+        for i in range(args.cpu_frames + 1):
+            fr = {k: torch.from_numpy(v) for k, v in syn.make_frame(i, img).items()}
+            po = {k: v.clone().requires_grad_() for k, v in pc.items()}
+            t1 = time.perf_counter()
+            o_rgb, o_mask, _ = og.render_path(po, fr, faces, w25, img)
+            gt = frames[i % len(frames)]
+            l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt["gt_rgb"].cpu()[None], gt["gt_mask"].cpu()[None])
+            (l1 + 5.0 * l2).backward()
+            times.append(time.perf_counter() - t1)
+        times = times[1:]  # first frame warms caches / page-faults
+        out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": f"{len(times)} frames of the same workload (fwd+bwd) through the CPU oracle, "
+                                         f"{threads} threads (torch + OpenMP), host has {cores} logical cores"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

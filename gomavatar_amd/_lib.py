@@ -1,0 +1,108 @@
+"""ctypes binding of libgom_hip.so (C ABI: include/gom_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to
+load, every product entry point raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p, POINTER
+
+import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the SAME libamdhip64 torch uses
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgom_hip.so")
+
+GOM_ABI_VERSION = 1
+GOM_FWD_REUSE_BINNING = 1
+GOM_LOSS_BLOCKS = 256
+(BUF_DEPTH, BUF_XY, BUF_CONIC_OPACITY, BUF_TILES_TOUCHED, BUF_RECT, BUF_TILE_BASE, BUF_KEYS, BUF_POINT_LIST, BUF_FINAL_T,
+ BUF_N_CONTRIB, BUF_STATUS) = range(11)
+OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE = 0, 1, 2
+KERNEL_NAMES = ("preprocess", "scan_tiles", "emit", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+class GomCamera(ctypes.Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("tanfovx", c_float), ("tanfovy", c_float),
+                ("view", c_float * 16), ("proj", c_float * 16), ("bg", c_float * 4)]
+
+
+# name -> (restype, argtypes); every symbol include/gom_hip.h declares
+SIGNATURES = {
+    "gom_last_error": (c_char_p, []),
+    "gom_abi_version": (c_int, []),
+    "gom_state_create": (c_void_p, []),
+    "gom_state_destroy": (None, [c_void_p]),
+    "gom_state_set_option": (c_int, [c_void_p, c_int, c_int64]),
+    "gom_state_poll": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32), c_void_p]),
+    "gom_state_kernel_times": (c_int, [c_void_p, POINTER(c_float)]),
+    "gom_state_export": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "gom_raster_forward": (c_int, [c_void_p, POINTER(GomCamera), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_uint32, c_void_p]),
+    "gom_raster_backward": (c_int, [c_void_p, POINTER(GomCamera), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_fk_forward": (c_int, [c_void_p] * 6),
+    "gom_fk_backward": (c_int, [c_void_p] * 7),
+    "gom_lbs_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_face_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "gom_face_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_vertex_backward": (c_int, [c_int, c_int] + [c_void_p] * 11),
+    "gom_l1_loss": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libgom_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m gomavatar_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gom_abi_version() != GOM_ABI_VERSION:
+        raise RuntimeError("libgom_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().gom_last_error()
+        raise RuntimeError(f"libgom_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    """The hipStream_t torch is currently enqueuing on."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return 0
+    assert t.is_cuda and t.is_contiguous(), "libgom_hip needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def make_camera(H: int, W: int, tanfovx: float, tanfovy: float, view16, proj16, bg) -> GomCamera:
+    c = GomCamera()
+    c.H, c.W = int(H), int(W)
+    c.tanfovx, c.tanfovy = float(tanfovx), float(tanfovy)
+    for i in range(16):
+        c.view[i] = float(view16[i])
+        c.proj[i] = float(proj16[i])
+    for i in range(4):
+        c.bg[i] = float(bg[i]) if i < len(bg) else 0.0
+    return c

@@ -1,0 +1,487 @@
+// Geometry half of the hot path: skeleton forward kinematics, linear-blend
+// skinning and the per-face Gaussian frame, forward and backward.
+//
+// Replaces ~150 eager PyTorch launches per frame in the reference
+// (utils/body_util.py:612-644 get_global_RTs/apply_lbs; models/model.py:225-234
+// + :27-41 Steiner frame; PyTorch3D so3_exp_map) with
+// 3 forward + 2(3) backward kernels.  Backward scatter to vertices goes through
+// a CSR vertex->corner adjacency: no atomics, bitwise reproducible.
+//
+// All of this is HBM/L2-bound streaming work (a few hundred flops per 100-200
+// bytes); layouts follow the reference's channel-first parameters ((3,N), (3,F),
+// (25,N)) so every per-thread read is a coalesced row read.
+#include "gom_internal.h"
+
+namespace {
+
+__constant__ int c_parent[24] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+
+__device__ void invert4x4(const float *m, float *inv) {
+    // cofactor expansion (row-major in, row-major out)
+    float t[16];
+    t[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    t[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    t[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    t[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    t[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    t[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    t[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    t[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    t[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    t[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    t[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    t[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    t[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    t[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    t[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    t[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const float det = m[0] * t[0] + m[1] * t[4] + m[2] * t[8] + m[3] * t[12];
+    const float id = 1.0f / det;
+    for (int i = 0; i < 16; i++) inv[i] = t[i] * id;
+}
+
+// ---- forward kinematics: one wave ------------------------------------------
+// RT[j] = top 3 rows of (prod_{chain} local[k]) * inverse(cnl_gtfms[j]).
+__global__ void __launch_bounds__(64) k_fk_fwd(const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
+                                               float *__restrict__ RT, float *__restrict__ save) {
+    __shared__ float L[24][16], G[24][16], Ci[24][16];
+    const int t = threadIdx.x;
+    if (t < 24) {
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) L[t][4 * r + c] = Rs[9 * t + 3 * r + c];
+            L[t][4 * r + 3] = Ts[3 * t + r];
+        }
+        L[t][12] = 0.f; L[t][13] = 0.f; L[t][14] = 0.f; L[t][15] = 1.f;
+        float m[16], inv[16];
+        for (int i = 0; i < 16; i++) m[i] = cnl[16 * t + i];
+        invert4x4(m, inv);
+        for (int i = 0; i < 16; i++) Ci[t][i] = inv[i];
+    }
+    __syncthreads();
+    if (t < 16) G[0][t] = L[0][t];
+    __syncthreads();
+    for (int i = 1; i < 24; i++) {
+        if (t < 16) {
+            const int p = c_parent[i], r = t >> 2, c = t & 3;
+            G[i][t] = G[p][4 * r + 0] * L[i][c] + G[p][4 * r + 1] * L[i][4 + c] + G[p][4 * r + 2] * L[i][8 + c] + G[p][4 * r + 3] * L[i][12 + c];
+        }
+        __syncthreads();
+    }
+    for (int o = t; o < 24 * 12; o += 64) {
+        const int j = o / 12, e = o % 12;
+        const int r = e < 9 ? e / 3 : e - 9, c = e < 9 ? e % 3 : 3;
+        RT[o] = G[j][4 * r + 0] * Ci[j][c] + G[j][4 * r + 1] * Ci[j][4 + c] + G[j][4 * r + 2] * Ci[j][8 + c] + G[j][4 * r + 3] * Ci[j][12 + c];
+    }
+    for (int o = t; o < 24 * 16; o += 64) {
+        save[(o / 16) * 32 + (o % 16)] = G[o / 16][o % 16];
+        save[(o / 16) * 32 + 16 + (o % 16)] = Ci[o / 16][o % 16];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_fk_bwd(const float *__restrict__ Rs, const float *__restrict__ Ts, const float *__restrict__ save,
+                                               const float *__restrict__ dRT, float *__restrict__ dRs, float *__restrict__ dTs) {
+    __shared__ float L[24][16], G[24][16], Ci[24][16], dG[24][16], dL[24][16];
+    const int t = threadIdx.x;
+    if (t < 24) {
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) L[t][4 * r + c] = Rs[9 * t + 3 * r + c];
+            L[t][4 * r + 3] = Ts[3 * t + r];
+        }
+        L[t][12] = 0.f; L[t][13] = 0.f; L[t][14] = 0.f; L[t][15] = 1.f;
+    }
+    for (int o = t; o < 24 * 16; o += 64) {
+        G[o / 16][o % 16] = save[(o / 16) * 32 + (o % 16)];
+        Ci[o / 16][o % 16] = save[(o / 16) * 32 + 16 + (o % 16)];
+    }
+    __syncthreads();
+    // dG[j] = dF[j] * Ci[j]^T, dF rows 0..2 = [dR | dT], row 3 = 0
+    for (int o = t; o < 24 * 16; o += 64) {
+        const int j = o / 16, r = (o % 16) >> 2, k = o & 3;
+        float acc = 0.f;
+        if (r < 3) {
+            for (int c = 0; c < 4; c++) {
+                const float df = c < 3 ? dRT[12 * j + 3 * r + c] : dRT[12 * j + 9 + r];
+                acc += df * Ci[j][4 * k + c];
+            }
+        }
+        dG[j][o % 16] = acc;
+    }
+    __syncthreads();
+    for (int i = 23; i >= 1; i--) {
+        const int p = c_parent[i];
+        float add = 0.f;
+        if (t < 16) {
+            const int r = t >> 2, c = t & 3;
+            // dL[i] = G[p]^T dG[i]
+            dL[i][t] = G[p][0 + r] * dG[i][c] + G[p][4 + r] * dG[i][4 + c] + G[p][8 + r] * dG[i][8 + c] + G[p][12 + r] * dG[i][12 + c];
+            // dG[p] += dG[i] L[i]^T
+            add = dG[i][4 * r + 0] * L[i][4 * c + 0] + dG[i][4 * r + 1] * L[i][4 * c + 1] + dG[i][4 * r + 2] * L[i][4 * c + 2] + dG[i][4 * r + 3] * L[i][4 * c + 3];
+        }
+        __syncthreads();
+        if (t < 16) dG[p][t] += add;
+        __syncthreads();
+    }
+    if (t < 16) dL[0][t] = dG[0][t];
+    __syncthreads();
+    for (int o = t; o < 24 * 9; o += 64) dRs[o] = dL[o / 9][4 * ((o % 9) / 3) + (o % 3)];
+    for (int o = t; o < 24 * 3; o += 64) dTs[o] = dL[o / 3][4 * (o % 3) + 3];
+}
+
+// ---- LBS: one thread per vertex ---------------------------------------------
+__global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
+                                                 const float *__restrict__ RT, float *__restrict__ out) {
+    extern __shared__ float s_rt[];
+    for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float x = xyz[n], y = xyz[(size_t)N + n], z = xyz[2 * (size_t)N + n];
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    for (int j = 0; j < J; j++) {
+        const float wj = w[(size_t)j * N + n];
+        if (wj != 0.f) {
+            const float *m = s_rt + 12 * j;
+            ox += (m[0] * x + m[1] * y + m[2] * z + m[9]) * wj;
+            oy += (m[3] * x + m[4] * y + m[5] * z + m[10]) * wj;
+            oz += (m[6] * x + m[7] * y + m[8] * z + m[11]) * wj;
+        }
+    }
+    out[n] = ox;
+    out[(size_t)N + n] = oy;
+    out[2 * (size_t)N + n] = oz;
+}
+
+// ---- per-face Gaussian frame --------------------------------------------------
+struct FaceFwd {
+    float v0[3], v1[3], v2[3];
+    float f1[3], f2[3], cs, sn, p, q;
+    float a0[3], a1[3], n[3], nn;
+    float A[3][3];    // columns 2a0, 2a1, sigma*n/|n|
+    float R[3][3], K[3][3], K2[3][3], th, th2, fac1, fac2;
+    bool clamped;
+    float B[3][3], M[3][3];
+};
+
+__device__ __forceinline__ void face_forward(const float *verts, int N, const int32_t *faces, const float *so3, const float *scale,
+                                             int F, int f, float sigma, FaceFwd &o, float *xyz3, float *s3) {
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.v0[k] = verts[(size_t)k * N + i0];
+        o.v1[k] = verts[(size_t)k * N + i1];
+        o.v2[k] = verts[(size_t)k * N + i2];
+    }
+    const float K2C = 0.28867513459481287f;  // 1 / (2 sqrt 3)
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        c[k] = ((o.v0[k] + o.v1[k]) + o.v2[k]) / 3.0f;
+        xyz3[k] = c[k];
+        o.f1[k] = 0.5f * (o.v2[k] - c[k]);
+        o.f2[k] = K2C * (o.v1[k] - o.v0[k]);
+    }
+    o.p = 2.f * o.f1[0] * o.f2[0] + 2.f * o.f1[1] * o.f2[1] + 2.f * o.f1[2] * o.f2[2];
+    o.q = (o.f1[0] * o.f1[0] + o.f1[1] * o.f1[1] + o.f1[2] * o.f1[2]) - (o.f2[0] * o.f2[0] + o.f2[1] * o.f2[1] + o.f2[2] * o.f2[2]);
+    const float t0 = atan2f(o.p, o.q) * 0.5f;
+    o.cs = cosf(t0);
+    o.sn = sinf(t0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.a0[k] = o.f1[k] * o.cs + o.f2[k] * o.sn;
+        o.a1[k] = o.f2[k] * o.cs - o.f1[k] * o.sn;
+    }
+    o.n[0] = o.a0[1] * o.a1[2] - o.a0[2] * o.a1[1];
+    o.n[1] = o.a0[2] * o.a1[0] - o.a0[0] * o.a1[2];
+    o.n[2] = o.a0[0] * o.a1[1] - o.a0[1] * o.a1[0];
+    o.nn = fmaxf(sqrtf(o.n[0] * o.n[0] + o.n[1] * o.n[1] + o.n[2] * o.n[2]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.A[k][0] = 2.f * o.a0[k];
+        o.A[k][1] = 2.f * o.a1[k];
+        o.A[k][2] = o.n[k] / o.nn * sigma;
+    }
+    // so3 exponential (PyTorch3D: theta^2 clamped at 1e-4)
+    const float wx = so3[f], wy = so3[(size_t)F + f], wz = so3[2 * (size_t)F + f];
+    const float n2 = wx * wx + wy * wy + wz * wz;
+    o.clamped = !(n2 > 1e-4f);
+    o.th2 = o.clamped ? 1e-4f : n2;
+    o.th = sqrtf(o.th2);
+    const float inv = 1.0f / o.th;
+    o.fac1 = inv * sinf(o.th);
+    o.fac2 = inv * inv * (1.0f - cosf(o.th));
+    const float K[3][3] = {{0.f, -wz, wy}, {wz, 0.f, -wx}, {-wy, wx, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            o.K[i][j] = K[i][j];
+            o.K2[i][j] = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
+        }
+    s3[0] = scale[f]; s3[1] = scale[(size_t)F + f]; s3[2] = scale[2 * (size_t)F + f];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            o.R[i][j] = o.fac1 * o.K[i][j] + o.fac2 * o.K2[i][j] + (i == j ? 1.f : 0.f);
+            o.B[i][j] = o.R[i][j] * s3[j];
+        }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.M[i][j] = o.A[i][0] * o.B[0][j] + o.A[i][1] * o.B[1][j] + o.A[i][2] * o.B[2][j];
+}
+
+__global__ void __launch_bounds__(256) k_face_fwd(int N, int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                  const float *__restrict__ so3, const float *__restrict__ scale, float sigma,
+                                                  float *__restrict__ xyz, float *__restrict__ cov6) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    FaceFwd o;
+    float c[3], s3[3];
+    face_forward(verts, N, faces, so3, scale, F, f, sigma, o, c, s3);
+    xyz[3 * f] = c[0]; xyz[3 * f + 1] = c[1]; xyz[3 * f + 2] = c[2];
+    const float (*M)[3] = o.M;
+    cov6[6 * f + 0] = M[0][0] * M[0][0] + M[0][1] * M[0][1] + M[0][2] * M[0][2];
+    cov6[6 * f + 1] = M[0][0] * M[1][0] + M[0][1] * M[1][1] + M[0][2] * M[1][2];
+    cov6[6 * f + 2] = M[0][0] * M[2][0] + M[0][1] * M[2][1] + M[0][2] * M[2][2];
+    cov6[6 * f + 3] = M[1][0] * M[1][0] + M[1][1] * M[1][1] + M[1][2] * M[1][2];
+    cov6[6 * f + 4] = M[1][0] * M[2][0] + M[1][1] * M[2][1] + M[1][2] * M[2][2];
+    cov6[6 * f + 5] = M[2][0] * M[2][0] + M[2][1] * M[2][1] + M[2][2] * M[2][2];
+}
+
+__global__ void __launch_bounds__(256) k_face_bwd(int N, int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                  const float *__restrict__ so3, const float *__restrict__ scale, float sigma,
+                                                  const float *__restrict__ d_xyz, const float *__restrict__ d_cov6,
+                                                  float *__restrict__ d_corner, float *__restrict__ d_so3, float *__restrict__ d_scale) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    FaceFwd o;
+    float cdummy[3], s3[3];
+    face_forward(verts, N, faces, so3, scale, F, f, sigma, o, cdummy, s3);
+    // dL/dM = 2 Gs M, Gs = symmetric gradient with halved off-diagonals
+    const float g0 = d_cov6[6 * f], g1 = d_cov6[6 * f + 1], g2 = d_cov6[6 * f + 2], g3 = d_cov6[6 * f + 3], g4 = d_cov6[6 * f + 4], g5 = d_cov6[6 * f + 5];
+    const float Gs2[3][3] = {{2.f * g0, g1, g2}, {g1, 2.f * g3, g4}, {g2, g4, 2.f * g5}};  // = 2*Gs
+    float dM[3][3], dA[3][3], dB[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dM[i][j] = Gs2[i][0] * o.M[0][j] + Gs2[i][1] * o.M[1][j] + Gs2[i][2] * o.M[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            dA[i][j] = dM[i][0] * o.B[j][0] + dM[i][1] * o.B[j][1] + dM[i][2] * o.B[j][2];   // dM B^T
+            dB[i][j] = o.A[0][i] * dM[0][j] + o.A[1][i] * dM[1][j] + o.A[2][i] * dM[2][j];   // A^T dM
+        }
+    // scale and rotation
+    float dS[3], dR[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) dS[j] = dB[0][j] * o.R[0][j] + dB[1][j] * o.R[1][j] + dB[2][j] * o.R[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dR[i][j] = dB[i][j] * s3[j];
+    // so3_exp backward
+    float dK[3][3];
+    float dfac1 = 0.f, dfac2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            dfac1 += dR[i][j] * o.K[i][j];
+            dfac2 += dR[i][j] * o.K2[i][j];
+            // d(K K): dR K^T + K^T dR
+            const float t1 = dR[i][0] * o.K[j][0] + dR[i][1] * o.K[j][1] + dR[i][2] * o.K[j][2];
+            const float t2 = o.K[0][i] * dR[0][j] + o.K[1][i] * dR[1][j] + o.K[2][i] * dR[2][j];
+            dK[i][j] = o.fac1 * dR[i][j] + o.fac2 * (t1 + t2);
+        }
+    float dw[3] = {dK[2][1] - dK[1][2], dK[0][2] - dK[2][0], dK[1][0] - dK[0][1]};
+    if (!o.clamped) {
+        const float th = o.th, sn = sinf(th), cs = cosf(th);
+        const float df1 = (th * cs - sn) / (th * th);
+        const float df2 = (th * sn - 2.f * (1.f - cs)) / (th * th * th);
+        const float dth = dfac1 * df1 + dfac2 * df2;
+        const float wx = so3[f], wy = so3[(size_t)F + f], wz = so3[2 * (size_t)F + f];
+        dw[0] += dth * wx / th;
+        dw[1] += dth * wy / th;
+        dw[2] += dth * wz / th;
+    }
+    d_so3[f] = dw[0]; d_so3[(size_t)F + f] = dw[1]; d_so3[2 * (size_t)F + f] = dw[2];
+    d_scale[f] = dS[0]; d_scale[(size_t)F + f] = dS[1]; d_scale[2 * (size_t)F + f] = dS[2];
+    // Steiner frame backward
+    float da0[3], da1[3], dnh[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { da0[k] = 2.f * dA[k][0]; da1[k] = 2.f * dA[k][1]; dnh[k] = sigma * dA[k][2]; }
+    {
+        float nh[3] = {o.n[0] / o.nn, o.n[1] / o.nn, o.n[2] / o.nn};
+        const float dot = nh[0] * dnh[0] + nh[1] * dnh[1] + nh[2] * dnh[2];
+        float dn[3];
+        const bool degenerate = !(o.nn > 1e-12f);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dn[k] = degenerate ? dnh[k] / o.nn : (dnh[k] - nh[k] * dot) / o.nn;
+        // n = a0 x a1: da0 += a1 x dn ; da1 += dn x a0
+        da0[0] += o.a1[1] * dn[2] - o.a1[2] * dn[1];
+        da0[1] += o.a1[2] * dn[0] - o.a1[0] * dn[2];
+        da0[2] += o.a1[0] * dn[1] - o.a1[1] * dn[0];
+        da1[0] += dn[1] * o.a0[2] - dn[2] * o.a0[1];
+        da1[1] += dn[2] * o.a0[0] - dn[0] * o.a0[2];
+        da1[2] += dn[0] * o.a0[1] - dn[1] * o.a0[0];
+    }
+    float df1[3], df2[3];
+    float dt0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        df1[k] = o.cs * da0[k] - o.sn * da1[k];
+        df2[k] = o.sn * da0[k] + o.cs * da1[k];
+        dt0 += da0[k] * o.a1[k] - da1[k] * o.a0[k];
+    }
+    {
+        const float den = o.p * o.p + o.q * o.q;
+        const float dp = den > 0.f ? 0.5f * dt0 * o.q / den : 0.f;
+        const float dq = den > 0.f ? -0.5f * dt0 * o.p / den : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            df1[k] += 2.f * o.f2[k] * dp + 2.f * o.f1[k] * dq;
+            df2[k] += 2.f * o.f1[k] * dp - 2.f * o.f2[k] * dq;
+        }
+    }
+    const float K2C = 0.28867513459481287f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float dc = (d_xyz[3 * f + k] - 0.5f * df1[k]) / 3.0f;
+        d_corner[9 * f + 0 + k] = dc - K2C * df2[k];
+        d_corner[9 * f + 3 + k] = dc + K2C * df2[k];
+        d_corner[9 * f + 6 + k] = dc + 0.5f * df1[k];
+    }
+}
+
+// ---- vertex gather + LBS backward ----------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
+                                                    const float *__restrict__ RT, const int32_t *__restrict__ csr_off,
+                                                    const int32_t *__restrict__ csr_idx, const float *__restrict__ d_corner,
+                                                    const float *__restrict__ d_extra, float *__restrict__ d_obs,
+                                                    float *__restrict__ d_xyz, float *__restrict__ dRT) {
+    extern __shared__ float s_rt[];
+    for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = n < N;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+        if (csr_off) {
+            const int b = csr_off[n], e = csr_off[n + 1];
+            for (int k = b; k < e; k++) {
+                const int ci = csr_idx[k];
+                g[0] += d_corner[3 * (size_t)ci];
+                g[1] += d_corner[3 * (size_t)ci + 1];
+                g[2] += d_corner[3 * (size_t)ci + 2];
+            }
+        }
+        if (d_extra) {
+            g[0] += d_extra[n];
+            g[1] += d_extra[(size_t)N + n];
+            g[2] += d_extra[2 * (size_t)N + n];
+        }
+        if (d_obs) {
+            d_obs[n] = g[0];
+            d_obs[(size_t)N + n] = g[1];
+            d_obs[2 * (size_t)N + n] = g[2];
+        }
+    }
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (ok) { x = xyz[n]; y = xyz[(size_t)N + n]; z = xyz[2 * (size_t)N + n]; }
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < J; j++) {
+        const float wj = ok ? w[(size_t)j * N + n] : 0.f;
+        if (wj != 0.f) {
+            const float *m = s_rt + 12 * j;
+            ox += (m[0] * g[0] + m[3] * g[1] + m[6] * g[2]) * wj;
+            oy += (m[1] * g[0] + m[4] * g[1] + m[7] * g[2]) * wj;
+            oz += (m[2] * g[0] + m[5] * g[1] + m[8] * g[2]) * wj;
+        }
+        if (dRT) {
+            if (__ballot(wj != 0.f) != 0ull) {
+                const float v[12] = {wj * g[0] * x, wj * g[0] * y, wj * g[0] * z, wj * g[1] * x, wj * g[1] * y, wj * g[1] * z,
+                                     wj * g[2] * x, wj * g[2] * y, wj * g[2] * z, wj * g[0], wj * g[1], wj * g[2]};
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const float s = wave_sum(v[q]);
+                    if (lane == 0) atomicAdd(&dRT[12 * j + q], s);
+                }
+            }
+        }
+    }
+    if (ok) {
+        d_xyz[n] = ox;
+        d_xyz[(size_t)N + n] = oy;
+        d_xyz[2 * (size_t)N + n] = oz;
+    }
+}
+
+}  // namespace
+
+extern "C" int gom_fk_forward(const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream) {
+    if (!cnl_gtfms || !dst_Rs || !dst_Ts || !RT || !fk_save) { gom_set_error("gom_fk_forward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_fk_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const float *fk_save, const float *dRT, float *d_dst_Rs,
+                               float *d_dst_Ts, void *stream) {
+    if (!dst_Rs || !dst_Ts || !fk_save || !dRT || !d_dst_Rs || !d_dst_Ts) { gom_set_error("gom_fk_backward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_fk_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_Rs, dst_Ts, fk_save, dRT, d_dst_Rs, d_dst_Ts);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream) {
+    if (N < 0 || J <= 0 || J > 64) { gom_set_error("gom_lbs_forward: bad sizes N=%d J=%d", N, J); return -1; }
+    if (N == 0) return 0;
+    if (!xyz || !weights || !RT || !out) { gom_set_error("gom_lbs_forward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights, RT, out);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_face_forward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                                float sigma, float *xyz, float *cov6, void *stream) {
+    if (N < 0 || F < 0) { gom_set_error("gom_face_forward: bad sizes"); return -1; }
+    if (F == 0) return 0;
+    if (!verts || !faces || !so3 || !scale || !xyz || !cov6) { gom_set_error("gom_face_forward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_face_fwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma, xyz, cov6);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                                 float sigma, const float *d_xyz, const float *d_cov6, float *d_corner, float *d_so3,
+                                 float *d_scale, void *stream) {
+    if (N < 0 || F < 0) { gom_set_error("gom_face_backward: bad sizes"); return -1; }
+    if (F == 0) return 0;
+    if (!verts || !faces || !so3 || !scale || !d_xyz || !d_cov6 || !d_corner || !d_so3 || !d_scale) { gom_set_error("gom_face_backward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_face_bwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma,
+                       d_xyz, d_cov6, d_corner, d_so3, d_scale);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_vertex_backward(int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
+                                   const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
+                                   float *d_xyz, float *dRT, void *stream) {
+    if (N < 0 || J <= 0 || J > 64) { gom_set_error("gom_vertex_backward: bad sizes"); return -1; }
+    if (N == 0) return 0;
+    if (!xyz || !weights || !RT || !d_xyz) { gom_set_error("gom_vertex_backward: null pointer"); return -1; }
+    if ((csr_off == nullptr) != (csr_idx == nullptr) || (csr_off && !d_corner)) { gom_set_error("gom_vertex_backward: inconsistent CSR arguments"); return -1; }
+    hipLaunchKernelGGL(k_vertex_bwd, dim3((N + 255) / 256), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights,
+                       RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, dRT);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,218 @@
+// C-ABI entry points of libgom_hip.so (see include/gom_hip.h) and the
+// GomState scratch management.  Host code only; kernels live in the other
+// translation units.
+#include <stdarg.h>
+#include <string.h>
+
+#include "gom_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void gom_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *gom_last_error(void) { return g_err; }
+extern "C" int gom_abi_version(void) { return GOM_ABI_VERSION; }
+
+template <typename T>
+static int grow(T **p, size_t count) {
+    if (*p) {
+        GOM_HIP_CHECK(hipFree(*p));
+        *p = nullptr;
+    }
+    GOM_HIP_CHECK(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    return 0;
+}
+
+extern "C" GomState *gom_state_create(void) {
+    GomState *s = new GomState();
+    if (hipGetDevice(&s->device) != hipSuccess) {
+        gom_set_error("hipGetDevice failed (no HIP device?)");
+        delete s;
+        return nullptr;
+    }
+    if (hipMalloc((void **)&s->status, sizeof(GomDevStatus)) != hipSuccess ||
+        hipMemset(s->status, 0, sizeof(GomDevStatus)) != hipSuccess) {
+        gom_set_error("hipMalloc(status) failed");
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+extern "C" void gom_state_destroy(GomState *s) {
+    if (!s) return;
+    void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->tile_base,
+                    s->tile_cursor, s->tile_done, s->keys, s->point_list, s->partial, s->final_T, s->n_contrib, s->status};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
+    if (!s) { gom_set_error("null state"); return -1; }
+    switch (option) {
+        case GOM_OPT_SORT_CAP:
+            if (value < 1 || value > GOM_SORT_CAP_MAX) { gom_set_error("sort cap must be in [1, %d]", GOM_SORT_CAP_MAX); return -1; }
+            s->sortCap = (int)value;
+            return 0;
+        case GOM_OPT_PAIR_CAPACITY:
+            if (value < 0 || value > 0xffffffffLL) { gom_set_error("pair capacity out of range"); return -1; }
+            s->wantPairs = value;
+            return 0;
+        case GOM_OPT_PROFILE:
+            if (value && !s->ev[0]) {
+                for (int i = 0; i < 2 * GOM_NUM_KERNELS; i++) GOM_HIP_CHECK(hipEventCreate(&s->ev[i]));
+            }
+            s->profile = value != 0;
+            return 0;
+        default:
+            gom_set_error("unknown option %d", option);
+            return -1;
+    }
+}
+
+// Make sure the scratch fits (P, H, W).  Reallocation synchronises the device
+// (hipFree); it only happens when a dimension grows.
+static int ensure_capacity(GomState *s, int P, int H, int W) {
+    const int gx = (W + GOM_TILE - 1) / GOM_TILE, gy = (H + GOM_TILE - 1) / GOM_TILE;
+    const int tiles = gx * gy;
+    const int pix = H * W;
+    if (P > s->capP) {
+        const int cap = P + P / 8 + 256;
+        if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
+            grow(&s->rect, cap) || grow(&s->radii, cap))
+            return -2;
+        s->capP = cap;
+    }
+    if (tiles > s->capTiles) {
+        if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||
+            grow(&s->tile_done, tiles))
+            return -2;
+        GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
+        s->capTiles = tiles;
+    }
+    if (pix > s->capPix) {
+        if (grow(&s->final_T, pix) || grow(&s->n_contrib, pix)) return -2;
+        s->capPix = pix;
+    }
+    // Pair buffers: sized for 288 GB of HBM, not for frugality.  Default 16 pairs
+    // per Gaussian (the GoMAvatar workload averages ~2.7) and at least 4 M.
+    int64_t want = s->wantPairs > 0 ? s->wantPairs : (int64_t)P * 16;
+    if (s->wantPairs <= 0 && want < (4 << 20)) want = 4 << 20;
+    if (want > 0xffffffffLL) want = 0xffffffffLL;
+    if (want != s->capPairs && (want > s->capPairs || s->wantPairs > 0)) {
+        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) ||
+            grow(&s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
+            return -2;
+        s->capPairs = want;
+    }
+    s->gx = gx;
+    s->gy = gy;
+    return 0;
+}
+
+static bool valid_dims(int P, int C, const GomCamera *cam) {
+    if (!cam) { gom_set_error("null camera"); return false; }
+    if (P < 0) { gom_set_error("negative P"); return false; }
+    if (C != 3 && C != 4) { gom_set_error("C must be 3 or 4 (got %d)", C); return false; }
+    if (cam->H <= 0 || cam->W <= 0 || cam->H > 65535 * 16 || cam->W > 65535 * 16) { gom_set_error("bad image size %dx%d", cam->H, cam->W); return false; }
+    return true;
+}
+
+extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
+                                  const float *colors, const float *opacity, float *out_color, int32_t *radii,
+                                  uint32_t flags, void *stream) {
+    if (!s) { gom_set_error("null state"); return -1; }
+    if (!valid_dims(P, C, cam)) return -1;
+    if (!out_color || (P > 0 && (!means3D || !cov6 || !colors || !opacity))) { gom_set_error("null tensor pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool reuse = (flags & GOM_FWD_REUSE_BINNING) != 0;
+    if (reuse) {
+        if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W) {
+            gom_set_error("GOM_FWD_REUSE_BINNING without a matching previous forward");
+            return -1;
+        }
+    } else {
+        if (int rc = ensure_capacity(s, P, cam->H, cam->W)) return rc;
+        s->P = P; s->H = cam->H; s->W = cam->W;
+        if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
+        if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
+    }
+    s->C = C;
+    if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, !reuse, st)) return rc;
+    if (reuse && radii) GOM_HIP_CHECK(hipMemcpyAsync(radii, s->radii, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    s->haveForward = true;
+    return 0;
+}
+
+extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
+                                   const float *colors, const float *opacity, const float *dL_dcolor, float *dL_dmeans3D,
+                                   float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D, void *stream) {
+    (void)opacity;
+    if (!s) { gom_set_error("null state"); return -1; }
+    if (!valid_dims(P, C, cam)) return -1;
+    if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W) {
+        gom_set_error("gom_raster_backward without a matching forward on this state");
+        return -1;
+    }
+    if (!dL_dcolor || !dL_dmeans3D || !dL_dcov6 || !dL_dcolors || !dL_dopacity) { gom_set_error("null gradient pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = gom_launch_render_backward(s, *cam, C, colors, dL_dcolor, st)) return rc;
+    if (int rc = gom_launch_preprocess_backward(s, *cam, P, C, means3D, cov6, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity,
+                                                dL_dmeans2D, st))
+        return rc;
+    return 0;
+}
+
+extern "C" int gom_state_poll(GomState *s, int64_t *num_pairs, int32_t *overflow, void *stream) {
+    if (!s) { gom_set_error("null state"); return -1; }
+    GomDevStatus h;
+    GOM_HIP_CHECK(hipMemcpyAsync(&h, s->status, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GOM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (num_pairs) *num_pairs = h.num_pairs;
+    if (overflow) *overflow = (int32_t)h.overflow;
+    return 0;
+}
+
+extern "C" int gom_state_kernel_times(GomState *s, float *ms_out) {
+    if (!s || !ms_out) { gom_set_error("null argument"); return -1; }
+    for (int k = 0; k < GOM_NUM_KERNELS; k++) {
+        ms_out[k] = -1.f;
+        if (s->ev[0] && s->evValid[k]) {
+            GOM_HIP_CHECK(hipEventSynchronize(s->ev[2 * k + 1]));
+            GOM_HIP_CHECK(hipEventElapsedTime(&ms_out[k], s->ev[2 * k], s->ev[2 * k + 1]));
+        }
+    }
+    return 0;
+}
+
+extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_bytes, void *stream) {
+    if (!s || !s->haveForward) { gom_set_error("export without a forward"); return -1; }
+    const void *src = nullptr;
+    int64_t bytes = 0;
+    const int64_t P = s->P, tiles = (int64_t)s->gx * s->gy, pix = (int64_t)s->H * s->W;
+    switch (id) {
+        case GOM_BUF_DEPTH: src = s->depth; bytes = P * 4; break;
+        case GOM_BUF_XY: src = s->xy; bytes = P * 8; break;
+        case GOM_BUF_CONIC_OPACITY: src = s->conic_opacity; bytes = P * 16; break;
+        case GOM_BUF_TILES_TOUCHED: src = s->tiles_touched; bytes = P * 4; break;
+        case GOM_BUF_RECT: src = s->rect; bytes = P * 8; break;
+        case GOM_BUF_TILE_BASE: src = s->tile_base; bytes = (tiles + 1) * 4; break;
+        case GOM_BUF_KEYS: src = s->keys; bytes = dst_bytes < s->capPairs * 8 ? dst_bytes : s->capPairs * 8; break;
+        case GOM_BUF_POINT_LIST: src = s->point_list; bytes = dst_bytes < s->capPairs * 4 ? dst_bytes : s->capPairs * 4; break;
+        case GOM_BUF_FINAL_T: src = s->final_T; bytes = pix * 4; break;
+        case GOM_BUF_N_CONTRIB: src = s->n_contrib; bytes = pix * 4; break;
+        case GOM_BUF_STATUS: src = s->status; bytes = 16; break;
+        default: gom_set_error("unknown buffer id %d", id); return -1;
+    }
+    if (dst_bytes < bytes) { gom_set_error("export buffer too small (%lld < %lld)", (long long)dst_bytes, (long long)bytes); return -1; }
+    if (bytes > 0) GOM_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

@@ -1,0 +1,96 @@
+// Internal definitions shared by the translation units of libgom_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "gom_hip.h"
+
+#define GOM_TILE 16
+#define GOM_SORT_CAP_MAX 8192       // tile-list entries sortable in LDS (64 KiB of 64-bit keys)
+#define GOM_PARTIAL_STRIDE 12       // floats per (tile, gaussian) partial-gradient record (10 used)
+#define GOM_BWD_CHUNK 256           // tile-list entries per LDS accumulation round in render backward
+
+struct GomDevStatus {
+    uint32_t num_pairs;
+    uint32_t overflow;
+    uint32_t pad0, pad1;
+};
+
+struct GomState {
+    int device = 0;
+    // capacities
+    int capP = 0, capTiles = 0, capPix = 0;
+    int64_t capPairs = 0;
+    int64_t wantPairs = 0;           // user-set pair capacity (0 = auto)
+    int sortCap = GOM_SORT_CAP_MAX;
+    // last forward
+    int P = 0, H = 0, W = 0, C = 0, gx = 0, gy = 0;
+    bool haveForward = false;
+    // per gaussian
+    float *depth = nullptr;
+    float2 *xy = nullptr;
+    float4 *conic_opacity = nullptr;
+    uint32_t *tiles_touched = nullptr;
+    ushort4 *rect = nullptr;
+    int32_t *radii = nullptr;
+    // per tile
+    uint32_t *tile_count = nullptr;
+    uint32_t *tile_base = nullptr;    // [tiles+1]
+    uint32_t *tile_cursor = nullptr;
+    uint32_t *tile_done = nullptr;    // entries of each tile that own a valid partial record
+    // per pair
+    uint64_t *keys = nullptr;
+    uint32_t *point_list = nullptr;
+    float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE]
+    // per pixel
+    float *final_T = nullptr;
+    uint32_t *n_contrib = nullptr;
+    GomDevStatus *status = nullptr;
+    // optional per-kernel HIP-event timing (GOM_OPT_PROFILE); events bracket each launch on the caller's stream
+    bool profile = false;
+    hipEvent_t ev[2 * GOM_NUM_KERNELS] = {};
+    bool evValid[GOM_NUM_KERNELS] = {};
+};
+
+struct GomKernelTimer {
+    GomState *s; int k; hipStream_t st;
+    GomKernelTimer(GomState *s_, int k_, hipStream_t st_) : s(s_), k(k_), st(st_) {
+        if (s->profile) { (void)hipEventRecord(s->ev[2 * k], st); }
+    }
+    ~GomKernelTimer() {
+        if (s->profile) { (void)hipEventRecord(s->ev[2 * k + 1], st); s->evValid[k] = true; }
+    }
+};
+
+void gom_set_error(const char *fmt, ...);
+
+#define GOM_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            gom_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+#define GOM_LAUNCH_CHECK()                                                                        \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e != hipSuccess) {                                                                   \
+            gom_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -3;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+// ---- launchers (one per kernel family; defined in the .hip files) ----------
+int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
+                          const float *opacity, int32_t *radii_out, hipStream_t st);
+int gom_launch_scan_emit(GomState *s, int P, hipStream_t st);
+int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color,
+                              bool do_sort, hipStream_t st);
+int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const float *colors, const float *dL_dcolor,
+                               hipStream_t st);
+int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
+                                   const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
+                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st);

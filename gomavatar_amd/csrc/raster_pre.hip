@@ -1,0 +1,473 @@
+// Per-Gaussian kernels of the splat rasterizer: projection + EWA footprint,
+// tile counting, tile-offset scan, pair emission, and the per-Gaussian backward.
+//
+// Replaces preprocessCUDA / InclusiveSum / duplicateWithKeys /
+// computeCov2DCUDA+preprocessCUDA(backward) of the CUDA extension the
+// reference calls at models/modules/renderer/gaussian.py:83-91
+// (algorithm: SURVEY.md App. A.1, A.2, A.5).
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: the floating-point operation
+// order below is the bit-exact binning contract shared with the CPU oracle
+// (radii, tile rects, depth key bits must be identical on both sides).
+//
+// MI355X design notes
+//  * binning is a per-tile counting sort, not a global 64-bit radix sort:
+//    count (LDS histogram per 256-Gaussian block, one global atomic per touched
+//    tile) -> single-block scan over tiles -> emit into exact per-tile ranges
+//    (LDS-aggregated slot reservation) -> per-tile LDS sort in the render kernel.
+//    4 launches instead of CUB's ~15, no device->host read of the pair count.
+//  * the backward gathers per-(tile,gaussian) partial sums written by the
+//    render backward (no float atomics anywhere -> bitwise reproducible).
+#include "gom_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int f2i_sat(float x) {
+    if (!(x >= -1073741824.0f)) return -1073741824;
+    if (x >= 1073741824.0f) return 1073741824;
+    return (int)x;
+}
+
+struct ProjJac {
+    float t[3];
+    float M0[3], M1[3];
+    float xmul, ymul;
+};
+
+__device__ __forceinline__ void xform4x3(const float *m, const float *p, float *o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform4x4(const float *m, const float *p, float *o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+__device__ __forceinline__ void proj_jacobian(const GomCamera &cam, const float *mean, float fx, float fy, ProjJac &o) {
+    const float *v = cam.view;
+    float t[3];
+    xform4x3(v, mean, t);
+    const float limx = 1.3f * cam.tanfovx;
+    const float limy = 1.3f * cam.tanfovy;
+    const float txtz = t[0] / t[2];
+    const float tytz = t[1] / t[2];
+    o.xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    o.ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    {
+        const float cx = -limx > txtz ? -limx : txtz;
+        const float cy = -limy > tytz ? -limy : tytz;
+        t[0] = (limx < cx ? limx : cx) * t[2];
+        t[1] = (limy < cy ? limy : cy) * t[2];
+    }
+    const float J00 = fx / t[2];
+    const float J02 = -(fx * t[0]) / (t[2] * t[2]);
+    const float J11 = fy / t[2];
+    const float J12 = -(fy * t[1]) / (t[2] * t[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.M0[k] = J00 * v[4 * k + 0] + J02 * v[4 * k + 2];
+        o.M1[k] = J11 * v[4 * k + 1] + J12 * v[4 * k + 2];
+    }
+    o.t[0] = t[0];
+    o.t[1] = t[1];
+    o.t[2] = t[2];
+}
+
+__device__ __forceinline__ void cov2d_from(const float *c6, const ProjJac &pj, float &a, float &b, float &c, float *SM0, float *SM1) {
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        SM0[k] = S[k][0] * pj.M0[0] + S[k][1] * pj.M0[1] + S[k][2] * pj.M0[2];
+        SM1[k] = S[k][0] * pj.M1[0] + S[k][1] * pj.M1[1] + S[k][2] * pj.M1[2];
+    }
+    a = (pj.M0[0] * SM0[0] + pj.M0[1] * SM0[1] + pj.M0[2] * SM0[2]) + 0.3f;
+    b = pj.M0[0] * SM1[0] + pj.M0[1] * SM1[1] + pj.M0[2] * SM1[2];
+    c = (pj.M1[0] * SM1[0] + pj.M1[1] * SM1[1] + pj.M1[2] * SM1[2]) + 0.3f;
+}
+
+// ---------------------------------------------------------------- A.1 ------
+// One thread per Gaussian.  LDS_HIST: per-block tile histogram in LDS, flushed
+// with one global atomic per touched tile; otherwise direct global atomics
+// (tile grids too large for LDS).
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const float *__restrict__ means,
+                                                    const float *__restrict__ cov6, const float *__restrict__ opacity,
+                                                    float *__restrict__ depth, float2 *__restrict__ xy,
+                                                    float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
+                                                    ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
+                                                    int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
+                                                    int gx, int gy) {
+    extern __shared__ uint32_t s_hist[];
+    const int n_tiles = gx * gy;
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) {
+        float o_depth = 0.f, o_x = 0.f, o_y = 0.f, o_cx = 0.f, o_cy = 0.f, o_cz = 0.f, o_op = 0.f;
+        int o_rad = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        uint32_t o_tiles = 0;
+        const float fx = (float)cam.W / (2.0f * cam.tanfovx);
+        const float fy = (float)cam.H / (2.0f * cam.tanfovy);
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        float pv[3];
+        xform4x3(cam.view, p, pv);
+        if (pv[2] > 0.2f) {
+            float ph[4];
+            xform4x4(cam.proj, p, ph);
+            const float pw = 1.0f / (ph[3] + 0.0000001f);
+            const float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
+            ProjJac pj;
+            proj_jacobian(cam, p, fx, fy, pj);
+            float c6[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
+            float a, b, c, SM0[3], SM1[3];
+            cov2d_from(c6, pj, a, b, c, SM0, SM1);
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (a + c);
+                const float dd = mid * mid - det;
+                const float disc = sqrtf(0.1f > dd ? 0.1f : dd);
+                const float lam1 = mid + disc, lam2 = mid - disc;
+                const float rad_f = ceilf(3.0f * sqrtf(lam1 > lam2 ? lam1 : lam2));
+                const int rad = f2i_sat(rad_f);
+                const float px = ((ndcx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+                const float py = ((ndcy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+                const int rx0 = min(gx, max(0, f2i_sat((px - (float)rad) / 16.0f)));
+                const int ry0 = min(gy, max(0, f2i_sat((py - (float)rad) / 16.0f)));
+                const int rx1 = min(gx, max(0, f2i_sat((px + (float)rad + 15.0f) / 16.0f)));
+                const int ry1 = min(gy, max(0, f2i_sat((py + (float)rad + 15.0f) / 16.0f)));
+                if ((rx1 - rx0) * (ry1 - ry0) != 0) {
+                    o_depth = pv[2];
+                    o_rad = rad;
+                    o_x = px;
+                    o_y = py;
+                    o_cx = c * det_inv;
+                    o_cy = -b * det_inv;
+                    o_cz = a * det_inv;
+                    o_op = opacity[i];
+                    o_tiles = (uint32_t)((rx1 - rx0) * (ry1 - ry0));
+                    x0 = rx0; y0 = ry0; x1 = rx1; y1 = ry1;
+                }
+            }
+        }
+        depth[i] = o_depth;
+        radii[i] = o_rad;
+        if (radii_user) radii_user[i] = o_rad;
+        xy[i] = make_float2(o_x, o_y);
+        conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
+        tiles_touched[i] = o_tiles;
+        rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
+                else atomicAdd(&tile_count[y * gx + x], 1u);
+            }
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const uint32_t c = s_hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- A.2a -----
+// Exclusive scan of the per-tile counts (single 1024-thread block), resets the
+// counters for the next frame and publishes D + the overflow flag.
+__global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
+                                                     uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ tile_done,
+                                                     int n_tiles, GomDevStatus *__restrict__ status, uint32_t cap_pairs) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + tid;
+        uint32_t v = 0;
+        if (i < n_tiles) {
+            v = tile_count[i];
+            tile_count[i] = 0;
+            tile_done[i] = 0;
+        }
+        // inclusive scan within the wave
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wave[wid] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; w++) wave_off += s_wave[w];
+        const uint32_t carry = s_carry;
+        const uint32_t excl = carry + wave_off + (x - v);
+        if (i < n_tiles) {
+            tile_base[i] = excl;
+            tile_cursor[i] = excl;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_off + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = s_carry;
+        tile_base[n_tiles] = total;
+        status->num_pairs = total;
+        status->overflow = total > cap_pairs ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------- A.2b -----
+// Emit (depth_bits << 32 | gaussian) into the tile's exact range.  The order
+// inside a range is arbitrary here; the per-tile sort on the unique 64-bit key
+// makes the final list identical to a stable sort on (tile, depth bits).
+template <bool LDS_AGG>
+__global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                              const ushort4 *__restrict__ rect, uint32_t *__restrict__ tile_cursor,
+                                              uint64_t *__restrict__ keys, int gx, int gy,
+                                              const GomDevStatus *__restrict__ status) {
+    extern __shared__ uint32_t s_mem[];
+    if (status->overflow) return;
+    const int n_tiles = gx * gy;
+    uint32_t *s_cnt = s_mem;
+    uint32_t *s_base = s_mem + n_tiles;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool vis = (i < P) && (radii[i] > 0);
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    uint64_t key = 0;
+    if (vis) {
+        r = rect[i];
+        key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+    }
+    if (LDS_AGG) {
+        for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) atomicAdd(&s_cnt[y * gx + x], 1u);
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const uint32_t c = s_cnt[t];
+            if (c) {
+                s_base[t] = atomicAdd(&tile_cursor[t], c);
+                s_cnt[t] = 0;
+            }
+        }
+        __syncthreads();
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) {
+                const int t = y * gx + x;
+                const uint32_t slot = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+                keys[slot] = key;
+            }
+    } else {
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) {
+                const uint32_t slot = atomicAdd(&tile_cursor[y * gx + x], 1u);
+                keys[slot] = key;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- A.5 ------
+// One thread per Gaussian: gather the per-(tile, gaussian) partial sums the
+// render backward left in `partial` (position found by binary search on the
+// unique sort key), then conic -> cov2D -> (cov3D, mean3D) and the projection
+// term of the screen-space mean gradient.
+template <int C>
+__global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, const float *__restrict__ means,
+                                                        const float *__restrict__ cov6, const int32_t *__restrict__ radii,
+                                                        const float *__restrict__ depth, const ushort4 *__restrict__ rect,
+                                                        const float4 *__restrict__ conic_opacity,
+                                                        const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_done,
+                                                        const uint64_t *__restrict__ keys, const float *__restrict__ partial,
+                                                        int gx, const GomDevStatus *__restrict__ status,
+                                                        float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
+                                                        float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
+                                                        float *__restrict__ dL_dmeans2D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[GOM_PARTIAL_STRIDE];
+#pragma unroll
+    for (int k = 0; k < GOM_PARTIAL_STRIDE; k++) acc[k] = 0.f;
+    float g2x = 0.f, g2y = 0.f, gop = 0.f;
+    const bool bad = status->overflow != 0;
+    if (!bad && radii[i] > 0) {
+        const ushort4 r = rect[i];
+        const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) {
+                const int t = y * gx + x;
+                const uint32_t base = tile_base[t];
+                const uint32_t lim = tile_done[t];
+                uint32_t lo = 0, hi = lim;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (keys[base + mid] < key) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < lim && keys[base + lo] == key) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(partial + (size_t)(base + lo) * GOM_PARTIAL_STRIDE);
+                    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
+                    acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+                    acc[8] += p2.x; acc[9] += p2.y;
+                }
+            }
+        // record layout: [0..3] colours, [4] sum Q, [5] sum Q dx, [6] sum Q dy, [7] sum Q dx dx, [8] sum Q dx dy, [9] sum Q dy dy
+        // with Q = G * dL/dalpha and d = centre - pixel (App. A.4 regrouped).
+        const float4 co = conic_opacity[i];
+        const float o = co.w;
+        g2x = -(0.5f * (float)cam.W) * o * (co.x * acc[5] + co.y * acc[6]);
+        g2y = -(0.5f * (float)cam.H) * o * (co.z * acc[6] + co.y * acc[5]);
+        const float gxx = -0.5f * o * acc[7];
+        const float gxy = -0.5f * o * acc[8];
+        const float gyy = -0.5f * o * acc[9];
+        gop = acc[4];
+
+        const float fx = (float)cam.W / (2.0f * cam.tanfovx);
+        const float fy = (float)cam.H / (2.0f * cam.tanfovy);
+        const float *v = cam.view, *pr = cam.proj;
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        ProjJac pj;
+        proj_jacobian(cam, p, fx, fy, pj);
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
+        float a, b, c, SM0[3], SM1[3];
+        cov2d_from(c6, pj, a, b, c, SM0, SM1);
+        const float denom = a * c - b * b;
+        const float d2 = 1.0f / (denom * denom + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (d2 != 0.0f) {
+            dL_da = d2 * (-c * c * gxx + 2.0f * b * c * gxy + (denom - a * c) * gyy);
+            dL_dc = d2 * (-a * a * gyy + 2.0f * a * b * gxy + (denom - a * c) * gxx);
+            dL_db = d2 * 2.0f * (b * c * gxx - (denom + 2.0f * b * b) * gxy + a * b * gyy);
+            const float *M0 = pj.M0, *M1 = pj.M1;
+            gc[0] = M0[0] * M0[0] * dL_da + M0[0] * M1[0] * dL_db + M1[0] * M1[0] * dL_dc;
+            gc[3] = M0[1] * M0[1] * dL_da + M0[1] * M1[1] * dL_db + M1[1] * M1[1] * dL_dc;
+            gc[5] = M0[2] * M0[2] * dL_da + M0[2] * M1[2] * dL_db + M1[2] * M1[2] * dL_dc;
+            gc[1] = 2.0f * M0[0] * M0[1] * dL_da + (M0[0] * M1[1] + M0[1] * M1[0]) * dL_db + 2.0f * M1[0] * M1[1] * dL_dc;
+            gc[2] = 2.0f * M0[0] * M0[2] * dL_da + (M0[0] * M1[2] + M0[2] * M1[0]) * dL_db + 2.0f * M1[0] * M1[2] * dL_dc;
+            gc[4] = 2.0f * M0[2] * M0[1] * dL_da + (M0[1] * M1[2] + M0[2] * M1[1]) * dL_db + 2.0f * M1[1] * M1[2] * dL_dc;
+        }
+        float dM0[3], dM1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dM0[k] = 2.0f * SM0[k] * dL_da + SM1[k] * dL_db;
+            dM1[k] = 2.0f * SM1[k] * dL_dc + SM0[k] * dL_db;
+        }
+        const float dJ00 = v[0] * dM0[0] + v[4] * dM0[1] + v[8] * dM0[2];
+        const float dJ02 = v[2] * dM0[0] + v[6] * dM0[1] + v[10] * dM0[2];
+        const float dJ11 = v[1] * dM1[0] + v[5] * dM1[1] + v[9] * dM1[2];
+        const float dJ12 = v[2] * dM1[0] + v[6] * dM1[1] + v[10] * dM1[2];
+        const float tz = 1.0f / pj.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = pj.xmul * -fx * tz2 * dJ02;
+        const float dty = pj.ymul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * pj.t[0]) * tz3 * dJ02 + (2.0f * fy * pj.t[1]) * tz3 * dJ12;
+        gm[0] = v[0] * dtx + v[1] * dty + v[2] * dtz;
+        gm[1] = v[4] * dtx + v[5] * dty + v[6] * dtz;
+        gm[2] = v[8] * dtx + v[9] * dty + v[10] * dtz;
+        float ph[4];
+        xform4x4(pr, p, ph);
+        const float mw = 1.0f / (ph[3] + 0.0000001f);
+        const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+        gm[0] += (pr[0] * mw - pr[3] * mul1) * g2x + (pr[1] * mw - pr[3] * mul2) * g2y;
+        gm[1] += (pr[4] * mw - pr[7] * mul1) * g2x + (pr[5] * mw - pr[7] * mul2) * g2y;
+        gm[2] += (pr[8] * mw - pr[11] * mul1) * g2x + (pr[9] * mw - pr[11] * mul2) * g2y;
+    }
+    if (bad) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+        gm[0] = gm[1] = gm[2] = nanv;
+#pragma unroll
+        for (int k = 0; k < 6; k++) gc[k] = nanv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = nanv;
+        gop = g2x = g2y = nanv;
+    }
+    dL_dmeans[3 * i] = gm[0];
+    dL_dmeans[3 * i + 1] = gm[1];
+    dL_dmeans[3 * i + 2] = gm[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov6[6 * i + k] = gc[k];
+#pragma unroll
+    for (int k = 0; k < C; k++) dL_dcolors[C * i + k] = acc[k];
+    dL_dopacity[i] = gop;
+    if (dL_dmeans2D) {
+        dL_dmeans2D[3 * i] = g2x;
+        dL_dmeans2D[3 * i + 1] = g2y;
+        dL_dmeans2D[3 * i + 2] = 0.f;
+    }
+}
+
+}  // namespace
+
+#define GOM_LDS_TILE_LIMIT 8192
+
+int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
+                          const float *opacity, int32_t *radii_out, hipStream_t st) {
+    const int n_tiles = s->gx * s->gy;
+    const int blocks = (P + 255) / 256;
+    if (blocks == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_PREPROCESS, st);
+    if (n_tiles <= GOM_LDS_TILE_LIMIT)
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), n_tiles * sizeof(uint32_t), st, cam, P, means3D, cov6,
+                           opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
+                           s->tile_count, s->gx, s->gy);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, opacity, s->depth,
+                           s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->gx,
+                           s->gy);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_launch_scan_emit(GomState *s, int P, hipStream_t st) {
+    const int n_tiles = s->gx * s->gy;
+    const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
+    {
+        GomKernelTimer timer(s, GOM_K_SCAN, st);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->tile_done,
+                           n_tiles, s->status, cap);
+    }
+    GOM_LAUNCH_CHECK();
+    const int blocks = (P + 255) / 256;
+    if (blocks == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_EMIT, st);
+    if (n_tiles <= GOM_LDS_TILE_LIMIT)
+        hipLaunchKernelGGL(k_emit<true>, dim3(blocks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, P, s->depth, s->radii,
+                           s->rect, s->tile_cursor, s->keys, s->gx, s->gy, s->status);
+    else
+        hipLaunchKernelGGL(k_emit<false>, dim3(blocks), dim3(256), 0, st, P, s->depth, s->radii, s->rect, s->tile_cursor,
+                           s->keys, s->gx, s->gy, s->status);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
+                                   const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
+                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st) {
+    const int blocks = (P + 255) / 256;
+    if (blocks == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
+    if (C == 3)
+        hipLaunchKernelGGL(k_preprocess_bwd<3>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii, s->depth,
+                           s->rect, s->conic_opacity, s->tile_base, s->tile_done, s->keys, s->partial, s->gx, s->status,
+                           dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
+    else
+        hipLaunchKernelGGL(k_preprocess_bwd<4>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii, s->depth,
+                           s->rect, s->conic_opacity, s->tile_base, s->tile_done, s->keys, s->partial, s->gx, s->status,
+                           dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,62 @@
+"""Photometric losses of the hot path, HIP-backed.
+
+`l1_photometric` fuses the reference's `unpack` (train.py:53-55) with the L1
+rgb and L1 mask terms of `compute_loss` (train.py:101-111) and their backward
+into one kernel; `compute_loss_l1` keeps the reference's return structure
+({'rgb': {'unscaled','scaled'}, 'mask': {...}}).  No CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class _L1Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, shade, gt_rgb, gt_mask, bg, c_rgb, c_mask):
+        lib = _lib.load()
+        C, H, W = pred.shape
+        assert C == 4, "pred must be the rasterizer's (4,H,W) output: albedo rgb + alpha"
+        p = pred.contiguous()
+        s = shade.contiguous() if shade is not None else None
+        dpred = torch.empty_like(p)
+        dshade = torch.empty_like(s) if s is not None else None
+        partials = torch.empty((_lib.GOM_LOSS_BLOCKS, 2), dtype=torch.float32, device=p.device)
+        _lib.check(lib.gom_l1_loss(H, W, _lib.ptr(p), _lib.ptr(s), _lib.ptr(gt_rgb.contiguous()), _lib.ptr(gt_mask.contiguous()),
+                                   _lib.ptr(bg.contiguous().float()), float(c_rgb), float(c_mask), 1.0, _lib.ptr(dpred), _lib.ptr(dshade),
+                                   _lib.ptr(partials), _lib.stream_ptr()))
+        sums = partials.sum(0)
+        l_rgb = sums[0] / (3.0 * H * W)
+        l_mask = sums[1] / float(H * W)
+        ctx.save_for_backward(dpred, dshade if dshade is not None else torch.empty(0, device=p.device))
+        ctx.has_shade = s is not None
+        total = c_rgb * l_rgb + c_mask * l_mask
+        ctx.mark_non_differentiable(l_rgb, l_mask)
+        return total, l_rgb, l_mask
+
+    @staticmethod
+    def backward(ctx, g_total, _g_rgb, _g_mask):
+        dpred, dshade = ctx.saved_tensors
+        return dpred * g_total, (dshade * g_total if ctx.has_shade else None), None, None, None, None, None
+
+
+def l1_photometric(pred_chw: torch.Tensor, gt_rgb: torch.Tensor, gt_mask: torch.Tensor, bgcolor: torch.Tensor,
+                   shade: Optional[torch.Tensor] = None, c_rgb: float = 1.0, c_mask: float = 5.0):
+    """pred_chw (4,H,W) = rasterizer output (albedo rgb, alpha); gt_rgb (H,W,3);
+    gt_mask (H,W); bgcolor (3,); shade (H,W) optional shading factor.
+    Returns (c_rgb*L_rgb + c_mask*L_mask, L_rgb, L_mask)."""
+    if not pred_chw.is_cuda:
+        raise RuntimeError("gomavatar_amd.losses: tensors must be on the HIP device (no CPU fallback)")
+    return _L1Photometric.apply(pred_chw, shade, gt_rgb, gt_mask, bgcolor.reshape(-1)[:3], c_rgb, c_mask)
+
+
+def compute_loss_l1(pred_chw, gt_rgb, gt_mask, bgcolor, loss_cfg=None, shade=None):
+    """The rgb + mask entries of the reference's `compute_loss` dict."""
+    c_rgb = loss_cfg.rgb.coeff if loss_cfg is not None else 1.0
+    c_mask = loss_cfg.mask.coeff if loss_cfg is not None else 5.0
+    total, l_rgb, l_mask = l1_photometric(pred_chw, gt_rgb, gt_mask, bgcolor, shade, c_rgb, c_mask)
+    losses = {"rgb": {"unscaled": l_rgb, "scaled": l_rgb * c_rgb}, "mask": {"unscaled": l_mask, "scaled": l_mask * c_mask}}
+    return total, losses

@@ -1,0 +1,122 @@
+"""The per-frame hot path as one pre-planned launch sequence (no autograd, no
+allocation, no host sync): the production fast path used by bench.py, by the
+frame-parallel trainer and by smoke().
+
+    FK -> LBS -> per-face Gaussians -> splat forward (one 4-channel pass)
+       -> fused unpack + L1(rgb) + L1(mask) forward/backward
+       -> splat backward -> face backward -> vertex gather + LBS backward
+
+i.e. reference models/model.py:213-250 + models/modules/renderer/gaussian.py:22-100
++ train.py:53-55,101-111 and the autograd backward of all of it, as 12 kernel
+launches on one stream.  Gradients land in `self.grads` (vertices (3,N), so3
+(3,F), scale (3,F), appearance (3,F)) and are bitwise reproducible.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .geometry import MeshTopology, N_JOINTS
+from .rasterizer import RasterState
+
+
+class RenderStep:
+    def __init__(self, faces: torch.Tensor, n_verts: int, img_hw, lbs_weights: torch.Tensor, sigma: float = 1e-3,
+                 c_rgb: float = 1.0, c_mask: float = 5.0, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = self.device
+        self.topo = MeshTopology(faces, n_verts, device=dev)
+        self.N, self.F = int(n_verts), self.topo.n_faces
+        self.H, self.W = int(img_hw[0]), int(img_hw[1])
+        self.sigma, self.c_rgb, self.c_mask = float(sigma), float(c_rgb), float(c_mask)
+        self.lbs_weights = lbs_weights.to(dev, torch.float32).contiguous()
+        assert self.lbs_weights.shape == (N_JOINTS + 1, self.N)
+        f32 = dict(dtype=torch.float32, device=dev)
+        N, F, H, W = self.N, self.F, self.H, self.W
+        self.state = RasterState()
+        # forward intermediates
+        self.RT = torch.empty((N_JOINTS, 12), **f32)
+        self.fk_save = torch.empty((N_JOINTS, 32), **f32)
+        self.v_obs = torch.empty((3, N), **f32)
+        self.xyz = torch.empty((F, 3), **f32)
+        self.cov6 = torch.empty((F, 6), **f32)
+        self.feat = torch.ones((F, 4), **f32)       # rgb + constant 1 (alpha channel), gaussian.py:49
+        self.opacity = torch.ones((F,), **f32)      # model.py:242
+        self.image = torch.empty((4, H, W), **f32)  # albedo rgb + mask, CHW
+        self.radii = torch.empty((F,), dtype=torch.int32, device=dev)
+        self.loss_partials = torch.zeros((_lib.GOM_LOSS_BLOCKS, 2), **f32)
+        # backward intermediates
+        self.d_image = torch.empty((4, H, W), **f32)
+        self.d_xyz = torch.empty((F, 3), **f32)
+        self.d_cov6 = torch.empty((F, 6), **f32)
+        self.d_feat = torch.empty((F, 4), **f32)
+        self.d_opacity = torch.empty((F,), **f32)
+        self.d_corner = torch.empty((F, 3, 3), **f32)
+        self.grads: Dict[str, torch.Tensor] = {
+            "vertices": torch.empty((3, N), **f32), "so3": torch.empty((3, F), **f32), "scale": torch.empty((3, F), **f32),
+            "appearance": torch.empty((3, F), **f32)}
+        self.cam = None
+
+    # -- inputs ---------------------------------------------------------------
+    def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
+        """K (3,3), E (4,4) host arrays/tensors -> rasterizer camera, as
+        gaussian.py:30-47,53-66 (znear 0.001, zfar 100)."""
+        import math
+        import numpy as np
+        K = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32).reshape(3, 3)
+        E = np.asarray(E.detach().cpu() if torch.is_tensor(E) else E, dtype=np.float32).reshape(4, 4)
+        w, h = self.W, self.H
+        fx, fy, px, py = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+        tanfovx = math.tan(2 * math.atan(w / (2 * fx)) * 0.5)
+        tanfovy = math.tan(2 * math.atan(h / (2 * fy)) * 0.5)
+        znear, zfar = 0.001, 100
+        K_ndc = np.array([[2 * fx / w, 0, (2 * px - w) / w, 0], [0, 2 * fy / h, (2 * py - h) / h, 0],
+                          [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]], dtype=np.float32)
+        view = np.ascontiguousarray(E.T)
+        proj = (E.T @ K_ndc.T).astype(np.float32)
+        self.cam = _lib.make_camera(h, w, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
+
+    # -- one frame --------------------------------------------------------------
+    def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
+                         target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True) -> None:
+        """params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
+        frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
+        target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors."""
+        lib, P = self.lib, _lib.ptr
+        st = _lib.stream_ptr()
+        N, F, H, W = self.N, self.F, self.H, self.W
+        chk = _lib.check
+        v, so3, scale, app = params["vertices"], params["so3"], params["scale"], params["appearance"]
+        chk(lib.gom_fk_forward(P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"]), P(self.RT), P(self.fk_save), st))
+        chk(lib.gom_lbs_forward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.v_obs), st))
+        chk(lib.gom_face_forward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.xyz), P(self.cov6), st))
+        self.feat[:, :3].copy_(app.t())  # (3,F) parameter -> (F,3) feature rows
+        cam = ctypes.byref(self.cam)
+        chk(lib.gom_raster_forward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
+                                   P(self.image), P(self.radii), 0, st))
+        chk(lib.gom_l1_loss(H, W, P(self.image), 0, P(target_rgb), P(target_mask), P(bgcolor), self.c_rgb, self.c_mask, 1.0,
+                            P(self.d_image), 0, P(self.loss_partials), st))
+        if not backward:
+            return
+        chk(lib.gom_raster_backward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
+                                    P(self.d_image), P(self.d_xyz), P(self.d_cov6), P(self.d_feat), P(self.d_opacity), 0, st))
+        chk(lib.gom_face_backward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.d_xyz), P(self.d_cov6),
+                                  P(self.d_corner), P(self.grads["so3"]), P(self.grads["scale"]), st))
+        chk(lib.gom_vertex_backward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.topo.csr_off), P(self.topo.csr_idx),
+                                    P(self.d_corner), 0, 0, P(self.grads["vertices"]), 0, st))
+        self.grads["appearance"].copy_(self.d_feat[:, :3].t())
+
+    def losses(self):
+        """(L_rgb, L_mask) of the last frame as 0-d device tensors."""
+        s = self.loss_partials.sum(0)
+        return s[0] / (3.0 * self.H * self.W), s[1] / float(self.H * self.W)
+
+    def rgb_mask(self):
+        """Last rendered (1,H,W,3) albedo and (1,H,W) mask, the layout
+        gaussian.py:93-100 returns."""
+        pred = self.image.permute(1, 2, 0)[None]
+        return pred[..., :3], pred[..., 3]

@@ -1,0 +1,163 @@
+/*
+ * gom_hip.h -- C ABI of libgom_hip.so, the MI355X (gfx950) implementation of
+ * the GoMAvatar per-frame hot path.
+ *
+ * Plain C: device pointers + sizes + a hipStream_t passed as void*.  No torch
+ * types cross this boundary.  Every entry point only ENQUEUES work on the given
+ * stream (no host synchronisation, no allocation in the steady state), so a
+ * whole frame is hipGraph-capturable.  All functions return 0 on success and
+ * a negative code on failure; gom_last_error() then returns a description
+ * (thread-local).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the wenj/GoMAvatar tree):
+ *
+ *   gom_raster_forward / gom_raster_backward
+ *       diff_gaussian_rasterization._C.rasterize_gaussians(_backward), i.e. the
+ *       CUDA extension behind `GaussianRasterizer.forward`, called from
+ *       models/modules/renderer/gaussian.py:83-91 (settings built at :53-67).
+ *   gom_fk_forward / gom_fk_backward
+ *       utils/body_util.py:612-638  get_global_RTs  (+ :591-609).
+ *   gom_lbs_forward, gom_vertex_backward
+ *       utils/body_util.py:641-644  apply_lbs.
+ *   gom_face_forward / gom_face_backward
+ *       models/model.py:225-234 (centroid, so3_exp_map, Steiner frame :27-41,
+ *       covariance) + gaussian.py:71-75 (6-pack).
+ *   gom_l1_loss
+ *       train.py:53-55 (unpack) + train.py:101-111 (L1 rgb, L1 mask) and their
+ *       autograd backward.
+ */
+#ifndef GOM_HIP_H
+#define GOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOM_ABI_VERSION 1
+
+/* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
+ * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
+ * the row-major tensors the reference passes (viewmatrix = E^T,
+ * projmatrix = E^T K_ndc^T). bg: up to 4 channels (only the first C are read). */
+typedef struct GomCamera {
+    int32_t H, W;
+    float tanfovx, tanfovy;
+    float view[16];
+    float proj[16];
+    float bg[4];
+} GomCamera;
+
+typedef struct GomState GomState; /* opaque: binning/geometry/image scratch of one in-flight frame */
+
+/* flags for gom_raster_forward */
+#define GOM_FWD_REUSE_BINNING 1u /* geometry+camera identical to the previous forward on this state:
+                                    skip projection/binning/sort, composite new colours only */
+
+/* buffer ids for gom_state_export (bit-exact parity checks) */
+enum {
+    GOM_BUF_DEPTH = 0,       /* float  [P]            */
+    GOM_BUF_XY = 1,          /* float  [P][2]         */
+    GOM_BUF_CONIC_OPACITY = 2, /* float [P][4]        */
+    GOM_BUF_TILES_TOUCHED = 3, /* uint32 [P]          */
+    GOM_BUF_RECT = 4,        /* uint16 [P][4] xmin ymin xmax ymax (tiles) */
+    GOM_BUF_TILE_BASE = 5,   /* uint32 [tiles+1] exclusive scan of per-tile counts = range starts */
+    GOM_BUF_KEYS = 6,        /* uint64 [D] sorted (depth_bits<<32 | gaussian) per tile range       */
+    GOM_BUF_POINT_LIST = 7,  /* uint32 [D] sorted gaussian ids                                      */
+    GOM_BUF_FINAL_T = 8,     /* float  [H][W]         */
+    GOM_BUF_N_CONTRIB = 9,   /* uint32 [H][W]         */
+    GOM_BUF_STATUS = 10      /* uint32 [4]: num_pairs, overflow, 0, 0 */
+};
+
+/* options for gom_state_set_option */
+enum {
+    GOM_OPT_SORT_CAP = 0,   /* max tile-list length sorted in LDS (<= compiled cap); smaller values force the
+                               global-memory fallback sort -- used by tests */
+    GOM_OPT_PAIR_CAPACITY = 1, /* capacity (entries) of the (tile, gaussian) pair buffers */
+    GOM_OPT_PROFILE = 2        /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
+};
+
+/* kernel ids for gom_state_kernel_times */
+enum {
+    GOM_K_PREPROCESS = 0, GOM_K_SCAN = 1, GOM_K_EMIT = 2, GOM_K_RENDER_FWD = 3,
+    GOM_K_RENDER_BWD = 4, GOM_K_PREPROCESS_BWD = 5
+};
+#define GOM_NUM_KERNELS 6
+
+const char *gom_last_error(void);
+int gom_abi_version(void);
+
+GomState *gom_state_create(void);          /* on the current HIP device */
+void gom_state_destroy(GomState *s);
+int gom_state_set_option(GomState *s, int option, int64_t value);
+/* Synchronises `stream` and reports the last forward's pair count and whether
+ * the pair buffers overflowed (outputs of an overflowed frame are NaN). */
+int gom_state_poll(GomState *s, int64_t *num_pairs, int32_t *overflow, void *stream);
+/* With GOM_OPT_PROFILE on: synchronises and returns the duration (ms) of each raster kernel's most
+ * recent launch on this state, measured with HIP events on the stream it was launched on
+ * (-1 for kernels that have not run). ms_out has GOM_NUM_KERNELS entries. */
+int gom_state_kernel_times(GomState *s, float *ms_out);
+/* Asynchronous copy of an internal buffer into caller device memory. */
+int gom_state_export(GomState *s, int buffer_id, void *dst_device, int64_t dst_bytes, void *stream);
+
+/* ---- splat rasterizer (C = 3 or 4 channels) -------------------------------
+ * means3D [P][3], cov6 [P][6] (xx xy xz yy yz zz), colors [P][C], opacity [P]
+ * out_color [C][H][W], radii [P] int32 (may be NULL). */
+int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int C,
+                       const float *means3D, const float *cov6, const float *colors, const float *opacity,
+                       float *out_color, int32_t *radii, uint32_t flags, void *stream);
+
+/* dL_dcolor [C][H][W] -> dL_dmeans3D [P][3], dL_dcov6 [P][6], dL_dcolors [P][C],
+ * dL_dopacity [P], dL_dmeans2D [P][3] (screen space, z = 0; may be NULL).
+ * Must follow the gom_raster_forward on the same state with the same inputs. */
+int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C,
+                        const float *means3D, const float *cov6, const float *colors, const float *opacity,
+                        const float *dL_dcolor,
+                        float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
+                        void *stream);
+
+/* ---- skeleton + skinning ----------------------------------------------------
+ * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]
+ * (row-major 3x3 R then T).  fk_save [24][32] keeps the chain for backward. */
+int gom_fk_forward(const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream);
+int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const float *fk_save, const float *dRT,
+                    float *d_dst_Rs, float *d_dst_Ts, void *stream);
+/* xyz [3][N] channel-first, weights [J+1][N] (row J = background, ignored), RT [J][12] -> out [3][N] */
+int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream);
+
+/* ---- per-face Gaussians -----------------------------------------------------
+ * verts [3][N], faces [F][3] int32, so3 [3][F], scale [3][F], sigma ->
+ * xyz [F][3], cov6 [F][6]. */
+int gom_face_forward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                     float sigma, float *xyz, float *cov6, void *stream);
+/* d_xyz [F][3], d_cov6 [F][6] -> d_corner [F][3][3] (per face corner, xyz), d_so3 [3][F], d_scale [3][F] */
+int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                      float sigma, const float *d_xyz, const float *d_cov6,
+                      float *d_corner, float *d_so3, float *d_scale, void *stream);
+/* Gathers per-corner gradients onto vertices through the CSR vertex->corner
+ * adjacency (csr_off [N+1], csr_idx [3F] = face*3+corner; no atomics), adds
+ * d_verts_extra [3][N] (may be NULL), and applies the LBS backward:
+ * d_xyz [3][N] = sum_j w_j R_j^T g.  If dRT != NULL also accumulates
+ * dRT [J][12] += sum_n w_jn (g_n x_n^T | g_n) (dRT must be zeroed by the caller). */
+int gom_vertex_backward(int N, int J, const float *xyz, const float *weights, const float *RT,
+                        const int32_t *csr_off, const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra,
+                        float *d_verts_obs, float *d_xyz, float *dRT, void *stream);
+
+/* ---- photometric L1 losses ---------------------------------------------------
+ * pred [4][H][W] (albedo rgb + alpha, the rasterizer's CHW output), shade [H][W] or NULL,
+ * gt_rgb [H][W][3], gt_mask [H][W], bg [3].
+ * rgb' = albedo*shade*alpha + bg*(1-alpha);  L = c_rgb*mean|rgb'-gt| + c_mask*mean|alpha-gt_mask|.
+ * Writes dL_dpred [4][H][W] (scaled by grad_scale), dL_dshade [H][W] (may be NULL) and
+ * loss_partials [GOM_LOSS_BLOCKS][2] (per-block sums of |rgb'-gt| and |alpha-gt_mask|; the
+ * caller reduces them -- the gradient does not depend on the loss value). */
+#define GOM_LOSS_BLOCKS 256
+int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask, const float *bg,
+                float c_rgb, float c_mask, float grad_scale,
+                float *dL_dpred, float *dL_dshade, float *loss_partials, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOM_HIP_H */

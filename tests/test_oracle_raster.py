@@ -1,0 +1,111 @@
+"""Self-consistency of the C raster oracle (the reference ships no vectors for
+this third-party op: parity unpinned, see oracle/raster_oracle.c).  What can be
+pinned: structural invariants of the binning, the compositing identity, and the
+hand-written backward against fp64 finite differences of the forward."""
+import numpy as np
+import pytest
+
+from oracle import raster as orast
+from helpers import small_scene
+
+
+def test_binning_invariants():
+    cam, means, cov6, colors, op = small_scene(seed=3, P=600, H=70, W=90)
+    f = orast.forward(cam, means, cov6, colors, op)
+    gx, gy = (90 + 15) // 16, (70 + 15) // 16
+    assert f["ranges"].shape == (gx * gy, 2)
+    assert f["D"] == int(f["tiles_touched"].sum()) == int(f["offsets"][-1])
+    keys = f["keys"]
+    assert np.all(keys[1:] >= keys[:-1])                       # globally sorted by (tile, depth bits)
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    for t in range(gx * gy):
+        a, b = f["ranges"][t]
+        assert np.all(tiles[a:b] == t)
+        assert (b - a) == np.count_nonzero(tiles == t)
+    # ties keep ascending gaussian order (stable sort); list entries reference visible gaussians only
+    same = keys[1:] == keys[:-1]
+    assert np.all(f["point_list"][1:][same] > f["point_list"][:-1][same])
+    assert np.all(f["radii"][f["point_list"]] > 0)
+    # depth bits in the key are the float32 bits of the view-space depth
+    d = f["depth"][f["point_list"]].astype(np.float32).view(np.uint32)
+    assert np.array_equal((keys & np.uint64(0xffffffff)).astype(np.uint32), d)
+    # rect area == tiles_touched, rects inside the grid
+    r = f["rect"]
+    assert np.array_equal((r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1]), f["tiles_touched"].astype(np.int64))
+    assert r[:, 2].max() <= gx and r[:, 3].max() <= gy
+
+
+def test_compositing_identity_and_background():
+    cam, means, cov6, colors, op = small_scene(seed=4, P=500, H=64, W=64, opacity=(0.2, 1.0))
+    colors[:, 3] = 1.0
+    cam["bg"] = np.array([0.3, 0.6, 0.9, 0.0], np.float32)
+    f = orast.forward(cam, means, cov6, colors, op)
+    # channel 3 carries sum(alpha_i T_i): with the leftover transmittance it sums to one
+    np.testing.assert_allclose(f["color"][3] + f["final_T"], 1.0, atol=2e-6)
+    empty = f["n_contrib"] == 0
+    assert empty.any()
+    for ch in range(3):
+        np.testing.assert_allclose(f["color"][ch][empty], cam["bg"][ch] * f["final_T"][empty], atol=1e-7)
+    assert np.all(f["final_T"] >= 1e-4 - 1e-9)
+
+
+def test_edge_cases():
+    cam, means, cov6, colors, op = small_scene(seed=5, P=50, H=33, W=47)   # not multiples of 16
+    f = orast.forward(cam, means, cov6, colors, op)
+    assert f["color"].shape == (4, 33, 47)
+    # everything behind the near plane -> nothing rendered
+    f2 = orast.forward(cam, means - np.array([0, 0, 10], np.float32), cov6, colors, op)
+    assert f2["D"] == 0 and np.all(f2["radii"] == 0) and np.all(f2["n_contrib"] == 0) and np.all(f2["final_T"] == 1)
+    # a single huge gaussian covers every tile
+    big = np.array([[0.0, 0.0, 0.0]], np.float32)
+    c6 = np.array([[4.0, 0, 0, 4.0, 0, 4.0]], np.float32)
+    f3 = orast.forward(cam, big, c6, np.ones((1, 3), np.float32), np.ones(1, np.float32))
+    assert f3["tiles_touched"][0] == ((47 + 15) // 16) * ((33 + 15) // 16)
+    b = orast.backward(f3, np.ones((3, 33, 47), np.float32))
+    assert np.isfinite(b["dL_dmeans3D"]).all() and np.isfinite(b["dL_dcov6"]).all()
+
+
+def test_f32_matches_f64():
+    cam, means, cov6, colors, op = small_scene(seed=6, P=800, H=96, W=96, opacity=(0.3, 1.0))
+    f32 = orast.forward(cam, means, cov6, colors, op, dtype=np.float32)
+    f64 = orast.forward(cam, means, cov6, colors, op, dtype=np.float64)
+    # ulp-level flips of the integer state are possible but must be rare
+    assert np.mean(f32["radii"] != f64["radii"]) < 5e-3
+    assert np.mean(np.abs(f32["color"] - f64["color"])) < 1e-5
+
+
+@pytest.mark.parametrize("C", [3, 4])
+def test_backward_against_finite_differences(C):
+    cam, means, cov6, colors, op = small_scene(seed=7, P=120, H=48, W=48, opacity=(0.3, 0.8), scale=0.06, C=C)
+    cam["bg"] = np.array([0.2, 0.5, 0.1, 0.4], np.float32)
+    means, cov6, colors, op = (a.astype(np.float64) for a in (means, cov6, colors, op))
+    rng = np.random.default_rng(0)
+    wimg = rng.normal(size=(C, 48, 48))
+
+    def loss(m, c6, col, o):
+        return float((orast.forward(cam, m, c6, col, o, dtype=np.float64)["color"] * wimg).sum())
+
+    f = orast.forward(cam, means, cov6, colors, op, dtype=np.float64)
+    g = orast.backward(f, wimg)
+    vis = np.nonzero(f["radii"] > 0)[0]
+    assert len(vis) > 30
+    checked = 0
+    for name, arr, grad in (("means", means, g["dL_dmeans3D"]), ("cov6", cov6, g["dL_dcov6"]), ("colors", colors, g["dL_dcolors"]), ("opacity", op, g["dL_dopacity"])):
+        for _ in range(12):
+            i = int(rng.choice(vis))
+            idx = (i,) if arr.ndim == 1 else (i, int(rng.integers(arr.shape[1])))
+            args = {"means": means, "cov6": cov6, "colors": colors, "opacity": op}
+            an = float(grad[idx])
+            errs = []
+            # the forward has measure-zero jumps (alpha < 1/255 cut, T < 1e-4 stop, ceil of the radius); a step that
+            # straddles one is detected by disagreeing step sizes, so accept the best of three.
+            for eps in (1e-6, 1e-7, 3e-8):
+                hi = {k: v.copy() for k, v in args.items()}
+                lo = {k: v.copy() for k, v in args.items()}
+                hi[name][idx] += eps
+                lo[name][idx] -= eps
+                fd = (loss(hi["means"], hi["cov6"], hi["colors"], hi["opacity"]) - loss(lo["means"], lo["cov6"], lo["colors"], lo["opacity"])) / (2 * eps)
+                errs.append(abs(fd - an) / max(1.0, abs(fd), abs(an)))
+            assert min(errs) <= 1e-4, (name, idx, an, errs)
+            checked += 1
+    assert checked == 48
