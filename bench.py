@@ -57,8 +57,11 @@ def algorithmic_bytes(P, D, HW, C):
         "preprocess": P * (12 + 24 + 4 * C + 4) + P * (8 + 4 + 16 + 4 + 4),
         "scan_tiles": 0,
         "emit": 12 * D,
-        "render_fwd": D * (4 + 8 + 16 + 4 * C) + HW * (4 * C + 4 + 4),
-        "render_bwd": HW * (4 * C + 4 + 4) + D * (4 + 8 + 16 + 4 * C) + P * (8 + 12 + 4 + 4 * C),
+        "sort": 2 * 12 * D,                                   # one read + one write of the (key, value) pairs
+        "seg_T": D * (4 + 8 + 16),                             # transmittance pre-pass: list + geometry attributes
+        "seg_fwd": D * (4 + 8 + 16 + 4 * C),                  # B_ren_fwd, per-entry part
+        "combine": HW * (4 * C + 4 + 4),                      # B_ren_fwd, per-pixel part
+        "seg_bwd": HW * (4 * C + 4 + 4) + D * (4 + 8 + 16 + 4 * C) + P * (8 + 12 + 4 + 4 * C),   # B_ren_bwd
         "preprocess_bwd": P * (12 + 24 + 4 + 12 + 8) + P * (12 + 24),
     }
 

@@ -13,15 +13,16 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_
 import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the SAME libamdhip64 torch uses
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgom_hip.so")
+LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
 GOM_ABI_VERSION = 1
 GOM_FWD_REUSE_BINNING = 1
+GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
 (BUF_DEPTH, BUF_XY, BUF_CONIC_OPACITY, BUF_TILES_TOUCHED, BUF_RECT, BUF_TILE_BASE, BUF_KEYS, BUF_POINT_LIST, BUF_FINAL_T,
  BUF_N_CONTRIB, BUF_STATUS) = range(11)
 OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE = 0, 1, 2
-KERNEL_NAMES = ("preprocess", "scan_tiles", "emit", "render_fwd", "render_bwd", "preprocess_bwd")
+KERNEL_NAMES = ("preprocess", "scan_tiles", "emit", "sort", "seg_T", "seg_fwd", "combine", "seg_bwd", "preprocess_bwd")
 
 
 class GomCamera(ctypes.Structure):
@@ -42,7 +43,7 @@ SIGNATURES = {
     "gom_raster_forward": (c_int, [c_void_p, POINTER(GomCamera), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_raster_backward": (c_int, [c_void_p, POINTER(GomCamera), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_fk_forward": (c_int, [c_void_p] * 6),
     "gom_fk_backward": (c_int, [c_void_p] * 7),
     "gom_lbs_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -89,7 +90,10 @@ def stream_ptr() -> int:
 
 
 def ptr(t) -> int:
-    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL).
+    The caller must keep `t` referenced until the launch that uses the pointer has been
+    enqueued: torch's caching allocator may hand a dead temporary's block to the next
+    allocation, whose producer kernel could then run BEFORE ours on the same stream."""
     if t is None:
         return 0
     assert t.is_cuda and t.is_contiguous(), "libgom_hip needs contiguous device tensors"

@@ -46,8 +46,9 @@ extern "C" GomState *gom_state_create(void) {
 
 extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
-    void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->tile_base,
-                    s->tile_cursor, s->tile_done, s->keys, s->point_list, s->partial, s->final_T, s->n_contrib, s->status};
+    void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
+                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_tile, s->seg_T,
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->final_T, s->n_contrib, s->scratch_img, s->status};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -87,19 +88,20 @@ static int ensure_capacity(GomState *s, int P, int H, int W) {
     if (P > s->capP) {
         const int cap = P + P / 8 + 256;
         if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
-            grow(&s->rect, cap) || grow(&s->radii, cap))
+            grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap))
             return -2;
         s->capP = cap;
     }
     if (tiles > s->capTiles) {
         if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||
-            grow(&s->tile_done, tiles))
+            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1))
             return -2;
         GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
         s->capTiles = tiles;
+        s->capSegs = 0;  // segment buffers depend on the tile count too
     }
     if (pix > s->capPix) {
-        if (grow(&s->final_T, pix) || grow(&s->n_contrib, pix)) return -2;
+        if (grow(&s->final_T, pix) || grow(&s->n_contrib, pix) || grow(&s->scratch_img, (size_t)pix * 4)) return -2;
         s->capPix = pix;
     }
     // Pair buffers: sized for 288 GB of HBM, not for frugality.  Default 16 pairs
@@ -108,10 +110,20 @@ static int ensure_capacity(GomState *s, int P, int H, int W) {
     if (s->wantPairs <= 0 && want < (4 << 20)) want = 4 << 20;
     if (want > 0xffffffffLL) want = 0xffffffffLL;
     if (want != s->capPairs && (want > s->capPairs || s->wantPairs > 0)) {
-        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) ||
+        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) || grow(&s->pair_pos, (size_t)want) ||
             grow(&s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
             return -2;
         s->capPairs = want;
+        s->capSegs = 0;
+    }
+    // every tile has at most count/GOM_SEG + 1 segments
+    const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
+    if (wantSegs > s->capSegs) {
+        const size_t n = (size_t)wantSegs;
+        if (grow(&s->seg_tile, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
+            grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX))
+            return -2;
+        s->capSegs = wantSegs;
     }
     s->gx = gx;
     s->gy = gy;
@@ -144,9 +156,10 @@ extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int 
         s->P = P; s->H = cam->H; s->W = cam->W;
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
         if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
+        if (int rc = gom_launch_sort(s, st)) return rc;
     }
     s->C = C;
-    if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, !reuse, st)) return rc;
+    if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, reuse, st)) return rc;
     if (reuse && radii) GOM_HIP_CHECK(hipMemcpyAsync(radii, s->radii, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     s->haveForward = true;
     return 0;
@@ -154,7 +167,8 @@ extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int 
 
 extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
                                    const float *colors, const float *opacity, const float *dL_dcolor, float *dL_dmeans3D,
-                                   float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D, void *stream) {
+                                   float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D, uint32_t flags,
+                                   void *stream) {
     (void)opacity;
     if (!s) { gom_set_error("null state"); return -1; }
     if (!valid_dims(P, C, cam)) return -1;
@@ -164,6 +178,9 @@ extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int
     }
     if (!dL_dcolor || !dL_dmeans3D || !dL_dcov6 || !dL_dcolors || !dL_dopacity) { gom_set_error("null gradient pointer"); return -1; }
     hipStream_t st = (hipStream_t)stream;
+    if (flags & GOM_BWD_RECOMPUTE_FORWARD) {
+        if (int rc = gom_launch_render_forward(s, *cam, C, colors, s->scratch_img, true, st)) return rc;
+    }
     if (int rc = gom_launch_render_backward(s, *cam, C, colors, dL_dcolor, st)) return rc;
     if (int rc = gom_launch_preprocess_backward(s, *cam, P, C, means3D, cov6, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity,
                                                 dL_dmeans2D, st))

@@ -9,12 +9,17 @@
 #define GOM_TILE 16
 #define GOM_SORT_CAP_MAX 8192       // tile-list entries sortable in LDS (64 KiB of 64-bit keys)
 #define GOM_PARTIAL_STRIDE 12       // floats per (tile, gaussian) partial-gradient record (10 used)
-#define GOM_BWD_CHUNK 256           // tile-list entries per LDS accumulation round in render backward
+#ifndef GOM_SEG
+#define GOM_SEG 128                 // tile-list entries per segment (the unit of parallel compositing), <= 256
+#endif
+#define GOM_TPX 256                 // pixels per tile = threads of the per-tile / per-segment workgroups
+#define GOM_SEG_GRID 1024           // workgroups launched for the segment kernels (grid-stride over segments)
 
 struct GomDevStatus {
     uint32_t num_pairs;
     uint32_t overflow;
-    uint32_t pad0, pad1;
+    uint32_t num_segs;
+    uint32_t pair_cursor;   // allocator for the per-gaussian ranges of pair_pos (reset by the scan kernel)
 };
 
 struct GomState {
@@ -38,14 +43,27 @@ struct GomState {
     uint32_t *tile_count = nullptr;
     uint32_t *tile_base = nullptr;    // [tiles+1]
     uint32_t *tile_cursor = nullptr;
-    uint32_t *tile_done = nullptr;    // entries of each tile that own a valid partial record
+    uint32_t *tile_nmax = nullptr;    // max n_contrib over the tile's pixels (entries beyond it are dead for backward)
+    uint32_t *seg_base = nullptr;     // [tiles+1] exclusive scan of ceil(count/GOM_SEG)
+    // per gaussian: start of its private range in pair_pos
+    uint32_t *pair_off = nullptr;
     // per pair
     uint64_t *keys = nullptr;
     uint32_t *point_list = nullptr;
+    uint32_t *pair_pos = nullptr;     // [capPairs] sorted position of (gaussian, k-th tile of its rect)
     float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE]
+    // per segment (x 256 pixels of the tile, quadrant-major)
+    int64_t capSegs = 0;
+    uint32_t *seg_tile = nullptr;     // [capSegs]
+    float *seg_T = nullptr;           // [capSegs][256]     product of (1-alpha) over the segment
+    float *seg_C = nullptr;           // [capSegs][4][256]  colour the segment adds to the pixel
+    uint32_t *seg_last = nullptr;     // [capSegs][256]     1+list index of the last contributing entry (0: none)
+    float *seg_Tend = nullptr;        // [capSegs][256]     transmittance after the segment (combine pass)
+    float *seg_Sbehind = nullptr;     // [capSegs][4][256]  colour still to come behind the segment
     // per pixel
     float *final_T = nullptr;
     uint32_t *n_contrib = nullptr;
+    float *scratch_img = nullptr;     // [4][capPix] image sink when the backward has to re-create its checkpoints
     GomDevStatus *status = nullptr;
     // optional per-kernel HIP-event timing (GOM_OPT_PROFILE); events bracket each launch on the caller's stream
     bool profile = false;
@@ -87,8 +105,9 @@ void gom_set_error(const char *fmt, ...);
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
                           const float *opacity, int32_t *radii_out, hipStream_t st);
 int gom_launch_scan_emit(GomState *s, int P, hipStream_t st);
-int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color,
-                              bool do_sort, hipStream_t st);
+int gom_launch_sort(GomState *s, hipStream_t st);
+int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
+                              hipStream_t st);
 int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const float *colors, const float *dL_dcolor,
                                hipStream_t st);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,

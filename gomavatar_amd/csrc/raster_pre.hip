@@ -17,7 +17,8 @@
 //    (LDS-aggregated slot reservation) -> per-tile LDS sort in the render kernel.
 //    4 launches instead of CUB's ~15, no device->host read of the pair count.
 //  * the backward gathers per-(tile,gaussian) partial sums written by the
-//    render backward (no float atomics anywhere -> bitwise reproducible).
+//    render backward through a position table (pair_pos) the sort fills in
+//    (no float atomics anywhere -> bitwise reproducible, no searching).
 #include "gom_internal.h"
 
 namespace {
@@ -99,9 +100,13 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
                                                     float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
                                                     ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
+                                                    uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
                                                     int gx, int gy) {
     extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_blockbase;
     const int n_tiles = gx * gy;
+    uint32_t my_tiles = 0;
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
         __syncthreads();
@@ -163,6 +168,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
         xy[i] = make_float2(o_x, o_y);
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
+        my_tiles = o_tiles;
         rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
@@ -170,8 +176,28 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
                 else atomicAdd(&tile_count[y * gx + x], 1u);
             }
     }
-    if (LDS_HIST) {
+    // Private range of this gaussian in pair_pos: block-level exclusive scan + ONE atomic per block
+    // (the order of the ranges is irrelevant, they only index a scratch table).
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        uint32_t x = my_tiles;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wsum[wid] = x;
         __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            s_blockbase = tot ? atomicAdd(&status->pair_cursor, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += s_wsum[w];
+        if (i < P) pair_off[i] = s_blockbase + woff + (x - my_tiles);
+    }
+    if (LDS_HIST) {
         for (int t = threadIdx.x; t < n_tiles; t += 256) {
             const uint32_t c = s_hist[t];
             if (c) atomicAdd(&tile_count[t], c);
@@ -180,50 +206,63 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
 }
 
 // ---------------------------------------------------------------- A.2a -----
-// Exclusive scan of the per-tile counts (single 1024-thread block), resets the
-// counters for the next frame and publishes D + the overflow flag.
-__global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
-                                                     uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ tile_done,
-                                                     int n_tiles, GomDevStatus *__restrict__ status, uint32_t cap_pairs) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+// Exclusive scans of the per-tile counts and of the per-tile segment counts
+// (single 1024-thread block); resets the counters for the next frame and
+// publishes D, the segment total and the overflow flag.
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
     __syncthreads();
+    if (lane == 63) s_wave[wid] = x;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+    for (int w = 0; w < 16; w++) {
+        const uint32_t sw = s_wave[w];
+        if (w < wid) wave_off += sw;
+        tot += sw;
+    }
+    total = tot;
+    return wave_off + (x - v);
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
+                                                     uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ seg_base,
+                                                     uint32_t *__restrict__ tile_nmax, int n_tiles,
+                                                     GomDevStatus *__restrict__ status, uint32_t cap_pairs) {
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x;
+    uint32_t carry = 0, seg_carry = 0;
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + tid;
         uint32_t v = 0;
         if (i < n_tiles) {
             v = tile_count[i];
             tile_count[i] = 0;
-            tile_done[i] = 0;
+            tile_nmax[i] = 0;
         }
-        // inclusive scan within the wave
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) s_wave[wid] = x;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (int w = 0; w < wid; w++) wave_off += s_wave[w];
-        const uint32_t carry = s_carry;
-        const uint32_t excl = carry + wave_off + (x - v);
+        uint32_t tot, stot;
+        const uint32_t excl = carry + block_excl_scan_1024(v, s_wave, tot);
+        const uint32_t sexcl = seg_carry + block_excl_scan_1024((v + GOM_SEG - 1) / GOM_SEG, s_wave, stot);
         if (i < n_tiles) {
             tile_base[i] = excl;
             tile_cursor[i] = excl;
+            seg_base[i] = sexcl;
         }
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wave_off + x;
-        __syncthreads();
+        carry += tot;
+        seg_carry += stot;
     }
     if (tid == 0) {
-        const uint32_t total = s_carry;
-        tile_base[n_tiles] = total;
-        status->num_pairs = total;
-        status->overflow = total > cap_pairs ? 1u : 0u;
+        tile_base[n_tiles] = carry;
+        seg_base[n_tiles] = seg_carry;
+        status->num_pairs = carry;
+        status->overflow = carry > cap_pairs ? 1u : 0u;
+        status->num_segs = carry > cap_pairs ? 0u : seg_carry;
+        status->pair_cursor = 0;
     }
 }
 
@@ -286,11 +325,11 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 template <int C>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, const float *__restrict__ means,
                                                         const float *__restrict__ cov6, const int32_t *__restrict__ radii,
-                                                        const float *__restrict__ depth, const ushort4 *__restrict__ rect,
+                                                        const uint32_t *__restrict__ tiles_touched,
                                                         const float4 *__restrict__ conic_opacity,
-                                                        const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_done,
-                                                        const uint64_t *__restrict__ keys, const float *__restrict__ partial,
-                                                        int gx, const GomDevStatus *__restrict__ status,
+                                                        const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_pos,
+                                                        const float *__restrict__ partial,
+                                                        const GomDevStatus *__restrict__ status,
                                                         float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
                                                         float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
                                                         float *__restrict__ dL_dmeans2D) {
@@ -303,27 +342,27 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, co
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
     const bool bad = status->overflow != 0;
     if (!bad && radii[i] > 0) {
-        const ushort4 r = rect[i];
-        const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
-        for (int y = r.y; y < r.w; y++)
-            for (int x = r.x; x < r.z; x++) {
-                const int t = y * gx + x;
-                const uint32_t base = tile_base[t];
-                const uint32_t lim = tile_done[t];
-                uint32_t lo = 0, hi = lim;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (keys[base + mid] < key) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo < lim && keys[base + lo] == key) {
-                    const float4 *pp = reinterpret_cast<const float4 *>(partial + (size_t)(base + lo) * GOM_PARTIAL_STRIDE);
-                    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-                    acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
-                    acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
-                    acc[8] += p2.x; acc[9] += p2.y;
+        // k-th tile of this gaussian's rect -> sorted position of that (tile, gaussian) pair -> its record.
+        // Independent loads, 4 in flight; fixed k order keeps the sum reproducible.
+        const uint32_t nt = tiles_touched[i];
+        const uint32_t *pp = pair_pos + pair_off[i];
+        for (uint32_t k0 = 0; k0 < nt; k0 += 4) {
+            float4 q0[4], q1[4], q2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + u < nt ? k0 + u : k0;
+                const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[k] * GOM_PARTIAL_STRIDE);
+                q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u < nt) {
+                    acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
+                    acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;
+                    acc[8] += q2[u].x; acc[9] += q2[u].y;
                 }
             }
+        }
         // record layout: [0..3] colours, [4] sum Q, [5] sum Q dx, [6] sum Q dy, [7] sum Q dx dx, [8] sum Q dx dy, [9] sum Q dy dy
         // with Q = G * dL/dalpha and d = centre - pixel (App. A.4 regrouped).
         const float4 co = conic_opacity[i];
@@ -423,11 +462,11 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), n_tiles * sizeof(uint32_t), st, cam, P, means3D, cov6,
                            opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
-                           s->tile_count, s->gx, s->gy);
+                           s->tile_count, s->pair_off, s->status, s->gx, s->gy);
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, opacity, s->depth,
-                           s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->gx,
-                           s->gy);
+                           s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
+                           s->status, s->gx, s->gy);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -437,8 +476,8 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st) {
     const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->tile_done,
-                           n_tiles, s->status, cap);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
+                           s->tile_nmax, n_tiles, s->status, cap);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;
@@ -461,12 +500,12 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
     if (C == 3)
-        hipLaunchKernelGGL(k_preprocess_bwd<3>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii, s->depth,
-                           s->rect, s->conic_opacity, s->tile_base, s->tile_done, s->keys, s->partial, s->gx, s->status,
+        hipLaunchKernelGGL(k_preprocess_bwd<3>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii,
+                           s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
                            dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
     else
-        hipLaunchKernelGGL(k_preprocess_bwd<4>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii, s->depth,
-                           s->rect, s->conic_opacity, s->tile_base, s->tile_done, s->keys, s->partial, s->gx, s->status,
+        hipLaunchKernelGGL(k_preprocess_bwd<4>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii,
+                           s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
                            dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
     GOM_LAUNCH_CHECK();
     return 0;

@@ -65,7 +65,8 @@ class _FK(torch.autograd.Function):
         Rs, Ts, save = ctx.saved_tensors
         dRs = torch.empty_like(Rs)
         dTs = torch.empty_like(Ts)
-        _lib.check(lib.gom_fk_backward(_lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(save), _lib.ptr(dRT.contiguous()), _lib.ptr(dRs),
+        g = dRT.contiguous()  # keep a reference until the launch is enqueued (see _lib.ptr)
+        _lib.check(lib.gom_fk_backward(_lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(save), _lib.ptr(g), _lib.ptr(dRs),
                                        _lib.ptr(dTs), _lib.stream_ptr()))
         return None, dRs.reshape(ctx.shapes[0]), dTs.reshape(ctx.shapes[1])
 
@@ -105,7 +106,8 @@ class _LBS(torch.autograd.Function):
         N, J = xyz.shape[1], RT.shape[0]
         d_xyz = torch.empty_like(xyz)
         dRT = torch.zeros_like(RT) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.gom_vertex_backward(N, J, _lib.ptr(xyz), _lib.ptr(weights), _lib.ptr(RT), 0, 0, 0, _lib.ptr(g.contiguous()),
+        g = g.contiguous()
+        _lib.check(lib.gom_vertex_backward(N, J, _lib.ptr(xyz), _lib.ptr(weights), _lib.ptr(RT), 0, 0, 0, _lib.ptr(g),
                                            0, _lib.ptr(d_xyz), _lib.ptr(dRT), _lib.stream_ptr()))
         return d_xyz, dRT, None
 
@@ -146,8 +148,9 @@ class _FaceGaussians(torch.autograd.Function):
         d_corner = torch.empty((F, 3, 3), dtype=torch.float32, device=v.device)
         d_so3 = torch.empty_like(w)
         d_scale = torch.empty_like(s)
+        g_xyz, g_cov6 = g_xyz.contiguous(), g_cov6.contiguous()
         _lib.check(lib.gom_face_backward(N, F, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), ctx.sigma,
-                                         _lib.ptr(g_xyz.contiguous()), _lib.ptr(g_cov6.contiguous()), _lib.ptr(d_corner),
+                                         _lib.ptr(g_xyz), _lib.ptr(g_cov6), _lib.ptr(d_corner),
                                          _lib.ptr(d_so3), _lib.ptr(d_scale), _lib.stream_ptr()))
         # CSR gather of the corner gradients onto vertices (deterministic)
         d_verts = _csr_gather(d_corner.reshape(-1, 3), topo, N)
@@ -162,8 +165,9 @@ def _csr_gather(corner_grads: torch.Tensor, topo: MeshTopology, N: int) -> torch
     out = torch.empty((3, N), dtype=torch.float32, device=dev)
     ident = torch.tensor([[1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]], dtype=torch.float32, device=dev)
     ones = torch.ones((3, N), dtype=torch.float32, device=dev)  # read-only: serves as xyz and as the (2,N) weights
+    corner_grads = corner_grads.contiguous()
     _lib.check(lib.gom_vertex_backward(N, 1, _lib.ptr(ones), _lib.ptr(ones), _lib.ptr(ident), _lib.ptr(topo.csr_off),
-                                       _lib.ptr(topo.csr_idx), _lib.ptr(corner_grads.contiguous()), 0, 0, _lib.ptr(out), 0,
+                                       _lib.ptr(topo.csr_idx), _lib.ptr(corner_grads), 0, 0, _lib.ptr(out), 0,
                                        _lib.stream_ptr()))
     return out
 
@@ -217,8 +221,9 @@ class _PosedFaceGaussians(torch.autograd.Function):
             g_xyz = torch.zeros((F, 3), dtype=torch.float32, device=dev)
         if g_cov6 is None:
             g_cov6 = torch.zeros((F, 6), dtype=torch.float32, device=dev)
+        g_xyz, g_cov6 = g_xyz.contiguous(), g_cov6.contiguous()
         _lib.check(lib.gom_face_backward(N, F, _lib.ptr(v_obs), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), ctx.sigma,
-                                         _lib.ptr(g_xyz.contiguous()), _lib.ptr(g_cov6.contiguous()), _lib.ptr(d_corner),
+                                         _lib.ptr(g_xyz), _lib.ptr(g_cov6), _lib.ptr(d_corner),
                                          _lib.ptr(d_so3), _lib.ptr(d_scale), st))
         need_pose = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         d_v = torch.empty_like(v)

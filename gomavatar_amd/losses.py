@@ -25,8 +25,9 @@ class _L1Photometric(torch.autograd.Function):
         dpred = torch.empty_like(p)
         dshade = torch.empty_like(s) if s is not None else None
         partials = torch.empty((_lib.GOM_LOSS_BLOCKS, 2), dtype=torch.float32, device=p.device)
-        _lib.check(lib.gom_l1_loss(H, W, _lib.ptr(p), _lib.ptr(s), _lib.ptr(gt_rgb.contiguous()), _lib.ptr(gt_mask.contiguous()),
-                                   _lib.ptr(bg.contiguous().float()), float(c_rgb), float(c_mask), 1.0, _lib.ptr(dpred), _lib.ptr(dshade),
+        gt_rgb, gt_mask, bg = gt_rgb.contiguous(), gt_mask.contiguous(), bg.contiguous().float()  # alive until enqueued
+        _lib.check(lib.gom_l1_loss(H, W, _lib.ptr(p), _lib.ptr(s), _lib.ptr(gt_rgb), _lib.ptr(gt_mask),
+                                   _lib.ptr(bg), float(c_rgb), float(c_mask), 1.0, _lib.ptr(dpred), _lib.ptr(dshade),
                                    _lib.ptr(partials), _lib.stream_ptr()))
         sums = partials.sum(0)
         l_rgb = sums[0] / (3.0 * H * W)

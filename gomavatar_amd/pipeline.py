@@ -103,7 +103,7 @@ class RenderStep:
         if not backward:
             return
         chk(lib.gom_raster_backward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
-                                    P(self.d_image), P(self.d_xyz), P(self.d_cov6), P(self.d_feat), P(self.d_opacity), 0, st))
+                                    P(self.d_image), P(self.d_xyz), P(self.d_cov6), P(self.d_feat), P(self.d_opacity), 0, 0, st))
         chk(lib.gom_face_backward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.d_xyz), P(self.d_cov6),
                                   P(self.d_corner), P(self.grads["so3"]), P(self.grads["scale"]), st))
         chk(lib.gom_vertex_backward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.topo.csr_off), P(self.topo.csr_idx),

@@ -54,6 +54,7 @@ class RasterState:
             raise RuntimeError("gom_state_create failed: " + lib.gom_last_error().decode())
         self.users = 0
         self.pool_key = None  # set by the pool for pooled states
+        self.owner = 0        # id of the forward whose colour-dependent checkpoints the state currently holds
 
     def __del__(self):
         try:
@@ -149,6 +150,8 @@ def camera_from_settings(rs: GaussianRasterizationSettings) -> _lib.GomCamera:
 
 
 class _Rasterize(torch.autograd.Function):
+    _next_id = 0
+
     @staticmethod
     def forward(ctx, means3D, means2D, colors, opacities, cov6, cam, lease, reuse):
         lib = _lib.load()
@@ -163,6 +166,9 @@ class _Rasterize(torch.autograd.Function):
         _lib.check(lib.gom_raster_forward(lease.st.handle, ctypes.byref(cam), P, C, _lib.ptr(means3D_c), _lib.ptr(cov_c),
                                           _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(out), _lib.ptr(radii),
                                           _lib.GOM_FWD_REUSE_BINNING if reuse else 0, _lib.stream_ptr()))
+        _Rasterize._next_id += 1
+        ctx.fid = _Rasterize._next_id
+        lease.st.owner = ctx.fid
         ctx.cam = cam
         ctx.lease = lease
         ctx.opac_shape = opacities.shape
@@ -183,7 +189,9 @@ class _Rasterize(torch.autograd.Function):
         d_m2d = torch.empty((P, 3), dtype=torch.float32, device=means3D.device)
         _lib.check(lib.gom_raster_backward(ctx.lease.st.handle, ctypes.byref(ctx.cam), P, C, _lib.ptr(means3D), _lib.ptr(cov6),
                                            _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(g), _lib.ptr(d_means), _lib.ptr(d_cov),
-                                           _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_m2d), _lib.stream_ptr()))
+                                           _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_m2d),
+                                           _lib.GOM_BWD_RECOMPUTE_FORWARD if ctx.lease.st.owner != ctx.fid else 0, _lib.stream_ptr()))
+        ctx.lease.st.owner = ctx.fid
         ctx.lease.finish()
         return d_means, d_m2d, d_col, d_op.reshape(ctx.opac_shape), d_cov, None, None, None
 

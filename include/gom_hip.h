@@ -68,7 +68,7 @@ enum {
     GOM_BUF_POINT_LIST = 7,  /* uint32 [D] sorted gaussian ids                                      */
     GOM_BUF_FINAL_T = 8,     /* float  [H][W]         */
     GOM_BUF_N_CONTRIB = 9,   /* uint32 [H][W]         */
-    GOM_BUF_STATUS = 10      /* uint32 [4]: num_pairs, overflow, 0, 0 */
+    GOM_BUF_STATUS = 10      /* uint32 [4]: num_pairs, overflow, num_segments, - */
 };
 
 /* options for gom_state_set_option */
@@ -81,10 +81,10 @@ enum {
 
 /* kernel ids for gom_state_kernel_times */
 enum {
-    GOM_K_PREPROCESS = 0, GOM_K_SCAN = 1, GOM_K_EMIT = 2, GOM_K_RENDER_FWD = 3,
-    GOM_K_RENDER_BWD = 4, GOM_K_PREPROCESS_BWD = 5
+    GOM_K_PREPROCESS = 0, GOM_K_SCAN = 1, GOM_K_EMIT = 2, GOM_K_SORT = 3, GOM_K_SEG_T = 4, GOM_K_SEG_FWD = 5,
+    GOM_K_COMBINE = 6, GOM_K_SEG_BWD = 7, GOM_K_PREPROCESS_BWD = 8
 };
-#define GOM_NUM_KERNELS 6
+#define GOM_NUM_KERNELS 9
 
 const char *gom_last_error(void);
 int gom_abi_version(void);
@@ -109,6 +109,11 @@ int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int C,
                        const float *means3D, const float *cov6, const float *colors, const float *opacity,
                        float *out_color, int32_t *radii, uint32_t flags, void *stream);
 
+/* flags for gom_raster_backward */
+#define GOM_BWD_RECOMPUTE_FORWARD 1u /* another forward with different COLOURS ran on this state since the forward
+                                        being differentiated (same geometry, GOM_FWD_REUSE_BINNING): re-create the
+                                        colour-dependent checkpoints first */
+
 /* dL_dcolor [C][H][W] -> dL_dmeans3D [P][3], dL_dcov6 [P][6], dL_dcolors [P][C],
  * dL_dopacity [P], dL_dmeans2D [P][3] (screen space, z = 0; may be NULL).
  * Must follow the gom_raster_forward on the same state with the same inputs. */
@@ -116,7 +121,7 @@ int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C,
                         const float *means3D, const float *cov6, const float *colors, const float *opacity,
                         const float *dL_dcolor,
                         float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
-                        void *stream);
+                        uint32_t flags, void *stream);
 
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]

@@ -1,0 +1,40 @@
+"""Per-wave cycle breakdown of the render forward (instrumented build)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from gomavatar_amd import _lib, rasterizer as R, synthetic as syn
+from gomavatar_amd.pipeline import RenderStep
+subdiv = int(os.environ.get("SUBDIV", "1")); img = 512
+body = syn.make_body(subdiv); N, F = body["canonical_vertex"].shape[0], body["faces"].shape[0]
+w = torch.from_numpy(body["canonical_lbs_weights"]).T; w25 = torch.cat([w, torch.zeros(1, N)], 0).contiguous()
+step = RenderStep(torch.from_numpy(body["faces"]), N, (img, img), w25)
+gp = syn.make_gaussian_params(F, 1)
+params = dict(vertices=torch.from_numpy(body["canonical_vertex"]).T.contiguous().cuda(), so3=torch.from_numpy(gp["so3"]).cuda(), scale=torch.from_numpy(gp["scale"]).cuda(), appearance=torch.from_numpy(gp["appearance"]).cuda())
+fr = syn.make_frame(0, img)
+d = {k: torch.from_numpy(fr[k][0]).contiguous().cuda() for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+step.set_camera(fr["K"][0], fr["E"][0])
+gt = torch.zeros((img, img, 3), device="cuda"); gm = torch.zeros((img, img), device="cuda"); bg = torch.zeros(3, device="cuda")
+step.state.set_option(_lib.OPT_PROFILE, 1)
+for _ in range(3):
+    step.forward_backward(params, d, gt, gm, bg)
+torch.cuda.synchronize()
+print("kernel ms", step.state.kernel_times_ms())
+lib = _lib.load()
+if hasattr(lib, "gom_debug_fetch"):
+    n = 8192 * 12
+    buf = (ctypes.c_ulonglong * n)()
+    lib.gom_debug_fetch(buf, n)
+    allb = np.frombuffer(buf, dtype=np.uint64)
+    a = allb[:1024 * 8].reshape(1024, 4, 2)
+    loadc = allb[8192 * 8:8192 * 8 + 4096].reshape(1024, 4).astype(np.int64) if False else allb[8192 * 4 * 2:8192 * 4 * 2 + 4096].reshape(1024, 4).astype(np.int64)
+    sort_c = (a[..., 0] >> np.uint64(32)).astype(np.int64); rend_c = (a[..., 0] & np.uint64(0xffffffff)).astype(np.int64)
+    batches = (a[..., 1] >> np.uint64(32)).astype(np.int64); surv = (a[..., 1] & np.uint64(0xffffffff)).astype(np.int64)
+    tot = sort_c + rend_c
+    order = np.argsort(-tot.max(1))[:12]
+    print("tile  sort_cyc  render_cyc(max wave)  batches  survivors  cyc/surv")
+    for t in order:
+        wv = int(np.argmax(tot[t]))
+        print(t, sort_c[t, wv], rend_c[t, wv], batches[t, wv], surv[t, wv], round(rend_c[t, wv] / max(1, surv[t, wv]), 1), "load_cyc", loadc[t, wv], "per batch", loadc[t, wv] // max(1, batches[t, wv]))
+    act = surv.sum(1) > 0
+    print("sum render cycles over waves", rend_c[act].sum(), "sum sort (per tile)", sort_c[act].max(1).sum(), "total survivors", surv.sum(), "batches", batches.sum())

