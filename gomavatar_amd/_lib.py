@@ -47,9 +47,10 @@ SIGNATURES = {
     "gom_fk_forward": (c_int, [c_void_p] * 6),
     "gom_fk_backward": (c_int, [c_void_p] * 7),
     "gom_lbs_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gom_face_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "gom_face_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
     "gom_face_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_vertex_backward": (c_int, [c_int, c_int] + [c_void_p] * 11),
     "gom_l1_loss": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p]),

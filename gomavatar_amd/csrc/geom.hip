@@ -233,9 +233,14 @@ __device__ __forceinline__ void face_forward(const float *verts, int N, const in
 
 __global__ void __launch_bounds__(256) k_face_fwd(int N, int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                   const float *__restrict__ so3, const float *__restrict__ scale, float sigma,
-                                                  float *__restrict__ xyz, float *__restrict__ cov6) {
+                                                  float *__restrict__ xyz, float *__restrict__ cov6,
+                                                  const float *__restrict__ appearance, float *__restrict__ feat4) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    if (feat4) {  // (3,F) colour parameter -> (F,4) rasterizer features [r g b 1] (gaussian.py:49), fused here
+        *reinterpret_cast<float4 *>(feat4 + 4 * (size_t)f) =
+            make_float4(appearance[f], appearance[(size_t)F + f], appearance[2 * (size_t)F + f], 1.0f);
+    }
     FaceFwd o;
     float c[3], s3[3];
     face_forward(verts, N, faces, so3, scale, F, f, sigma, o, c, s3);
@@ -252,9 +257,14 @@ __global__ void __launch_bounds__(256) k_face_fwd(int N, int F, const float *__r
 __global__ void __launch_bounds__(256) k_face_bwd(int N, int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                   const float *__restrict__ so3, const float *__restrict__ scale, float sigma,
                                                   const float *__restrict__ d_xyz, const float *__restrict__ d_cov6,
-                                                  float *__restrict__ d_corner, float *__restrict__ d_so3, float *__restrict__ d_scale) {
+                                                  float *__restrict__ d_corner, float *__restrict__ d_so3, float *__restrict__ d_scale,
+                                                  const float *__restrict__ d_feat4, float *__restrict__ d_appearance) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    if (d_appearance) {  // (F,4) feature gradient -> (3,F) colour-parameter gradient
+        const float4 g = *reinterpret_cast<const float4 *>(d_feat4 + 4 * (size_t)f);
+        d_appearance[f] = g.x; d_appearance[(size_t)F + f] = g.y; d_appearance[2 * (size_t)F + f] = g.z;
+    }
     FaceFwd o;
     float cdummy[3], s3[3];
     face_forward(verts, N, faces, so3, scale, F, f, sigma, o, cdummy, s3);
@@ -375,12 +385,22 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
     float g[3] = {0.f, 0.f, 0.f};
     if (ok) {
         if (csr_off) {
+            // 8 corners in flight per trip: a pole-like vertex with ~100 incident faces would otherwise
+            // serialise 100 dependent gathers.  Fixed order -> reproducible sums.
             const int b = csr_off[n], e = csr_off[n + 1];
-            for (int k = b; k < e; k++) {
-                const int ci = csr_idx[k];
-                g[0] += d_corner[3 * (size_t)ci];
-                g[1] += d_corner[3 * (size_t)ci + 1];
-                g[2] += d_corner[3 * (size_t)ci + 2];
+            for (int k0 = b; k0 < e; k0 += 8) {
+                float c[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int ci = csr_idx[min(k0 + u, e - 1)];
+                    c[u][0] = d_corner[3 * (size_t)ci];
+                    c[u][1] = d_corner[3 * (size_t)ci + 1];
+                    c[u][2] = d_corner[3 * (size_t)ci + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (k0 + u < e) { g[0] += c[u][0]; g[1] += c[u][1]; g[2] += c[u][2]; }
+                }
             }
         }
         if (d_extra) {
@@ -452,23 +472,26 @@ extern "C" int gom_lbs_forward(int N, int J, const float *xyz, const float *weig
 }
 
 extern "C" int gom_face_forward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
-                                float sigma, float *xyz, float *cov6, void *stream) {
+                                float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream) {
     if (N < 0 || F < 0) { gom_set_error("gom_face_forward: bad sizes"); return -1; }
     if (F == 0) return 0;
     if (!verts || !faces || !so3 || !scale || !xyz || !cov6) { gom_set_error("gom_face_forward: null pointer"); return -1; }
-    hipLaunchKernelGGL(k_face_fwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma, xyz, cov6);
+    if ((appearance == nullptr) != (feat4 == nullptr)) { gom_set_error("gom_face_forward: appearance and feat4 go together"); return -1; }
+    hipLaunchKernelGGL(k_face_fwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma, xyz, cov6,
+                       appearance, feat4);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                                  float sigma, const float *d_xyz, const float *d_cov6, float *d_corner, float *d_so3,
-                                 float *d_scale, void *stream) {
+                                 float *d_scale, const float *d_feat4, float *d_appearance, void *stream) {
     if (N < 0 || F < 0) { gom_set_error("gom_face_backward: bad sizes"); return -1; }
     if (F == 0) return 0;
     if (!verts || !faces || !so3 || !scale || !d_xyz || !d_cov6 || !d_corner || !d_so3 || !d_scale) { gom_set_error("gom_face_backward: null pointer"); return -1; }
+    if ((d_feat4 == nullptr) != (d_appearance == nullptr)) { gom_set_error("gom_face_backward: d_feat4 and d_appearance go together"); return -1; }
     hipLaunchKernelGGL(k_face_bwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma,
-                       d_xyz, d_cov6, d_corner, d_so3, d_scale);
+                       d_xyz, d_cov6, d_corner, d_so3, d_scale, d_feat4, d_appearance);
     GOM_LAUNCH_CHECK();
     return 0;
 }

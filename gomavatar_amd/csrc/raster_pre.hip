@@ -343,19 +343,20 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, co
     const bool bad = status->overflow != 0;
     if (!bad && radii[i] > 0) {
         // k-th tile of this gaussian's rect -> sorted position of that (tile, gaussian) pair -> its record.
-        // Independent loads, 4 in flight; fixed k order keeps the sum reproducible.
+        // Independent gathers, 8 records in flight per trip (a gaussian over 72 tiles costs 9 dependent round
+        // trips instead of 72); fixed k order keeps the sum reproducible.
         const uint32_t nt = tiles_touched[i];
         const uint32_t *pp = pair_pos + pair_off[i];
-        for (uint32_t k0 = 0; k0 < nt; k0 += 4) {
-            float4 q0[4], q1[4], q2[4];
+        for (uint32_t k0 = 0; k0 < nt; k0 += 8) {
+            float4 q0[8], q1[8], q2[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const uint32_t k = k0 + u < nt ? k0 + u : k0;
                 const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[k] * GOM_PARTIAL_STRIDE);
                 q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 if (k0 + u < nt) {
                     acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
                     acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;

@@ -203,12 +203,117 @@ __device__ __forceinline__ void bitonic_sort_u64(PTR keys, uint32_t n) {
     }
 }
 
+// Register-resident bitonic sort: 8 keys per thread (element i = 8*thread + r).  In the normalised network every
+// step pairs element i with i ^ mask (mask = 2^m - 1 for the mirror step of stage m, a power of two otherwise) and
+// leaves the minimum at the lower index.  mask < 8 stays inside a thread, mask < 512 inside a wave (ds_bpermute
+// shuffles, no barrier), and only masks >= 512 go through LDS -- 10 barrier-fenced exchanges for 8192 keys
+// instead of 91.
+__device__ __forceinline__ void cmpswap(uint64_t &lo, uint64_t &hi) {
+    const uint64_t a = lo, b = hi;
+    const bool sw = a > b;
+    lo = sw ? b : a;
+    hi = sw ? a : b;
+}
+
+template <int MASK>
+__device__ __forceinline__ void sort_step_regs(uint64_t (&x)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if ((r ^ MASK) > r) cmpswap(x[r], x[r ^ MASK]);
+}
+
+// lane ^ MASK exchange of one dword without touching LDS: DPP quad/row permutes for MASK < 16,
+// v_permlane16_swap / v_permlane32_swap (gfx950) for the row and half-wave bits.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t xor16(uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return ((threadIdx.x >> 4) & 1) ? r[0] : r[1];   // odd rows: vdst now holds the even neighbour, even rows: src0 holds the odd one
+}
+__device__ __forceinline__ uint32_t xor32(uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return ((threadIdx.x >> 5) & 1) ? r[0] : r[1];
+}
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (MASK == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) return dpp_mov<0x1B>(v);                  // quad_perm [3,2,1,0]
+    else if constexpr (MASK == 7) return dpp_mov<0x141>(v);                 // row_half_mirror
+    else if constexpr (MASK == 15) return dpp_mov<0x140>(v);                // row_mirror
+    else if constexpr (MASK == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // (l^7)^3
+    else if constexpr (MASK == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v)); // (l^15)^7
+    else if constexpr (MASK == 16) return xor16(v);
+    else if constexpr (MASK == 32) return xor32(v);
+    else if constexpr (MASK == 31) return xor16(dpp_mov<0x140>(v));
+    else if constexpr (MASK == 63) return xor32(xor16(dpp_mov<0x140>(v)));
+    else return 0;
+}
+template <int MASK>
+__device__ __forceinline__ void lanes_xor_u64x8(const uint64_t (&x)[8], uint64_t (&y)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t lo = lane_xor<MASK>((uint32_t)x[r]);
+        const uint32_t hi = lane_xor<MASK>((uint32_t)(x[r] >> 32));
+        y[r] = ((uint64_t)hi << 32) | lo;
+    }
+}
+
+// partner keys arrive in y[]; keep the minimum when this thread owns the lower index
+template <bool MIRROR>
+__device__ __forceinline__ void sort_step_merge(uint64_t (&x)[8], const uint64_t (&y)[8], bool lower) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint64_t o = y[MIRROR ? 7 - r : r];
+        const bool take = (o < x[r]) == lower;  // keys are unique (or both +inf padding, where either choice is the same)
+        x[r] = take ? o : x[r];
+    }
+}
+
+template <bool MIRROR>
+__device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask, uint64_t *s_x, bool wave_active, uint32_t n) {
+    // tmask = mask >> 3: partner thread = t ^ tmask; this thread owns the lower index iff the top bit of tmask is clear in t
+    const uint32_t t = threadIdx.x;
+    const bool lower = (t & (1u << (31 - __builtin_clz(tmask)))) == 0;
+    uint64_t y[8];
+    if (tmask < 64) {
+        if (!wave_active) return;  // this wave holds only +inf padding (wave-uniform)
+        switch (tmask) {  // wave-uniform
+            case 1: lanes_xor_u64x8<1>(x, y); break;
+            case 2: lanes_xor_u64x8<2>(x, y); break;
+            case 3: lanes_xor_u64x8<3>(x, y); break;
+            case 4: lanes_xor_u64x8<4>(x, y); break;
+            case 7: lanes_xor_u64x8<7>(x, y); break;
+            case 8: lanes_xor_u64x8<8>(x, y); break;
+            case 15: lanes_xor_u64x8<15>(x, y); break;
+            case 16: lanes_xor_u64x8<16>(x, y); break;
+            case 31: lanes_xor_u64x8<31>(x, y); break;
+            case 32: lanes_xor_u64x8<32>(x, y); break;
+            default: lanes_xor_u64x8<63>(x, y); break;
+        }
+    } else {
+        __syncthreads();  // previous readers of s_x are done (idle waves only keep the barriers company)
+        if (wave_active) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) s_x[r * 1024 + t] = x[r];  // transposed: conflict-free 8-byte lanes
+        }
+        __syncthreads();
+        if (!wave_active) return;
+        const bool partner_wrote = ((t ^ tmask) & ~63u) * 8 < n;  // padding-only waves wrote nothing: their keys are +inf
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = partner_wrote ? s_x[r * 1024 + (t ^ tmask)] : ~0ull;
+    }
+    sort_step_merge<MIRROR>(x, y, lower);
+}
+
 __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint32_t *__restrict__ seg_tile, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
                                                const GomDevStatus *__restrict__ status, uint32_t sort_cap) {
-    __shared__ uint64_t s_keys[GOM_SORT_CAP_MAX];
+    __shared__ uint64_t s_x[GOM_SORT_CAP_MAX];
     if (status->overflow) return;
     const int tile = blockIdx.x;
     const uint32_t base = tile_base[tile];
@@ -217,21 +322,63 @@ __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restric
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
     for (uint32_t i = threadIdx.x; i < nseg; i += 1024) seg_tile[sb + i] = (uint32_t)tile;
     const int tx = tile % gx, ty = tile / gx;
-    const bool in_lds = n <= sort_cap;
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) s_keys[i] = keys[base + i];
-        __syncthreads();
-        bitonic_sort_u64<1024>(s_keys, n);
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) keys[base + i] = s_keys[i];
+    const uint32_t t = threadIdx.x;
+    if (n <= sort_cap) {
+        uint32_t logN = 3;
+        while ((1u << logN) < n) logN++;
+#ifdef GOM_INSTRUMENT
+        const unsigned long long d0 = __builtin_readcyclecounter();
+#endif
+        uint64_t x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = 8 * t + r;
+            x[r] = i < n ? keys[base + i] : ~0ull;  // +inf padding never moves down: every comparator sorts ascending
+        }
+#ifdef GOM_INSTRUMENT
+        const unsigned long long d1 = __builtin_readcyclecounter();
+#endif
+        const bool wave_active = (t & ~63u) * 8 < n;  // waves past the list only hold padding
+        // stages m = 1..3 live entirely in registers
+        if (wave_active) {
+            sort_step_regs<1>(x);
+            sort_step_regs<3>(x); sort_step_regs<1>(x);
+            sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
+        }
+        for (uint32_t m = 4; m <= logN; m++) {
+            sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, n);
+            for (int q = (int)m - 2; q >= 3; q--) sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, n);
+            if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); }
+        }
+#ifdef GOM_INSTRUMENT
+        const unsigned long long d2 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = 8 * t + r;
+            if (i < n) {
+                keys[base + i] = x[r];
+                const uint32_t g = (uint32_t)x[r];
+                point_list[base + i] = g;
+                const ushort4 rc = rect[g];
+                const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
+                pair_pos[pair_off[g] + k] = base + i;
+            }
+        }
+#ifdef GOM_INSTRUMENT
+        if (t == 0 && tile < 8192) {
+            g_dbg[tile * 4 + 0] = d1 - d0; g_dbg[tile * 4 + 1] = d2 - d1; g_dbg[tile * 4 + 2] = __builtin_readcyclecounter() - d2; g_dbg[tile * 4 + 3] = n;
+        }
+#endif
     } else {
-        bitonic_sort_u64<1024>(keys + base, n);  // rare: list longer than the LDS capacity
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t g = (uint32_t)(in_lds ? s_keys[i] : keys[base + i]);
-        point_list[base + i] = g;
-        const ushort4 r = rect[g];
-        const uint32_t k = (uint32_t)(ty - (int)r.y) * (uint32_t)(r.z - r.x) + (uint32_t)(tx - (int)r.x);
-        pair_pos[pair_off[g] + k] = base + i;
+        bitonic_sort_u64<1024>(keys + base, n);  // rare: list longer than the LDS capacity, sorted in global memory
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t g = (uint32_t)keys[base + i];
+            point_list[base + i] = g;
+            const ushort4 rc = rect[g];
+            const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
+            pair_pos[pair_off[g] + k] = base + i;
+        }
     }
 }
 
@@ -458,38 +605,67 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, float
     uint32_t last = 0;
     int s_stop = (int)nseg - 1;  // last segment that contributed to this pixel
     bool going = true;
-    for (uint32_t sl = 0; sl < nseg; sl++) {
-        const size_t o = (size_t)(sb + sl) * GOM_TPX + threadIdx.x;
-        const float te = seg_Tend[o];
-        if (going) {
-            if (te == 0.f) {  // the pixel had stopped before this segment
-                going = false;
-                s_stop = (int)sl - 1;
-            } else {
+    // 8 segments per trip: all loads of a trip are issued before the (cheap, serial) fold, so the list of
+    // segments costs one memory latency per 8 instead of one per segment.
+    for (uint32_t s0 = 0; s0 < nseg; s0 += 8) {
+        float te[8], cs[8][C];
+        uint32_t ll[8];
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) acc[ch] += seg_C[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x];
-                const uint32_t ll = seg_last[o];
-                last = ll ? ll : last;
-                T = fabsf(te);
-                if (te < 0.f) {  // stop rule fired inside this segment
-                    going = false;
-                    s_stop = (int)sl;
+        for (int u = 0; u < 8; u++) {
+            const uint32_t sl = min(s0 + u, nseg - 1);
+            const size_t o = (size_t)(sb + sl) * GOM_TPX + threadIdx.x;
+            te[u] = seg_Tend[o];
+            ll[u] = seg_last[o];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) cs[u][ch] = seg_C[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t sl = s0 + u;
+            if (sl < nseg) {
+                if (going) {
+                    if (te[u] == 0.f) {  // the pixel had stopped before this segment
+                        going = false;
+                        s_stop = (int)sl - 1;
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) acc[ch] += cs[u][ch];
+                        last = ll[u] ? ll[u] : last;
+                        T = fabsf(te[u]);
+                        if (te[u] < 0.f) {  // stop rule fired inside this segment
+                            going = false;
+                            s_stop = (int)sl;
+                        }
+                    }
                 }
+                // checkpoint for the backward: T behind the segment (0 once the pixel is finished)
+                seg_Tend[(size_t)(sb + sl) * GOM_TPX + threadIdx.x] = (going || (int)sl <= s_stop) ? T : 0.f;
             }
         }
-        seg_Tend[o] = going || (int)sl <= s_stop ? T : 0.f;  // checkpoint for the backward: T behind the segment
     }
     // colour still to come behind each segment (small terms first: accurate suffix sums)
     {
         float S[C];
 #pragma unroll
         for (int ch = 0; ch < C; ch++) S[ch] = 0.f;
-        for (int sl = (int)nseg - 1; sl >= 0; sl--) {
+        for (int s1 = (int)nseg; s1 > 0; s1 -= 8) {
+            float cs[8][C];
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                const size_t oc = ((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x;
-                seg_Sbehind[oc] = S[ch];
-                if (sl <= s_stop) S[ch] += seg_C[oc];
+            for (int u = 0; u < 8; u++) {
+                const int sl = max(s1 - 1 - u, 0);
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) cs[u][ch] = seg_C[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int sl = s1 - 1 - u;
+                if (sl >= 0) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) {
+                        seg_Sbehind[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x] = S[ch];
+                        if (sl <= s_stop) S[ch] += cs[u][ch];
+                    }
+                }
             }
         }
     }

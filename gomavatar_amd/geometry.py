@@ -134,7 +134,7 @@ class _FaceGaussians(torch.autograd.Function):
         xyz = torch.empty((F, 3), dtype=torch.float32, device=v.device)
         cov6 = torch.empty((F, 6), dtype=torch.float32, device=v.device)
         _lib.check(lib.gom_face_forward(N, F, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), float(sigma), _lib.ptr(xyz),
-                                        _lib.ptr(cov6), _lib.stream_ptr()))
+                                        _lib.ptr(cov6), 0, 0, _lib.stream_ptr()))
         ctx.save_for_backward(v, w, s)
         ctx.topo, ctx.sigma = topo, float(sigma)
         return xyz, cov6
@@ -151,7 +151,7 @@ class _FaceGaussians(torch.autograd.Function):
         g_xyz, g_cov6 = g_xyz.contiguous(), g_cov6.contiguous()
         _lib.check(lib.gom_face_backward(N, F, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), ctx.sigma,
                                          _lib.ptr(g_xyz), _lib.ptr(g_cov6), _lib.ptr(d_corner),
-                                         _lib.ptr(d_so3), _lib.ptr(d_scale), _lib.stream_ptr()))
+                                         _lib.ptr(d_so3), _lib.ptr(d_scale), 0, 0, _lib.stream_ptr()))
         # CSR gather of the corner gradients onto vertices (deterministic)
         d_verts = _csr_gather(d_corner.reshape(-1, 3), topo, N)
         return d_verts, d_so3, d_scale, None, None
@@ -200,7 +200,7 @@ class _PosedFaceGaussians(torch.autograd.Function):
         _lib.check(lib.gom_fk_forward(_lib.ptr(cnl), _lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(RT), _lib.ptr(save), st))
         _lib.check(lib.gom_lbs_forward(N, N_JOINTS, _lib.ptr(v), _lib.ptr(lbs_weights), _lib.ptr(RT), _lib.ptr(v_obs), st))
         _lib.check(lib.gom_face_forward(N, F, _lib.ptr(v_obs), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), float(sigma),
-                                        _lib.ptr(xyz), _lib.ptr(cov6), st))
+                                        _lib.ptr(xyz), _lib.ptr(cov6), 0, 0, st))
         ctx.save_for_backward(v, w, s, Rs, Ts, RT, save, v_obs, lbs_weights)
         ctx.topo, ctx.sigma = topo, float(sigma)
         ctx.shapes = (dst_Rs.shape, dst_Ts.shape)
@@ -224,7 +224,7 @@ class _PosedFaceGaussians(torch.autograd.Function):
         g_xyz, g_cov6 = g_xyz.contiguous(), g_cov6.contiguous()
         _lib.check(lib.gom_face_backward(N, F, _lib.ptr(v_obs), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), ctx.sigma,
                                          _lib.ptr(g_xyz), _lib.ptr(g_cov6), _lib.ptr(d_corner),
-                                         _lib.ptr(d_so3), _lib.ptr(d_scale), st))
+                                         _lib.ptr(d_so3), _lib.ptr(d_scale), 0, 0, st))
         need_pose = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         d_v = torch.empty_like(v)
         dRT = torch.zeros_like(RT) if need_pose else None

@@ -7,7 +7,7 @@ frame-parallel trainer and by smoke().
        -> splat backward -> face backward -> vertex gather + LBS backward
 
 i.e. reference models/model.py:213-250 + models/modules/renderer/gaussian.py:22-100
-+ train.py:53-55,101-111 and the autograd backward of all of it, as 12 kernel
++ train.py:53-55,101-111 and the autograd backward of all of it, as 16 kernel
 launches on one stream.  Gradients land in `self.grads` (vertices (3,N), so3
 (3,F), scale (3,F), appearance (3,F)) and are bitwise reproducible.
 """
@@ -93,8 +93,8 @@ class RenderStep:
         v, so3, scale, app = params["vertices"], params["so3"], params["scale"], params["appearance"]
         chk(lib.gom_fk_forward(P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"]), P(self.RT), P(self.fk_save), st))
         chk(lib.gom_lbs_forward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.v_obs), st))
-        chk(lib.gom_face_forward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.xyz), P(self.cov6), st))
-        self.feat[:, :3].copy_(app.t())  # (3,F) parameter -> (F,3) feature rows
+        chk(lib.gom_face_forward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.xyz), P(self.cov6),
+                                 P(app), P(self.feat), st))  # also packs (3,F) colours into (F,4) feature rows
         cam = ctypes.byref(self.cam)
         chk(lib.gom_raster_forward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
                                    P(self.image), P(self.radii), 0, st))
@@ -105,10 +105,10 @@ class RenderStep:
         chk(lib.gom_raster_backward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
                                     P(self.d_image), P(self.d_xyz), P(self.d_cov6), P(self.d_feat), P(self.d_opacity), 0, 0, st))
         chk(lib.gom_face_backward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.d_xyz), P(self.d_cov6),
-                                  P(self.d_corner), P(self.grads["so3"]), P(self.grads["scale"]), st))
+                                  P(self.d_corner), P(self.grads["so3"]), P(self.grads["scale"]), P(self.d_feat),
+                                  P(self.grads["appearance"]), st))
         chk(lib.gom_vertex_backward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.topo.csr_off), P(self.topo.csr_idx),
                                     P(self.d_corner), 0, 0, P(self.grads["vertices"]), 0, st))
-        self.grads["appearance"].copy_(self.d_feat[:, :3].t())
 
     def losses(self):
         """(L_rgb, L_mask) of the last frame as 0-d device tensors."""

@@ -134,13 +134,15 @@ int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const 
 
 /* ---- per-face Gaussians -----------------------------------------------------
  * verts [3][N], faces [F][3] int32, so3 [3][F], scale [3][F], sigma ->
- * xyz [F][3], cov6 [F][6]. */
+ * xyz [F][3], cov6 [F][6].  Optional (both or neither): appearance [3][F] ->
+ * feat4 [F][4] = (r, g, b, 1), the rasterizer's colour rows (gaussian.py:49). */
 int gom_face_forward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
-                     float sigma, float *xyz, float *cov6, void *stream);
-/* d_xyz [F][3], d_cov6 [F][6] -> d_corner [F][3][3] (per face corner, xyz), d_so3 [3][F], d_scale [3][F] */
+                     float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream);
+/* d_xyz [F][3], d_cov6 [F][6] -> d_corner [F][3][3] (per face corner, xyz), d_so3 [3][F], d_scale [3][F].
+ * Optional (both or neither): d_feat4 [F][4] -> d_appearance [3][F]. */
 int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                       float sigma, const float *d_xyz, const float *d_cov6,
-                      float *d_corner, float *d_so3, float *d_scale, void *stream);
+                      float *d_corner, float *d_so3, float *d_scale, const float *d_feat4, float *d_appearance, void *stream);
 /* Gathers per-corner gradients onto vertices through the CSR vertex->corner
  * adjacency (csr_off [N+1], csr_idx [3F] = face*3+corner; no atomics), adds
  * d_verts_extra [3][N] (may be NULL), and applies the LBS backward:

@@ -22,19 +22,11 @@ torch.cuda.synchronize()
 print("kernel ms", step.state.kernel_times_ms())
 lib = _lib.load()
 if hasattr(lib, "gom_debug_fetch"):
-    n = 8192 * 12
+    n = 8192 * 4
     buf = (ctypes.c_ulonglong * n)()
     lib.gom_debug_fetch(buf, n)
-    allb = np.frombuffer(buf, dtype=np.uint64)
-    a = allb[:1024 * 8].reshape(1024, 4, 2)
-    loadc = allb[8192 * 8:8192 * 8 + 4096].reshape(1024, 4).astype(np.int64) if False else allb[8192 * 4 * 2:8192 * 4 * 2 + 4096].reshape(1024, 4).astype(np.int64)
-    sort_c = (a[..., 0] >> np.uint64(32)).astype(np.int64); rend_c = (a[..., 0] & np.uint64(0xffffffff)).astype(np.int64)
-    batches = (a[..., 1] >> np.uint64(32)).astype(np.int64); surv = (a[..., 1] & np.uint64(0xffffffff)).astype(np.int64)
-    tot = sort_c + rend_c
-    order = np.argsort(-tot.max(1))[:12]
-    print("tile  sort_cyc  render_cyc(max wave)  batches  survivors  cyc/surv")
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4)[:1024].astype(np.int64)
+    order = np.argsort(-(a[:, 0] + a[:, 1] + a[:, 2]))[:10]
+    print("tile  n  load_cyc sort_cyc write_cyc")
     for t in order:
-        wv = int(np.argmax(tot[t]))
-        print(t, sort_c[t, wv], rend_c[t, wv], batches[t, wv], surv[t, wv], round(rend_c[t, wv] / max(1, surv[t, wv]), 1), "load_cyc", loadc[t, wv], "per batch", loadc[t, wv] // max(1, batches[t, wv]))
-    act = surv.sum(1) > 0
-    print("sum render cycles over waves", rend_c[act].sum(), "sum sort (per tile)", sort_c[act].max(1).sum(), "total survivors", surv.sum(), "batches", batches.sum())
+        print(t, a[t, 3], a[t, 0], a[t, 1], a[t, 2])
