@@ -103,14 +103,14 @@ def main():
         return dict(vertices=torch.from_numpy(body["canonical_vertex"]).T.contiguous().to(dev), so3=torch.from_numpy(gp["so3"]).to(dev),
                     scale=torch.from_numpy(gp["scale"]).to(dev), appearance=torch.from_numpy(gp["appearance"]).to(dev))
 
-    # flat fp32 gradient buffer = the all-reduce payload; the hot path's gradients are views into it
+    # flat fp32 gradient buffer = the all-reduce payload; the hot path's gradients are views into it.
+    # Padded to the reference model's full parameter count so the collective moves what a real step moves.
+    from gomavatar_amd.parallel import FrameParallel, shapes_for_model
     n_own = 3 * N + 9 * F
-    flat = torch.zeros(max(n_own, MODEL_PARAMS_M if args.subdiv == 1 else n_own), dtype=torch.float32, device=dev)
-    off = 0
-    for k, shape in (("vertices", (3, N)), ("so3", (3, F)), ("scale", (3, F)), ("appearance", (3, F))):
-        n = shape[0] * shape[1]
-        step.grads[k] = flat[off:off + n].view(shape)
-        off += n
+    fp = FrameParallel(shapes_for_model(N, F), dev, pad_to=MODEL_PARAMS_M if args.subdiv == 1 else n_own)
+    flat = fp.grads.flat
+    for k in ("vertices", "so3", "scale", "appearance"):
+        step.grads[k] = fp.grads[k]
     params = dev_params(1)
     target_params = dev_params(2)
     frames = []
@@ -134,8 +134,7 @@ def main():
         d = frames[i % len(frames)]
         step.cam = d["cam"]
         step.forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
-        if world > 1:
-            dist.all_reduce(flat)
+        fp.all_reduce_grads()  # no-op at world size 1
 
     for i in range(args.warmup):
         run_step(i)
