@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
+    ap.add_argument("--inflight", type=int, default=8,
+                    help="independent frames in flight per GPU, each on its own HIP stream with its own scratch "
+                         "(a frame-parallel batch on one GPU); 1 = strictly one frame after the other")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the 17 kernels of a frame one by one instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     return ap.parse_args()
@@ -130,12 +134,25 @@ def main():
         frames.append(d)
     torch.cuda.synchronize()
 
+    # frames in flight: slot k owns a stream, a RenderStep (scratch + intermediates) and a gradient buffer
+    S = max(1, args.inflight)
+    slots = [dict(step=step, fp=fp, stream=torch.cuda.Stream(device=dev))]  # (the legacy NULL stream cannot be graph-captured)
+    for k in range(1, S):
+        st_k = RenderStep(faces, N, (img, img), w25, device=dev)
+        fp_k = FrameParallel(shapes_for_model(N, F), dev, pad_to=flat.numel())
+        for name in ("vertices", "so3", "scale", "appearance"):
+            st_k.grads[name] = fp_k.grads[name]
+        slots.append(dict(step=st_k, fp=fp_k, stream=torch.cuda.Stream(device=dev)))
+
     def run_step(i):
         d = frames[i % len(frames)]
-        step.cam = d["cam"]
-        step.forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
-        fp.all_reduce_grads()  # no-op at world size 1
+        sl = slots[i % S]
+        with torch.cuda.stream(sl["stream"]):
+            sl["step"].cam = d["cam"]
+            sl["step"].forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"], graph=not args.no_graph)
+            sl["fp"].all_reduce_grads()  # no-op at world size 1
 
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         run_step(i)
     torch.cuda.synchronize()
@@ -195,6 +212,7 @@ def main():
         "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, 1 frame per GPU per step"
                                + (", + RCCL all-reduce of the flat grad buffer" if world > 1 else ""),
                    "gaussians": F, "image": [img, img], "frames_per_step": world, "parallelism": f"frame-dp{world}",
+                   "frames_in_flight_per_gpu": S,
                    "allreduce_floats": int(flat.numel()) if world > 1 else 0},
         "roofline": roofline,
     }

@@ -30,6 +30,19 @@ class GomCamera(ctypes.Structure):
                 ("view", c_float * 16), ("proj", c_float * 16), ("bg", c_float * 4)]
 
 
+class GomFrame(ctypes.Structure):
+    _fields_ = ([("N", c_int32), ("F", c_int32), ("H", c_int32), ("W", c_int32), ("sigma", c_float), ("c_rgb", c_float),
+                 ("c_mask", c_float), ("cam", GomCamera)] +
+                [(n, c_void_p) for n in (
+                    "faces", "csr_off", "csr_idx", "lbs_weights", "vertices", "so3", "scale", "appearance", "cnl_gtfms", "dst_Rs",
+                    "dst_Ts", "gt_rgb", "gt_mask", "bgcolor", "image", "loss_partials", "g_vertices", "g_so3", "g_scale",
+                    "g_appearance", "work_RT", "work_fk", "work_vobs", "work_xyz", "work_cov6", "work_feat", "work_opacity",
+                    "work_dimage", "work_dxyz", "work_dcov6", "work_dfeat", "work_dopacity", "work_dcorner", "work_radii")])
+
+
+GOM_FRAME_FORWARD_ONLY = 1
+GOM_FRAME_USE_GRAPH = 2
+
 # name -> (restype, argtypes); every symbol include/gom_hip.h declares
 SIGNATURES = {
     "gom_last_error": (c_char_p, []),
@@ -52,6 +65,7 @@ SIGNATURES = {
     "gom_face_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_vertex_backward": (c_int, [c_int, c_int] + [c_void_p] * 11),
+    "gom_frame_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_uint32, c_void_p]),
     "gom_l1_loss": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -47,12 +47,16 @@ extern "C" GomState *gom_state_create(void) {
 extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
-                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_tile, s->seg_T,
-                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->final_T, s->n_contrib, s->scratch_img, s->status};
+                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &g : s->graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
     delete s;
 }
 
@@ -111,6 +115,7 @@ static int ensure_capacity(GomState *s, int P, int H, int W) {
     if (want > 0xffffffffLL) want = 0xffffffffLL;
     if (want != s->capPairs && (want > s->capPairs || s->wantPairs > 0)) {
         if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) || grow(&s->pair_pos, (size_t)want) ||
+            grow(&s->ent_geo, (size_t)want * 3) || grow(&s->ent_col, (size_t)want * 4) ||
             grow(&s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
             return -2;
         s->capPairs = want;
@@ -120,8 +125,9 @@ static int ensure_capacity(GomState *s, int P, int H, int W) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow(&s->seg_tile, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
-            grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX))
+        if (grow(&s->seg_desc, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
+            grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX) || grow(&s->sub_T, n * 4 * GOM_TPX) ||
+            grow(&s->sub_C, n * 16 * GOM_TPX) || grow(&s->sub_Tend, n * 4 * GOM_TPX))
             return -2;
         s->capSegs = wantSegs;
     }
@@ -231,5 +237,76 @@ extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_byte
     }
     if (dst_bytes < bytes) { gom_set_error("export buffer too small (%lld < %lld)", (long long)dst_bytes, (long long)bytes); return -1; }
     if (bytes > 0) GOM_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+static int frame_enqueue(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
+
+extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
+    if (!s || !f) { gom_set_error("gom_frame_forward_backward: null argument"); return -1; }
+    if (f->cam.H != f->H || f->cam.W != f->W) { gom_set_error("gom_frame_forward_backward: camera/image size mismatch"); return -1; }
+    // the legacy NULL stream cannot be captured; profiling wants individually timed launches
+    if (!(flags & GOM_FRAME_USE_GRAPH) || s->profile || stream == nullptr) return frame_enqueue(s, f, flags & ~GOM_FRAME_USE_GRAPH, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t kflags = flags & ~GOM_FRAME_USE_GRAPH;
+    s->graphClock++;
+    for (auto &g : s->graphs) {
+        if (g.flags == kflags && memcmp(&g.key, f, sizeof(GomFrame)) == 0) {
+            g.last_use = s->graphClock;
+            GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
+            s->P = f->F; s->H = f->H; s->W = f->W; s->C = 4; s->haveForward = true;
+            return 0;
+        }
+    }
+    // first use of this frame descriptor: allocate outside the capture, then record the launch sequence
+    if (int rc = ensure_capacity(s, f->F, f->H, f->W)) return rc;
+    GomGraphEntry e;
+    memcpy(&e.key, f, sizeof(GomFrame));
+    e.flags = kflags;
+    e.last_use = s->graphClock;
+    GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = frame_enqueue(s, f, kflags, stream);
+    hipError_t ce = hipStreamEndCapture(st, &e.graph);
+    if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return rc; }
+    if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return -2; }
+    GOM_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+    if (s->graphs.size() >= 64) {  // evict the least recently used capture
+        size_t victim = 0;
+        for (size_t i = 1; i < s->graphs.size(); i++)
+            if (s->graphs[i].last_use < s->graphs[victim].last_use) victim = i;
+        (void)hipGraphExecDestroy(s->graphs[victim].exec);
+        (void)hipGraphDestroy(s->graphs[victim].graph);
+        s->graphs[victim] = e;
+    } else {
+        s->graphs.push_back(e);
+    }
+    GOM_HIP_CHECK(hipGraphLaunch(e.exec, st));
+    return 0;
+}
+
+static int frame_enqueue(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
+    const int N = f->N, F = f->F, H = f->H, W = f->W, J = 24;
+    int rc;
+    if ((rc = gom_fk_forward(f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
+    if ((rc = gom_lbs_forward(N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
+    if ((rc = gom_face_forward(N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
+                               f->work_feat, stream)))
+        return rc;
+    if ((rc = gom_raster_forward(s, &f->cam, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image, f->work_radii, 0,
+                                 stream)))
+        return rc;
+    if ((rc = gom_l1_loss(H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage, nullptr,
+                          f->loss_partials, stream)))
+        return rc;
+    if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
+    if ((rc = gom_raster_backward(s, &f->cam, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage, f->work_dxyz,
+                                  f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream)))
+        return rc;
+    if ((rc = gom_face_backward(N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_dxyz, f->work_dcov6, f->work_dcorner,
+                                f->g_so3, f->g_scale, f->work_dfeat, f->g_appearance, stream)))
+        return rc;
+    if ((rc = gom_vertex_backward(N, J, f->vertices, f->lbs_weights, f->work_RT, f->csr_off, f->csr_idx, f->work_dcorner, nullptr, nullptr,
+                                  f->g_vertices, nullptr, stream)))
+        return rc;
     return 0;
 }

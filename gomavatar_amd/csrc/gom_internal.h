@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <vector>
 
 #include "gom_hip.h"
 
@@ -13,13 +14,23 @@
 #define GOM_SEG 128                 // tile-list entries per segment (the unit of parallel compositing), <= 256
 #endif
 #define GOM_TPX 256                 // pixels per tile = threads of the per-tile / per-segment workgroups
+#ifndef GOM_SEG_GRID
 #define GOM_SEG_GRID 1024           // workgroups launched for the segment kernels (grid-stride over segments)
+#endif
 
 struct GomDevStatus {
     uint32_t num_pairs;
     uint32_t overflow;
     uint32_t num_segs;
     uint32_t pair_cursor;   // allocator for the per-gaussian ranges of pair_pos (reset by the scan kernel)
+};
+
+struct GomGraphEntry {
+    GomFrame key;
+    uint32_t flags;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    uint64_t last_use;
 };
 
 struct GomState {
@@ -54,12 +65,18 @@ struct GomState {
     float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE]
     // per segment (x 256 pixels of the tile, quadrant-major)
     int64_t capSegs = 0;
-    uint32_t *seg_tile = nullptr;     // [capSegs]
+    uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
+    float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
+    float *ent_col = nullptr;         // [capPairs][4] list-ordered colours
     float *seg_T = nullptr;           // [capSegs][256]     product of (1-alpha) over the segment
     float *seg_C = nullptr;           // [capSegs][4][256]  colour the segment adds to the pixel
     uint32_t *seg_last = nullptr;     // [capSegs][256]     1+list index of the last contributing entry (0: none)
     float *seg_Tend = nullptr;        // [capSegs][256]     transmittance after the segment (combine pass)
     float *seg_Sbehind = nullptr;     // [capSegs][4][256]  colour still to come behind the segment
+    // per 32-entry sub-range of a segment (4 per segment) x 256 pixels
+    float *sub_T = nullptr;           // [capSegs][4][256]     product of (1-alpha) over the sub-range
+    float *sub_C = nullptr;           // [capSegs][4][4][256]  colour the sub-range really added to the pixel
+    float *sub_Tend = nullptr;        // [capSegs][4][256]     transmittance behind the sub-range
     // per pixel
     float *final_T = nullptr;
     uint32_t *n_contrib = nullptr;
@@ -69,6 +86,9 @@ struct GomState {
     bool profile = false;
     hipEvent_t ev[2 * GOM_NUM_KERNELS] = {};
     bool evValid[GOM_NUM_KERNELS] = {};
+    // captured whole-frame launch sequences (GOM_FRAME_USE_GRAPH), keyed by the exact frame descriptor
+    std::vector<GomGraphEntry> graphs;
+    uint64_t graphClock = 0;
 };
 
 struct GomKernelTimer {

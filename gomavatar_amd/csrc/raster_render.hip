@@ -310,9 +310,10 @@ __device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask
 
 __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
-                                               uint32_t *__restrict__ seg_tile, const ushort4 *__restrict__ rect,
+                                               uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
-                                               const GomDevStatus *__restrict__ status, uint32_t sort_cap) {
+                                               const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
+                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t sort_cap) {
     __shared__ uint64_t s_x[GOM_SORT_CAP_MAX];
     if (status->overflow) return;
     const int tile = blockIdx.x;
@@ -320,7 +321,9 @@ __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restric
     const uint32_t n = tile_base[tile + 1] - base;
     if (n == 0) return;
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
-    for (uint32_t i = threadIdx.x; i < nseg; i += 1024) seg_tile[sb + i] = (uint32_t)tile;
+    // one 16-byte descriptor per segment: the segment kernels start from a single load
+    for (uint32_t i = threadIdx.x; i < nseg; i += 1024)
+        seg_desc[sb + i] = make_uint4((uint32_t)tile, base + i * GOM_SEG, min((uint32_t)GOM_SEG, n - i * GOM_SEG), i);
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t t = threadIdx.x;
     if (n <= sort_cap) {
@@ -363,6 +366,11 @@ __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restric
                 const ushort4 rc = rect[g];
                 const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
                 pair_pos[pair_off[g] + k] = base + i;
+                // geometry of the entry in LIST order: the compositing kernels read it contiguously
+                const float2 c = xy[g];
+                const float4 co = conic_opacity[g];
+                float2 *dst = ent_geo + 3 * (size_t)(base + i);
+                dst[0] = c; dst[1] = make_float2(co.x, co.y); dst[2] = make_float2(co.z, co.w);
             }
         }
 #ifdef GOM_INSTRUMENT
@@ -378,90 +386,121 @@ __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restric
             const ushort4 rc = rect[g];
             const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
             pair_pos[pair_off[g] + k] = base + i;
+            const float2 c = xy[g];
+            const float4 co = conic_opacity[g];
+            float2 *dst = ent_geo + 3 * (size_t)(base + i);
+            dst[0] = c; dst[1] = make_float2(co.x, co.y); dst[2] = make_float2(co.z, co.w);
         }
     }
 }
 
-// ------------------------------------------------------------- staging -----
-// The 256 entries of a segment, SoA in LDS: x y a b c o col[C].
-template <int C>
-struct SegLds {
-    float v[6 + C][GOM_SEG];
-};
-
-template <int C>
-__device__ __forceinline__ void stage_segment(SegLds<C> &s, uint32_t cnt, const uint32_t *__restrict__ list, const float2 *__restrict__ xy,
-                                              const float4 *__restrict__ conic_opacity, const float *__restrict__ colors) {
-    const uint32_t i = threadIdx.x;
-    if (i < cnt) {
-        const uint32_t g = list[i];
-        const float2 c = xy[g];
-        const float4 co = conic_opacity[g];
-        s.v[0][i] = c.x; s.v[1][i] = c.y; s.v[2][i] = co.x; s.v[3][i] = co.y; s.v[4][i] = co.z; s.v[5][i] = co.w;
-        if (C == 4) {
-            const float4 cl = *reinterpret_cast<const float4 *>(colors + (size_t)g * 4);
-            s.v[6][i] = cl.x; s.v[7][i] = cl.y; s.v[8][i] = cl.z; s.v[6 + C - 1][i] = cl.w;
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) s.v[6 + ch][i] = colors[(size_t)g * C + ch];
-        }
-    }
-}
-
-// One lane's view of "its" entry of the current 64-batch.
+// ------------------------------------------------------------- entries -----
+// One lane's view of "its" entry of the wave's 32-entry sub-range.
 template <int C>
 struct EntryRegs {
-    float x, y, a, b, c, o, col[C];
+    float x, y, a, b, c, o, col[C > 0 ? C : 1];
     bool keep;
 };
 
+// The unit of work is one wave = (segment, quadrant q of 8x8 pixels, sub-range j of GOM_SUB = 32 list entries).
+// A single wave issues at most one VALU instruction every ~5 cycles on gfx950 (measured,
+// scripts/ubench/dpp_bench.hip) and most of a wave's life here is load latency, so the lists are cut into many
+// short independent pieces that the CU interleaves 8 per SIMD.  Workgroups are 4 waves: the four sub-ranges of a
+// (segment, quadrant) in the forward (they fold their results in LDS), the four quadrants of a (segment,
+// sub-range) in the backward (they sum their per-entry reductions in LDS).
+#define GOM_SUB 32
+#define GOM_NSUB (GOM_SEG / GOM_SUB)
+static_assert(GOM_SEG == 128 && GOM_NSUB == 4, "the segment kernels are written for 4 sub-ranges of 32 entries");
+
+// The <=32 entries of this wave's sub-range, read straight from the list-ordered records the sort left behind
+// (contiguous 24-byte geometry + 16-byte colour rows: coalesced, no LDS staging, no barrier): lanes 0..31 load
+// one entry each and test it against the wave's 8x8 rectangle.
 template <int C>
-__device__ __forceinline__ EntryRegs<C> fetch_entry(const SegLds<C> &s, uint32_t e, uint32_t cnt, float qx0, float qy0, float qx1, float qy1) {
+__device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col, uint32_t start,
+                                                 uint32_t cnt, int sub, int lane, float qx0, float qy0, float qx1, float qy1) {
     EntryRegs<C> r;
-    const uint32_t ee = e < cnt ? e : 0;
-    r.x = s.v[0][ee]; r.y = s.v[1][ee]; r.a = s.v[2][ee]; r.b = s.v[3][ee]; r.c = s.v[4][ee]; r.o = s.v[5][ee];
+    const uint32_t e = (uint32_t)sub * GOM_SUB + (uint32_t)lane;
+    const bool valid = lane < GOM_SUB && e < cnt;
+    r.x = r.y = r.a = r.b = r.c = r.o = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) r.col[ch] = s.v[6 + ch][ee];
-    r.keep = (e < cnt) && !cull_entry(r.x, r.y, r.a, r.b, r.c, r.o, qx0, qy0, qx1, qy1);
+    for (int ch = 0; ch < (C > 0 ? C : 1); ch++) r.col[ch] = 0.f;
+    if (valid) {
+        const float2 *g = ent_geo + 3 * (size_t)(start + e);
+        const float2 g0 = g[0], g1 = g[1], g2 = g[2];
+        r.x = g0.x; r.y = g0.y; r.a = g1.x; r.b = g1.y; r.c = g2.x; r.o = g2.y;
+        if (C > 0) {
+            const float4 cl = *reinterpret_cast<const float4 *>(ent_col + 4 * (size_t)(start + e));
+            r.col[0] = cl.x;
+            if (C > 1) r.col[1 % (C > 0 ? C : 1)] = cl.y;
+            if (C > 2) r.col[2 % (C > 0 ? C : 1)] = cl.z;
+            if (C > 3) r.col[3 % (C > 0 ? C : 1)] = cl.w;
+        }
+    }
+    r.keep = valid && !cull_entry(r.x, r.y, r.a, r.b, r.c, r.o, qx0, qy0, qx1, qy1);
     return r;
 }
 
+// colours of the list entries in LIST order (D x 4 floats); written by the T pre-pass when it runs, by this
+// kernel when a colour pass re-uses an existing binning
+template <int C>
+__global__ void __launch_bounds__(256) k_gather_colors(const uint32_t *__restrict__ point_list, const float *__restrict__ colors,
+                                                       float *__restrict__ ent_col, const GomDevStatus *__restrict__ status) {
+    if (status->overflow) return;
+    const uint32_t D = status->num_pairs;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D; i += gridDim.x * 256) {
+        const uint32_t g = point_list[i];
+        float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+        cl.x = colors[(size_t)g * C]; cl.y = colors[(size_t)g * C + 1]; cl.z = colors[(size_t)g * C + 2];
+        if (C == 4) cl.w = colors[(size_t)g * C + 3];
+        *reinterpret_cast<float4 *>(ent_col + 4 * (size_t)i) = cl;
+    }
+}
+
 // ------------------------------------------------- forward, pass A (T only) -
-// prod(1 - alpha) of every segment for every pixel of its tile, from alpha alone
-// (no colours, no stop rule).  Lets every later pass know the transmittance at
-// which each segment starts without walking the list serially.
-__global__ void __launch_bounds__(256) k_seg_T(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
-                                               const uint32_t *__restrict__ seg_tile, const uint32_t *__restrict__ point_list,
-                                               const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                               float *__restrict__ seg_T, const GomDevStatus *__restrict__ status) {
-    __shared__ float s[6][GOM_SEG];
+// prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
+// alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
+// starts without walking the list serially.
+template <int C>
+__global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+                                                const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
+                                                float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
+                                                const GomDevStatus *__restrict__ status) {
+    __shared__ float s_P[GOM_NSUB][64];
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
-        const uint32_t tile = seg_tile[seg];
-        const uint32_t base = tile_base[tile], n = tile_base[tile + 1] - base;
-        const uint32_t e0 = (seg - seg_base[tile]) * GOM_SEG;
-        const uint32_t cnt = min((uint32_t)GOM_SEG, n - e0);
-        __syncthreads();
-        if (threadIdx.x < cnt) {
-            const uint32_t g = point_list[base + e0 + threadIdx.x];
-            const float2 c = xy[g];
-            const float4 co = conic_opacity[g];
-            s[0][threadIdx.x] = c.x; s[1][threadIdx.x] = c.y; s[2][threadIdx.x] = co.x;
-            s[3][threadIdx.x] = co.y; s[4][threadIdx.x] = co.z; s[5][threadIdx.x] = co.w;
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
+    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+        const uint32_t seg = task >> 2;
+        const int q = (int)(task & 3);
+        const int pxi = q * 64 + lane;
+#ifdef GOM_INSTRUMENT
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const uint4 d = seg_desc[seg];
+        const uint32_t tile = d.x, start = d.y, cnt = d.z;
         const int tx = tile % gx, ty = tile / gx;
-        const float qx0 = (float)(tx * 16 + (wave & 1) * 8), qy0 = (float)(ty * 16 + (wave >> 1) * 8);
+        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
+        // pass-through: colours into list order for the compositing / backward kernels (nobody waits on it here)
+        if (q == 0 && threadIdx.x < cnt) {
+            const uint32_t g = point_list[start + threadIdx.x];
+            float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
+            cl.x = colors[(size_t)g * C]; cl.y = colors[(size_t)g * C + 1]; cl.z = colors[(size_t)g * C + 2];
+            if (C == 4) cl.w = colors[(size_t)g * C + 3];
+            *reinterpret_cast<float4 *>(ent_col + 4 * (size_t)(start + threadIdx.x)) = cl;
+        }
         float T = 1.f;
-        for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
-            const uint32_t e = b0 + lane, ee = e < cnt ? e : 0;
-            const float ex = s[0][ee], ey = s[1][ee], ea = s[2][ee], eb = s[3][ee], ec = s[4][ee], eo = s[5][ee];
-            const bool keep = e < cnt && !cull_entry(ex, ey, ea, eb, ec, eo, qx0, qy0, qx1, qy1);
-            unsigned long long mask = __ballot(keep);
+        {
+            const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
+            unsigned long long mask = __ballot(r.keep);
+#ifdef GOM_INSTRUMENT
+            const unsigned long long c1 = __builtin_readcyclecounter();
+            const unsigned nsurv = __builtin_popcountll(mask);
+#endif
+#ifdef GOM_EXP_NOCOMPUTE
+            T = r.x * 1e-30f + 1.f; mask = 0;
+#endif
             while (mask) {
                 float al[4];
 #pragma unroll
@@ -469,103 +508,176 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint32_t *__restric
                     const bool kv = mask != 0ull;
                     const int k = kv ? __builtin_ctzll(mask) : 0;
                     mask &= mask - 1;
-                    al[u] = entry_alpha(rl(ex, k), rl(ey, k), rl(ea, k), rl(eb, k), rl(ec, k), kv ? rl(eo, k) : 0.f, pfx, pfy);
+                    al[u] = entry_alpha(rl(r.x, k), rl(r.y, k), rl(r.a, k), rl(r.b, k), rl(r.c, k), kv ? rl(r.o, k) : 0.f, pfx, pfy);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) T = T * (1.f - al[u]);
             }
         }
-        seg_T[(size_t)seg * GOM_TPX + threadIdx.x] = T;
+        sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
+#ifndef GOM_EXP_NOBARRIER
+        __syncthreads();  // previous iteration's readers of s_P are done
+        s_P[sub][lane] = T;
+        __syncthreads();
+        if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((s_P[0][lane] * s_P[1][lane]) * s_P[2][lane]) * s_P[3][lane];
+#ifdef GOM_INSTRUMENT
+        if (threadIdx.x == 0 && seg < 8192) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_dbg[seg * 4] = rt0; g_dbg[seg * 4 + 1] = __builtin_amdgcn_s_memrealtime(); g_dbg[seg * 4 + 2] = ((unsigned long long)xcc << 32) | hwid; g_dbg[seg * 4 + 3] = blockIdx.x;
+        }
+#endif
+#else
+        if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = T;
+#endif
     }
 }
 
 // ---------------------------------------- forward, pass B (exact, per segment)
-// Every (tile, segment) composites its 256 entries with the reference's exact
-// per-pixel rules (skip, stop at T(1-alpha) < 1e-4), starting from the
-// transmittance the pixel has when it reaches the segment (product of the
-// earlier segments' prod(1-alpha)).  Stores the contribution, T after the
-// segment (negated if the stop rule fired inside) and the last contributor.
+// Every wave composites its <=32 entries with the reference's exact per-pixel rules (skip, stop at
+// T(1-alpha) < 1e-4), starting from the transmittance the pixel has when it reaches the sub-range (product of
+// the earlier pieces' prod(1-alpha)).  The four sub-ranges are then folded in LDS: the segment stores its
+// contribution, T after it (negated if the stop rule fired inside) and the last contributor; the per-sub-range
+// pieces are kept as checkpoints for the backward.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_fwd(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
-                                                 const uint32_t *__restrict__ seg_tile, const uint32_t *__restrict__ point_list,
-                                                 const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                                 const float *__restrict__ colors, const float *__restrict__ seg_T, float *__restrict__ seg_C,
-                                                 float *__restrict__ seg_Tend, uint32_t *__restrict__ seg_last,
-                                                 const GomDevStatus *__restrict__ status) {
-    __shared__ SegLds<C> s;
+__global__ void __launch_bounds__(256) k_seg_fwd(int gx, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+                                                  const float *__restrict__ ent_col, const float *__restrict__ seg_T,
+                                                  const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
+                                                  uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
+                                                  const GomDevStatus *__restrict__ status) {
+    __shared__ float s_c[GOM_NSUB][C][64];
+    __shared__ float s_t[GOM_NSUB][64];
+    __shared__ uint32_t s_l[GOM_NSUB][64];
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
-        const uint32_t tile = seg_tile[seg];
-        const uint32_t base = tile_base[tile], n = tile_base[tile + 1] - base;
-        const uint32_t sb = seg_base[tile];
-        const uint32_t e0 = (seg - sb) * GOM_SEG;
-        const uint32_t cnt = min((uint32_t)GOM_SEG, n - e0);
-        // transmittance at the start of this segment; 0 = the pixel has certainly stopped earlier.
-        // (In the 1e-5-wide borderline band the pixel stays alive; the combine pass honours the
-        //  exact stop flag of the earlier segment.)
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
+    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+        const uint32_t seg = task >> 2;
+        const int q = (int)(task & 3);
+        const int pxi = q * 64 + lane;
+        const uint4 d = seg_desc[seg];
+        const uint32_t tile = d.x, start = d.y, cnt = d.z, sb = seg - d.w;
+        const uint32_t e0 = d.w * GOM_SEG;
+        const int tx = tile % gx, ty = tile / gx;
+        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+        const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
+        const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
+        // issued early: the entry loads overlap the transmittance prefix below
+        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
+        // transmittance at the start of this sub-range; 0 = the pixel has certainly stopped earlier.
+        // (In the 1e-5-wide borderline band the pixel stays alive; the fold below / the combine pass honour
+        //  the exact stop flag of the earlier piece.)
         float T = 1.f;
-        for (uint32_t r = sb; r < seg; r++) {
-            const float Tn = T * seg_T[(size_t)r * GOM_TPX + threadIdx.x];
-            T = (Tn >= kStopT * 0.99999f) ? Tn : 0.f;
+        for (uint32_t r0 = sb; r0 < seg; r0 += 8) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = seg_T[(size_t)min(r0 + u, seg - 1) * GOM_TPX + pxi];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (r0 + u < seg) {
+                    const float Tn = T * p[u];
+                    T = (Tn >= kStopT * 0.99999f) ? Tn : 0.f;
+                }
+            }
+        }
+        {
+            float p[GOM_NSUB - 1];
+#pragma unroll
+            for (int u = 0; u < GOM_NSUB - 1; u++) p[u] = sub_T[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi];
+#pragma unroll
+            for (int u = 0; u < GOM_NSUB - 1; u++) {
+                if (u < sub) {
+                    const float Tn = T * p[u];
+                    T = (Tn >= kStopT * 0.99999f) ? Tn : 0.f;
+                }
+            }
         }
         float wl = T > 0.f ? 1.f : 0.f;  // lane still compositing (float mask: no SALU in the chain)
-        const bool any_alive = __syncthreads_or(wl != 0.f ? 1 : 0) != 0;
+        const bool any_alive = __syncthreads_or(wl != 0.f ? 1 : 0) != 0;  // also fences the LDS of the previous segment
+        if (!any_alive) {  // every pixel of the quadrant stopped before this segment
+            if (sub == 0) {
+                const size_t o = (size_t)seg * GOM_TPX + pxi;
+                seg_Tend[o] = 0.f;
+                seg_last[o] = 0;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) seg_C[((size_t)seg * 4 + ch) * GOM_TPX + pxi] = 0.f;
+            }
+            continue;
+        }
         float acc[C];
 #pragma unroll
         for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
         uint32_t last = 0;
-        if (any_alive) {
-            stage_segment<C>(s, cnt, point_list + base + e0, xy, conic_opacity, colors);
-            __syncthreads();
-            if (__ballot(wl != 0.f) != 0ull) {
-                const int tx = tile % gx, ty = tile / gx;
-                const float qx0 = (float)(tx * 16 + (wave & 1) * 8), qy0 = (float)(ty * 16 + (wave >> 1) * 8);
-                const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
-                const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
-                for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
-                    if (__ballot(wl != 0.f) == 0ull) break;
-                    const EntryRegs<C> r = fetch_entry<C>(s, b0 + lane, cnt, qx0, qy0, qx1, qy1);
-                    unsigned long long mask = __ballot(r.keep);
-                    while (mask) {
-                        int kk[4];
-                        float al[4], ecol[4][C];
+        if (__ballot(wl != 0.f) != 0ull) {
+            unsigned long long mask = __ballot(r.keep);
+            while (mask) {
+                int kk[4];
+                float al[4], ecol[4][C];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {  // independent alpha evaluations (ILP)
-                            const bool kv = mask != 0ull;
-                            const int k = kv ? __builtin_ctzll(mask) : 0;
-                            mask &= mask - 1;
-                            kk[u] = k;
-                            const float eo = kv ? rl(r.o, k) : 0.f;  // opacity 0 -> alpha 0 -> "skip"
-                            al[u] = entry_alpha(rl(r.x, k), rl(r.y, k), rl(r.a, k), rl(r.b, k), rl(r.c, k), eo, pfx, pfy);
+                for (int u = 0; u < 4; u++) {  // independent alpha evaluations (ILP)
+                    const bool kv = mask != 0ull;
+                    const int k = kv ? __builtin_ctzll(mask) : 0;
+                    mask &= mask - 1;
+                    kk[u] = k;
+                    const float eo = kv ? rl(r.o, k) : 0.f;  // opacity 0 -> alpha 0 -> "skip"
+                    al[u] = entry_alpha(rl(r.x, k), rl(r.y, k), rl(r.a, k), rl(r.b, k), rl(r.c, k), eo, pfx, pfy);
 #pragma unroll
-                            for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {  // the serial chain: T -> test_T -> select
-                            const float a = al[u] * wl;
-                            const float test_T = T * (1.f - a);
-                            const bool cont = test_T >= kStopT;  // reference: `test_T < 0.0001f -> done`
-                            const float w = cont ? a * T : 0.f;
-#pragma unroll
-                            for (int ch = 0; ch < C; ch++) acc[ch] += ecol[u][ch] * w;
-                            T = cont ? test_T : T;
-                            wl = cont ? wl : 0.f;
-                            last = (w > 0.f) ? (e0 + b0 + (uint32_t)kk[u] + 1u) : last;
-                        }
-                        if (__ballot(wl != 0.f) == 0ull) break;
-                    }
+                    for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
                 }
-            }
-            __syncthreads();  // LDS is restaged by the next segment of this workgroup
-        }
-        const size_t o = (size_t)seg * GOM_TPX + threadIdx.x;
-        // dead on arrival: T = 0.  stopped inside: -T.  still going: +T.
-        seg_Tend[o] = (T > 0.f && wl == 0.f) ? -T : T;
-        seg_last[o] = last;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) seg_C[((size_t)seg * 4 + ch) * GOM_TPX + threadIdx.x] = acc[ch];
+                for (int u = 0; u < 4; u++) {  // the serial chain: T -> test_T -> select
+                    const float a = al[u] * wl;
+                    const float test_T = T * (1.f - a);
+                    const bool cont = test_T >= kStopT;  // reference: `test_T < 0.0001f -> done`
+                    const float w = cont ? a * T : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) acc[ch] += ecol[u][ch] * w;
+                    T = cont ? test_T : T;
+                    wl = cont ? wl : 0.f;
+                    last = (w > 0.f) ? (e0 + (uint32_t)sub * GOM_SUB + (uint32_t)kk[u] + 1u) : last;
+                }
+                if (__ballot(wl != 0.f) == 0ull) break;
+            }
+        }
+        // dead on arrival: T = 0.  stopped inside: -T.  still going: +T.
+        s_t[sub][lane] = (T > 0.f && wl == 0.f) ? -T : T;
+        s_l[sub][lane] = last;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) s_c[sub][ch][lane] = acc[ch];
+        __syncthreads();
+        if (sub == 0) {  // fold the four pieces of this segment for pixel pxi
+            float Tc = 0.f, tot[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) tot[ch] = 0.f;
+            uint32_t lastc = 0;
+            bool going = true, stopped = false, any = false;
+#pragma unroll
+            for (int u = 0; u < GOM_NSUB; u++) {
+                const float te = s_t[u][lane];
+                const bool counts = going && te != 0.f;
+                if (going && te == 0.f) going = false;  // had stopped before this piece
+                if (counts) {
+                    any = true;
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) tot[ch] += s_c[u][ch][lane];
+                    lastc = s_l[u][lane] ? s_l[u][lane] : lastc;
+                    Tc = fabsf(te);
+                    if (te < 0.f) { going = false; stopped = true; }
+                }
+                // checkpoints for the backward: what this piece really added, and T behind it
+                sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++)
+                    sub_C[(((size_t)seg * GOM_NSUB + u) * 4 + ch) * GOM_TPX + pxi] = counts ? s_c[u][ch][lane] : 0.f;
+            }
+            const size_t o = (size_t)seg * GOM_TPX + pxi;
+            seg_Tend[o] = !any ? 0.f : (stopped ? -Tc : Tc);
+            seg_last[o] = lastc;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) seg_C[((size_t)seg * 4 + ch) * GOM_TPX + pxi] = tot[ch];
+        }
     }
 }
 
@@ -684,109 +796,128 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, float
 // ---------------------------------------------------------------- backward -
 template <int C>
 __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, float bg0, float bg1, float bg2, float bg3,
-                                                 const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
-                                                 const uint32_t *__restrict__ seg_tile, const uint32_t *__restrict__ tile_nmax,
-                                                 const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
-                                                 const float4 *__restrict__ conic_opacity, const float *__restrict__ colors,
-                                                 const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                 const float *__restrict__ dL_dpix, const float *__restrict__ seg_Tend,
-                                                 const float *__restrict__ seg_Sbehind, float *__restrict__ partial,
-                                                 const GomDevStatus *__restrict__ status) {
+                                                  const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ tile_nmax,
+                                                  const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
+                                                  const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                  const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
+                                                  const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
+                                                  float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
     constexpr int NV = 6 + C;  // values reduced per entry
-    __shared__ SegLds<C> s;
-    __shared__ float s_acc[4][GOM_SEG][10];
+    __shared__ float s_acc[4][GOM_SUB][10];  // [quadrant][entry of the sub-range][value]
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 quadrants of one (segment, sub-range)
+    const int pxi = q * 64 + lane;
     const size_t HW = (size_t)H * W;
-    for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
-        const uint32_t tile = seg_tile[seg];
-        const uint32_t base = tile_base[tile], n = tile_base[tile + 1] - base;
-        const uint32_t e0 = (seg - seg_base[tile]) * GOM_SEG;
-        const uint32_t cnt = min((uint32_t)GOM_SEG, n - e0);
-        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(base + e0 + threadIdx.x) * GOM_PARTIAL_STRIDE);
-        if (e0 >= tile_nmax[tile]) {  // every pixel of the tile stopped before this segment: all-zero records
-            if (threadIdx.x < cnt) {
+    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+        const uint32_t seg = task >> 2;
+        const int sub = (int)(task & 3);
+        const uint4 d = seg_desc[seg];
+        const uint32_t tile = d.x, start = d.y, cnt = d.z;
+        const uint32_t e0 = d.w * GOM_SEG;
+        if ((uint32_t)sub * GOM_SUB >= cnt) continue;  // no entries in this sub-range
+        const uint32_t scnt = min((uint32_t)GOM_SUB, cnt - (uint32_t)sub * GOM_SUB);
+        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * GOM_SUB + threadIdx.x) * GOM_PARTIAL_STRIDE);
+        if (e0 + (uint32_t)sub * GOM_SUB >= tile_nmax[tile]) {  // every pixel of the tile stopped before this sub-range: all-zero records
+            if (threadIdx.x < scnt) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 rec[0] = z; rec[1] = z; rec[2] = z;
             }
             continue;
         }
-        __syncthreads();
-        stage_segment<C>(s, cnt, point_list + base + e0, xy, conic_opacity, colors);
-        for (int i = threadIdx.x; i < 4 * GOM_SEG * 10; i += 256) (&s_acc[0][0][0])[i] = 0.f;
+        __syncthreads();  // the previous segment's flush is done
+        for (int i = threadIdx.x; i < 4 * GOM_SUB * 10; i += 256) (&s_acc[0][0][0])[i] = 0.f;
         __syncthreads();
 
         const int tx = tile % gx, ty = tile / gx;
-        const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
-        const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+        const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
+        const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
         const bool inside = px < W && py < H;
         const size_t pix = (size_t)py * W + px;
         const float pfx = (float)px, pfy = (float)py;
-        const float qx0 = (float)(tx * 16 + (wave & 1) * 8), qy0 = (float)(ty * 16 + (wave >> 1) * 8);
+        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
-        const float T_final = inside ? final_T[pix] : 0.f;
         const uint32_t my_last = inside ? n_contrib[pix] : 0u;
-        float dpix[C], bg_dot = 0.f;
-        {
-            const float bg[4] = {bg0, bg1, bg2, bg3};
+        const uint32_t wmax = wave_max_u32(my_last);
+        const uint32_t s0 = e0 + (uint32_t)sub * GOM_SUB;  // list index of this wave's first entry
+        if (wmax > s0) {
+            const float T_final = final_T[inside ? pix : 0];
+            float dpix[C], bg_dot = 0.f;
+            {
+                const float bg[4] = {bg0, bg1, bg2, bg3};
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    dpix[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
+                    bg_dot += bg[ch] * dpix[ch];
+                }
+            }
+            // checkpoint: state just behind this sub-range (T there; colour still to come = behind the segment
+            // + the later pieces of this segment, smallest terms first)
+            float T = sub_Tend[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi];
+            float accum_rec[C], last_color[C], last_alpha = 0.f;
+            const float invT = T > 0.f ? 1.f / T : 0.f;
 #pragma unroll
             for (int ch = 0; ch < C; ch++) {
-                dpix[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
-                bg_dot += bg[ch] * dpix[ch];
+                float S = seg_Sbehind[((size_t)seg * 4 + ch) * GOM_TPX + pxi];
+#pragma unroll
+                for (int u = GOM_NSUB - 1; u > 0; u--)
+                    if (u > sub) S += sub_C[(((size_t)seg * GOM_NSUB + u) * 4 + ch) * GOM_TPX + pxi];
+                accum_rec[ch] = S * invT;
+                last_color[ch] = 0.f;
             }
-        }
-        // checkpoint written by the combine pass: state just behind this segment
-        const size_t o = (size_t)seg * GOM_TPX + threadIdx.x;
-        float T = seg_Tend[o];
-        float accum_rec[C], last_color[C], last_alpha = 0.f;
-        const float invT = T > 0.f ? 1.f / T : 0.f;
-#pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-            accum_rec[ch] = seg_Sbehind[((size_t)seg * 4 + ch) * GOM_TPX + threadIdx.x] * invT;
-            last_color[ch] = 0.f;
-        }
-        const uint32_t wmax = wave_max_u32(my_last);
-        if (wmax > e0) {
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
-            for (int b0 = (int)((lim - 1) & ~63u); b0 >= 0; b0 -= 64) {
-                const EntryRegs<C> r = fetch_entry<C>(s, (uint32_t)b0 + lane, lim, qx0, qy0, qx1, qy1);
-                unsigned long long mask = __ballot(r.keep);
-                while (mask) {
-                    const int k = 63 - __builtin_clzll(mask);
-                    mask &= ~(1ull << k);
-                    const uint32_t el = (uint32_t)b0 + (uint32_t)k;  // index inside the segment
-                    const float ex = rl(r.x, k), ey = rl(r.y, k);
-                    const float ea = rl(r.a, k), eb = rl(r.b, k), ec = rl(r.c, k), eo = rl(r.o, k);
-                    float ecol[C];
+            const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1);
+            unsigned long long mask = __ballot(r.keep);
+            // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
+            // T / accum_rec recurrences, then interleaved DPP reductions.
+            while (mask) {
+                int kk[4];
+                bool kv[4];
+                float al[4], G0[4], dxs[4], dys[4], ecol[4][C];
 #pragma unroll
-                    for (int ch = 0; ch < C; ch++) ecol[ch] = rl(r.col[ch], k);
-                    const float dx = ex - pfx, dy = ey - pfy;
+                for (int u = 0; u < 4; u++) {
+                    kv[u] = mask != 0ull;
+                    const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
+                    mask &= ~(1ull << k);  // k = 0 when the mask is already empty: clearing bit 0 of 0 is a no-op
+                    kk[u] = k;
+                    const float eo = kv[u] ? rl(r.o, k) : 0.f;
+                    const float dx = rl(r.x, k) - pfx, dy = rl(r.y, k) - pfy;
+                    const float ea = rl(r.a, k), eb = rl(r.b, k), ec = rl(r.c, k);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
                     const float power = -0.5f * (ea * dx * dx + ec * dy * dy) - eb * dx * dy;
-                    const float G0 = __expf(power);
-                    float a = fminf(kMaxAlpha, eo * G0);
+                    const float g = __expf(power);
+                    float a = fminf(kMaxAlpha, eo * g);
                     a = (power <= 0.f) ? a : 0.f;
                     a = (a >= kMinAlpha) ? a : 0.f;
-                    a = (e0 + el < my_last) ? a : 0.f;  // beyond this pixel's last contributor
-                    if (__ballot(a > 0.f) == 0ull) continue;
+                    a = (s0 + (uint32_t)k < my_last) ? a : 0.f;  // beyond this pixel's last contributor
+                    al[u] = a;
+                    G0[u] = (a > 0.f) ? g : 0.f;
+                    dxs[u] = dx;
+                    dys[u] = dy;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;  // wave-uniform
                     // An entry with a == 0 is replayed as a zero-alpha layer: the recurrences below then
                     // leave T / accum_rec exactly as skipping would (App. A.4), without divergent branches.
-                    const float G = (a > 0.f) ? G0 : 0.f;
-                    const float inv1ma = __frcp_rn(1.f - a);  // v_rcp_f32: 1 ulp, shared by both divisions
+                    const float a = al[u];
+                    const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);  // v_rcp_f32 (1 ulp), shared by both divisions
                     T = T * inv1ma;
                     const float w = a * T;
                     float dL_dalpha = 0.f, v[NV];
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) {
                         accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = ecol[ch];
-                        dL_dalpha += (ecol[ch] - accum_rec[ch]) * dpix[ch];
+                        last_color[ch] = ecol[u][ch];
+                        dL_dalpha += (ecol[u][ch] - accum_rec[ch]) * dpix[ch];
                         v[ch] = w * dpix[ch];
                     }
                     dL_dalpha *= T;
                     last_alpha = a;
                     dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                    const float Q = G * dL_dalpha;
+                    const float Q = G0[u] * dL_dalpha;
+                    const float dx = dxs[u], dy = dys[u];
                     v[C + 0] = Q;
                     v[C + 1] = Q * dx;
                     v[C + 2] = Q * dy;
@@ -795,21 +926,21 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, float bg0
                     v[C + 5] = Q * dy * dy;
                     wave_sum_lane63_n<NV>(v);
                     if (lane == 63) {
-                        float *dst = &s_acc[wave][el][0];
+                        float *dst = &s_acc[q][kk[u]][0];
 #pragma unroll
                         for (int ch = 0; ch < C; ch++) dst[ch] = v[ch];
 #pragma unroll
-                        for (int q = 0; q < 6; q++) dst[4 + q] = v[C + q];
+                        for (int qq = 0; qq < 6; qq++) dst[4 + qq] = v[C + qq];
                     }
                 }
             }
         }
         __syncthreads();
-        if (threadIdx.x < cnt) {  // one 48-byte record per entry, waves summed in a fixed order
+        if (threadIdx.x < scnt) {  // one 48-byte record per entry, quadrants summed in a fixed order
             float rr[10];
 #pragma unroll
-            for (int q = 0; q < 10; q++)
-                rr[q] = ((s_acc[0][threadIdx.x][q] + s_acc[1][threadIdx.x][q]) + s_acc[2][threadIdx.x][q]) + s_acc[3][threadIdx.x][q];
+            for (int qq = 0; qq < 10; qq++)
+                rr[qq] = ((s_acc[0][threadIdx.x][qq] + s_acc[1][threadIdx.x][qq]) + s_acc[2][threadIdx.x][qq]) + s_acc[3][threadIdx.x][qq];
             rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
             rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
             rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
@@ -823,8 +954,8 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     const int n_tiles = s->gx * s->gy;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SORT, st);
-    hipLaunchKernelGGL(k_sort, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_tile,
-                       s->rect, s->pair_off, s->pair_pos, s->status, (uint32_t)s->sortCap);
+    hipLaunchKernelGGL(k_sort, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
+                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, (uint32_t)s->sortCap);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -833,17 +964,26 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
                               hipStream_t st) {
     const int n_tiles = s->gx * s->gy;
     if (n_tiles == 0) return 0;
-    if (!reuse_T) {  // depends on geometry only: shared by every colour pass over the same binning
+    {
         GomKernelTimer timer(s, GOM_K_SEG_T, st);
-        hipLaunchKernelGGL(k_seg_T, dim3(GOM_SEG_GRID), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->seg_tile, s->point_list,
-                           s->xy, s->conic_opacity, s->seg_T, s->status);
+        if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
+            if (C == 3)
+                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->point_list, s->ent_geo, colors,
+                                   s->ent_col, s->seg_T, s->sub_T, s->status);
+            else
+                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->point_list, s->ent_geo, colors,
+                                   s->ent_col, s->seg_T, s->sub_T, s->status);
+        } else {  // only the colours changed: bring them into list order
+            if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
+            else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
+        }
     }
     GOM_LAUNCH_CHECK();
     {
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->seg_tile,     \
-                       s->point_list, s->xy, s->conic_opacity, colors, s->seg_T, s->seg_C, s->seg_Tend, s->seg_last, s->status)
+    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
     }
@@ -863,13 +1003,14 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 
 int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const float *colors, const float *dL_dcolor,
                                hipStream_t st) {
+    (void)colors;  // already in list order (ent_col) from the forward / checkpoint re-creation
     const int n_tiles = s->gx * s->gy;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #define GOM_SB(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID), dim3(256), 0, st, s->H, s->W, s->gx, cam.bg[0], cam.bg[1], cam.bg[2], \
-                       cam.bg[3], s->tile_base, s->seg_base, s->seg_tile, s->tile_nmax, s->point_list, s->xy, s->conic_opacity,   \
-                       colors, s->final_T, s->n_contrib, dL_dcolor, s->seg_Tend, s->seg_Sbehind, s->partial, s->status)
+    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->H, s->W, s->gx, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB
     GOM_LAUNCH_CHECK();

@@ -60,6 +60,7 @@ class RenderStep:
             "vertices": torch.empty((3, N), **f32), "so3": torch.empty((3, F), **f32), "scale": torch.empty((3, F), **f32),
             "appearance": torch.empty((3, F), **f32)}
         self.cam = None
+        self._frame = None
 
     # -- inputs ---------------------------------------------------------------
     def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
@@ -81,34 +82,37 @@ class RenderStep:
         self.cam = _lib.make_camera(h, w, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
 
     # -- one frame --------------------------------------------------------------
+    def _frame_struct(self) -> "_lib.GomFrame":
+        P = _lib.ptr
+        f = _lib.GomFrame()
+        f.N, f.F, f.H, f.W = self.N, self.F, self.H, self.W
+        f.sigma, f.c_rgb, f.c_mask = self.sigma, self.c_rgb, self.c_mask
+        f.faces, f.csr_off, f.csr_idx, f.lbs_weights = P(self.topo.faces), P(self.topo.csr_off), P(self.topo.csr_idx), P(self.lbs_weights)
+        f.image, f.loss_partials = P(self.image), P(self.loss_partials)
+        f.work_RT, f.work_fk, f.work_vobs = P(self.RT), P(self.fk_save), P(self.v_obs)
+        f.work_xyz, f.work_cov6, f.work_feat, f.work_opacity = P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity)
+        f.work_dimage, f.work_dxyz, f.work_dcov6 = P(self.d_image), P(self.d_xyz), P(self.d_cov6)
+        f.work_dfeat, f.work_dopacity, f.work_dcorner, f.work_radii = P(self.d_feat), P(self.d_opacity), P(self.d_corner), P(self.radii)
+        return f
+
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
-                         target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True) -> None:
-        """params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
+                         target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False) -> None:
+        """One native call (`gom_frame_forward_backward`) that enqueues the 17 kernels of the frame.
+        params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
         frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
         target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors."""
-        lib, P = self.lib, _lib.ptr
-        st = _lib.stream_ptr()
-        N, F, H, W = self.N, self.F, self.H, self.W
-        chk = _lib.check
-        v, so3, scale, app = params["vertices"], params["so3"], params["scale"], params["appearance"]
-        chk(lib.gom_fk_forward(P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"]), P(self.RT), P(self.fk_save), st))
-        chk(lib.gom_lbs_forward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.v_obs), st))
-        chk(lib.gom_face_forward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.xyz), P(self.cov6),
-                                 P(app), P(self.feat), st))  # also packs (3,F) colours into (F,4) feature rows
-        cam = ctypes.byref(self.cam)
-        chk(lib.gom_raster_forward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
-                                   P(self.image), P(self.radii), 0, st))
-        chk(lib.gom_l1_loss(H, W, P(self.image), 0, P(target_rgb), P(target_mask), P(bgcolor), self.c_rgb, self.c_mask, 1.0,
-                            P(self.d_image), 0, P(self.loss_partials), st))
-        if not backward:
-            return
-        chk(lib.gom_raster_backward(self.state.handle, cam, F, 4, P(self.xyz), P(self.cov6), P(self.feat), P(self.opacity),
-                                    P(self.d_image), P(self.d_xyz), P(self.d_cov6), P(self.d_feat), P(self.d_opacity), 0, 0, st))
-        chk(lib.gom_face_backward(N, F, P(self.v_obs), P(self.topo.faces), P(so3), P(scale), self.sigma, P(self.d_xyz), P(self.d_cov6),
-                                  P(self.d_corner), P(self.grads["so3"]), P(self.grads["scale"]), P(self.d_feat),
-                                  P(self.grads["appearance"]), st))
-        chk(lib.gom_vertex_backward(N, N_JOINTS, P(v), P(self.lbs_weights), P(self.RT), P(self.topo.csr_off), P(self.topo.csr_idx),
-                                    P(self.d_corner), 0, 0, P(self.grads["vertices"]), 0, st))
+        P = _lib.ptr
+        f = self._frame
+        if f is None:
+            f = self._frame = self._frame_struct()
+        f.cam = self.cam
+        f.vertices, f.so3, f.scale, f.appearance = P(params["vertices"]), P(params["so3"]), P(params["scale"]), P(params["appearance"])
+        f.cnl_gtfms, f.dst_Rs, f.dst_Ts = P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"])
+        f.gt_rgb, f.gt_mask, f.bgcolor = P(target_rgb), P(target_mask), P(bgcolor)
+        g = self.grads
+        f.g_vertices, f.g_so3, f.g_scale, f.g_appearance = P(g["vertices"]), P(g["so3"]), P(g["scale"]), P(g["appearance"])
+        flags = (0 if backward else _lib.GOM_FRAME_FORWARD_ONLY) | (_lib.GOM_FRAME_USE_GRAPH if graph else 0)
+        _lib.check(self.lib.gom_frame_forward_backward(self.state.handle, ctypes.byref(f), flags, _lib.stream_ptr()))
 
     def losses(self):
         """(L_rgb, L_mask) of the last frame as 0-d device tensors."""

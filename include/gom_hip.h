@@ -164,6 +164,42 @@ int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float
                 float c_rgb, float c_mask, float grad_scale,
                 float *dL_dpred, float *dL_dshade, float *loss_partials, void *stream);
 
+/* ---- whole frame ---------------------------------------------------------------
+ * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused
+ * unpack + L1 losses (forward and backward) -> splat backward -> face backward -> vertex gather + LBS backward
+ * (reference models/model.py:213-250, renderer/gaussian.py:22-100, train.py:53-55,101-111 and their autograd
+ * backward).  17 kernel launches enqueued back to back from native code; every pointer is caller-owned device
+ * memory, `work_*` are scratch tensors of the stated sizes. */
+typedef struct GomFrame {
+    int32_t N, F, H, W;                 /* vertices, faces (= Gaussians), image size; 24 joints                  */
+    float sigma, c_rgb, c_mask;         /* Steiner normal thickness; loss coefficients                          */
+    GomCamera cam;
+    /* mesh topology (static until subdivide) */
+    const int32_t *faces;               /* [F][3]                                                               */
+    const int32_t *csr_off, *csr_idx;   /* [N+1], [3F] vertex -> face*3+corner                                  */
+    const float *lbs_weights;           /* [25][N]                                                              */
+    /* parameters (reference layouts) */
+    const float *vertices, *so3, *scale, *appearance;   /* [3][N] [3][F] [3][F] [3][F]                          */
+    /* per-frame inputs */
+    const float *cnl_gtfms, *dst_Rs, *dst_Ts;           /* [24][4][4] [24][3][3] [24][3]                        */
+    const float *gt_rgb, *gt_mask, *bgcolor;            /* [H][W][3] [H][W] [3]                                 */
+    /* outputs */
+    float *image;                       /* [4][H][W] albedo rgb + alpha                                         */
+    float *loss_partials;               /* [GOM_LOSS_BLOCKS][2]                                                 */
+    float *g_vertices, *g_so3, *g_scale, *g_appearance; /* gradients, same layouts as the parameters            */
+    /* scratch */
+    float *work_RT, *work_fk;           /* [24][12], [24][32]                                                   */
+    float *work_vobs;                   /* [3][N] posed vertices (also an output for callers that need it)      */
+    float *work_xyz, *work_cov6, *work_feat, *work_opacity;   /* [F][3] [F][6] [F][4] [F] (opacity preset to 1) */
+    float *work_dimage, *work_dxyz, *work_dcov6, *work_dfeat, *work_dopacity, *work_dcorner; /* [4][H][W] [F][3] [F][6] [F][4] [F] [F][9] */
+    int32_t *work_radii;                /* [F]                                                                  */
+} GomFrame;
+
+#define GOM_FRAME_FORWARD_ONLY 1u
+#define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
+                                       hipGraph on first use and replay it afterwards: one submission instead of 17 */
+int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
