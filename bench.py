@@ -173,26 +173,42 @@ def main():
     assert not overflow, "pair buffer overflow during the benchmark"
     assert all(torch.isfinite(g).all() for g in step.grads.values()), "non-finite gradients"
 
-    # ---------------- per-kernel times (HIP events on the launch stream) ----------------
-    step.state.set_option(_lib.OPT_PROFILE, 1)
-    acc = {}
-    n_prof = 24
-    for i in range(n_prof):
-        d = frames[i % len(frames)]
-        step.cam = d["cam"]
-        step.forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
-        for k, v in step.state.kernel_times_ms().items():
-            acc[k] = acc.get(k, 0.0) + v
-        nd, _ = step.state.poll()
-        acc["D"] = acc.get("D", 0) + nd
-    step.state.set_option(_lib.OPT_PROFILE, 0)
+    # ---------------- per-kernel times: HIP events recorded by the library on each launch stream ----------------
+    # Same loop, same frames in flight as the timed region (profiling brackets every launch with events, so the
+    # frame is enqueued kernel by kernel instead of replayed from its graph).  The rocprofv3 --kernel-trace --stats
+    # summary of this very command (profiles/) must agree with these averages.
+    for sl in slots:
+        sl["step"].state.set_option(_lib.OPT_PROFILE, 1)
+    acc, n_prof = {}, 0
+    rounds = max(4, 48 // S)
+    for r in range(rounds):
+        for k in range(S):
+            run_step(r * S + k)
+        for sl in slots:
+            for kname, v in sl["step"].state.kernel_times_ms().items():
+                acc[kname] = acc.get(kname, 0.0) + v
+            nd, _ = sl["step"].state.poll()
+            acc["D"] = acc.get("D", 0) + nd
+            n_prof += 1
+    for sl in slots:
+        sl["step"].state.set_option(_lib.OPT_PROFILE, 0)
+    torch.cuda.synchronize()
     kt = {k: acc[k] / n_prof for k in _lib.KERNEL_NAMES}
     D_avg = acc["D"] / n_prof
     abytes = algorithmic_bytes(F, D_avg, img * img, 4)
     dom = max(kt, key=kt.get)
     achieved = abytes[dom] / (kt[dom] * 1e-3) / 1e9
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_us": round(kt[dom] * 1e3, 2),
+    # HBM traffic of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, FETCH doubled per
+    # MI355X_MICROARCH.md), recorded by scripts/collect_profiles.sh into profiles/<round>_traffic.json
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tj) and args.subdiv == 1 and img == 512:
+        try:
+            traffic = int(json.load(open(tj)).get("k_" + dom, {}).get("hbm_bytes")) or None
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_us": round(kt[dom] * 1e3, 2),
                 "algorithmic_bytes": int(abytes[dom]),
                 "all_kernels_us": {k: round(v * 1e3, 2) for k, v in kt.items()}, "pairs_D": int(D_avg)}
 

@@ -308,7 +308,7 @@ __device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask
     sort_step_merge<MIRROR>(x, y, lower);
 }
 
-__global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
+__global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
@@ -348,29 +348,64 @@ __global__ void __launch_bounds__(1024) k_sort(int gx, const uint32_t *__restric
             sort_step_regs<3>(x); sort_step_regs<1>(x);
             sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
         }
+#ifdef GOM_INSTRUMENT
+        unsigned long long t_dpp = 0, t_lds = 0, t_reg = 0;
+#define GOM_TIC const unsigned long long tic_ = __builtin_readcyclecounter()
+#define GOM_TOC(acc) acc += __builtin_readcyclecounter() - tic_
+#else
+#define GOM_TIC
+#define GOM_TOC(acc)
+#endif
         for (uint32_t m = 4; m <= logN; m++) {
-            sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, n);
-            for (int q = (int)m - 2; q >= 3; q--) sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, n);
-            if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); }
+            { GOM_TIC; sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, n);
+#ifdef GOM_INSTRUMENT
+              if ((((1u << m) - 1) >> 3) < 64) { GOM_TOC(t_dpp); } else { GOM_TOC(t_lds); }
+#endif
+            }
+            for (int q = (int)m - 2; q >= 3; q--) {
+                GOM_TIC; sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, n);
+#ifdef GOM_INSTRUMENT
+                if (((1u << q) >> 3) < 64) { GOM_TOC(t_dpp); } else { GOM_TOC(t_lds); }
+#endif
+            }
+            { GOM_TIC; if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); } GOM_TOC(t_reg); }
         }
+#ifdef GOM_INSTRUMENT
+        if (t == 0 && tile < 8192) { g_dbg[8192 * 4 + tile * 3] = t_dpp; g_dbg[8192 * 4 + tile * 3 + 1] = t_lds; g_dbg[8192 * 4 + tile * 3 + 2] = t_reg; }
+#endif
 #ifdef GOM_INSTRUMENT
         const unsigned long long d2 = __builtin_readcyclecounter();
 #endif
+        // write-out, 4 entries per trip: their gathers are issued before the first dependent store
+        // (8 at once would push the kernel past 64 VGPRs and halve the workgroups per CU)
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t i = 8 * t + r;
-            if (i < n) {
-                keys[base + i] = x[r];
-                const uint32_t g = (uint32_t)x[r];
-                point_list[base + i] = g;
-                const ushort4 rc = rect[g];
-                const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
-                pair_pos[pair_off[g] + k] = base + i;
-                // geometry of the entry in LIST order: the compositing kernels read it contiguously
-                const float2 c = xy[g];
-                const float4 co = conic_opacity[g];
-                float2 *dst = ent_geo + 3 * (size_t)(base + i);
-                dst[0] = c; dst[1] = make_float2(co.x, co.y); dst[2] = make_float2(co.z, co.w);
+        for (int r0 = 0; r0 < 8; r0 += 4) {
+            ushort4 rc[4];
+            uint32_t po[4];
+            float2 cxy[4];
+            float4 cco[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = 8 * t + r0 + u;
+                const uint32_t g = i < n ? (uint32_t)x[r0 + u] : 0u;
+                rc[u] = rect[g];
+                po[u] = pair_off[g];
+                cxy[u] = xy[g];
+                cco[u] = conic_opacity[g];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = 8 * t + r0 + u;
+                if (i < n) {
+                    const uint32_t g = (uint32_t)x[r0 + u];
+                    keys[base + i] = x[r0 + u];
+                    point_list[base + i] = g;
+                    const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
+                    pair_pos[po[u] + k] = base + i;
+                    // geometry of the entry in LIST order: the compositing kernels read it contiguously
+                    float2 *dst = ent_geo + 3 * (size_t)(base + i);
+                    dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
+                }
             }
         }
 #ifdef GOM_INSTRUMENT
@@ -473,9 +508,6 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__
         const uint32_t seg = task >> 2;
         const int q = (int)(task & 3);
         const int pxi = q * 64 + lane;
-#ifdef GOM_INSTRUMENT
-        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
         const int tx = tile % gx, ty = tile / gx;
@@ -494,10 +526,6 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__
         {
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
             unsigned long long mask = __ballot(r.keep);
-#ifdef GOM_INSTRUMENT
-            const unsigned long long c1 = __builtin_readcyclecounter();
-            const unsigned nsurv = __builtin_popcountll(mask);
-#endif
 #ifdef GOM_EXP_NOCOMPUTE
             T = r.x * 1e-30f + 1.f; mask = 0;
 #endif
@@ -520,15 +548,6 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__
         s_P[sub][lane] = T;
         __syncthreads();
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((s_P[0][lane] * s_P[1][lane]) * s_P[2][lane]) * s_P[3][lane];
-#ifdef GOM_INSTRUMENT
-        if (threadIdx.x == 0 && seg < 8192) {
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            g_dbg[seg * 4] = rt0; g_dbg[seg * 4 + 1] = __builtin_amdgcn_s_memrealtime(); g_dbg[seg * 4 + 2] = ((unsigned long long)xcc << 32) | hwid; g_dbg[seg * 4 + 3] = blockIdx.x;
-        }
-#endif
 #else
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = T;
 #endif

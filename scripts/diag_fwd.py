@@ -22,22 +22,12 @@ torch.cuda.synchronize()
 print("kernel ms", step.state.kernel_times_ms())
 lib = _lib.load()
 if hasattr(lib, "gom_debug_fetch"):
-    step.forward_backward(params, d, gt, gm, bg, backward=False); torch.cuda.synchronize()
-    n = 8192 * 4
+    n = 8192 * 8
     buf = (ctypes.c_ulonglong * n)()
     lib.gom_debug_fetch(buf, n)
-    nseg = min(8192, int(step.state.export(_lib.BUF_STATUS, torch.empty(4, dtype=torch.int32, device="cuda")).cpu().numpy()[2]))
-    a = np.frombuffer(buf, dtype=np.uint64)[: nseg * 4].reshape(nseg, 4)
-    t0 = a[:, 0].astype(np.int64); t1 = a[:, 1].astype(np.int64); base = t0.min()
-    t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0   # us (100 MHz)
-    hw = a[:, 2]; xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xf; hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
-    cu = (hwid >> 8) & 0xf; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
-    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
-    dur = t1 - t0
-    print("k_seg_T blocks", nseg, "span us", t1.max(), "block dur us mean/p50/p90/max", dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), dur.max())
-    print("distinct CUs used", len(np.unique(cuid)), "blocks per CU max", np.bincount(np.unique(cuid, return_inverse=True)[1]).max())
-    for T in (1, 3, 5, 8, 12, 16, 20, 25, 30):
-        print("  t=%2d us: blocks running %d" % (T, int(((t0 <= T) & (t1 > T)).sum())))
-    late = np.argsort(-t1)[:5]
-    print("last finishers (start,end,dur,blockIdx):", [(round(t0[i], 1), round(t1[i], 1), round(dur[i], 1), int(a[i, 3])) for i in late])
-    print("start time pct", np.percentile(t0, [1, 25, 50, 75, 99]))
+    allb = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+    a = allb[: 1024 * 4].reshape(1024, 4); ph = allb[8192 * 4: 8192 * 4 + 1024 * 3].reshape(1024, 3)
+    order = np.argsort(-(a[:, 1]))[:8]
+    print("tile n load sort write | dpp lds reg")
+    for t in order:
+        print(t, a[t, 3], a[t, 0], a[t, 1], a[t, 2], "|", ph[t, 0], ph[t, 1], ph[t, 2])
