@@ -64,7 +64,7 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
     if (!s) { gom_set_error("null state"); return -1; }
     switch (option) {
         case GOM_OPT_SORT_CAP:
-            if (value < 1 || value > GOM_SORT_CAP_MAX) { gom_set_error("sort cap must be in [1, %d]", GOM_SORT_CAP_MAX); return -1; }
+            if (value < 64 || value > GOM_SORT_CAP_MAX) { gom_set_error("sort cap must be in [64, %d]", GOM_SORT_CAP_MAX); return -1; }
             s->sortCap = (int)value;
             return 0;
         case GOM_OPT_PAIR_CAPACITY:

@@ -42,13 +42,6 @@
 // serial T chain never round-trips through SALU/VCC logic.
 #include "gom_internal.h"
 
-#ifdef GOM_INSTRUMENT
-__device__ unsigned long long g_dbg[8192 * 12];
-extern "C" int gom_debug_fetch(unsigned long long *host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
-}
-#endif
-
 namespace {
 
 constexpr float kStopT = 0.0001f;          // App. A.3: stop when T(1-alpha) < 1e-4
@@ -154,53 +147,52 @@ __device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float
 // ---------------------------------------------------------------- sort ------
 // Normalised bitonic network on n unique 64-bit keys: every comparator orders
 // ascending, so indices >= n behave as +inf padding and are simply skipped.
-// 4 comparators per thread per trip with all loads issued first.
-template <int NT, typename PTR>
-__device__ __forceinline__ void bitonic_sort_u64(PTR keys, uint32_t n) {
-    for (uint32_t m = 1; (1u << (m - 1)) < n; m++) {
-        const uint32_t k = 1u << m, half = k >> 1;
-        {
-            const uint32_t total = ((n + k - 1) >> m) << (m - 1);
-            for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
-                uint32_t lo[4], hi[4];
-                uint64_t a[4], b[4];
-                bool ok[4];
+// The two step kinds below work on the list in global memory (only used for the
+// strides that span more than one register-sorted chunk, see k_sort); 4
+// comparators per thread per trip with all loads issued first.
+template <int NT>
+__device__ __forceinline__ void global_mirror_step(uint64_t *keys, uint32_t n, uint32_t m) {
+    const uint32_t k = 1u << m, half = k >> 1;
+    const uint32_t total = ((n + k - 1) >> m) << (m - 1);
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
+        uint32_t lo[4], hi[4];
+        uint64_t a[4], b[4];
+        bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + NT * u;
-                    const uint32_t blk = i >> (m - 1), off = i & (half - 1);
-                    lo[u] = (blk << m) + off;
-                    hi[u] = (blk << m) + (k - 1 - off);
-                    ok[u] = i < total && hi[u] < n;
-                    if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[hi[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[hi[u]] = a[u]; }
-            }
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + NT * u;
+            const uint32_t blk = i >> (m - 1), off = i & (half - 1);
+            lo[u] = (blk << m) + off;
+            hi[u] = (blk << m) + (k - 1 - off);
+            ok[u] = i < total && hi[u] < n;
+            if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[hi[u]]; }
         }
-        __syncthreads();
-        for (int q = (int)m - 2; q >= 0; q--) {
-            const uint32_t j = 1u << q;
-            const uint32_t total = ((n + 2 * j - 1) >> (q + 1)) << q;
-            for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
-                uint32_t lo[4];
-                uint64_t a[4], b[4];
-                bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + NT * u;
-                    lo[u] = ((i >> q) << (q + 1)) + (i & (j - 1));
-                    ok[u] = i < total && lo[u] + j < n;
-                    if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[lo[u] + j]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[lo[u] + j] = a[u]; }
-            }
-            __syncthreads();
-        }
+        for (int u = 0; u < 4; u++)
+            if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[hi[u]] = a[u]; }
     }
+    __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ void global_stride_step(uint64_t *keys, uint32_t n, uint32_t q) {
+    const uint32_t j = 1u << q;
+    const uint32_t total = ((n + 2 * j - 1) >> (q + 1)) << q;
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
+        uint32_t lo[4];
+        uint64_t a[4], b[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + NT * u;
+            lo[u] = ((i >> q) << (q + 1)) + (i & (j - 1));
+            ok[u] = i < total && lo[u] + j < n;
+            if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[lo[u] + j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[lo[u] + j] = a[u]; }
+    }
+    __syncthreads();
 }
 
 // Register-resident bitonic sort: 8 keys per thread (element i = 8*thread + r).  In the normalised network every
@@ -308,12 +300,16 @@ __device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask
     sort_step_merge<MIRROR>(x, y, lower);
 }
 
+// One workgroup per tile.  Lists of up to 2^log_chunk (= 8192) keys are sorted entirely in registers / DPP / LDS.
+// Longer lists (a handful of tiles at the 220k-Gaussian configuration) are cut into chunks of that size: pass 0
+// sorts every chunk, pass p > 0 runs stage log_chunk + p of the same network -- its strides >= one chunk as
+// global-memory steps, the rest again per chunk in registers.
 __global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t sort_cap) {
+                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t log_chunk) {
     __shared__ uint64_t s_x[GOM_SORT_CAP_MAX];
     if (status->overflow) return;
     const int tile = blockIdx.x;
@@ -326,106 +322,79 @@ __global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__rest
         seg_desc[sb + i] = make_uint4((uint32_t)tile, base + i * GOM_SEG, min((uint32_t)GOM_SEG, n - i * GOM_SEG), i);
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t t = threadIdx.x;
-    if (n <= sort_cap) {
-        uint32_t logN = 3;
-        while ((1u << logN) < n) logN++;
-#ifdef GOM_INSTRUMENT
-        const unsigned long long d0 = __builtin_readcyclecounter();
-#endif
-        uint64_t x[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t i = 8 * t + r;
-            x[r] = i < n ? keys[base + i] : ~0ull;  // +inf padding never moves down: every comparator sorts ascending
+    const uint32_t LC = log_chunk;
+    uint32_t logN = 3;
+    while ((1u << logN) < n) logN++;
+    const uint32_t nchunk = (n + (1u << LC) - 1) >> LC;
+    const uint32_t npass = logN > LC ? logN - LC + 1 : 1;
+    for (uint32_t pass = 0; pass < npass; pass++) {
+        const uint32_t m_lo = pass == 0 ? 4 : LC + pass;
+        const uint32_t m_hi = pass == 0 ? min(logN, LC) : LC + pass;
+        const bool last = pass + 1 == npass;
+        if (pass) {
+            global_mirror_step<1024>(keys + base, n, m_lo);
+            for (int q = (int)m_lo - 2; q >= (int)LC; q--) global_stride_step<1024>(keys + base, n, (uint32_t)q);
         }
-#ifdef GOM_INSTRUMENT
-        const unsigned long long d1 = __builtin_readcyclecounter();
-#endif
-        const bool wave_active = (t & ~63u) * 8 < n;  // waves past the list only hold padding
-        // stages m = 1..3 live entirely in registers
-        if (wave_active) {
-            sort_step_regs<1>(x);
-            sort_step_regs<3>(x); sort_step_regs<1>(x);
-            sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
-        }
-#ifdef GOM_INSTRUMENT
-        unsigned long long t_dpp = 0, t_lds = 0, t_reg = 0;
-#define GOM_TIC const unsigned long long tic_ = __builtin_readcyclecounter()
-#define GOM_TOC(acc) acc += __builtin_readcyclecounter() - tic_
-#else
-#define GOM_TIC
-#define GOM_TOC(acc)
-#endif
-        for (uint32_t m = 4; m <= logN; m++) {
-            { GOM_TIC; sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, n);
-#ifdef GOM_INSTRUMENT
-              if ((((1u << m) - 1) >> 3) < 64) { GOM_TOC(t_dpp); } else { GOM_TOC(t_lds); }
-#endif
-            }
-            for (int q = (int)m - 2; q >= 3; q--) {
-                GOM_TIC; sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, n);
-#ifdef GOM_INSTRUMENT
-                if (((1u << q) >> 3) < 64) { GOM_TOC(t_dpp); } else { GOM_TOC(t_lds); }
-#endif
-            }
-            { GOM_TIC; if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); } GOM_TOC(t_reg); }
-        }
-#ifdef GOM_INSTRUMENT
-        if (t == 0 && tile < 8192) { g_dbg[8192 * 4 + tile * 3] = t_dpp; g_dbg[8192 * 4 + tile * 3 + 1] = t_lds; g_dbg[8192 * 4 + tile * 3 + 2] = t_reg; }
-#endif
-#ifdef GOM_INSTRUMENT
-        const unsigned long long d2 = __builtin_readcyclecounter();
-#endif
-        // write-out, 4 entries per trip: their gathers are issued before the first dependent store
-        // (8 at once would push the kernel past 64 VGPRs and halve the workgroups per CU)
+        for (uint32_t c = 0; c < nchunk; c++) {
+            const uint32_t cbase = base + (c << LC);
+            const uint32_t cn = min(1u << LC, n - (c << LC));
+            uint64_t x[8];
 #pragma unroll
-        for (int r0 = 0; r0 < 8; r0 += 4) {
-            ushort4 rc[4];
-            uint32_t po[4];
-            float2 cxy[4];
-            float4 cco[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = 8 * t + r0 + u;
-                const uint32_t g = i < n ? (uint32_t)x[r0 + u] : 0u;
-                rc[u] = rect[g];
-                po[u] = pair_off[g];
-                cxy[u] = xy[g];
-                cco[u] = conic_opacity[g];
+            for (int r = 0; r < 8; r++) {
+                const uint32_t i = 8 * t + r;
+                x[r] = i < cn ? keys[cbase + i] : ~0ull;  // +inf padding never moves down: every comparator sorts ascending
             }
+            const bool wave_active = (t & ~63u) * 8 < cn;  // waves past the chunk only hold padding
+            if (pass == 0 && wave_active) {  // stages m = 1..3 live entirely in registers
+                sort_step_regs<1>(x);
+                sort_step_regs<3>(x); sort_step_regs<1>(x);
+                sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
+            }
+            for (uint32_t m = m_lo; m <= m_hi; m++) {
+                if (m <= LC) sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, cn);
+                for (int q = (int)min(m - 2, LC - 1); q >= 3; q--) sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, cn);
+                if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); }
+            }
+            if (!last) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = 8 * t + r0 + u;
-                if (i < n) {
-                    const uint32_t g = (uint32_t)x[r0 + u];
-                    keys[base + i] = x[r0 + u];
-                    point_list[base + i] = g;
-                    const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
-                    pair_pos[po[u] + k] = base + i;
-                    // geometry of the entry in LIST order: the compositing kernels read it contiguously
-                    float2 *dst = ent_geo + 3 * (size_t)(base + i);
-                    dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
+                for (int r = 0; r < 8; r++)
+                    if (8 * t + r < cn) keys[cbase + 8 * t + r] = x[r];
+                continue;
+            }
+            // write-out, 4 entries per trip: their gathers are issued before the first dependent store
+            // (8 at once would push the kernel past 64 VGPRs and halve the workgroups per CU)
+#pragma unroll
+            for (int r0 = 0; r0 < 8; r0 += 4) {
+                ushort4 rc[4];
+                uint32_t po[4];
+                float2 cxy[4];
+                float4 cco[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = 8 * t + r0 + u;
+                    const uint32_t g = i < cn ? (uint32_t)x[r0 + u] : 0u;
+                    rc[u] = rect[g];
+                    po[u] = pair_off[g];
+                    cxy[u] = xy[g];
+                    cco[u] = conic_opacity[g];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = 8 * t + r0 + u;
+                    if (i < cn) {
+                        const uint32_t g = (uint32_t)x[r0 + u];
+                        keys[cbase + i] = x[r0 + u];
+                        point_list[cbase + i] = g;
+                        const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
+                        pair_pos[po[u] + k] = cbase + i;
+                        // geometry of the entry in LIST order: the compositing kernels read it contiguously
+                        float2 *dst = ent_geo + 3 * (size_t)(cbase + i);
+                        dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
+                    }
                 }
             }
         }
-#ifdef GOM_INSTRUMENT
-        if (t == 0 && tile < 8192) {
-            g_dbg[tile * 4 + 0] = d1 - d0; g_dbg[tile * 4 + 1] = d2 - d1; g_dbg[tile * 4 + 2] = __builtin_readcyclecounter() - d2; g_dbg[tile * 4 + 3] = n;
-        }
-#endif
-    } else {
-        bitonic_sort_u64<1024>(keys + base, n);  // rare: list longer than the LDS capacity, sorted in global memory
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-            const uint32_t g = (uint32_t)keys[base + i];
-            point_list[base + i] = g;
-            const ushort4 rc = rect[g];
-            const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
-            pair_pos[pair_off[g] + k] = base + i;
-            const float2 c = xy[g];
-            const float4 co = conic_opacity[g];
-            float2 *dst = ent_geo + 3 * (size_t)(base + i);
-            dst[0] = c; dst[1] = make_float2(co.x, co.y); dst[2] = make_float2(co.z, co.w);
-        }
+        if (!last) __syncthreads();  // the chunk write-backs are visible to the next pass's global steps
     }
 }
 
@@ -974,7 +943,7 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SORT, st);
     hipLaunchKernelGGL(k_sort, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, (uint32_t)s->sortCap);
+                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, (uint32_t)(31 - __builtin_clz((unsigned)s->sortCap)));
     GOM_LAUNCH_CHECK();
     return 0;
 }

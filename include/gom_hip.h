@@ -73,8 +73,8 @@ enum {
 
 /* options for gom_state_set_option */
 enum {
-    GOM_OPT_SORT_CAP = 0,   /* max tile-list length sorted in LDS (<= compiled cap); smaller values force the
-                               global-memory fallback sort -- used by tests */
+    GOM_OPT_SORT_CAP = 0,   /* tile-list length sorted in one register/LDS chunk (64..8192, rounded down to a power of
+                               two; default 8192); longer lists take the chunked merge path -- lowered by tests */
     GOM_OPT_PAIR_CAPACITY = 1, /* capacity (entries) of the (tile, gaussian) pair buffers */
     GOM_OPT_PROFILE = 2        /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
 };

@@ -60,8 +60,9 @@ def test_forward_dense_tiles_lds_and_fallback_sort_agree():
     cam, means, cov6, colors, op = small_scene(seed=21, P=6000, H=64, W=64, spread=0.12, scale=0.02, opacity=1.0)
     img_a, f, e = _compare_forward(cam, means, cov6, colors, op)
     assert (np.diff(e["tile_base"].astype(np.int64))).max() > 1024
-    img_b, _, _ = _compare_forward(cam, means, cov6, colors, op, sort_cap=64)
-    np.testing.assert_array_equal(img_a, img_b)
+    for cap in (64, 512):   # lists longer than the chunk: chunk sorts + global merge passes
+        img_b, _, _ = _compare_forward(cam, means, cov6, colors, op, sort_cap=cap)
+        np.testing.assert_array_equal(img_a, img_b)
 
 
 def test_forward_equal_depth_ties_keep_gaussian_order():
@@ -197,3 +198,41 @@ def test_body_frame_512_properties():
     for t in np.nonzero(np.diff(e["tile_base"].astype(np.int64)))[0][:50]:
         a, b = e["tile_base"][t], e["tile_base"][t + 1]
         assert np.all(k[a + 1:b] > k[a:b - 1])                               # strictly sorted per tile
+
+
+@pytest.mark.parametrize("subdiv,img", [(1, 1024), (2, 1024)])
+def test_body_frame_large_configs(subdiv, img):
+    """BASELINE configs[3]/[5] shapes (55 104 and 220 416 Gaussians at 1024x1024): the longest tile lists exceed one
+    8192-key sort chunk at 220k, so this also covers the chunked merge path at full size.  Forward bit-exact binning
+    + image parity, backward against the fp64 oracle."""
+    from gpu_util import hip_forward, export_state, assert_binning_bit_exact
+    sc = body_scene(subdiv, frame=1, img=img)
+    with torch.no_grad():
+        Rs, Ts = og.fk_global_RTs(sc["frame"]["cnl_gtfms"], sc["frame"]["dst_Rs"], sc["frame"]["dst_Ts"])
+        v_obs = og.lbs(sc["params"]["vertices"].unsqueeze(0), Rs, Ts, sc["lbs_weights"])[0]
+        xyz_t, cov_t = og.face_gaussians(v_obs, sc["faces"], sc["params"]["so3"], sc["params"]["scale"], 1e-3)
+    cam = og.camera_from_KE(sc["frame"]["K"][0].numpy(), sc["frame"]["E"][0].numpy(), img, img)
+    F = sc["faces"].shape[0]
+    xyz, cov6 = xyz_t.numpy(), og.pack_cov6(cov_t).numpy()
+    colors = np.concatenate([sc["params"]["appearance"].numpy().T, np.ones((F, 1), np.float32)], 1)
+    op = np.ones(F, np.float32)
+    out, radii, st, t = hip_forward(cam, xyz, cov6, colors, op, requires_grad=True)
+    f = orast.forward(cam, xyz, cov6, colors, op)
+    e = export_state(st, F, img, img)
+    assert_binning_bit_exact(e, f)
+    if subdiv == 2:
+        assert np.diff(e["tile_base"].astype(np.int64)).max() > 8192
+    imgs = out.detach().cpu().numpy()
+    assert_image_parity(imgs, f["color"])
+    np.testing.assert_allclose(imgs[3] + e["final_T"], 1.0, atol=3e-6)
+    rng = np.random.default_rng(5)
+    wimg = rng.normal(size=(4, img, img)).astype(np.float32)
+    (out * torch.from_numpy(wimg).cuda()).sum().backward()
+    f64 = orast.forward(cam, xyz, cov6, colors, op, dtype=np.float64)
+    g = orast.backward(f64, wimg.astype(np.float64))
+    for name, got, ref in (("means3D", t[0].grad, g["dL_dmeans3D"]), ("cov6", t[1].grad, g["dL_dcov6"]), ("colors", t[2].grad, g["dL_dcolors"])):
+        got = got.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref)
+        assert np.quantile(err, 0.999) <= 2e-4 * scale, (name, np.quantile(err, 0.999), scale)
+        assert np.median(err) <= 1e-6 * scale, (name, np.median(err), scale)
