@@ -1,18 +1,20 @@
 #!/usr/bin/env python
 """bench.py -- rendered frames/sec (fwd+bwd) of the GoMAvatar hot path on MI355X.
 
-One "step" = one frame through the whole hot path, forward AND backward:
+One "step" = one batch of B frames (--batch, default 8) per GPU through the
+whole hot path, forward AND backward, in ONE sequence of 17 kernel launches:
 FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused
 unpack+L1(rgb)+L1(mask) loss fwd/bwd -> splat backward -> face backward ->
-vertex gather + LBS backward, producing gradients for vertices / so3 / scale /
-appearance.  Workload (BASELINE.json metric): 512x512, 55 104 Gaussians
-(SMPL-topology body, one midpoint subdivision), synthetic poses/cameras/targets
-already resident in HBM when the timed region starts.
+vertex gather + LBS backward -> sum of the per-frame gradients, producing the
+batch gradient for vertices / so3 / scale / appearance.  Workload (BASELINE.json
+metric): 512x512, 55 104 Gaussians (SMPL-topology body, one midpoint
+subdivision), synthetic poses/cameras/targets already resident in HBM when the
+timed region starts.  `value` counts FRAMES per second (B per step per GPU).
 
-N > 1 (launched by torch.distributed.run): frame-parallel data parallelism, one
-frame per GPU per step, plus ONE RCCL all-reduce of the flat fp32 gradient
-buffer (951 023 floats = the reference model's full parameter count) inside
-the timed step.  Weak scaling: per-GPU work is fixed.
+N > 1 (launched by torch.distributed.run): frame-parallel data parallelism, B
+frames per GPU per step, plus ONE RCCL all-reduce of the flat fp32 gradient
+buffer (951 023 floats = the reference model's full parameter count) per step
+inside the timed region.  Weak scaling: per-GPU work is fixed.
 
 Prints one JSON line on rank 0 (contract in the task statement) carrying
 `roofline` (dominant kernel, HIP-event timed on its own stream) and, at N=1,
@@ -45,10 +47,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
-    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
-    ap.add_argument("--inflight", type=int, default=8,
-                    help="independent frames in flight per GPU, each on its own HIP stream with its own scratch "
-                         "(a frame-parallel batch on one GPU); 1 = strictly one frame after the other")
+    ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames cycled through")
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU, rendered by one batched launch sequence")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
+                         "1 = strictly one step after the other")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the 17 kernels of a frame one by one instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -100,7 +103,9 @@ def main():
     w = torch.from_numpy(body["canonical_lbs_weights"]).T
     w25 = torch.cat([w, torch.zeros(1, N)], 0).contiguous()
     faces = torch.from_numpy(body["faces"])
-    step = RenderStep(faces, N, (img, img), w25, device=dev)
+    B = max(1, args.batch)
+    gen = RenderStep(faces, N, (img, img), w25, device=dev)   # single-frame instance: renders the targets
+    step = RenderStep(faces, N, (img, img), w25, device=dev, batch=B)
 
     def dev_params(seed):
         gp = syn.make_gaussian_params(F, seed)
@@ -118,38 +123,51 @@ def main():
     params = dev_params(1)
     target_params = dev_params(2)
     frames = []
-    for i in range(args.frames):
+    for i in range(max(args.frames, B)):
         fr = syn.make_frame(rank * 1000 + i, img)  # each rank renders different frames
         d = {k: torch.from_numpy(fr[k][0]).contiguous().to(dev) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
         d["K"], d["E"], d["bg"] = fr["K"][0], fr["E"][0], torch.from_numpy(fr["bgcolor"][0]).to(dev)
         # target = render of a different parameter set (so gradients are non-zero), produced by the HIP path itself
-        step.set_camera(d["K"], d["E"])
+        gen.set_camera(d["K"], d["E"])
         dummy_rgb = torch.zeros((img, img, 3), device=dev)
         dummy_m = torch.zeros((img, img), device=dev)
-        step.forward_backward(target_params, d, dummy_rgb, dummy_m, d["bg"], backward=False)
-        rgb, mask = step.rgb_mask()
+        gen.forward_backward(target_params, d, dummy_rgb, dummy_m, d["bg"], backward=False)
+        rgb, mask = gen.rgb_mask()
         d["gt_rgb"] = (rgb[0] * mask[0, ..., None] + d["bg"] * (1 - mask[0, ..., None])).contiguous().clone()
         d["gt_mask"] = mask[0].contiguous().clone()
-        d["cam"] = step.cam
         frames.append(d)
     torch.cuda.synchronize()
+    del gen
+    # batches of B consecutive frames: stacked per-frame inputs + one device camera array each
+    batches = []
+    for j in range(len(frames) // B):
+        grp = frames[j * B:(j + 1) * B]
+        bt = {k: torch.stack([g[k] for g in grp]).contiguous() for k in ("cnl_gtfms", "dst_Rs", "dst_Ts", "gt_rgb", "gt_mask", "bg")}
+        if B == 1:
+            bt = {k: v[0] for k, v in bt.items()}
+        step.set_cameras([g["K"] for g in grp], [g["E"] for g in grp]) if B > 1 else step.set_camera(grp[0]["K"], grp[0]["E"])
+        torch.cuda.synchronize()
+        bt["cams_dev"], bt["cam"] = step.cams_dev.clone(), step.cam
+        batches.append(bt)
 
-    # frames in flight: slot k owns a stream, a RenderStep (scratch + intermediates) and a gradient buffer
+    # steps in flight: slot k owns a stream, a RenderStep (scratch + intermediates) and a gradient buffer
     S = max(1, args.inflight)
     slots = [dict(step=step, fp=fp, stream=torch.cuda.Stream(device=dev))]  # (the legacy NULL stream cannot be graph-captured)
     for k in range(1, S):
-        st_k = RenderStep(faces, N, (img, img), w25, device=dev)
+        st_k = RenderStep(faces, N, (img, img), w25, device=dev, batch=B)
         fp_k = FrameParallel(shapes_for_model(N, F), dev, pad_to=flat.numel())
         for name in ("vertices", "so3", "scale", "appearance"):
             st_k.grads[name] = fp_k.grads[name]
         slots.append(dict(step=st_k, fp=fp_k, stream=torch.cuda.Stream(device=dev)))
 
     def run_step(i):
-        d = frames[i % len(frames)]
+        bt = batches[i % len(batches)]
         sl = slots[i % S]
         with torch.cuda.stream(sl["stream"]):
-            sl["step"].cam = d["cam"]
-            sl["step"].forward_backward(params, d, d["gt_rgb"], d["gt_mask"], d["bg"], graph=not args.no_graph)
+            sl["step"].cam = bt["cam"]
+            if B > 1:
+                sl["step"].cams_dev.copy_(bt["cams_dev"], non_blocking=True)   # this step's cameras (device array read by the kernels)
+            sl["step"].forward_backward(params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=not args.no_graph)
             sl["fp"].all_reduce_grads()  # no-op at world size 1
 
     torch.cuda.synchronize()
@@ -195,7 +213,7 @@ def main():
     torch.cuda.synchronize()
     kt = {k: acc[k] / n_prof for k in _lib.KERNEL_NAMES}
     D_avg = acc["D"] / n_prof
-    abytes = algorithmic_bytes(F, D_avg, img * img, 4)
+    abytes = algorithmic_bytes(F * B, D_avg, img * img * B, 4)   # per launch: B frames (D_avg already counts all B)
     dom = max(kt, key=kt.get)
     achieved = abytes[dom] / (kt[dom] * 1e-3) / 1e9
     # HBM traffic of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, FETCH doubled per
@@ -204,7 +222,8 @@ def main():
     tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if os.path.exists(tj) and args.subdiv == 1 and img == 512:
         try:
-            traffic = int(json.load(open(tj)).get("k_" + dom, {}).get("hbm_bytes")) or None
+            tjd = json.load(open(tj))
+            traffic = (int(tjd.get("k_" + dom, {}).get("hbm_bytes")) or None) if tjd.get("batch", 1) == B else None
         except Exception:
             traffic = None
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -214,7 +233,7 @@ def main():
 
     out = {
         "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians",
-        "value": round(world * args.steps / elapsed, 2),
+        "value": round(world * B * args.steps / elapsed, 2),
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -225,10 +244,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, 1 frame per GPU per step"
-                               + (", + RCCL all-reduce of the flat grad buffer" if world > 1 else ""),
-                   "gaussians": F, "image": [img, img], "frames_per_step": world, "parallelism": f"frame-dp{world}",
-                   "frames_in_flight_per_gpu": S,
+        "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, {B} frames per GPU per step "
+                               "(one batched launch sequence)" + (", + RCCL all-reduce of the flat grad buffer" if world > 1 else ""),
+                   "gaussians": F, "image": [img, img], "frames_per_step": world * B, "frames_per_gpu_per_step": B,
+                   "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S,
                    "allreduce_floats": int(flat.numel()) if world > 1 else 0},
         "roofline": roofline,
     }

@@ -46,6 +46,10 @@ __global__ void __launch_bounds__(64) k_fk_fwd(const float *__restrict__ cnl, co
                                                float *__restrict__ RT, float *__restrict__ save) {
     __shared__ float L[24][16], G[24][16], Ci[24][16];
     const int t = threadIdx.x;
+    {  // blockIdx.x = frame of a batched launch
+        const size_t fr = blockIdx.x;
+        cnl += fr * 24 * 16; Rs += fr * 24 * 9; Ts += fr * 24 * 3; RT += fr * 24 * 12; save += fr * 24 * 32;
+    }
     if (t < 24) {
         for (int r = 0; r < 3; r++) {
             for (int c = 0; c < 3; c++) L[t][4 * r + c] = Rs[9 * t + 3 * r + c];
@@ -131,6 +135,8 @@ __global__ void __launch_bounds__(64) k_fk_bwd(const float *__restrict__ Rs, con
 __global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
                                                  const float *__restrict__ RT, float *__restrict__ out) {
     extern __shared__ float s_rt[];
+    RT += (size_t)blockIdx.y * J * 12;  // blockIdx.y = frame of a batched launch (shared canonical vertices and weights)
+    out += (size_t)blockIdx.y * 3 * N;
     for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -237,6 +243,11 @@ __global__ void __launch_bounds__(256) k_face_fwd(int N, int F, const float *__r
                                                   const float *__restrict__ appearance, float *__restrict__ feat4) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    {  // blockIdx.y = frame of a batched launch: per-frame posed vertices in, per-frame Gaussians out
+        const size_t fr = blockIdx.y;
+        verts += fr * 3 * N; xyz += fr * 3 * F; cov6 += fr * 6 * F;
+        if (feat4) feat4 += fr * 4 * F;
+    }
     if (feat4) {  // (3,F) colour parameter -> (F,4) rasterizer features [r g b 1] (gaussian.py:49), fused here
         *reinterpret_cast<float4 *>(feat4 + 4 * (size_t)f) =
             make_float4(appearance[f], appearance[(size_t)F + f], appearance[2 * (size_t)F + f], 1.0f);
@@ -261,6 +272,12 @@ __global__ void __launch_bounds__(256) k_face_bwd(int N, int F, const float *__r
                                                   const float *__restrict__ d_feat4, float *__restrict__ d_appearance) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    {  // blockIdx.y = frame of a batched launch; the parameter gradients go to per-frame slices (summed by k_sum_frames)
+        const size_t fr = blockIdx.y;
+        verts += fr * 3 * N; d_xyz += fr * 3 * F; d_cov6 += fr * 6 * F; d_corner += fr * 9 * F;
+        d_so3 += fr * 3 * F; d_scale += fr * 3 * F;
+        if (d_appearance) { d_feat4 += fr * 4 * F; d_appearance += fr * 3 * F; }
+    }
     if (d_appearance) {  // (F,4) feature gradient -> (3,F) colour-parameter gradient
         const float4 g = *reinterpret_cast<const float4 *>(d_feat4 + 4 * (size_t)f);
         d_appearance[f] = g.x; d_appearance[(size_t)F + f] = g.y; d_appearance[2 * (size_t)F + f] = g.z;
@@ -376,8 +393,16 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
                                                     const float *__restrict__ RT, const int32_t *__restrict__ csr_off,
                                                     const int32_t *__restrict__ csr_idx, const float *__restrict__ d_corner,
                                                     const float *__restrict__ d_extra, float *__restrict__ d_obs,
-                                                    float *__restrict__ d_xyz, float *__restrict__ dRT) {
+                                                    float *__restrict__ d_xyz, float *__restrict__ dRT, int F) {
     extern __shared__ float s_rt[];
+    {  // blockIdx.y = frame of a batched launch (F = faces, the stride of d_corner)
+        const size_t fr = blockIdx.y;
+        RT += fr * J * 12; d_xyz += fr * 3 * N;
+        if (d_corner) d_corner += fr * 9 * F;
+        if (d_extra) d_extra += fr * 3 * N;
+        if (d_obs) d_obs += fr * 3 * N;
+        if (dRT) dRT += fr * J * 12;
+    }
     for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -445,13 +470,48 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
     }
 }
 
+// dst_k[i] = sum_b src_k[b * n_k + i] for up to four tensors in one launch, frames in a fixed order
+// (bitwise reproducible)
+struct SumFramesArgs {
+    size_t n[4];
+    const float *src[4];
+    float *dst[4];
+};
+__global__ void __launch_bounds__(256) k_sum_frames(int B, SumFramesArgs a) {
+    const size_t total = a.n[0] + a.n[1] + a.n[2] + a.n[3];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t j = i;
+        int k = 0;
+        while (j >= a.n[k]) { j -= a.n[k]; k++; }
+        const float *src = a.src[k];
+        float acc = 0.f;
+        for (int b = 0; b < B; b++) acc += src[(size_t)b * a.n[k] + j];
+        a.dst[k][j] = acc;
+    }
+}
+
 }  // namespace
 
-extern "C" int gom_fk_forward(const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream) {
-    if (!cnl_gtfms || !dst_Rs || !dst_Ts || !RT || !fk_save) { gom_set_error("gom_fk_forward: null pointer"); return -1; }
-    hipLaunchKernelGGL(k_fk_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save);
+int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
+                    float *d2, size_t n3, const float *s3, float *d3, void *stream) {
+    SumFramesArgs a = {{n0, n1, n2, n3}, {s0, s1, s2, s3}, {d0, d1, d2, d3}};
+    const size_t total = n0 + n1 + n2 + n3;
+    if (total == 0) return 0;
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_sum_frames, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, B, a);
     GOM_LAUNCH_CHECK();
     return 0;
+}
+
+int gom_fk_forward_batch(int B, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream) {
+    if (!cnl_gtfms || !dst_Rs || !dst_Ts || !RT || !fk_save) { gom_set_error("gom_fk_forward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_fk_fwd, dim3(B), dim3(64), 0, (hipStream_t)stream, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_fk_forward(const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream) {
+    return gom_fk_forward_batch(1, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save, stream);
 }
 
 extern "C" int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const float *fk_save, const float *dRT, float *d_dst_Rs,
@@ -462,23 +522,45 @@ extern "C" int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const f
     return 0;
 }
 
-extern "C" int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream) {
+int gom_lbs_forward_batch(int B, int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream) {
     if (N < 0 || J <= 0 || J > 64) { gom_set_error("gom_lbs_forward: bad sizes N=%d J=%d", N, J); return -1; }
     if (N == 0) return 0;
     if (!xyz || !weights || !RT || !out) { gom_set_error("gom_lbs_forward: null pointer"); return -1; }
-    hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights, RT, out);
+    hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256, B), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights, RT, out);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream) {
+    return gom_lbs_forward_batch(1, N, J, xyz, weights, RT, out, stream);
+}
+
+int gom_face_forward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                           float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream) {
+    if (N < 0 || F < 0) { gom_set_error("gom_face_forward: bad sizes"); return -1; }
+    if (F == 0) return 0;
+    if (!verts || !faces || !so3 || !scale || !xyz || !cov6) { gom_set_error("gom_face_forward: null pointer"); return -1; }
+    if ((appearance == nullptr) != (feat4 == nullptr)) { gom_set_error("gom_face_forward: appearance and feat4 go together"); return -1; }
+    hipLaunchKernelGGL(k_face_fwd, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma, xyz, cov6,
+                       appearance, feat4);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gom_face_forward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                                 float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream) {
-    if (N < 0 || F < 0) { gom_set_error("gom_face_forward: bad sizes"); return -1; }
+    return gom_face_forward_batch(1, N, F, verts, faces, so3, scale, sigma, xyz, cov6, appearance, feat4, stream);
+}
+
+int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                            float sigma, const float *d_xyz, const float *d_cov6, float *d_corner, float *d_so3,
+                            float *d_scale, const float *d_feat4, float *d_appearance, void *stream) {
+    if (N < 0 || F < 0) { gom_set_error("gom_face_backward: bad sizes"); return -1; }
     if (F == 0) return 0;
-    if (!verts || !faces || !so3 || !scale || !xyz || !cov6) { gom_set_error("gom_face_forward: null pointer"); return -1; }
-    if ((appearance == nullptr) != (feat4 == nullptr)) { gom_set_error("gom_face_forward: appearance and feat4 go together"); return -1; }
-    hipLaunchKernelGGL(k_face_fwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma, xyz, cov6,
-                       appearance, feat4);
+    if (!verts || !faces || !so3 || !scale || !d_xyz || !d_cov6 || !d_corner || !d_so3 || !d_scale) { gom_set_error("gom_face_backward: null pointer"); return -1; }
+    if ((d_feat4 == nullptr) != (d_appearance == nullptr)) { gom_set_error("gom_face_backward: d_feat4 and d_appearance go together"); return -1; }
+    hipLaunchKernelGGL(k_face_bwd, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma,
+                       d_xyz, d_cov6, d_corner, d_so3, d_scale, d_feat4, d_appearance);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -486,12 +568,19 @@ extern "C" int gom_face_forward(int N, int F, const float *verts, const int32_t 
 extern "C" int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                                  float sigma, const float *d_xyz, const float *d_cov6, float *d_corner, float *d_so3,
                                  float *d_scale, const float *d_feat4, float *d_appearance, void *stream) {
-    if (N < 0 || F < 0) { gom_set_error("gom_face_backward: bad sizes"); return -1; }
-    if (F == 0) return 0;
-    if (!verts || !faces || !so3 || !scale || !d_xyz || !d_cov6 || !d_corner || !d_so3 || !d_scale) { gom_set_error("gom_face_backward: null pointer"); return -1; }
-    if ((d_feat4 == nullptr) != (d_appearance == nullptr)) { gom_set_error("gom_face_backward: d_feat4 and d_appearance go together"); return -1; }
-    hipLaunchKernelGGL(k_face_bwd, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, F, verts, faces, so3, scale, sigma,
-                       d_xyz, d_cov6, d_corner, d_so3, d_scale, d_feat4, d_appearance);
+    return gom_face_backward_batch(1, N, F, verts, faces, so3, scale, sigma, d_xyz, d_cov6, d_corner, d_so3, d_scale, d_feat4,
+                                   d_appearance, stream);
+}
+
+int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
+                              const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
+                              float *d_xyz, float *dRT, void *stream) {
+    if (N < 0 || J <= 0 || J > 64) { gom_set_error("gom_vertex_backward: bad sizes"); return -1; }
+    if (N == 0) return 0;
+    if (!xyz || !weights || !RT || !d_xyz) { gom_set_error("gom_vertex_backward: null pointer"); return -1; }
+    if ((csr_off == nullptr) != (csr_idx == nullptr) || (csr_off && !d_corner)) { gom_set_error("gom_vertex_backward: inconsistent CSR arguments"); return -1; }
+    hipLaunchKernelGGL(k_vertex_bwd, dim3((N + 255) / 256, B), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights,
+                       RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, dRT, F);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -499,12 +588,6 @@ extern "C" int gom_face_backward(int N, int F, const float *verts, const int32_t
 extern "C" int gom_vertex_backward(int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
                                    const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
                                    float *d_xyz, float *dRT, void *stream) {
-    if (N < 0 || J <= 0 || J > 64) { gom_set_error("gom_vertex_backward: bad sizes"); return -1; }
-    if (N == 0) return 0;
-    if (!xyz || !weights || !RT || !d_xyz) { gom_set_error("gom_vertex_backward: null pointer"); return -1; }
-    if ((csr_off == nullptr) != (csr_idx == nullptr) || (csr_off && !d_corner)) { gom_set_error("gom_vertex_backward: inconsistent CSR arguments"); return -1; }
-    hipLaunchKernelGGL(k_vertex_bwd, dim3((N + 255) / 256), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights,
-                       RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, dRT);
-    GOM_LAUNCH_CHECK();
-    return 0;
+    return gom_vertex_backward_batch(1, 0, N, J, xyz, weights, RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, dRT,
+                                     stream);
 }

@@ -48,7 +48,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,
-                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status};
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->batch_grads};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -85,10 +85,15 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
 
 // Make sure the scratch fits (P, H, W).  Reallocation synchronises the device
 // (hipFree); it only happens when a dimension grows.
-static int ensure_capacity(GomState *s, int P, int H, int W) {
+static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B = 1) {
     const int gx = (W + GOM_TILE - 1) / GOM_TILE, gy = (H + GOM_TILE - 1) / GOM_TILE;
-    const int tiles = gx * gy;
-    const int pix = H * W;
+    if ((int64_t)P_frame * B > 0x7fffffffLL || (int64_t)gy * B > 65535 || (int64_t)H * W * B > 0x7fffffffLL) {
+        gom_set_error("batch of %d frames too large (P=%d, %dx%d)", B, P_frame, H, W);
+        return -1;
+    }
+    const int P = P_frame * B;
+    const int tiles = gx * gy * B;
+    const int pix = H * W * B;
     if (P > s->capP) {
         const int cap = P + P / 8 + 256;
         if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
@@ -133,6 +138,7 @@ static int ensure_capacity(GomState *s, int P, int H, int W) {
     }
     s->gx = gx;
     s->gy = gy;
+    s->B = B;
     return 0;
 }
 
@@ -144,41 +150,49 @@ static bool valid_dims(int P, int C, const GomCamera *cam) {
     return true;
 }
 
-extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
-                                  const float *colors, const float *opacity, float *out_color, int32_t *radii,
-                                  uint32_t flags, void *stream) {
+// P, H, W are per frame; B frames with device-resident cameras `cams` (nullptr: one frame, camera by value).
+// All tensors then carry a leading B dimension.
+static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamera *cams, int B, int P, int C, const float *means3D,
+                               const float *cov6, const float *colors, const float *opacity, float *out_color, int32_t *radii,
+                               uint32_t flags, void *stream) {
     if (!s) { gom_set_error("null state"); return -1; }
     if (!valid_dims(P, C, cam)) return -1;
     if (!out_color || (P > 0 && (!means3D || !cov6 || !colors || !opacity))) { gom_set_error("null tensor pointer"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     const bool reuse = (flags & GOM_FWD_REUSE_BINNING) != 0;
     if (reuse) {
-        if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W) {
+        if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W || s->B != B || s->cams != cams) {
             gom_set_error("GOM_FWD_REUSE_BINNING without a matching previous forward");
             return -1;
         }
     } else {
-        if (int rc = ensure_capacity(s, P, cam->H, cam->W)) return rc;
-        s->P = P; s->H = cam->H; s->W = cam->W;
+        if (int rc = ensure_capacity(s, P, cam->H, cam->W, B)) return rc;
+        s->P = P; s->H = cam->H; s->W = cam->W; s->cams = cams;
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
         if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
         if (int rc = gom_launch_sort(s, st)) return rc;
     }
     s->C = C;
     if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, reuse, st)) return rc;
-    if (reuse && radii) GOM_HIP_CHECK(hipMemcpyAsync(radii, s->radii, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (reuse && radii) GOM_HIP_CHECK(hipMemcpyAsync(radii, s->radii, (size_t)P * B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     s->haveForward = true;
     return 0;
 }
 
-extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
-                                   const float *colors, const float *opacity, const float *dL_dcolor, float *dL_dmeans3D,
-                                   float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D, uint32_t flags,
-                                   void *stream) {
+extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
+                                  const float *colors, const float *opacity, float *out_color, int32_t *radii,
+                                  uint32_t flags, void *stream) {
+    return raster_forward_impl(s, cam, nullptr, 1, P, C, means3D, cov6, colors, opacity, out_color, radii, flags, stream);
+}
+
+static int raster_backward_impl(GomState *s, const GomCamera *cam, const GomCamera *cams, int B, int P, int C, const float *means3D,
+                                const float *cov6, const float *colors, const float *opacity, const float *dL_dcolor,
+                                float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
+                                uint32_t flags, void *stream) {
     (void)opacity;
     if (!s) { gom_set_error("null state"); return -1; }
     if (!valid_dims(P, C, cam)) return -1;
-    if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W) {
+    if (!s->haveForward || s->P != P || s->H != cam->H || s->W != cam->W || s->B != B || s->cams != cams) {
         gom_set_error("gom_raster_backward without a matching forward on this state");
         return -1;
     }
@@ -192,6 +206,14 @@ extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int
                                                 dL_dmeans2D, st))
         return rc;
     return 0;
+}
+
+extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C, const float *means3D, const float *cov6,
+                                   const float *colors, const float *opacity, const float *dL_dcolor, float *dL_dmeans3D,
+                                   float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D, uint32_t flags,
+                                   void *stream) {
+    return raster_backward_impl(s, cam, nullptr, 1, P, C, means3D, cov6, colors, opacity, dL_dcolor, dL_dmeans3D, dL_dcov6, dL_dcolors,
+                                dL_dopacity, dL_dmeans2D, flags, stream);
 }
 
 extern "C" int gom_state_poll(GomState *s, int64_t *num_pairs, int32_t *overflow, void *stream) {
@@ -220,7 +242,7 @@ extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_byte
     if (!s || !s->haveForward) { gom_set_error("export without a forward"); return -1; }
     const void *src = nullptr;
     int64_t bytes = 0;
-    const int64_t P = s->P, tiles = (int64_t)s->gx * s->gy, pix = (int64_t)s->H * s->W;
+    const int64_t P = (int64_t)s->P * s->B, tiles = (int64_t)s->gx * s->gy * s->B, pix = (int64_t)s->H * s->W * s->B;
     switch (id) {
         case GOM_BUF_DEPTH: src = s->depth; bytes = P * 4; break;
         case GOM_BUF_XY: src = s->xy; bytes = P * 8; break;
@@ -240,32 +262,49 @@ extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_byte
     return 0;
 }
 
-static int frame_enqueue(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
+static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream);
 
-extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
+// per-frame slices of the parameter gradients of a batched call: [so3 | scale | appearance : B x 3F each][vertices : B x 3N]
+static int ensure_batch_grads(GomState *s, int B, int N, int F) {
+    const size_t need = B > 1 ? (size_t)B * (9 * (size_t)F + 3 * (size_t)N) : 0;
+    if (need > s->capBatchGrads) {
+        if (grow(&s->batch_grads, need)) return -2;
+        s->capBatchGrads = need;
+    }
+    return 0;
+}
+
+static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream) {
     if (!s || !f) { gom_set_error("gom_frame_forward_backward: null argument"); return -1; }
     if (f->cam.H != f->H || f->cam.W != f->W) { gom_set_error("gom_frame_forward_backward: camera/image size mismatch"); return -1; }
+    if (B < 1 || (B > 1 && !cams)) { gom_set_error("batched frame call needs B >= 1 and a device camera array"); return -1; }
     // the legacy NULL stream cannot be captured; profiling wants individually timed launches
-    if (!(flags & GOM_FRAME_USE_GRAPH) || s->profile || stream == nullptr) return frame_enqueue(s, f, flags & ~GOM_FRAME_USE_GRAPH, stream);
+    if (!(flags & GOM_FRAME_USE_GRAPH) || s->profile || stream == nullptr) {
+        if (int rc = ensure_batch_grads(s, B, f->N, f->F)) return rc;
+        return frame_enqueue(s, f, B, cams, flags & ~GOM_FRAME_USE_GRAPH, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     const uint32_t kflags = flags & ~GOM_FRAME_USE_GRAPH;
     s->graphClock++;
     for (auto &g : s->graphs) {
-        if (g.flags == kflags && memcmp(&g.key, f, sizeof(GomFrame)) == 0) {
+        if (g.flags == kflags && g.B == B && g.cams == cams && memcmp(&g.key, f, sizeof(GomFrame)) == 0) {
             g.last_use = s->graphClock;
             GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
-            s->P = f->F; s->H = f->H; s->W = f->W; s->C = 4; s->haveForward = true;
+            s->P = f->F; s->H = f->H; s->W = f->W; s->C = 4; s->B = B; s->cams = cams; s->haveForward = true;
             return 0;
         }
     }
     // first use of this frame descriptor: allocate outside the capture, then record the launch sequence
-    if (int rc = ensure_capacity(s, f->F, f->H, f->W)) return rc;
+    if (int rc = ensure_capacity(s, f->F, f->H, f->W, B)) return rc;
+    if (int rc = ensure_batch_grads(s, B, f->N, f->F)) return rc;
     GomGraphEntry e;
     memcpy(&e.key, f, sizeof(GomFrame));
     e.flags = kflags;
+    e.B = B;
+    e.cams = cams;
     e.last_use = s->graphClock;
     GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = frame_enqueue(s, f, kflags, stream);
+    const int rc = frame_enqueue(s, f, B, cams, kflags, stream);
     hipError_t ce = hipStreamEndCapture(st, &e.graph);
     if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return rc; }
     if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return -2; }
@@ -284,29 +323,49 @@ extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32
     return 0;
 }
 
-static int frame_enqueue(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
+extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
+    return frame_call(s, f, 1, nullptr, flags, stream);
+}
+
+extern "C" int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_t B, const GomCamera *cams_device, uint32_t flags,
+                                          void *stream) {
+    return frame_call(s, f, B, cams_device, flags, stream);
+}
+
+static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream) {
     const int N = f->N, F = f->F, H = f->H, W = f->W, J = 24;
     int rc;
-    if ((rc = gom_fk_forward(f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
-    if ((rc = gom_lbs_forward(N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
-    if ((rc = gom_face_forward(N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
-                               f->work_feat, stream)))
+    if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
+    if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
+    if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
+                                     f->work_feat, stream)))
         return rc;
-    if ((rc = gom_raster_forward(s, &f->cam, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image, f->work_radii, 0,
-                                 stream)))
+    if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
+                                  f->work_radii, 0, stream)))
         return rc;
-    if ((rc = gom_l1_loss(H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage, nullptr,
-                          f->loss_partials, stream)))
+    if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
+                                nullptr, f->loss_partials, stream)))
         return rc;
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
-    if ((rc = gom_raster_backward(s, &f->cam, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage, f->work_dxyz,
-                                  f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream)))
+    if ((rc = raster_backward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage,
+                                   f->work_dxyz, f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream)))
         return rc;
-    if ((rc = gom_face_backward(N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_dxyz, f->work_dcov6, f->work_dcorner,
-                                f->g_so3, f->g_scale, f->work_dfeat, f->g_appearance, stream)))
+    // B > 1: every frame writes its own slice, one more launch sums them in frame order (no atomics: reproducible)
+    const size_t F3 = 3 * (size_t)F, N3 = 3 * (size_t)N;
+    float *b_so3 = B > 1 ? s->batch_grads : f->g_so3;
+    float *b_scale = B > 1 ? s->batch_grads + B * F3 : f->g_scale;
+    float *b_app = B > 1 ? s->batch_grads + 2 * B * F3 : f->g_appearance;
+    float *b_vert = B > 1 ? s->batch_grads + 3 * B * F3 : f->g_vertices;
+    if ((rc = gom_face_backward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_dxyz, f->work_dcov6,
+                                      f->work_dcorner, b_so3, b_scale, f->work_dfeat, b_app, stream)))
         return rc;
-    if ((rc = gom_vertex_backward(N, J, f->vertices, f->lbs_weights, f->work_RT, f->csr_off, f->csr_idx, f->work_dcorner, nullptr, nullptr,
-                                  f->g_vertices, nullptr, stream)))
+    if ((rc = gom_vertex_backward_batch(B, F, N, J, f->vertices, f->lbs_weights, f->work_RT, f->csr_off, f->csr_idx, f->work_dcorner,
+                                        nullptr, nullptr, b_vert, nullptr, stream)))
         return rc;
+    if (B > 1) {
+        if ((rc = gom_sum_frames4(B, F3, b_so3, f->g_so3, F3, b_scale, f->g_scale, F3, b_app, f->g_appearance, N3, b_vert, f->g_vertices,
+                                  stream)))
+            return rc;
+    }
     return 0;
 }

@@ -9,6 +9,7 @@
 
 #define GOM_TILE 16
 #define GOM_SORT_CAP_MAX 8192       // tile-list entries sortable in LDS (64 KiB of 64-bit keys)
+#define GOM_SORT_SMALL 2048         // lists up to this length are sorted by the 256-thread instantiation of k_sort
 #define GOM_PARTIAL_STRIDE 12       // floats per (tile, gaussian) partial-gradient record (10 used)
 #ifndef GOM_SEG
 #define GOM_SEG 128                 // tile-list entries per segment (the unit of parallel compositing), <= 256
@@ -28,6 +29,8 @@ struct GomDevStatus {
 struct GomGraphEntry {
     GomFrame key;
     uint32_t flags;
+    int B;
+    const GomCamera *cams;
     hipGraph_t graph;
     hipGraphExec_t exec;
     uint64_t last_use;
@@ -40,9 +43,14 @@ struct GomState {
     int64_t capPairs = 0;
     int64_t wantPairs = 0;           // user-set pair capacity (0 = auto)
     int sortCap = GOM_SORT_CAP_MAX;
-    // last forward
+    // last forward (P, H, W, gx, gy are PER FRAME; a batched launch stacks B frames: B*P Gaussians on a gx x B*gy tile grid)
     int P = 0, H = 0, W = 0, C = 0, gx = 0, gy = 0;
+    int B = 1;
+    const GomCamera *cams = nullptr;  // device array of B cameras for a batched launch; nullptr: the by-value camera
     bool haveForward = false;
+    // per-frame parameter gradients of a batched frame call, summed by k_sum_frames
+    float *batch_grads = nullptr;
+    size_t capBatchGrads = 0;
     // per gaussian
     float *depth = nullptr;
     float2 *xy = nullptr;
@@ -130,6 +138,22 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
                               hipStream_t st);
 int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const float *colors, const float *dL_dcolor,
                                hipStream_t st);
+// batched (B frames per launch) geometry / loss launches behind the single-frame C-ABI entry points
+int gom_fk_forward_batch(int B, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream);
+int gom_lbs_forward_batch(int B, int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream);
+int gom_face_forward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                           float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream);
+int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
+                            float sigma, const float *d_xyz, const float *d_cov6, float *d_corner, float *d_so3, float *d_scale,
+                            const float *d_feat4, float *d_appearance, void *stream);
+int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
+                              const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
+                              float *d_xyz, float *dRT, void *stream);
+int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
+                      const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
+                      float *loss_partials, void *stream);
+int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
+                    float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
                                    const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
                                    float *dL_dopacity, float *dL_dmeans2D, hipStream_t st);

@@ -18,6 +18,13 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
                                                  const float *__restrict__ bg, float k_rgb, float k_mask,
                                                  float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials) {
     __shared__ float s_red[2][4];
+    {  // blockIdx.y = frame of a batched launch: [B][4][HW] images, [B][HW][3] targets, [B][3] backgrounds
+        const size_t fr = blockIdx.y;
+        pred += fr * 4 * HW; gt_rgb += fr * 3 * HW; gt_mask += fr * HW; bg += fr * 3; dpred += fr * 4 * HW;
+        partials += fr * 2 * gridDim.x;
+        if (shade) shade += fr * HW;
+        if (dshade) dshade += fr * HW;
+    }
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     float sum_rgb = 0.f, sum_mask = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
@@ -53,16 +60,23 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
 
 }  // namespace
 
-extern "C" int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
-                           const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                           float *loss_partials, void *stream) {
+int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
+                      const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
+                      float *loss_partials, void *stream) {
     if (H <= 0 || W <= 0) { gom_set_error("gom_l1_loss: bad image size"); return -1; }
     if (!pred || !gt_rgb || !gt_mask || !bg || !dL_dpred || !loss_partials) { gom_set_error("gom_l1_loss: null pointer"); return -1; }
     const int HW = H * W;
     const float k_rgb = grad_scale * c_rgb / (3.0f * (float)HW);
     const float k_mask = grad_scale * c_mask / (float)HW;
-    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
+    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
                        k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials);
     GOM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
+                           const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
+                           float *loss_partials, void *stream) {
+    return gom_l1_loss_batch(1, H, W, pred, shade, gt_rgb, gt_mask, bg, c_rgb, c_mask, grad_scale, dL_dpred, dL_dshade, loss_partials,
+                             stream);
 }

@@ -93,8 +93,18 @@ __device__ __forceinline__ void cov2d_from(const float *c6, const ProjJac &pj, f
 // One thread per Gaussian.  LDS_HIST: per-block tile histogram in LDS, flushed
 // with one global atomic per touched tile; otherwise direct global atomics
 // (tile grids too large for LDS).
+// Batched launches (B frames, see gom_batch_forward_backward): blockIdx.y = frame.  The frames are laid out as ONE
+// tall problem -- Gaussian i of frame b is global Gaussian b*P + i, tile (x, y) of frame b is tile (x, b*gy + y)
+// of a gx x (B*gy) grid -- so that scan, emit, sort and the segment kernels see a single, larger frame.  Only
+// the camera, the tile-row offset and (in the pixel kernels) the image addressing know about b.
+__device__ __forceinline__ GomCamera pick_camera(const GomCamera &cam, const GomCamera *__restrict__ cams, int b) {
+    GomCamera c = cam;
+    if (cams) c = cams[b];
+    return c;
+}
+
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const float *__restrict__ means,
+__global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
                                                     const float *__restrict__ cov6, const float *__restrict__ opacity,
                                                     float *__restrict__ depth, float2 *__restrict__ xy,
                                                     float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
@@ -105,7 +115,17 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_blockbase;
-    const int n_tiles = gx * gy;
+    const int n_tiles = gx * gy;  // per frame
+    const int fr = blockIdx.y;
+    const GomCamera cam = pick_camera(cam1, cams, fr);
+    {  // this frame's slice of every per-Gaussian / per-tile array
+        const size_t go = (size_t)fr * P;
+        means += 3 * go; cov6 += 6 * go; opacity += go; depth += go; xy += go; conic_opacity += go; tiles_touched += go;
+        rect += go; radii += go; pair_off += go;
+        if (radii_user) radii_user += go;
+        tile_count += (size_t)fr * n_tiles;
+    }
+    const int ty_off = fr * gy;  // tile rows of this frame in the stacked grid
     uint32_t my_tiles = 0;
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
@@ -169,7 +189,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam, int P, const 
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
         my_tiles = o_tiles;
-        rect[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+        rect[i] = make_ushort4((unsigned short)x0, (unsigned short)(y0 + ty_off), (unsigned short)x1, (unsigned short)(y1 + ty_off));
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
                 if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
@@ -277,17 +297,22 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
                                               const GomDevStatus *__restrict__ status) {
     extern __shared__ uint32_t s_mem[];
     if (status->overflow) return;
-    const int n_tiles = gx * gy;
+    const int n_tiles = gx * gy;  // per frame
+    const int fr = blockIdx.y;
     uint32_t *s_cnt = s_mem;
     uint32_t *s_base = s_mem + n_tiles;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool vis = (i < P) && (radii[i] > 0);
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)fr * P + il;  // global Gaussian id: the low key bits stay unique across the batch
+    const bool vis = (il < P) && (radii[i] > 0);
     ushort4 r = make_ushort4(0, 0, 0, 0);
     uint64_t key = 0;
     if (vis) {
         r = rect[i];
         key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
     }
+    tile_cursor += (size_t)fr * n_tiles;  // rect rows are stacked: bring them back to this frame's tile block
+    r.y -= (unsigned short)(vis ? fr * gy : 0);
+    r.w -= (unsigned short)(vis ? fr * gy : 0);
     if (LDS_AGG) {
         for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
         __syncthreads();
@@ -323,7 +348,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 // unique sort key), then conic -> cov2D -> (cov3D, mean3D) and the projection
 // term of the screen-space mean gradient.
 template <int C>
-__global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, const float *__restrict__ means,
+__global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
                                                         const float *__restrict__ cov6, const int32_t *__restrict__ radii,
                                                         const uint32_t *__restrict__ tiles_touched,
                                                         const float4 *__restrict__ conic_opacity,
@@ -335,6 +360,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam, int P, co
                                                         float *__restrict__ dL_dmeans2D) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    const int fr = blockIdx.y;
+    const GomCamera cam = pick_camera(cam1, cams, fr);
+    {
+        const size_t go = (size_t)fr * P;
+        means += 3 * go; cov6 += 6 * go; radii += go; tiles_touched += go; conic_opacity += go; pair_off += go;
+        dL_dmeans += 3 * go; dL_dcov6 += 6 * go; dL_dcolors += C * go; dL_dopacity += go;
+        if (dL_dmeans2D) dL_dmeans2D += 3 * go;
+    }
     float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float acc[GOM_PARTIAL_STRIDE];
 #pragma unroll
@@ -460,12 +493,13 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS, st);
+    const dim3 grid(blocks, s->B);
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), n_tiles * sizeof(uint32_t), st, cam, P, means3D, cov6,
+        hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), n_tiles * sizeof(uint32_t), st, cam, s->cams, P, means3D, cov6,
                            opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
                            s->tile_count, s->pair_off, s->status, s->gx, s->gy);
     else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, opacity, s->depth,
+        hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, opacity, s->depth,
                            s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
                            s->status, s->gx, s->gy);
     GOM_LAUNCH_CHECK();
@@ -478,17 +512,18 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st) {
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
-                           s->tile_nmax, n_tiles, s->status, cap);
+                           s->tile_nmax, n_tiles * s->B, s->status, cap);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_EMIT, st);
+    const dim3 grid(blocks, s->B);
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
-        hipLaunchKernelGGL(k_emit<true>, dim3(blocks), dim3(256), 2 * n_tiles * sizeof(uint32_t), st, P, s->depth, s->radii,
+        hipLaunchKernelGGL(k_emit<true>, grid, dim3(256), 2 * n_tiles * sizeof(uint32_t), st, P, s->depth, s->radii,
                            s->rect, s->tile_cursor, s->keys, s->gx, s->gy, s->status);
     else
-        hipLaunchKernelGGL(k_emit<false>, dim3(blocks), dim3(256), 0, st, P, s->depth, s->radii, s->rect, s->tile_cursor,
+        hipLaunchKernelGGL(k_emit<false>, grid, dim3(256), 0, st, P, s->depth, s->radii, s->rect, s->tile_cursor,
                            s->keys, s->gx, s->gy, s->status);
     GOM_LAUNCH_CHECK();
     return 0;
@@ -500,12 +535,13 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
+    const dim3 grid(blocks, s->B);
     if (C == 3)
-        hipLaunchKernelGGL(k_preprocess_bwd<3>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii,
+        hipLaunchKernelGGL(k_preprocess_bwd<3>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii,
                            s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
                            dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
     else
-        hipLaunchKernelGGL(k_preprocess_bwd<4>, dim3(blocks), dim3(256), 0, st, cam, P, means3D, cov6, s->radii,
+        hipLaunchKernelGGL(k_preprocess_bwd<4>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii,
                            s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
                            dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
     GOM_LAUNCH_CHECK();

@@ -264,7 +264,7 @@ __device__ __forceinline__ void sort_step_merge(uint64_t (&x)[8], const uint64_t
     }
 }
 
-template <bool MIRROR>
+template <bool MIRROR, int NT>
 __device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask, uint64_t *s_x, bool wave_active, uint32_t n) {
     // tmask = mask >> 3: partner thread = t ^ tmask; this thread owns the lower index iff the top bit of tmask is clear in t
     const uint32_t t = threadIdx.x;
@@ -289,36 +289,40 @@ __device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask
         __syncthreads();  // previous readers of s_x are done (idle waves only keep the barriers company)
         if (wave_active) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) s_x[r * 1024 + t] = x[r];  // transposed: conflict-free 8-byte lanes
+            for (int r = 0; r < 8; r++) s_x[r * NT + t] = x[r];  // transposed: conflict-free 8-byte lanes
         }
         __syncthreads();
         if (!wave_active) return;
         const bool partner_wrote = ((t ^ tmask) & ~63u) * 8 < n;  // padding-only waves wrote nothing: their keys are +inf
 #pragma unroll
-        for (int r = 0; r < 8; r++) y[r] = partner_wrote ? s_x[r * 1024 + (t ^ tmask)] : ~0ull;
+        for (int r = 0; r < 8; r++) y[r] = partner_wrote ? s_x[r * NT + (t ^ tmask)] : ~0ull;
     }
     sort_step_merge<MIRROR>(x, y, lower);
 }
 
-// One workgroup per tile.  Lists of up to 2^log_chunk (= 8192) keys are sorted entirely in registers / DPP / LDS.
+// One workgroup per tile.  Lists of up to 2^log_chunk (= 8 * NT) keys are sorted entirely in registers / DPP / LDS.
 // Longer lists (a handful of tiles at the 220k-Gaussian configuration) are cut into chunks of that size: pass 0
 // sorts every chunk, pass p > 0 runs stage log_chunk + p of the same network -- its strides >= one chunk as
 // global-memory steps, the rest again per chunk in registers.
-__global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
+// Two instantiations share the tiles: NT = 256 takes the lists of up to 2048 entries (16 KiB of LDS and 4 waves per
+// workgroup, so a CU holds 8 of them instead of 2 mostly idle 16-wave ones), NT = 1024 the longer ones.
+template <int NT>
+__global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t log_chunk) {
-    __shared__ uint64_t s_x[GOM_SORT_CAP_MAX];
+                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t log_chunk,
+                                               uint32_t small_max) {
+    __shared__ uint64_t s_x[8 * NT];
     if (status->overflow) return;
     const int tile = blockIdx.x;
     const uint32_t base = tile_base[tile];
     const uint32_t n = tile_base[tile + 1] - base;
-    if (n == 0) return;
+    if (n == 0 || (n <= small_max) != (NT == 256)) return;  // the other instantiation's tile
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
     // one 16-byte descriptor per segment: the segment kernels start from a single load
-    for (uint32_t i = threadIdx.x; i < nseg; i += 1024)
+    for (uint32_t i = threadIdx.x; i < nseg; i += NT)
         seg_desc[sb + i] = make_uint4((uint32_t)tile, base + i * GOM_SEG, min((uint32_t)GOM_SEG, n - i * GOM_SEG), i);
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t t = threadIdx.x;
@@ -332,8 +336,8 @@ __global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__rest
         const uint32_t m_hi = pass == 0 ? min(logN, LC) : LC + pass;
         const bool last = pass + 1 == npass;
         if (pass) {
-            global_mirror_step<1024>(keys + base, n, m_lo);
-            for (int q = (int)m_lo - 2; q >= (int)LC; q--) global_stride_step<1024>(keys + base, n, (uint32_t)q);
+            global_mirror_step<NT>(keys + base, n, m_lo);
+            for (int q = (int)m_lo - 2; q >= (int)LC; q--) global_stride_step<NT>(keys + base, n, (uint32_t)q);
         }
         for (uint32_t c = 0; c < nchunk; c++) {
             const uint32_t cbase = base + (c << LC);
@@ -351,8 +355,8 @@ __global__ void __launch_bounds__(1024, 8) k_sort(int gx, const uint32_t *__rest
                 sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
             }
             for (uint32_t m = m_lo; m <= m_hi; m++) {
-                if (m <= LC) sort_step_cross<true>(x, ((1u << m) - 1) >> 3, s_x, wave_active, cn);
-                for (int q = (int)min(m - 2, LC - 1); q >= 3; q--) sort_step_cross<false>(x, (1u << q) >> 3, s_x, wave_active, cn);
+                if (m <= LC) sort_step_cross<true, NT>(x, ((1u << m) - 1) >> 3, s_x, wave_active, cn);
+                for (int q = (int)min(m - 2, LC - 1); q >= 3; q--) sort_step_cross<false, NT>(x, (1u << q) >> 3, s_x, wave_active, cn);
                 if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); }
             }
             if (!last) {
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(256) k_gather_colors(const uint32_t *__restric
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
 // starts without walking the list serially.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                 const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
                                                 float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
                                                 const GomDevStatus *__restrict__ status) {
@@ -479,7 +483,7 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__
         const int pxi = q * 64 + lane;
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
-        const int tx = tile % gx, ty = tile / gx;
+        const int tx = tile % gx, ty = (tile / gx) % gy;  // row inside the tile's own frame (batched launches stack the frames)
         const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, const uint4 *__restrict__
 // contribution, T after it (negated if the stop rule fired inside) and the last contributor; the per-sub-range
 // pieces are kept as checkpoints for the backward.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_fwd(int gx, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+__global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, const uint4 *__restrict
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z, sb = seg - d.w;
         const uint32_t e0 = d.w * GOM_SEG;
-        const int tx = tile % gx, ty = tile / gx;
+        const int tx = tile % gx, ty = (tile / gx) % gy;  // row inside the tile's own frame (batched launches stack the frames)
         const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
@@ -671,7 +675,8 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, const uint4 *__restrict
 
 // ----------------------------------------------- forward, pass C (assembly) -
 template <int C>
-__global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+                                                     const GomCamera *__restrict__ cams,
                                                      const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_C,
                                                      const uint32_t *__restrict__ seg_last, float *__restrict__ seg_Tend,
                                                      float *__restrict__ seg_Sbehind, float *__restrict__ out_color,
@@ -679,14 +684,21 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, float
                                                      uint32_t *__restrict__ tile_nmax, const GomDevStatus *__restrict__ status) {
     __shared__ uint32_t s_nmax[4];
     const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)py * W + px;
-    const float bg[4] = {bg0, bg1, bg2, bg3};
+    out_color += (size_t)fr * C * HW;
+    final_T += (size_t)fr * HW;
+    n_contrib += (size_t)fr * HW;
+    float bg[4] = {bg0, bg1, bg2, bg3};
+    if (cams) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
+    }
     if (status->overflow) {  // pair buffers too small: poison loudly
         if (inside) {
             const float nanv = __uint_as_float(0x7fc00000u);
@@ -783,7 +795,8 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, float
 
 // ---------------------------------------------------------------- backward -
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+                                                  const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ tile_nmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
@@ -817,25 +830,30 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, float bg0
         for (int i = threadIdx.x; i < 4 * GOM_SUB * 10; i += 256) (&s_acc[0][0][0])[i] = 0.f;
         __syncthreads();
 
-        const int tx = tile % gx, ty = tile / gx;
+        const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
         const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
         const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
         const bool inside = px < W && py < H;
         const size_t pix = (size_t)py * W + px;
+        const size_t fpix = (size_t)fr * HW + pix;  // per-pixel state of the stacked frames
         const float pfx = (float)px, pfy = (float)py;
         const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
-        const uint32_t my_last = inside ? n_contrib[pix] : 0u;
+        const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
         const uint32_t wmax = wave_max_u32(my_last);
         const uint32_t s0 = e0 + (uint32_t)sub * GOM_SUB;  // list index of this wave's first entry
         if (wmax > s0) {
-            const float T_final = final_T[inside ? pix : 0];
+            const float T_final = final_T[inside ? fpix : 0];
             float dpix[C], bg_dot = 0.f;
             {
-                const float bg[4] = {bg0, bg1, bg2, bg3};
+                float bg[4] = {bg0, bg1, bg2, bg3};
+                if (cams) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
+                }
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) {
-                    dpix[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
+                    dpix[ch] = inside ? dL_dpix[((size_t)fr * C + ch) * HW + pix] : 0.f;
                     bg_dot += bg[ch] * dpix[ch];
                 }
             }
@@ -939,27 +957,36 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, float bg0
 }  // namespace
 
 int gom_launch_sort(GomState *s, hipStream_t st) {
-    const int n_tiles = s->gx * s->gy;
+    const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SORT, st);
-    hipLaunchKernelGGL(k_sort, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, (uint32_t)(31 - __builtin_clz((unsigned)s->sortCap)));
+    const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)s->sortCap));  // log2 of the chunk (13 unless a test lowered it)
+    // A single frame is latency-bound by its longest list: one launch.  A batch is throughput-bound: the short lists
+    // (the vast majority) go to 4-wave workgroups that pack 8 per CU.
+    const uint32_t small_max = s->B > 1 ? GOM_SORT_SMALL : 0u;
+    if (small_max) {
+        hipLaunchKernelGGL(k_sort<256>, dim3(n_tiles), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
+                           s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, lc < 11u ? lc : 11u, small_max);
+        GOM_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_sort<1024>, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
+                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, lc, small_max);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st) {
-    const int n_tiles = s->gx * s->gy;
+    const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     {
         GomKernelTimer timer(s, GOM_K_SEG_T, st);
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
             if (C == 3)
-                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->point_list, s->ent_geo, colors,
+                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
                                    s->ent_col, s->seg_T, s->sub_T, s->status);
             else
-                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->point_list, s->ent_geo, colors,
+                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
                                    s->ent_col, s->seg_T, s->sub_T, s->status);
         } else {  // only the colours changed: bring them into list order
             if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
@@ -970,7 +997,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     {
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
+    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
                        s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
@@ -979,8 +1006,8 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     {
         GomKernelTimer timer(s, GOM_K_COMBINE, st);
 #define GOM_CF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, cam.bg[0], cam.bg[1], cam.bg[2], \
-                       cam.bg[3], s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
+    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
                        s->n_contrib, s->tile_nmax, s->status)
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
@@ -992,12 +1019,12 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const float *colors, const float *dL_dcolor,
                                hipStream_t st) {
     (void)colors;  // already in list order (ent_col) from the forward / checkpoint re-creation
-    const int n_tiles = s->gx * s->gy;
+    const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #define GOM_SB(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->H, s->W, s->gx, cam.bg[0], cam.bg[1], cam.bg[2], \
-                       cam.bg[3], s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->cams, s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
                        s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB

@@ -7,9 +7,13 @@ frame-parallel trainer and by smoke().
        -> splat backward -> face backward -> vertex gather + LBS backward
 
 i.e. reference models/model.py:213-250 + models/modules/renderer/gaussian.py:22-100
-+ train.py:53-55,101-111 and the autograd backward of all of it, as 16 kernel
++ train.py:53-55,101-111 and the autograd backward of all of it, as 17 kernel
 launches on one stream.  Gradients land in `self.grads` (vertices (3,N), so3
 (3,F), scale (3,F), appearance (3,F)) and are bitwise reproducible.
+
+`batch=B > 1` runs B frames through the SAME 17 launches (every kernel covers
+all B frames; `gom_batch_forward_backward`): per-frame tensors get a leading B
+dimension, the gradients are the sum over the B frames.
 """
 from __future__ import annotations
 
@@ -25,7 +29,7 @@ from .rasterizer import RasterState
 
 class RenderStep:
     def __init__(self, faces: torch.Tensor, n_verts: int, img_hw, lbs_weights: torch.Tensor, sigma: float = 1e-3,
-                 c_rgb: float = 1.0, c_mask: float = 5.0, device: Optional[torch.device] = None):
+                 c_rgb: float = 1.0, c_mask: float = 5.0, device: Optional[torch.device] = None, batch: int = 1):
         self.lib = _lib.load()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         dev = self.device
@@ -37,25 +41,32 @@ class RenderStep:
         assert self.lbs_weights.shape == (N_JOINTS + 1, self.N)
         f32 = dict(dtype=torch.float32, device=dev)
         N, F, H, W = self.N, self.F, self.H, self.W
+        self.B = int(batch)
+        assert self.B >= 1
+        lead = () if self.B == 1 else (self.B,)   # per-frame tensors: leading batch dimension when B > 1
         self.state = RasterState()
         # forward intermediates
-        self.RT = torch.empty((N_JOINTS, 12), **f32)
-        self.fk_save = torch.empty((N_JOINTS, 32), **f32)
-        self.v_obs = torch.empty((3, N), **f32)
-        self.xyz = torch.empty((F, 3), **f32)
-        self.cov6 = torch.empty((F, 6), **f32)
-        self.feat = torch.ones((F, 4), **f32)       # rgb + constant 1 (alpha channel), gaussian.py:49
-        self.opacity = torch.ones((F,), **f32)      # model.py:242
-        self.image = torch.empty((4, H, W), **f32)  # albedo rgb + mask, CHW
-        self.radii = torch.empty((F,), dtype=torch.int32, device=dev)
-        self.loss_partials = torch.zeros((_lib.GOM_LOSS_BLOCKS, 2), **f32)
+        self.RT = torch.empty(lead + (N_JOINTS, 12), **f32)
+        self.fk_save = torch.empty(lead + (N_JOINTS, 32), **f32)
+        self.v_obs = torch.empty(lead + (3, N), **f32)
+        self.xyz = torch.empty(lead + (F, 3), **f32)
+        self.cov6 = torch.empty(lead + (F, 6), **f32)
+        self.feat = torch.ones(lead + (F, 4), **f32)       # rgb + constant 1 (alpha channel), gaussian.py:49
+        self.opacity = torch.ones(lead + (F,), **f32)      # model.py:242
+        self.image = torch.empty(lead + (4, H, W), **f32)  # albedo rgb + mask, CHW
+        self.radii = torch.empty(lead + (F,), dtype=torch.int32, device=dev)
+        self.loss_partials = torch.zeros(lead + (_lib.GOM_LOSS_BLOCKS, 2), **f32)
         # backward intermediates
-        self.d_image = torch.empty((4, H, W), **f32)
-        self.d_xyz = torch.empty((F, 3), **f32)
-        self.d_cov6 = torch.empty((F, 6), **f32)
-        self.d_feat = torch.empty((F, 4), **f32)
-        self.d_opacity = torch.empty((F,), **f32)
-        self.d_corner = torch.empty((F, 3, 3), **f32)
+        self.d_image = torch.empty(lead + (4, H, W), **f32)
+        self.d_xyz = torch.empty(lead + (F, 3), **f32)
+        self.d_cov6 = torch.empty(lead + (F, 6), **f32)
+        self.d_feat = torch.empty(lead + (F, 4), **f32)
+        self.d_opacity = torch.empty(lead + (F,), **f32)
+        self.d_corner = torch.empty(lead + (F, 3, 3), **f32)
+        # device-resident cameras of a batched call (one GomCamera per frame) + pinned staging
+        self.cams_dev = torch.zeros((self.B, ctypes.sizeof(_lib.GomCamera)), dtype=torch.uint8, device=dev)
+        self._cams_host = torch.zeros((self.B, ctypes.sizeof(_lib.GomCamera)), dtype=torch.uint8).pin_memory() \
+            if dev.type == "cuda" else None
         self.grads: Dict[str, torch.Tensor] = {
             "vertices": torch.empty((3, N), **f32), "so3": torch.empty((3, F), **f32), "scale": torch.empty((3, F), **f32),
             "appearance": torch.empty((3, F), **f32)}
@@ -63,9 +74,24 @@ class RenderStep:
         self._frame = None
 
     # -- inputs ---------------------------------------------------------------
+    def set_cameras(self, Ks, Es, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
+        """One (K, E) per frame of the batch -> device camera array (async copy on the current stream)."""
+        assert len(Ks) == self.B and len(Es) == self.B
+        for b in range(self.B):
+            cam = self._make_camera(Ks[b], Es[b], bg4)
+            self._cams_host[b] = torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8)
+            if b == 0:
+                self.cam = cam
+        self.cams_dev.copy_(self._cams_host, non_blocking=True)
+
     def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
         """K (3,3), E (4,4) host arrays/tensors -> rasterizer camera, as
         gaussian.py:30-47,53-66 (znear 0.001, zfar 100)."""
+        if self.B > 1:
+            return self.set_cameras([K] * self.B, [E] * self.B, bg4)
+        self.cam = self._make_camera(K, E, bg4)
+
+    def _make_camera(self, K, E, bg4):
         import math
         import numpy as np
         K = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32).reshape(3, 3)
@@ -79,7 +105,7 @@ class RenderStep:
                           [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]], dtype=np.float32)
         view = np.ascontiguousarray(E.T)
         proj = (E.T @ K_ndc.T).astype(np.float32)
-        self.cam = _lib.make_camera(h, w, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
+        return _lib.make_camera(h, w, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
 
     # -- one frame --------------------------------------------------------------
     def _frame_struct(self) -> "_lib.GomFrame":
@@ -97,10 +123,11 @@ class RenderStep:
 
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
                          target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False) -> None:
-        """One native call (`gom_frame_forward_backward`) that enqueues the 17 kernels of the frame.
+        """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 17 kernels.
         params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
         frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
-        target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors."""
+        target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors.
+        With batch=B > 1 every frame/target tensor has a leading B dimension."""
         P = _lib.ptr
         f = self._frame
         if f is None:
@@ -112,15 +139,20 @@ class RenderStep:
         g = self.grads
         f.g_vertices, f.g_so3, f.g_scale, f.g_appearance = P(g["vertices"]), P(g["so3"]), P(g["scale"]), P(g["appearance"])
         flags = (0 if backward else _lib.GOM_FRAME_FORWARD_ONLY) | (_lib.GOM_FRAME_USE_GRAPH if graph else 0)
-        _lib.check(self.lib.gom_frame_forward_backward(self.state.handle, ctypes.byref(f), flags, _lib.stream_ptr()))
+        if self.B == 1:
+            _lib.check(self.lib.gom_frame_forward_backward(self.state.handle, ctypes.byref(f), flags, _lib.stream_ptr()))
+        else:
+            _lib.check(self.lib.gom_batch_forward_backward(self.state.handle, ctypes.byref(f), self.B, P(self.cams_dev), flags,
+                                                           _lib.stream_ptr()))
 
     def losses(self):
-        """(L_rgb, L_mask) of the last frame as 0-d device tensors."""
-        s = self.loss_partials.sum(0)
-        return s[0] / (3.0 * self.H * self.W), s[1] / float(self.H * self.W)
+        """(L_rgb, L_mask) of the last frame as 0-d device tensors ((B,) tensors when batched)."""
+        s = self.loss_partials.sum(-2)
+        return s[..., 0] / (3.0 * self.H * self.W), s[..., 1] / float(self.H * self.W)
 
     def rgb_mask(self):
-        """Last rendered (1,H,W,3) albedo and (1,H,W) mask, the layout
-        gaussian.py:93-100 returns."""
-        pred = self.image.permute(1, 2, 0)[None]
+        """Last rendered (B,H,W,3) albedo and (B,H,W) mask, the layout
+        gaussian.py:93-100 returns (B = 1 unless batched)."""
+        img = self.image if self.B > 1 else self.image[None]
+        pred = img.permute(0, 2, 3, 1)
         return pred[..., :3], pred[..., 3]

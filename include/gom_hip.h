@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 1
+#define GOM_ABI_VERSION 2
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -199,6 +199,18 @@ typedef struct GomFrame {
 #define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
                                        hipGraph on first use and replay it afterwards: one submission instead of 17 */
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
+
+/* B frames in ONE launch sequence (the same 17 kernels, each over all B frames): the launch-latency- and tail-bound
+ * kernels of a single 512x512 frame become B times larger launches, which is what fills 256 CUs.  The reference has
+ * batch size 1 (train.py:309-349); a batch here is B frames whose gradients are SUMMED, i.e. one optimizer step on B
+ * frames, the same semantics as the frame-parallel all-reduce across GPUs.
+ *   - every per-frame input, output and scratch pointer of `f` (cnl_gtfms, dst_Rs, dst_Ts, gt_rgb, gt_mask, bgcolor,
+ *     image, loss_partials, work_*) carries a leading dimension B; parameters, topology and the g_* gradient
+ *     outputs (sum over the B frames, accumulated in frame order: bitwise reproducible) keep their single-frame shapes;
+ *   - `cams_device` is a DEVICE array of B GomCamera (same H, W as f->cam; view/proj/bg/tanfov per frame): a replayed
+ *     hipGraph picks up new cameras without re-capture.  f->cam only provides H and W.
+ *   - results are bit-identical to B separate gom_frame_forward_backward calls. */
+int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_t B, const GomCamera *cams_device, uint32_t flags, void *stream);
 
 #ifdef __cplusplus
 }

@@ -85,13 +85,16 @@ __global__ void k_swap(float *out, unsigned long long *cyc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 int main() {
-    float *out; unsigned long long *cyc, h;
-    hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 8);
-    struct { const char *name; int threads; } cfgs[] = {{"1 wave/SIMD (256 thr)", 256}, {"4 waves/SIMD (1024 thr)", 1024}};
+    float *out; unsigned long long *cyc, h; hipEvent_t e0, e1; float ms; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMalloc(&out, 1 << 26); hipMalloc(&cyc, 8);
+    struct { const char *name; int threads, blocks; } cfgs[] = {{"1 wave/SIMD (256 thr), 1 block", 256, 1}, {"4 waves/SIMD (1024 thr), 1 block", 1024, 1},
+                                                                {"4 waves/SIMD, 256 blocks (whole chip)", 1024, 256}, {"8 waves/SIMD, 512 blocks (whole chip)", 1024, 512}};
     for (auto &c : cfgs) {
-        printf("== %s, 1 block: cycles per instruction (per wave) ==\n", c.name);
-#define RUN(K, ...) for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(K, dim3(1), dim3(c.threads), 0, 0, out, cyc, ##__VA_ARGS__); hipDeviceSynchronize(); } \
-        hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); printf("  %-14s %.2f\n", #K, (double)h / (ITERS * 10.0));
+        printf("== %s: cycles per instruction (per wave, block 0) ==\n", c.name);
+#define RUN(K, ...) for (int rep = 0; rep < 2; rep++) { hipEventRecord(e0, 0); hipLaunchKernelGGL(K, dim3(c.blocks), dim3(c.threads), 0, 0, out, cyc, ##__VA_ARGS__); hipEventRecord(e1, 0); hipDeviceSynchronize(); } \
+        hipEventElapsedTime(&ms, e0, e1); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); \
+        printf("  %-14s %.2f cycles/instr (wave 0 counter)   kernel %.1f us -> %.2f ns per wave-instr per SIMD\n", #K, (double)h / (ITERS * 10.0), ms * 1e3, \
+               ms * 1e6 / (ITERS * 10.0 * ((double)c.blocks * c.threads / 64 / (c.blocks < 256 ? 4.0 * c.blocks : 1024.0))));
         RUN(k_fma) RUN(k_chain) RUN(k_dpp) RUN(k_bcast) RUN(k_readlane, 3) RUN(k_swap)
     }
     return 0;
