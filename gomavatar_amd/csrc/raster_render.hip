@@ -145,61 +145,15 @@ __device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float
 }
 
 // ---------------------------------------------------------------- sort ------
-// Normalised bitonic network on n unique 64-bit keys: every comparator orders
-// ascending, so indices >= n behave as +inf padding and are simply skipped.
-// The two step kinds below work on the list in global memory (only used for the
-// strides that span more than one register-sorted chunk, see k_sort); 4
-// comparators per thread per trip with all loads issued first.
-template <int NT>
-__device__ __forceinline__ void global_mirror_step(uint64_t *keys, uint32_t n, uint32_t m) {
-    const uint32_t k = 1u << m, half = k >> 1;
-    const uint32_t total = ((n + k - 1) >> m) << (m - 1);
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
-        uint32_t lo[4], hi[4];
-        uint64_t a[4], b[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + NT * u;
-            const uint32_t blk = i >> (m - 1), off = i & (half - 1);
-            lo[u] = (blk << m) + off;
-            hi[u] = (blk << m) + (k - 1 - off);
-            ok[u] = i < total && hi[u] < n;
-            if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[hi[u]]; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[hi[u]] = a[u]; }
-    }
-    __syncthreads();
-}
-template <int NT>
-__device__ __forceinline__ void global_stride_step(uint64_t *keys, uint32_t n, uint32_t q) {
-    const uint32_t j = 1u << q;
-    const uint32_t total = ((n + 2 * j - 1) >> (q + 1)) << q;
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += NT * 4) {
-        uint32_t lo[4];
-        uint64_t a[4], b[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + NT * u;
-            lo[u] = ((i >> q) << (q + 1)) + (i & (j - 1));
-            ok[u] = i < total && lo[u] + j < n;
-            if (ok[u]) { a[u] = keys[lo[u]]; b[u] = keys[lo[u] + j]; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (ok[u] && a[u] > b[u]) { keys[lo[u]] = b[u]; keys[lo[u] + j] = a[u]; }
-    }
-    __syncthreads();
-}
-
-// Register-resident bitonic sort: 8 keys per thread (element i = 8*thread + r).  In the normalised network every
-// step pairs element i with i ^ mask (mask = 2^m - 1 for the mirror step of stage m, a power of two otherwise) and
-// leaves the minimum at the lower index.  mask < 8 stays inside a thread, mask < 512 inside a wave (ds_bpermute
-// shuffles, no barrier), and only masks >= 512 go through LDS -- 10 barrier-fenced exchanges for 8192 keys
-// instead of 91.
+// Per-tile merge sort of the unique 64-bit keys (depth_bits << 32 | gaussian): identical to the reference's stable
+// radix order on (tile, depth bits) because ties in depth fall back to the Gaussian index.
+//
+// Every thread owns 8 consecutive list positions.  It sorts its 8 keys in registers (19 compare-exchanges), then
+// log2(n/8) merge levels follow: the sorted runs of length L sit in LDS, each thread finds by binary search
+// ("merge path") where its 8 outputs start in the two runs being merged and merges 8 elements sequentially.
+// O(n log n) work instead of the O(n log^2 n) of a bitonic network -- 4-5x fewer instructions at n = 2048..8192,
+// which matters because a batched launch is VALU-bound here (scripts/ubench/dpp_bench.hip: ~2.6 cycles per wave
+// instruction per SIMD at best).
 __device__ __forceinline__ void cmpswap(uint64_t &lo, uint64_t &hi) {
     const uint64_t a = lo, b = hi;
     const bool sw = a > b;
@@ -214,107 +168,96 @@ __device__ __forceinline__ void sort_step_regs(uint64_t (&x)[8]) {
         if ((r ^ MASK) > r) cmpswap(x[r], x[r ^ MASK]);
 }
 
-// lane ^ MASK exchange of one dword without touching LDS: DPP quad/row permutes for MASK < 16,
-// v_permlane16_swap / v_permlane32_swap (gfx950) for the row and half-wave bits.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t xor16(uint32_t v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    return ((threadIdx.x >> 4) & 1) ? r[0] : r[1];   // odd rows: vdst now holds the even neighbour, even rows: src0 holds the odd one
-}
-__device__ __forceinline__ uint32_t xor32(uint32_t v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return ((threadIdx.x >> 5) & 1) ? r[0] : r[1];
-}
-template <int MASK>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-    if constexpr (MASK == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
-    else if constexpr (MASK == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
-    else if constexpr (MASK == 3) return dpp_mov<0x1B>(v);                  // quad_perm [3,2,1,0]
-    else if constexpr (MASK == 7) return dpp_mov<0x141>(v);                 // row_half_mirror
-    else if constexpr (MASK == 15) return dpp_mov<0x140>(v);                // row_mirror
-    else if constexpr (MASK == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // (l^7)^3
-    else if constexpr (MASK == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v)); // (l^15)^7
-    else if constexpr (MASK == 16) return xor16(v);
-    else if constexpr (MASK == 32) return xor32(v);
-    else if constexpr (MASK == 31) return xor16(dpp_mov<0x140>(v));
-    else if constexpr (MASK == 63) return xor32(xor16(dpp_mov<0x140>(v)));
-    else return 0;
-}
-template <int MASK>
-__device__ __forceinline__ void lanes_xor_u64x8(const uint64_t (&x)[8], uint64_t (&y)[8]) {
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t lo = lane_xor<MASK>((uint32_t)x[r]);
-        const uint32_t hi = lane_xor<MASK>((uint32_t)(x[r] >> 32));
-        y[r] = ((uint64_t)hi << 32) | lo;
-    }
+// normalised bitonic network on 8 registers (every comparator ascending)
+__device__ __forceinline__ void sort8_regs(uint64_t (&x)[8]) {
+    sort_step_regs<1>(x);
+    sort_step_regs<3>(x); sort_step_regs<1>(x);
+    sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
 }
 
-// partner keys arrive in y[]; keep the minimum when this thread owns the lower index
-template <bool MIRROR>
-__device__ __forceinline__ void sort_step_merge(uint64_t (&x)[8], const uint64_t (&y)[8], bool lower) {
+// Outputs [o, o+8) of the merge of the sorted runs A = src[0, la) and B = src[L, L + lb)  (la, lb = real lengths;
+// positions past la + lb yield +inf).  PTR: LDS or global pointer to uint64_t.
+template <typename PTR>
+__device__ __forceinline__ void merge8(PTR src, uint32_t L, uint32_t la, uint32_t lb, uint32_t o, uint64_t (&out)[8]) {
+    const uint64_t INF = ~0ull;
+    if (o >= la + lb) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint64_t o = y[MIRROR ? 7 - r : r];
-        const bool take = (o < x[r]) == lower;  // keys are unique (or both +inf padding, where either choice is the same)
-        x[r] = take ? o : x[r];
+        for (int k = 0; k < 8; k++) out[k] = INF;
+        return;
     }
-}
-
-template <bool MIRROR, int NT>
-__device__ __forceinline__ void sort_step_cross(uint64_t (&x)[8], uint32_t tmask, uint64_t *s_x, bool wave_active, uint32_t n) {
-    // tmask = mask >> 3: partner thread = t ^ tmask; this thread owns the lower index iff the top bit of tmask is clear in t
-    const uint32_t t = threadIdx.x;
-    const bool lower = (t & (1u << (31 - __builtin_clz(tmask)))) == 0;
-    uint64_t y[8];
-    if (tmask < 64) {
-        if (!wave_active) return;  // this wave holds only +inf padding (wave-uniform)
-        switch (tmask) {  // wave-uniform
-            case 1: lanes_xor_u64x8<1>(x, y); break;
-            case 2: lanes_xor_u64x8<2>(x, y); break;
-            case 3: lanes_xor_u64x8<3>(x, y); break;
-            case 4: lanes_xor_u64x8<4>(x, y); break;
-            case 7: lanes_xor_u64x8<7>(x, y); break;
-            case 8: lanes_xor_u64x8<8>(x, y); break;
-            case 15: lanes_xor_u64x8<15>(x, y); break;
-            case 16: lanes_xor_u64x8<16>(x, y); break;
-            case 31: lanes_xor_u64x8<31>(x, y); break;
-            case 32: lanes_xor_u64x8<32>(x, y); break;
-            default: lanes_xor_u64x8<63>(x, y); break;
+    // merge path: i = how many of the first o outputs come from A
+    uint32_t lo = o > lb ? o - lb : 0u, hi = o < la ? o : la;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t a = src[mid], b = src[L + (o - 1 - mid)];
+        if (a < b) lo = mid + 1; else hi = mid;
+    }
+    uint32_t i = lo, j = o - lo;
+    uint64_t a = i < la ? src[i] : INF;
+    uint64_t b = j < lb ? src[L + j] : INF;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const bool take = a <= b;   // unique keys; +inf only ever ties with +inf
+        out[k] = take ? a : b;
+        i += take ? 1u : 0u;
+        j += take ? 0u : 1u;
+        if (k < 7) {
+            const bool ok = take ? (i < la) : (j < lb);
+            const uint64_t v = ok ? src[take ? i : L + j] : INF;
+            a = take ? v : a;
+            b = take ? b : v;
         }
-    } else {
-        __syncthreads();  // previous readers of s_x are done (idle waves only keep the barriers company)
-        if (wave_active) {
+    }
+}
+
+// Sorts keys[0, n) (n <= 8 * NT) in place in registers + LDS; on return thread t holds positions 8t .. 8t+7 in x.
+template <int NT>
+__device__ __forceinline__ void block_merge_sort(const uint64_t *__restrict__ keys, uint32_t n, uint64_t *s_x, uint64_t (&x)[8]) {
+    const uint32_t t = threadIdx.x;
+    uint32_t n_pad = 8;
+    while (n_pad < n) n_pad <<= 1;
+    const bool active = 8 * t < n_pad;
+    // coalesced (striped) global loads, then blocked ownership (8 consecutive positions per thread) through LDS
 #pragma unroll
-            for (int r = 0; r < 8; r++) s_x[r * NT + t] = x[r];  // transposed: conflict-free 8-byte lanes
+    for (int r = 0; r < 8; r++) {
+        const uint32_t i = (uint32_t)r * NT + t;
+        if ((uint32_t)r * NT < n_pad) s_x[i] = i < n ? keys[i] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = active ? s_x[8 * t + r] : ~0ull;
+    if (active) sort8_regs(x);
+    for (uint32_t L = 8; L < n_pad; L <<= 1) {
+        __syncthreads();  // readers of the previous level are done
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) *reinterpret_cast<ulonglong2 *>(s_x + 8 * t + r) = make_ulonglong2(x[r], x[r + 1]);
         }
         __syncthreads();
-        if (!wave_active) return;
-        const bool partner_wrote = ((t ^ tmask) & ~63u) * 8 < n;  // padding-only waves wrote nothing: their keys are +inf
-#pragma unroll
-        for (int r = 0; r < 8; r++) y[r] = partner_wrote ? s_x[r * NT + (t ^ tmask)] : ~0ull;
+        if (active) {
+            const uint32_t pbase = (8 * t) & ~(2 * L - 1), o = 8 * t - pbase;
+            const uint32_t la = n > pbase ? min(L, n - pbase) : 0u;
+            const uint32_t lb = n > pbase + L ? min(L, n - pbase - L) : 0u;
+            merge8(s_x + pbase, L, la, lb, o, x);
+        }
     }
-    sort_step_merge<MIRROR>(x, y, lower);
 }
 
-// One workgroup per tile.  Lists of up to 2^log_chunk (= 8 * NT) keys are sorted entirely in registers / DPP / LDS.
-// Longer lists (a handful of tiles at the 220k-Gaussian configuration) are cut into chunks of that size: pass 0
-// sorts every chunk, pass p > 0 runs stage log_chunk + p of the same network -- its strides >= one chunk as
-// global-memory steps, the rest again per chunk in registers.
-// Two instantiations share the tiles: NT = 256 takes the lists of up to 2048 entries (16 KiB of LDS and 4 waves per
-// workgroup, so a CU holds 8 of them instead of 2 mostly idle 16-wave ones), NT = 1024 the longer ones.
+// One workgroup per tile.  Lists of up to 2^log_chunk (= 8 * NT) keys are sorted in registers + LDS.  Longer lists
+// (a handful of tiles at the 220k-Gaussian configuration) are cut into chunks of that size, each sorted as above,
+// and the chunks are then merged level by level in global memory (ping-pong with `scratch`).
+// Two instantiations share the tiles of a batched launch: NT = 256 takes the lists of up to 2048 entries (16 KiB
+// of LDS and 4 waves per workgroup, so a CU holds 8 of them instead of 2 mostly idle 16-wave ones), NT = 1024 the
+// longer ones.
 template <int NT>
 __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                               float2 *__restrict__ ent_geo, const GomDevStatus *__restrict__ status, uint32_t log_chunk,
-                                               uint32_t small_max) {
-    __shared__ uint64_t s_x[8 * NT];
+                                               float2 *__restrict__ ent_geo, uint64_t *__restrict__ scratch,
+                                               const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * NT];
     if (status->overflow) return;
     const int tile = blockIdx.x;
     const uint32_t base = tile_base[tile];
@@ -326,79 +269,91 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
         seg_desc[sb + i] = make_uint4((uint32_t)tile, base + i * GOM_SEG, min((uint32_t)GOM_SEG, n - i * GOM_SEG), i);
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t t = threadIdx.x;
-    const uint32_t LC = log_chunk;
-    uint32_t logN = 3;
-    while ((1u << logN) < n) logN++;
-    const uint32_t nchunk = (n + (1u << LC) - 1) >> LC;
-    const uint32_t npass = logN > LC ? logN - LC + 1 : 1;
-    for (uint32_t pass = 0; pass < npass; pass++) {
-        const uint32_t m_lo = pass == 0 ? 4 : LC + pass;
-        const uint32_t m_hi = pass == 0 ? min(logN, LC) : LC + pass;
-        const bool last = pass + 1 == npass;
-        if (pass) {
-            global_mirror_step<NT>(keys + base, n, m_lo);
-            for (int q = (int)m_lo - 2; q >= (int)LC; q--) global_stride_step<NT>(keys + base, n, (uint32_t)q);
-        }
-        for (uint32_t c = 0; c < nchunk; c++) {
-            const uint32_t cbase = base + (c << LC);
-            const uint32_t cn = min(1u << LC, n - (c << LC));
-            uint64_t x[8];
+    const uint32_t CH = 1u << log_chunk;
+    if (n <= CH) {
+        uint64_t x[8];
+        block_merge_sort<NT>(keys + base, n, s_x, x);
+        // blocked -> striped through LDS (thread t: positions t, NT + t, ...): every store of the write-out below is
+        // then a contiguous run per wave instead of 64 separate cache lines
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t i = 8 * t + r;
-                x[r] = i < cn ? keys[cbase + i] : ~0ull;  // +inf padding never moves down: every comparator sorts ascending
+        for (int r = 0; r < 8; r += 2) *reinterpret_cast<ulonglong2 *>(s_x + 8 * t + r) = make_ulonglong2(x[r], x[r + 1]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = s_x[r * NT + t];
+        // write-out, 4 entries per trip: their gathers are issued before the first dependent store
+        // (8 at once would push the kernel past 64 VGPRs and halve the workgroups per CU)
+#pragma unroll
+        for (int r0 = 0; r0 < 8; r0 += 4) {
+            if ((uint32_t)r0 * NT >= n) break;  // block-uniform: nothing left in the upper stripes
+            ushort4 rc[4];
+            uint32_t po[4];
+            float2 cxy[4];
+            float4 cco[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (uint32_t)(r0 + u) * NT + t;
+                const uint32_t g = i < n ? (uint32_t)x[r0 + u] : 0u;
+                rc[u] = rect[g];
+                po[u] = pair_off[g];
+                cxy[u] = xy[g];
+                cco[u] = conic_opacity[g];
             }
-            const bool wave_active = (t & ~63u) * 8 < cn;  // waves past the chunk only hold padding
-            if (pass == 0 && wave_active) {  // stages m = 1..3 live entirely in registers
-                sort_step_regs<1>(x);
-                sort_step_regs<3>(x); sort_step_regs<1>(x);
-                sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
-            }
-            for (uint32_t m = m_lo; m <= m_hi; m++) {
-                if (m <= LC) sort_step_cross<true, NT>(x, ((1u << m) - 1) >> 3, s_x, wave_active, cn);
-                for (int q = (int)min(m - 2, LC - 1); q >= 3; q--) sort_step_cross<false, NT>(x, (1u << q) >> 3, s_x, wave_active, cn);
-                if (wave_active) { sort_step_regs<4>(x); sort_step_regs<2>(x); sort_step_regs<1>(x); }
-            }
-            if (!last) {
 #pragma unroll
-                for (int r = 0; r < 8; r++)
-                    if (8 * t + r < cn) keys[cbase + 8 * t + r] = x[r];
-                continue;
-            }
-            // write-out, 4 entries per trip: their gathers are issued before the first dependent store
-            // (8 at once would push the kernel past 64 VGPRs and halve the workgroups per CU)
-#pragma unroll
-            for (int r0 = 0; r0 < 8; r0 += 4) {
-                ushort4 rc[4];
-                uint32_t po[4];
-                float2 cxy[4];
-                float4 cco[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = 8 * t + r0 + u;
-                    const uint32_t g = i < cn ? (uint32_t)x[r0 + u] : 0u;
-                    rc[u] = rect[g];
-                    po[u] = pair_off[g];
-                    cxy[u] = xy[g];
-                    cco[u] = conic_opacity[g];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = 8 * t + r0 + u;
-                    if (i < cn) {
-                        const uint32_t g = (uint32_t)x[r0 + u];
-                        keys[cbase + i] = x[r0 + u];
-                        point_list[cbase + i] = g;
-                        const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
-                        pair_pos[po[u] + k] = cbase + i;
-                        // geometry of the entry in LIST order: the compositing kernels read it contiguously
-                        float2 *dst = ent_geo + 3 * (size_t)(cbase + i);
-                        dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
-                    }
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (uint32_t)(r0 + u) * NT + t;
+                if (i < n) {
+                    const uint32_t g = (uint32_t)x[r0 + u];
+                    keys[base + i] = x[r0 + u];
+                    point_list[base + i] = g;
+                    const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
+                    pair_pos[po[u] + k] = base + i;
+                    // geometry of the entry in LIST order: the compositing kernels read it contiguously
+                    float2 *dst = ent_geo + 3 * (size_t)(base + i);
+                    dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
                 }
             }
         }
-        if (!last) __syncthreads();  // the chunk write-backs are visible to the next pass's global steps
+        return;
+    }
+    // ---- rare: list longer than one chunk
+    for (uint32_t c0 = 0; c0 < n; c0 += CH) {
+        const uint32_t cn = min(CH, n - c0);
+        uint64_t x[8];
+        block_merge_sort<NT>(keys + base + c0, cn, s_x, x);
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            if (8 * t + r < cn) keys[base + c0 + 8 * t + r] = x[r];
+        __syncthreads();  // s_x is re-used by the next chunk
+    }
+    uint64_t *src = keys + base, *dst = scratch + base;
+    for (uint32_t L = CH; L < n; L <<= 1) {
+        __syncthreads();  // the previous level's (or the chunk sorts') global writes are visible to the block
+        for (uint32_t o8 = 8 * t; o8 < n; o8 += 8 * NT) {
+            const uint32_t pbase = o8 & ~(2 * L - 1);
+            const uint32_t la = min(L, n - pbase);
+            const uint32_t lb = n > pbase + L ? min(L, n - pbase - L) : 0u;
+            uint64_t y[8];
+            merge8(src + pbase, L, la, lb, o8 - pbase, y);
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (o8 + r < n) dst[o8 + r] = y[r];
+        }
+        uint64_t *tmp = src; src = dst; dst = tmp;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += NT) {
+        const uint64_t key = src[i];
+        const uint32_t g = (uint32_t)key;
+        keys[base + i] = key;   // (a no-op copy when the last level landed in `keys`)
+        point_list[base + i] = g;
+        const ushort4 rc = rect[g];
+        const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
+        pair_pos[pair_off[g] + k] = base + i;
+        const float2 c = xy[g];
+        const float4 co = conic_opacity[g];
+        float2 *d2 = ent_geo + 3 * (size_t)(base + i);
+        d2[0] = c; d2[1] = make_float2(co.x, co.y); d2[2] = make_float2(co.z, co.w);
     }
 }
 
@@ -966,11 +921,13 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     const uint32_t small_max = s->B > 1 ? GOM_SORT_SMALL : 0u;
     if (small_max) {
         hipLaunchKernelGGL(k_sort<256>, dim3(n_tiles), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                           s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, lc < 11u ? lc : 11u, small_max);
+                           s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial),
+                           s->status, lc < 11u ? lc : 11u, small_max);
         GOM_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_sort<1024>, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, s->status, lc, small_max);
+                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial), s->status,
+                       lc, small_max);
     GOM_LAUNCH_CHECK();
     return 0;
 }
