@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
     ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames cycled through")
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU, rendered by one batched launch sequence")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
                          "1 = strictly one step after the other")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the 17 kernels of a frame one by one instead of replaying a hipGraph")
@@ -208,6 +208,14 @@ def main():
             nd, _ = sl["step"].state.poll()
             acc["D"] = acc.get("D", 0) + nd
             n_prof += 1
+    # the same kernels with ONE step in flight (nothing else on the GPU): what a launch costs when it owns the chip
+    iso, n_iso = {}, 8
+    for r in range(n_iso):
+        torch.cuda.synchronize()
+        run_step(r * S)          # slot 0
+        torch.cuda.synchronize()
+        for kname, v in slots[0]["step"].state.kernel_times_ms().items():
+            iso[kname] = iso.get(kname, 0.0) + v / n_iso
     for sl in slots:
         sl["step"].state.set_option(_lib.OPT_PROFILE, 0)
     torch.cuda.synchronize()
@@ -229,7 +237,10 @@ def main():
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_us": round(kt[dom] * 1e3, 2),
                 "algorithmic_bytes": int(abytes[dom]),
-                "all_kernels_us": {k: round(v * 1e3, 2) for k, v in kt.items()}, "pairs_D": int(D_avg)}
+                "all_kernels_us": {k: round(v * 1e3, 2) for k, v in kt.items()}, "pairs_D": int(D_avg),
+                # same launch with the GPU to itself (one step in flight): duration and the fraction it would reach
+                "alone": {"avg_us": round(iso[dom] * 1e3, 2), "frac": round(abytes[dom] / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                          "all_kernels_us": {k: round(iso[k] * 1e3, 2) for k in _lib.KERNEL_NAMES}}}
 
     out = {
         "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians",

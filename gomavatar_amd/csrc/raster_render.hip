@@ -9,33 +9,36 @@
 // A GoMAvatar frame touches only ~170 of 1024 tiles and a few of them hold
 // >5 000 Gaussians; "one workgroup per tile walks its list" leaves the chip idle
 // behind those tiles.  Alpha compositing is associative, so the list of every
-// tile is cut into segments of 256 entries and the work is spread over
-// (tile, segment) pairs -- ~750 workgroups for 256 CUs:
+// tile is cut into segments of GOM_SEG = 128 entries, every segment into 4
+// sub-ranges of 32, and the unit of work is one wave = (segment, 8x8 pixel
+// quadrant, sub-range): ~19 000 independent waves per frame, x B for a batched
+// launch (B frames stacked into one tall tile grid, see raster_pre.hip).
 //
-//   k_sort         per tile, 1024 threads: normalised bitonic network on the
-//                  unique (depth_bits<<32 | gaussian) keys in LDS -> identical to
-//                  the reference's stable (tile, depth) radix order.
-//   k_seg_fwd      per (tile, segment): the 256 entries are staged in LDS once;
-//                  each of the 4 waves composites them over its own 8x8 pixel
-//                  quadrant STARTING FROM T = 1 and stores (prod(1-alpha),
-//                  colour, last contributor) per pixel.
-//   k_combine_fwd  per tile: folds the segment results front to back.  While
-//                  T * T_seg stays above the 1e-4 stop threshold the fold is one
-//                  fma per channel; the segment in which a pixel crosses the
-//                  threshold is re-walked entry by entry with the reference's
-//                  exact stop rule (so n_contrib / final_T keep their meaning).
-//                  Also emits per-segment checkpoints (T after the segment,
-//                  colour still behind it) for the backward.
-//   k_seg_bwd      per (tile, segment): back-to-front replay from the
-//                  checkpoint; the 6+C per-pixel terms of every entry are reduced
-//                  over the wave with DPP row_shr/row_bcast adds, the four waves
-//                  are summed in LDS in a fixed order and one 48-byte record per
-//                  (tile, entry) is written.  No float atomics anywhere.
+//   k_sort         per tile: merge-path merge sort of the unique
+//                  (depth_bits<<32 | gaussian) keys in registers + LDS ->
+//                  identical to the reference's stable (tile, depth) radix order.
+//                  Also leaves the entries' geometry in LIST order (ent_geo) so
+//                  the compositing kernels stream contiguous 24-byte records.
+//   k_seg_T        pass A: prod(1-alpha) of every sub-range and segment for every
+//                  pixel of the tile, from alpha alone (no colours, no stop rule).
+//   k_seg_fwd      pass B: every wave composites its <=32 entries with the
+//                  reference's exact per-pixel rules, starting from the
+//                  transmittance pass A implies; the 4 sub-ranges are folded in
+//                  LDS (contribution, T behind, last contributor, stop flag).
+//   k_combine_fwd  pass C, per tile: folds the segments front to back, writes the
+//                  image / final_T / n_contrib and per-segment checkpoints (T
+//                  behind the segment, colour still to come) for the backward.
+//   k_seg_bwd      per (segment, sub-range), 4 quadrants per workgroup:
+//                  back-to-front replay from the checkpoint; the 6+C per-pixel
+//                  terms of every entry are reduced over the wave with fused
+//                  v_add_f32_dpp chains, the four quadrants are summed in LDS in
+//                  a fixed order and one 48-byte record per (tile, entry) is
+//                  written.  No float atomics anywhere.
 //
-// Inside a wave, lane = pixel.  Per 64-entry batch lane = ENTRY first: every
-// lane tests one entry against the wave's 8x8 rectangle with a conservative
-// bound on the largest alpha it can reach there; a 64-bit ballot then drives a
-// scalar loop over the survivors only, whose attributes are broadcast with
+// Inside a wave, lane = pixel.  Per sub-range lane = ENTRY first: every lane
+// tests one entry against the wave's 8x8 rectangle with a conservative bound on
+// the largest alpha it can reach there; a 64-bit ballot then drives a scalar
+// loop over the survivors only (~35 %), whose attributes are broadcast with
 // v_readlane (SGPR operands).  Entries skipped this way are exactly those the
 // reference skips for all 64 pixels (`alpha < 1/255 -> continue`).  The blend
 // loop is branch-free and keeps its state in VGPRs (float masks) so that the
@@ -454,9 +457,6 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__re
         {
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
             unsigned long long mask = __ballot(r.keep);
-#ifdef GOM_EXP_NOCOMPUTE
-            T = r.x * 1e-30f + 1.f; mask = 0;
-#endif
             while (mask) {
                 float al[4];
 #pragma unroll
@@ -471,14 +471,10 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__re
             }
         }
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
-#ifndef GOM_EXP_NOBARRIER
         __syncthreads();  // previous iteration's readers of s_P are done
         s_P[sub][lane] = T;
         __syncthreads();
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((s_P[0][lane] * s_P[1][lane]) * s_P[2][lane]) * s_P[3][lane];
-#else
-        if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = T;
-#endif
     }
 }
 
