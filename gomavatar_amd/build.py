@@ -22,6 +22,7 @@ SOURCES = [
     ("raster_render.hip", []),
     ("geom.hip", []),
     ("loss.hip", []),
+    ("lpips.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           f"-I{_INC}", f"-I{_CSRC}"]

@@ -1,0 +1,137 @@
+"""LPIPS-VGG perceptual loss (reference utils/lpips/lpips.py:23-123, called at
+train.py:113-121 as `LPIPS(net='vgg')(2*pred-1, 2*gt-1)`).
+
+    in0, in1 (B,3,H,W) in [-1,1] -> ScalingLayer -> VGG16 conv trunk -> 5 taps
+    (relu1_2, relu2_2, relu3_3, relu4_3, relu5_3) -> per tap: channel-normalise,
+    squared difference, 1x1 "lin" layer, spatial mean -> sum over taps -> (B,1,1,1)
+
+Split for MI355X: the trunk is 13 plain 3x3 convolutions (GEMM-shaped, library
+territory: torch -> MIOpen / hipBLASLt, fp32 like the reference or bf16); the
+LPIPS-specific head is a fused HIP kernel pair per tap (`csrc/lpips.hip`) instead
+of ~12 element-wise/reduction launches with full-size temporaries.
+
+Weights: the five `lin` vectors are the LPIPS v0.1 VGG weights
+(`data/lpips_vgg_lin_v0.1.npz`, 1 472 floats, BSD-licensed, converted by
+scripts/make_goldens.py).  The ImageNet VGG16 trunk cannot be fetched offline:
+the trunk is randomly initialised from a seed unless `load_trunk_state_dict` is
+given torchvision's `vgg16().features` state dict.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+# torchvision vgg16().features: conv indices 0,2 | 5,7 | 10,12,14 | 17,19,21 | 24,26,28 ; max-pools at 4, 9, 16, 23
+VGG16_CONV_INDEX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+VGG16_CHANNELS = (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)
+TAP_AFTER_CONV = (1, 3, 6, 9, 12)          # relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 (pretrained_networks.py:103-112)
+POOL_BEFORE_CONV = (2, 4, 7, 10)           # a 2x2 max-pool precedes these convs
+LIN_CHANNELS = (64, 128, 256, 512, 512)
+SHIFT = (-0.030, -0.088, -0.188)           # ScalingLayer, lpips.py:126-133
+SCALE = (0.458, 0.448, 0.450)
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "lpips_vgg_lin_v0.1.npz")
+
+
+def seeded_trunk(seed: int = 0) -> List[torch.Tensor]:
+    """He-initialised VGG16 conv weights/biases [w0, b0, w1, b1, ...] from a CPU generator (deterministic)."""
+    g = torch.Generator().manual_seed(int(seed))
+    out, cin = [], 3
+    for cout in VGG16_CHANNELS:
+        out.append(torch.randn(cout, cin, 3, 3, generator=g) * float(np.sqrt(2.0 / (cin * 9))))
+        out.append(torch.randn(cout, generator=g) * 0.01)
+        cin = cout
+    return out
+
+
+def trunk_features(x: torch.Tensor, wb: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """The 5 taps of the VGG16 trunk (pretrained_networks.py:96-134)."""
+    taps, h = [], x
+    for i in range(13):
+        if i in POOL_BEFORE_CONV:
+            h = F.max_pool2d(h, 2, 2)
+        h = F.relu(F.conv2d(h, wb[2 * i].to(h.dtype), wb[2 * i + 1].to(h.dtype), padding=1))
+        if i in TAP_AFTER_CONV:
+            taps.append(h)
+    return taps
+
+
+class _LpipsHead(torch.autograd.Function):
+    """One tap: (f0, f1, w) -> (B,) values, through the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, w):
+        lib = _lib.load()
+        f0c, f1c = f0.float().contiguous(), f1.float().contiguous()
+        B, C, H, W = f0c.shape
+        partials = torch.empty((B, _lib.GOM_LOSS_BLOCKS), dtype=torch.float32, device=f0c.device)
+        _lib.check(lib.gom_lpips_layer_forward(B, C, H * W, _lib.ptr(f0c), _lib.ptr(f1c), _lib.ptr(w), _lib.ptr(partials), _lib.stream_ptr()))
+        ctx.save_for_backward(f0c, f1c, w)
+        ctx.in_dtype = f0.dtype
+        return partials.sum(1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f0c, f1c, w = ctx.saved_tensors
+        lib = _lib.load()
+        B, C, H, W = f0c.shape
+        go = grad_out.float().contiguous()
+        d_f0 = torch.empty_like(f0c)
+        _lib.check(lib.gom_lpips_layer_backward(B, C, H * W, _lib.ptr(f0c), _lib.ptr(f1c), _lib.ptr(w), _lib.ptr(go), _lib.ptr(d_f0),
+                                                _lib.stream_ptr()))
+        return d_f0.to(ctx.in_dtype), None, None   # the target branch carries no gradient (train.py passes the ground truth)
+
+
+class LPIPS(torch.nn.Module):
+    """Mirror of the reference's `LPIPS(net='vgg')` (lpips.py:23-79 defaults: pretrained lin layers, version 0.1,
+    eval mode, non-spatial): `forward(in0, in1, retPerLayer=False, normalize=False)` -> (B,1,1,1)."""
+
+    def __init__(self, net: str = "vgg", trunk_seed: int = 0, trunk_dtype: torch.dtype = torch.float32, device=None):
+        super().__init__()
+        if net not in ("vgg", "vgg16"):
+            raise NotImplementedError("only the VGG variant is on GoMAvatar's path (train.py:299-303)")
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        lin = np.load(_DATA)
+        self.lins = [torch.from_numpy(lin[f"lin{k}"].astype(np.float32).reshape(-1)).to(dev).contiguous() for k in range(5)]
+        self.trunk = [t.to(dev) for t in seeded_trunk(trunk_seed)]
+        self.trunk_dtype = trunk_dtype
+        self.shift = torch.tensor(SHIFT, device=dev).view(1, 3, 1, 1)
+        self.scale = torch.tensor(SCALE, device=dev).view(1, 3, 1, 1)
+        self.eval()
+
+    def load_trunk_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """torchvision `vgg16().features` (or `vgg16()`) state dict -> trunk weights."""
+        dev = self.trunk[0].device
+        for i, idx in enumerate(VGG16_CONV_INDEX):
+            wk = f"features.{idx}.weight" if f"features.{idx}.weight" in sd else f"{idx}.weight"
+            bk = wk.replace("weight", "bias")
+            assert tuple(sd[wk].shape) == tuple(self.trunk[2 * i].shape), (wk, sd[wk].shape)
+            self.trunk[2 * i] = sd[wk].detach().to(dev, torch.float32).contiguous()
+            self.trunk[2 * i + 1] = sd[bk].detach().to(dev, torch.float32).contiguous()
+
+    def features(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = ((x - self.shift) / self.scale).to(self.trunk_dtype)
+        return trunk_features(x, self.trunk)
+
+    def forward(self, in0: torch.Tensor, in1: torch.Tensor, retPerLayer: bool = False, normalize: bool = False):
+        if normalize:   # inputs in [0,1] (lpips.py:82-84)
+            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+        with torch.no_grad():
+            f1 = self.features(in1)
+        f0 = self.features(in0)
+        res = [_LpipsHead.apply(f0[k], f1[k], self.lins[k]).view(-1, 1, 1, 1) for k in range(5)]
+        val = res[0]
+        for k in range(1, 5):
+            val = val + res[k]
+        return (val, res) if retPerLayer else val
+
+
+def lpips_loss(lpips: LPIPS, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:
+    """train.py:113-117: mean over the batch of LPIPS(2*pred-1, 2*gt-1) for (B,H,W,3) images in [0,1]."""
+    return lpips(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1).mean()

@@ -26,6 +26,9 @@
  *   gom_l1_loss
  *       train.py:53-55 (unpack) + train.py:101-111 (L1 rgb, L1 mask) and their
  *       autograd backward.
+ *   gom_lpips_layer_forward / gom_lpips_layer_backward
+ *       utils/lpips/lpips.py:104-115 (normalize_tensor, squared difference, lin layer, spatial average;
+ *       utils/lpips/__init__.py:40-42) for one VGG tap, called from train.py:113-121.
  */
 #ifndef GOM_HIP_H
 #define GOM_HIP_H
@@ -163,6 +166,16 @@ int gom_vertex_backward(int N, int J, const float *xyz, const float *weights, co
 int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask, const float *bg,
                 float c_rgb, float c_mask, float grad_scale,
                 float *dL_dpred, float *dL_dshade, float *loss_partials, void *stream);
+
+/* ---- LPIPS head, one feature tap per call (utils/lpips/lpips.py:104-115) -----------------------------------------
+ * f0 (prediction branch), f1 (target branch): [B][C][HW] fp32 feature maps of the VGG trunk; w [C] = the tap's
+ * NetLinLayer weights (1x1 conv, no bias; Dropout is inert in eval mode, lpips.py:78-79).
+ *   value_b = mean_hw sum_c w_c (f0_c/m0 - f1_c/m1)^2,  m = sqrt(sum_c f_c^2 + 1e-10) + 1e-10   (normalize_tensor)
+ * forward: partials [B][GOM_LOSS_BLOCKS], value_b = sum of row b (no atomics; the caller reduces).
+ * backward: d_f0 [B][C][HW] = grad_out[b] * d value_b / d f0 (grad_out [B] in device memory). */
+int gom_lpips_layer_forward(int B, int C, int HW, const float *f0, const float *f1, const float *w, float *partials, void *stream);
+int gom_lpips_layer_backward(int B, int C, int HW, const float *f0, const float *f1, const float *w, const float *grad_out,
+                             float *d_f0, void *stream);
 
 /* ---- whole frame ---------------------------------------------------------------
  * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused

@@ -156,6 +156,41 @@ def main():
         call0_means3D=calls[0]["means3D"].numpy(), call0_colors=calls[0]["colors_precomp"].numpy(), call0_cov6=calls[0]["cov3D_precomp"].numpy(),
         call1_colors=calls[1]["colors_precomp"].numpy(), call0_opacities=calls[0]["opacities"].numpy(),
         focal2fov=np.float64(ref_cu.focal2fov(1250.0, 512)))
+    # ---------------- LPIPS-VGG ----------------
+    # lin weights (data): LPIPS v0.1 VGG, 5 x (1,C,1,1) -> product data file
+    sd = torch.load(os.path.join(REF, "utils", "lpips", "weights", "v0.1", "vgg.pth"), map_location="cpu")
+    lin = {f"lin{k}": sd[f"lin{k}.model.1.weight"].numpy().reshape(-1).astype(np.float32) for k in range(5)}
+    os.makedirs(os.path.join(REPO, "gomavatar_amd", "data"), exist_ok=True)
+    np.savez(os.path.join(REPO, "gomavatar_amd", "data", "lpips_vgg_lin_v0.1.npz"), **lin)
+    # the reference's own LPIPS class with torchvision's ImageNet trunk replaced by our seeded random VGG16
+    # (same layer indices as torchvision's vgg16().features, which pretrained_networks.py:99-112 slices by index)
+    from gomavatar_amd import lpips as our_lpips  # noqa: E402  (seeded_trunk only: weights are data)
+    wb = our_lpips.seeded_trunk(0)
+    feats, ci = [], 0
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+    cin = 3
+    for v in cfg:
+        if v == "M":
+            feats.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            conv = torch.nn.Conv2d(cin, v, kernel_size=3, padding=1)
+            with torch.no_grad():
+                conv.weight.copy_(wb[2 * ci]); conv.bias.copy_(wb[2 * ci + 1])
+            feats += [conv, torch.nn.ReLU(inplace=False)]
+            cin = v; ci += 1
+    tv = _stub("torchvision")
+    tvm = _stub("torchvision.models")
+    tv.models = tvm
+    tvm.vgg16 = lambda pretrained=False: types.SimpleNamespace(features=torch.nn.Sequential(*feats))
+    from utils.lpips.lpips import LPIPS as RefLPIPS  # noqa: E402
+    ref = RefLPIPS(net="vgg", verbose=False)
+    g = torch.Generator().manual_seed(5)
+    in0 = torch.rand(2, 3, 64, 48, generator=g) * 2 - 1
+    in1 = (in0 + 0.3 * torch.randn(2, 3, 64, 48, generator=g)).clamp(-1, 1)
+    with torch.no_grad():
+        val, res = ref(in0, in1, retPerLayer=True)
+    np.savez_compressed(os.path.join(OUT, "lpips_vgg.npz"), in0=in0.numpy(), in1=in1.numpy(), trunk_seed=np.int64(0),
+                        val=val.numpy(), **{f"res{k}": res[k].numpy() for k in range(5)})
     print("goldens written to", OUT, sorted(os.listdir(OUT)))
 
 
