@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p, POINTER
 
 import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the SAME libamdhip64 torch uses
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     "gom_face_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_vertex_backward": (c_int, [c_int, c_int] + [c_void_p] * 11),
+    "gom_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "gom_lpips_layer_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_frame_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_uint32, c_void_p]),

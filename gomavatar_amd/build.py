@@ -23,6 +23,7 @@ SOURCES = [
     ("geom.hip", []),
     ("loss.hip", []),
     ("lpips.hip", []),
+    ("metrics.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           f"-I{_INC}", f"-I{_CSRC}"]

@@ -26,6 +26,8 @@
  *   gom_l1_loss
  *       train.py:53-55 (unpack) + train.py:101-111 (L1 rgb, L1 mask) and their
  *       autograd backward.
+ *   gom_ssim
+ *       eval.py:106-108 (skimage structural_similarity, multichannel) and eval.py:157 (torchmetrics SSIM).
  *   gom_lpips_layer_forward / gom_lpips_layer_backward
  *       utils/lpips/lpips.py:104-115 (normalize_tensor, squared difference, lin layer, spatial average;
  *       utils/lpips/__init__.py:40-42) for one VGG tap, called from train.py:113-121.
@@ -176,6 +178,14 @@ int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float
 int gom_lpips_layer_forward(int B, int C, int HW, const float *f0, const float *f1, const float *w, float *partials, void *stream);
 int gom_lpips_layer_backward(int B, int C, int HW, const float *f0, const float *f1, const float *w, const float *grad_out,
                              float *d_f0, void *stream);
+
+/* ---- SSIM (evaluation metric; eval.py:106-108,157) --------------------------------------------
+ * img0, img1 [H][W][C] fp32; weights [win][win] fp64 window (sums to 1; win odd); the SSIM map is evaluated where the
+ * window lies inside the image.  partials [GOM_LOSS_BLOCKS] fp64: their sum / ((H-win+1)(W-win+1)C) is the mean SSIM.
+ *   skimage 0.18 (eval.py:107): win 7 uniform, cov_norm 49/48, C1 = (0.01*2)^2, C2 = (0.03*2)^2 (float input => data_range 2)
+ *   torchmetrics (eval.py:157): win 11 gaussian sigma 1.5, cov_norm 1, C1 = 0.01^2, C2 = 0.03^2 */
+int gom_ssim(int H, int W, int C, const float *img0, const float *img1, int win, const double *weights, double cov_norm, double C1,
+             double C2, double *partials, void *stream);
 
 /* ---- whole frame ---------------------------------------------------------------
  * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused
