@@ -65,6 +65,18 @@ SIGNATURES = {
     "gom_face_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_vertex_backward": (c_int, [c_int, c_int] + [c_void_p] * 11),
+    "gom_conv3x3_bf16": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_uint32, c_void_p]),
+    "gom_conv3x3_splits": (c_int, [c_int] * 5),
+    "gom_conv3x3_bf16_splitk": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_uint32, c_int, c_void_p, c_void_p]),
+    "gom_maxpool2x2_bf16": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "gom_maxpool2x2_backward_bf16": (c_int, [c_int] * 4 + [c_void_p] * 3 + [c_int, c_void_p]),
+    "gom_lpips_prepare_bf16": (c_int, [c_int] * 3 + [c_void_p] * 3),
+    "gom_lpips_unprepare_bf16": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "gom_lpips_layer_forward_nhwc_bf16": (c_int, [c_int] * 3 + [c_void_p] * 5),
+    "gom_lpips_layer_backward_nhwc_bf16": (c_int, [c_int] * 3 + [c_void_p] * 6),
+    "gom_lpips_vgg_create": (c_void_p, [c_void_p] * 6),
+    "gom_lpips_vgg_destroy": (None, [c_void_p]),
+    "gom_lpips_vgg_value_and_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "gom_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "gom_lpips_layer_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

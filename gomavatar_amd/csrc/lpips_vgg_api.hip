@@ -1,0 +1,162 @@
+// LPIPS-VGG value and image gradient as ONE native call on the bf16 matrix-core trunk (vgg_bf16.hip):
+// 2 x (prepare + 13 convolutions + 4 pools) forward, 5 head forwards, then 5 head backwards + 4 pool backwards +
+// 13 backward-data convolutions + the image gradient -- ~75 launches enqueued back to back on the caller's stream
+// (hipGraph-capturable: no allocation after the first call of a given size, no host sync).
+// Replaces train.py:113-121 (LPIPS(2*pred-1, 2*gt-1).mean() and its autograd backward).
+#include <string.h>
+
+#include "gom_internal.h"
+
+namespace {
+const int kPoolBefore[13] = {0, 0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0};
+const int kTapIndex[13] = {-1, 0, -1, 1, -1, -1, 2, -1, -1, 3, -1, -1, 4};
+}  // namespace
+
+struct GomLpipsVgg {
+    const void *w_fwd[13], *w_bwd[13];
+    const float *bias[13], *lin[5];
+    int cin[13], cout[13];
+    // workspace for (B, H, W)
+    int B = 0, H = 0, W = 0;
+    void *x[2] = {nullptr, nullptr};            // trunk inputs (B,H,W,32)
+    void *act[2][13] = {};                       // post-ReLU activations of both images
+    void *pooled[2][13] = {};                    // pool outputs feeding conv i (i in kPoolBefore)
+    void *grad[2] = {nullptr, nullptr};          // ping-pong gradient buffers (largest activation)
+    void *gtap = nullptr;                        // head gradient of the current tap
+    float *splitk = nullptr;
+    float *go = nullptr;                         // [B] d value / d value_b
+    size_t splitk_elems = 0;
+};
+
+static void lp_free(GomLpipsVgg *h) {
+    void *ptrs[] = {h->x[0], h->x[1], h->grad[0], h->grad[1], h->gtap, h->splitk, h->go};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < 13; i++) {
+            if (h->act[k][i]) (void)hipFree(h->act[k][i]);
+            if (h->pooled[k][i]) (void)hipFree(h->pooled[k][i]);
+            h->act[k][i] = h->pooled[k][i] = nullptr;
+        }
+    h->x[0] = h->x[1] = h->grad[0] = h->grad[1] = h->gtap = nullptr;
+    h->splitk = nullptr; h->go = nullptr;
+    h->B = h->H = h->W = 0;
+}
+
+extern "C" GomLpipsVgg *gom_lpips_vgg_create(const void *const *w_fwd, const void *const *w_bwd, const float *const *bias, const float *const *lin,
+                                             const int32_t *cin, const int32_t *cout) {
+    if (!w_fwd || !w_bwd || !bias || !lin || !cin || !cout) { gom_set_error("gom_lpips_vgg_create: null argument"); return nullptr; }
+    GomLpipsVgg *h = new GomLpipsVgg();
+    for (int i = 0; i < 13; i++) { h->w_fwd[i] = w_fwd[i]; h->w_bwd[i] = w_bwd[i]; h->bias[i] = bias[i]; h->cin[i] = cin[i]; h->cout[i] = cout[i]; }
+    for (int k = 0; k < 5; k++) h->lin[k] = lin[k];
+    return h;
+}
+
+extern "C" void gom_lpips_vgg_destroy(GomLpipsVgg *h) {
+    if (!h) return;
+    lp_free(h);
+    delete h;
+}
+
+static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
+    if (h->B == B && h->H == H && h->W == W) return 0;
+    lp_free(h);
+    size_t maxact = 0, maxsplit = 0;
+    int hh = H, ww = W;
+    for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->x[k], (size_t)B * H * W * 32 * 2));
+    for (int i = 0; i < 13; i++) {
+        if (kPoolBefore[i]) {
+            hh /= 2; ww /= 2;
+            for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->pooled[k][i], (size_t)B * hh * ww * h->cin[i] * 2));
+        }
+        const size_t n = (size_t)B * hh * ww * h->cout[i];
+        for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->act[k][i], n * 2));
+        maxact = n > maxact ? n : maxact;
+        const size_t nin = (size_t)B * hh * ww * (h->cin[i] < 64 ? 64 : h->cin[i]);
+        maxact = nin > maxact ? nin : maxact;
+        const size_t sf = (size_t)gom_conv3x3_splits(B, hh, ww, h->cin[i], h->cout[i]) * n;
+        const size_t sb = (size_t)gom_conv3x3_splits(B, hh, ww, h->cout[i], h->cin[i] < 64 ? 64 : h->cin[i]) * nin;
+        maxsplit = sf > maxsplit ? sf : maxsplit;
+        maxsplit = sb > maxsplit ? sb : maxsplit;
+    }
+    for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->grad[k], maxact * 2));
+    GOM_HIP_CHECK(hipMalloc(&h->gtap, maxact * 2));
+    GOM_HIP_CHECK(hipMalloc((void **)&h->splitk, maxsplit * sizeof(float)));
+    GOM_HIP_CHECK(hipMalloc((void **)&h->go, (size_t)B * sizeof(float)));
+    h->splitk_elems = maxsplit;
+    h->B = B; h->H = H; h->W = W;
+    return 0;
+}
+
+static int lp_conv(GomLpipsVgg *h, int B, int hh, int ww, int cin, int cout, const void *in, const void *wt, const float *bias, const void *mask,
+                   void *out, uint32_t flags, void *stream) {
+    const int s = gom_conv3x3_splits(B, hh, ww, cin, cout);
+    return gom_conv3x3_bf16_splitk(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? h->splitk : nullptr, stream);
+}
+
+__global__ void k_fill(float *p, int n, float v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
+                                            float grad_scale, float *d_pred, void *stream) {
+    if (!h || !pred || !gt || !value_partials) { gom_set_error("gom_lpips_vgg_value_and_grad: null argument"); return -1; }
+    if (B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) { gom_set_error("gom_lpips_vgg_value_and_grad: H and W must be multiples of 16"); return -1; }
+    int rc;
+    if ((rc = lp_ensure(h, B, H, W))) return rc;
+    const float *img[2] = {pred, gt};
+    for (int k = 0; k < 2; k++) {
+        if ((rc = gom_lpips_prepare_bf16(B, H, W, img[k], h->x[k], stream))) return rc;
+        int hh = H, ww = W;
+        const void *cur = h->x[k];
+        for (int i = 0; i < 13; i++) {
+            if (kPoolBefore[i]) {
+                if ((rc = gom_maxpool2x2_bf16(B, hh, ww, h->cin[i], cur, h->pooled[k][i], stream))) return rc;
+                hh /= 2; ww /= 2;
+                cur = h->pooled[k][i];
+            }
+            if ((rc = lp_conv(h, B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k][i], GOM_CONV_RELU, stream))) return rc;
+            cur = h->act[k][i];
+        }
+    }
+    {   // heads
+        int hh = H, ww = W;
+        for (int i = 0; i < 13; i++) {
+            if (kPoolBefore[i]) { hh /= 2; ww /= 2; }
+            const int t = kTapIndex[i];
+            if (t < 0) continue;
+            if ((rc = gom_lpips_layer_forward_nhwc_bf16(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t],
+                                                        value_partials + (size_t)t * B * GOM_LOSS_BLOCKS, stream)))
+                return rc;
+        }
+    }
+    if (!d_pred) return 0;
+    hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->go, B, grad_scale);
+    GOM_LAUNCH_CHECK();
+    // backward: g = gradient w.r.t. the pre-ReLU output of conv i, walking the trunk of image 0 in reverse
+    int hs[13], wsz[13];
+    {
+        int hh = H, ww = W;
+        for (int i = 0; i < 13; i++) { if (kPoolBefore[i]) { hh /= 2; ww /= 2; } hs[i] = hh; wsz[i] = ww; }
+    }
+    const void *g = nullptr;
+    int pp = 0;
+    for (int i = 12; i >= 0; i--) {
+        const int hh = hs[i], ww = wsz[i], t = kTapIndex[i];
+        if (t >= 0) {
+            void *gh = h->gtap;
+            if ((rc = gom_lpips_layer_backward_nhwc_bf16(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh, stream))) return rc;
+            if (g) {  // g = gradient w.r.t. the pooled activation feeding conv i+1
+                if ((rc = gom_maxpool2x2_backward_bf16(B, hh, ww, h->cout[i], h->act[0][i], g, gh, 1, stream))) return rc;
+            }
+            g = gh;
+        }
+        const int co = h->cin[i] < 64 ? 64 : h->cin[i];
+        const void *mask = (i > 0 && !kPoolBefore[i]) ? h->act[0][i - 1] : nullptr;
+        void *dst = h->grad[pp];
+        pp ^= 1;
+        if ((rc = lp_conv(h, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, stream))) return rc;
+        g = dst;
+    }
+    return gom_lpips_unprepare_bf16(B, H, W, 64, g, d_pred, stream);
+}

@@ -1,0 +1,417 @@
+// bf16 VGG16 trunk of LPIPS on the matrix cores (reference utils/lpips/pretrained_networks.py:96-134 runs torchvision's
+// fp32 convolutions through cuDNN; utils/lpips/lpips.py:81-123 is the head).  The trunk is 13 3x3 convolutions =
+// 160 GFLOP per 512x512 image, 480 GFLOP per training step (two images forward, one backward): the only
+// GEMM-shaped work of a GoMAvatar step that is large enough for MFMA, and ~97 % of the step's time when run through
+// the library convolutions (scripts/bench_modes.py).
+//
+//   k_conv3x3_bf16      implicit GEMM, NHWC bf16 activations, fp32 accumulation in v_mfma_f32_16x16x32_bf16.
+//                       Workgroup = 8x16 output pixels x 64 output channels, 4 waves (2 pixel rows x 64 channels
+//                       each = 2x4 MFMA tiles).  Per 32-input-channel chunk the 10x18 halo patch and the 9x64x32
+//                       weight block are staged in LDS once; the nine taps are shifted views of the same patch.
+//                       A = weights [co][k], B = pixels [px][k]  ->  D[co][px]: every lane ends up with 4
+//                       consecutive output channels of one pixel (one 8-byte NHWC store).
+//                       Epilogue: + bias, ReLU, or (backward-data) * [forward activation > 0].
+//                       The backward-data convolution is the same kernel on 180-degree-rotated, transposed weights.
+//   k_maxpool2_*        2x2 max-pool forward / backward (argmax recomputed from the saved input)
+//   k_lpips_prepare     (B,H,W,3) fp32 image in [0,1] -> ScalingLayer(2x-1) -> NHWC bf16 padded to 32 channels
+//   k_lpips_head_nhwc_* the LPIPS head of lpips.hip for NHWC bf16 taps (one wave per pixel group)
+#include "gom_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;  // storage type
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+constexpr int kTileH = 8, kTileW = 16, kBN = 64, kKC = 32;
+constexpr int kPatchW = kTileW + 2, kPatchPx = (kTileH + 2) * kPatchW;  // 18, 180
+
+// in  [B][H][W][Cin]  bf16 (Cin multiple of 32);  wt [Cin/32][9][Cout][32] bf16 (Cout multiple of 64)
+// out [B][H][W][Cout] bf16;  bias fp32 [Cout] or null;  mask (same shape as out) or null: out *= (mask > 0)
+// SPLITK: blockIdx.z = image * splits + s; this block sums only its share of the input-channel chunks and stores raw fp32
+// partial sums to `partial` [splits][B][H][W][Cout]; k_splitk_epilogue adds them up and applies bias / ReLU / mask.  Used
+// for the deep layers (64x64 and 32x32 pixels: 8-32 pixel tiles), which would otherwise leave most of the 256 CUs idle.
+template <bool RELU, bool SPLITK>
+__global__ void __launch_bounds__(256) k_conv3x3_bf16(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
+                                                      const bf16_t *__restrict__ wt, const float *__restrict__ bias,
+                                                      const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
+                                                      float *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) bf16_t s_in[kPatchPx * kKC];   // 11 520 B
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[9 * kBN * kKC];      // 36 864 B
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * kTileH;
+    const int co0 = blockIdx.y * kBN;
+    const int zb = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, zs = SPLITK ? (int)blockIdx.z % splits : 0;
+    const size_t img = (size_t)zb * H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = Cin / kKC;
+    const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
+    for (int cc = cc_lo; cc < cc_hi; cc++) {
+        __syncthreads();  // the previous chunk's MFMA reads are done
+        for (int idx = tid; idx < kPatchPx * 4; idx += 256) {
+            const int px = idx >> 2, part = idx & 3;
+            const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const uint4 *>(in + (img + (size_t)gy * W + gx) * Cin + cc * kKC + part * 8);
+            *reinterpret_cast<uint4 *>(s_in + px * kKC + part * 8) = v;
+        }
+        {
+            const bf16_t *wsrc = wt + ((size_t)cc * 9 * Cout + co0) * kKC;
+            for (int idx = tid; idx < 9 * kBN * 4; idx += 256) {
+                const int tap = idx >> 8, r = idx & 255;  // 256 16-byte units per tap (64 co x 32 ci)
+                *reinterpret_cast<uint4 *>(s_w + tap * kBN * kKC + r * 8) =
+                    *reinterpret_cast<const uint4 *>(wsrc + (size_t)tap * Cout * kKC + r * 8);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            bf16x8 bfrag[2], afrag[4];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                bfrag[m] = *reinterpret_cast<const bf16x8 *>(s_in + ((2 * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+                afrag[n] = *reinterpret_cast<const bf16x8 *>(s_w + (tap * kBN + n * 16 + l15) * kKC + kg * 8);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
+        }
+    }
+    // D[i = co][j = px]: lane holds co = 4*kg + r (r = 0..3) of pixel column l15
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int gy = ty0 + 2 * wave + m, gx = tx0 + l15;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
+        if (SPLITK) {
+            float *dst = partial + (size_t)zs * (gridDim.z / splits) * H * W * Cout + pix;   // [splits][B][H][W][Cout]
+#pragma unroll
+            for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + co0 + n * 16 + kg * 4) = acc[m][n];
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int co = co0 + n * 16 + kg * 4;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+            }
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (mask) {
+                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
+                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
+            }
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(out + pix + co) = o;
+        }
+    }
+}
+
+// sum of the split-K partials + bias, ReLU, mask -> bf16; 4 channels per thread
+__global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n4, int Cout, int splits, const float *__restrict__ partial,
+                                                         const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out,
+                                                         int relu) {
+    const size_t stride = n4 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4 *>(partial + 4 * i);
+        for (int s = 1; s < splits; s++) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 4 * i);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        const int co = (int)((4 * i) % Cout);
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+        }
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (mask) {
+            const uint2 mk = *reinterpret_cast<const uint2 *>(mask + 4 * i);
+            const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
+        }
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2 *>(out + 4 * i) = o;
+    }
+}
+
+// ---- 2x2 max-pool (NHWC bf16), 8 channels per thread ------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, bf16_t *__restrict__ y) {
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * C8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
+        const bf16_t *src = x + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c8 * 8;
+        uint4 q[4] = {*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + C),
+                      *reinterpret_cast<const uint4 *>(src + (size_t)W * C), *reinterpret_cast<const uint4 *>(src + (size_t)W * C + C)};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]) + k, *w1 = reinterpret_cast<const uint32_t *>(&q[1]) + k;
+            const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]) + k, *w3 = reinterpret_cast<const uint32_t *>(&q[3]) + k;
+            const float lo = fmaxf(fmaxf(bf2f((bf16_t)(*w0 & 0xffff)), bf2f((bf16_t)(*w1 & 0xffff))), fmaxf(bf2f((bf16_t)(*w2 & 0xffff)), bf2f((bf16_t)(*w3 & 0xffff))));
+            const float hi = fmaxf(fmaxf(bf2f((bf16_t)(*w0 >> 16)), bf2f((bf16_t)(*w1 >> 16))), fmaxf(bf2f((bf16_t)(*w2 >> 16)), bf2f((bf16_t)(*w3 >> 16))));
+            o[k] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        }
+        *reinterpret_cast<uint4 *>(y + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dx (+)= dy routed to the first maximum of each window (row-major order, like the reference framework), times the
+// ReLU derivative [x > 0] of the layer that produced x (x = the pool's input = a post-ReLU activation);
+// accumulate: dx already holds another gradient (the LPIPS head's) for this activation
+__global__ void __launch_bounds__(256) k_maxpool2_bwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                      bf16_t *__restrict__ dx, int accumulate) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = bf2f(x[base + off[k]]);
+        int am = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++)
+            if (v[k] > v[am]) am = k;
+        const float g = bf2f(dy[i]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float add = (k == am && v[am] > 0.f) ? g : 0.f;
+            dx[base + off[k]] = f2bf(accumulate ? bf2f(dx[base + off[k]]) + add : add);
+        }
+    }
+}
+
+// ---- image -> trunk input: ((2x - 1) - shift) / scale, NHWC bf16 padded to 32 channels ------------------------------
+__global__ void __launch_bounds__(256) k_lpips_prepare(size_t npix, const float *__restrict__ rgb, bf16_t *__restrict__ out) {
+    const float shift[3] = {-0.030f, -0.088f, -0.188f}, scale[3] = {0.458f, 0.448f, 0.450f};
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+        uint32_t w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = 0u;
+        bf16_t c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[k] = f2bf(((2.f * rgb[3 * p + k] - 1.f) - shift[k]) / scale[k]);
+        w[0] = (uint32_t)c[0] | ((uint32_t)c[1] << 16);
+        w[1] = (uint32_t)c[2];
+        uint4 *dst = reinterpret_cast<uint4 *>(out + p * 32);
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+}
+// gradient wrt the (B,H,W,3) image in [0,1] from the gradient wrt the trunk input (first 3 of Cpad channels)
+__global__ void __launch_bounds__(256) k_lpips_unprepare(size_t npix, int Cpad, const bf16_t *__restrict__ d_in, float *__restrict__ d_rgb) {
+    const float scale[3] = {0.458f, 0.448f, 0.450f};
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) d_rgb[3 * p + k] = bf2f(d_in[p * Cpad + k]) * (2.f / scale[k]);
+    }
+}
+
+// ---- LPIPS head on NHWC bf16 taps: 16 lanes per pixel, each lane strides over the channels 8 at a time ----------------
+constexpr float kEps = 1e-10f;
+__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a DPP row
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) { f[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); f[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
+                                                         const float *__restrict__ w, const float *__restrict__ grad_out,
+                                                         float *__restrict__ partials, bf16_t *__restrict__ d_f0) {
+    __shared__ float s_red[4];
+    const size_t b = blockIdx.y;
+    f0 += b * HW * C; f1 += b * HW * C;
+    if (BWD) d_f0 += b * HW * C;
+    const int sub = threadIdx.x & 15;                 // lane inside the pixel's 16-lane group
+    const size_t grp = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4, ngrp = ((size_t)gridDim.x * 256) >> 4;
+    const float go = BWD ? grad_out[b] * (2.0f / (float)HW) : 0.f;
+    float acc = 0.f;
+    for (size_t p = grp; p < HW; p += ngrp) {
+        const bf16_t *a = f0 + p * C, *bb = f1 + p * C;
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = sub * 8; c < C; c += 128) {
+            float x[8], y[8];
+            unpack8(*reinterpret_cast<const uint4 *>(a + c), x);
+            unpack8(*reinterpret_cast<const uint4 *>(bb + c), y);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s0 += x[k] * x[k]; s1 += y[k] * y[k]; }
+        }
+        s0 = sum16(s0); s1 = sum16(s1);
+        const float n0 = sqrtf(s0 + kEps);
+        const float i0 = 1.f / (n0 + kEps), i1 = 1.f / (sqrtf(s1 + kEps) + kEps);
+        float v = 0.f;   // forward: sum w d^2 ; backward: sum w d f0
+        for (int c = sub * 8; c < C; c += 128) {
+            float x[8], y[8];
+            unpack8(*reinterpret_cast<const uint4 *>(a + c), x);
+            unpack8(*reinterpret_cast<const uint4 *>(bb + c), y);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float d = x[k] * i0 - y[k] * i1;
+                v += BWD ? w[c + k] * d * x[k] : w[c + k] * d * d;
+            }
+        }
+        v = sum16(v);
+        if (!BWD) {
+            acc += (sub == 0) ? v : 0.f;
+        } else {
+            const float kk = v * i0 * i0 / n0;
+            for (int c = sub * 8; c < C; c += 128) {
+                float x[8], y[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a + c), x);
+                unpack8(*reinterpret_cast<const uint4 *>(bb + c), y);
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // times the ReLU derivative of the tap's own layer (x = 0 <=> the pre-activation was clipped)
+                    const float g0 = x[2 * k] > 0.f ? go * (w[c + 2 * k] * (x[2 * k] * i0 - y[2 * k] * i1) * i0 - x[2 * k] * kk) : 0.f;
+                    const float g1 = x[2 * k + 1] > 0.f ? go * (w[c + 2 * k + 1] * (x[2 * k + 1] * i0 - y[2 * k + 1] * i1) * i0 - x[2 * k + 1] * kk) : 0.f;
+                    o[k] = (uint32_t)f2bf(g0) | ((uint32_t)f2bf(g1) << 16);
+                }
+                *reinterpret_cast<uint4 *>(d_f0 + p * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)HW;
+    }
+}
+
+}  // namespace
+
+extern "C" int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                                void *out, uint32_t flags, void *stream) {
+    return gom_conv3x3_bf16_splitk(B, H, W, Cin, Cout, in, wt, bias, mask, out, flags, 1, nullptr, stream);
+}
+
+extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
+    const long blocks = (long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH) * (Cout / kBN) * B;
+    int s = 1;
+    while (s < 16 && blocks * s < 512 && (Cin / kKC) % (2 * s) == 0) s *= 2;   // >= 2 workgroups per CU, equal shares of the chunks
+    // (measured on MI355X: 512 plain workgroups beat 2 x 512 split ones -- the fp32 partials and the second launch cost more)
+    return s;
+}
+
+extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                                       void *out, uint32_t flags, int splits, float *workspace, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kKC || Cout % kBN) { gom_set_error("gom_conv3x3_bf16: Cin %% 32 / Cout %% 64 / sizes"); return -1; }
+    if (!in || !wt || !out) { gom_set_error("gom_conv3x3_bf16: null pointer"); return -1; }
+    if (splits < 1 || (splits > 1 && (!workspace || (Cin / kKC) % splits))) { gom_set_error("gom_conv3x3_bf16: bad split-K arguments"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH), Cout / kBN, B * splits);
+    const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
+    if (splits > 1) {
+        hipLaunchKernelGGL((k_conv3x3_bf16<false, true>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace);
+        GOM_LAUNCH_CHECK();
+        const size_t n4 = (size_t)B * H * W * Cout / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, n4, Cout, splits, workspace,
+                           bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0);
+    } else if (flags & GOM_CONV_RELU) {
+        hipLaunchKernelGGL((k_conv3x3_bf16<true, false>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+    } else {
+        hipLaunchKernelGGL((k_conv3x3_bf16<false, false>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+    }
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_maxpool2x2_bf16(int B, int H, int W, int C, const void *x, void *y, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % 8) { gom_set_error("gom_maxpool2x2_bf16: bad sizes"); return -1; }
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(k_maxpool2_fwd, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, B, H, W, C,
+                       (const bf16_t *)x, (bf16_t *)y);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_maxpool2x2_backward_bf16(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) { gom_set_error("gom_maxpool2x2_backward_bf16: bad sizes"); return -1; }
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0, (hipStream_t)stream, B, H, W, C,
+                       (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, accumulate);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lpips_prepare_bf16(int B, int H, int W, const float *rgb, void *out32, void *stream) {
+    const size_t npix = (size_t)B * H * W;
+    if (!rgb || !out32 || npix == 0) { gom_set_error("gom_lpips_prepare_bf16: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_lpips_prepare, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, npix, rgb,
+                       (bf16_t *)out32);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lpips_unprepare_bf16(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, void *stream) {
+    const size_t npix = (size_t)B * H * W;
+    if (!d_in || !d_rgb || npix == 0 || Cpad < 3) { gom_set_error("gom_lpips_unprepare_bf16: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_lpips_unprepare, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, npix, Cpad,
+                       (const bf16_t *)d_in, d_rgb);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lpips_layer_forward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, void *stream) {
+    if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_forward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
+    hipLaunchKernelGGL(k_lpips_head_nhwc<false>, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w,
+                       nullptr, partials, nullptr);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0,
+                                                  void *stream) {
+    if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_backward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
+    const size_t groups = ((size_t)HW + 15) / 16;
+    hipLaunchKernelGGL(k_lpips_head_nhwc<true>, dim3((unsigned)(groups < 4096 ? groups : 4096), B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0,
+                       (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

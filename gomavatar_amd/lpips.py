@@ -135,3 +135,106 @@ class LPIPS(torch.nn.Module):
 def lpips_loss(lpips: LPIPS, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:
     """train.py:113-117: mean over the batch of LPIPS(2*pred-1, 2*gt-1) for (B,H,W,3) images in [0,1]."""
     return lpips(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1).mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 trunk on the matrix cores (csrc/vgg_bf16.hip): hand-written implicit-GEMM 3x3 convolutions instead of the library's
+# ---------------------------------------------------------------------------------------------------------------------
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, 3, 3) fp32 -> [Cin_p/32][9][Cout_p][32] bf16 (Cin padded to 32, Cout to 64 with zeros)."""
+    co, ci = w.shape[0], w.shape[1]
+    cop, cip = _pad_to(co, 64), _pad_to(ci, 32)
+    wp = torch.zeros(cop, cip, 3, 3, dtype=torch.float32, device=w.device)
+    wp[:co, :ci] = w
+    return wp.permute(2, 3, 0, 1).reshape(9, cop, cip // 32, 32).permute(2, 0, 1, 3).contiguous().to(torch.bfloat16)
+
+
+def pack_conv_weight_backward(w: torch.Tensor) -> torch.Tensor:
+    """Weights of the backward-data convolution: dX = conv3x3(dY, rot180(W) with in/out channels swapped)."""
+    return pack_conv_weight(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
+
+
+class LPIPSMatrixCore:
+    """LPIPS-VGG value AND gradient w.r.t. the predicted image in one pass (train.py:113-121 semantics:
+    `mean_b LPIPS(2*pred-1, 2*gt-1)`), bf16 activations / fp32 accumulation on MFMA.
+
+        value, d_pred = m.value_and_grad(pred (B,H,W,3) in [0,1], gt (B,H,W,3))      # d_pred = d value / d pred
+
+    H and W must be multiples of 16 (four 2x2 pools)."""
+
+    def __init__(self, trunk_seed: int = 0, device=None):
+        self.lib = _lib.load()
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        lin = np.load(_DATA)
+        self.lins = [torch.from_numpy(lin[f"lin{k}"].astype(np.float32).reshape(-1)).to(dev).contiguous() for k in range(5)]
+        self._h = None
+        self.set_trunk([t.to(dev) for t in seeded_trunk(trunk_seed)])
+
+    def set_trunk(self, wb: Sequence[torch.Tensor]) -> None:
+        if getattr(self, "_h", None):
+            self.lib.gom_lpips_vgg_destroy(self._h)
+            self._h = None
+        self.w_fwd = [pack_conv_weight(wb[2 * i]) for i in range(13)]
+        self.w_bwd = [pack_conv_weight_backward(wb[2 * i]) for i in range(13)]
+        self.bias = [torch.cat([wb[2 * i + 1].float(), torch.zeros(_pad_to(wb[2 * i + 1].numel(), 64) - wb[2 * i + 1].numel(), device=self.device)]).contiguous()
+                     for i in range(13)]
+        self.cin = [_pad_to(wb[2 * i].shape[1], 32) for i in range(13)]
+        self.cout = [_pad_to(wb[2 * i].shape[0], 64) for i in range(13)]
+
+    def load_trunk_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        wb = []
+        for idx in VGG16_CONV_INDEX:
+            wk = f"features.{idx}.weight" if f"features.{idx}.weight" in sd else f"{idx}.weight"
+            wb += [sd[wk].detach().to(self.device, torch.float32), sd[wk.replace("weight", "bias")].detach().to(self.device, torch.float32)]
+        self.set_trunk(wb)
+
+    # -- one native call ---------------------------------------------------------------------------------------------
+    def _handle(self):
+        if self._h is None:
+            import ctypes
+            arr = lambda ts: (ctypes.c_void_p * len(ts))(*[_lib.ptr(t) for t in ts])
+            ints = lambda v: (ctypes.c_int32 * len(v))(*v)
+            self._keep = (arr(self.w_fwd), arr(self.w_bwd), arr(self.bias), arr(self.lins), ints(self.cin), ints(self.cout))
+            self._h = self.lib.gom_lpips_vgg_create(*self._keep)
+            if not self._h:
+                _lib.check(-1)
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.gom_lpips_vgg_destroy(self._h)
+            self._h = None
+
+    def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True):
+        """(mean_b LPIPS_b, d/d pred of it): ~75 kernel launches from one `gom_lpips_vgg_value_and_grad` call."""
+        assert pred.is_cuda and pred.dim() == 4 and pred.shape[-1] == 3 and pred.shape == gt.shape
+        B, H, W, _ = pred.shape
+        p32, g32 = pred.detach().float().contiguous(), gt.detach().float().contiguous()
+        partials = torch.empty((5, B, _lib.GOM_LOSS_BLOCKS), dtype=torch.float32, device=pred.device)
+        d_pred = torch.empty((B, H, W, 3), dtype=torch.float32, device=pred.device) if want_grad else None
+        _lib.check(self.lib.gom_lpips_vgg_value_and_grad(self._handle(), B, H, W, _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(partials), 1.0 / B,
+                                                         _lib.ptr(d_pred), _lib.stream_ptr()))
+        return partials.sum(2).sum(0).mean(), d_pred
+
+    def loss(self, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:
+        """Differentiable `lpips_loss` (train.py:113-117) for autograd callers."""
+        return _LpipsMC.apply(rgb_pred, rgb_gt, self)
+
+
+class _LpipsMC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, model):
+        value, d_pred = model.value_and_grad(pred, gt, want_grad=pred.requires_grad)
+        ctx.save_for_backward(d_pred)
+        ctx.dtype = pred.dtype
+        return value
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return (d_pred * g).to(ctx.dtype), None, None

@@ -26,6 +26,8 @@
  *   gom_l1_loss
  *       train.py:53-55 (unpack) + train.py:101-111 (L1 rgb, L1 mask) and their
  *       autograd backward.
+ *   gom_conv3x3_bf16, gom_maxpool2x2_*, gom_lpips_prepare_bf16, gom_lpips_layer_*_nhwc_bf16
+ *       utils/lpips/pretrained_networks.py:96-134 (VGG16 trunk) + utils/lpips/lpips.py:81-133 on the matrix cores.
  *   gom_ssim
  *       eval.py:106-108 (skimage structural_similarity, multichannel) and eval.py:157 (torchmetrics SSIM).
  *   gom_lpips_layer_forward / gom_lpips_layer_backward
@@ -178,6 +180,47 @@ int gom_l1_loss(int H, int W, const float *pred, const float *shade, const float
 int gom_lpips_layer_forward(int B, int C, int HW, const float *f0, const float *f1, const float *w, float *partials, void *stream);
 int gom_lpips_layer_backward(int B, int C, int HW, const float *f0, const float *f1, const float *w, const float *grad_out,
                              float *d_f0, void *stream);
+
+/* ---- bf16 VGG16 trunk of LPIPS on the matrix cores (utils/lpips/pretrained_networks.py:96-134) ---------------------
+ * Activations are NHWC bf16.  gom_conv3x3_bf16: 3x3, stride 1, zero padding 1; Cin multiple of 32, Cout multiple of 64;
+ * weights packed [Cin/32][9 taps (ky*3+kx)][Cout][32] bf16; bias fp32 [Cout] or NULL; flags GOM_CONV_RELU;
+ * mask (same shape as out) or NULL: out = (mask > 0) ? out : 0 -- the ReLU derivative of the layer below, which makes
+ * the same kernel the backward-data convolution when given the 180-degree-rotated, transposed weights.
+ * gom_maxpool2x2_*: 2x2 / stride 2 pooling and its backward (x = the pool's input, a post-ReLU activation; the routed
+ * gradient is also multiplied by [x > 0]; accumulate != 0: dx += ...).
+ * gom_lpips_prepare_bf16: (B,H,W,3) fp32 image in [0,1] -> ((2x-1) - shift)/scale (lpips.py:126-133, train.py:113),
+ * NHWC bf16 padded to 32 channels; gom_lpips_unprepare_bf16: gradient wrt that image from the gradient wrt the trunk input.
+ * gom_lpips_layer_*_nhwc_bf16: the LPIPS head (see gom_lpips_layer_forward) on NHWC bf16 taps; C = 64 or k*128.  The
+ * backward returns the gradient w.r.t. the tap's PRE-ReLU value (d/d f0 times [f0 > 0]): what the backward-data
+ * convolution of the layer consumes. */
+#define GOM_CONV_RELU 1u
+int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                     void *out, uint32_t flags, void *stream);
+/* split-K variant for layers with few pixel tiles: `splits` workgroups share the input channels of an output tile, fp32
+ * partial sums go through workspace [splits][B][H][W][Cout] and a second launch applies bias / ReLU / mask.
+ * gom_conv3x3_splits returns the split count the library would pick (1 = plain kernel). */
+int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout);
+int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                            void *out, uint32_t flags, int splits, float *workspace, void *stream);
+int gom_maxpool2x2_bf16(int B, int H, int W, int C, const void *x, void *y, void *stream);
+int gom_maxpool2x2_backward_bf16(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, void *stream);
+int gom_lpips_prepare_bf16(int B, int H, int W, const float *rgb, void *out32, void *stream);
+int gom_lpips_unprepare_bf16(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, void *stream);
+int gom_lpips_layer_forward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, void *stream);
+int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out,
+                                       void *d_f0, void *stream);
+
+/* LPIPS-VGG value and image gradient in one native call (train.py:113-121 and its backward) on the kernels above.
+ * create: 13 packed forward / backward-data weight tensors, 13 biases (fp32, padded to cout), 5 lin vectors, padded channel
+ * counts cin[13] / cout[13]; all DEVICE pointers that must outlive the handle.
+ * value_and_grad: pred, gt (B,H,W,3) fp32 in [0,1], H and W multiples of 16.  value_partials [5][B][GOM_LOSS_BLOCKS]:
+ * LPIPS of image b = sum over taps and blocks.  d_pred (B,H,W,3) = grad_scale * d LPIPS_b / d pred (NULL: value only). */
+typedef struct GomLpipsVgg GomLpipsVgg;
+GomLpipsVgg *gom_lpips_vgg_create(const void *const *w_fwd, const void *const *w_bwd, const float *const *bias, const float *const *lin,
+                                  const int32_t *cin, const int32_t *cout);
+void gom_lpips_vgg_destroy(GomLpipsVgg *h);
+int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
+                                 float grad_scale, float *d_pred, void *stream);
 
 /* ---- SSIM (evaluation metric; eval.py:106-108,157) --------------------------------------------
  * img0, img1 [H][W][C] fp32; weights [win][win] fp64 window (sums to 1; win odd); the SSIM map is evaluated where the

@@ -1,0 +1,93 @@
+"""The hand-written bf16 MFMA trunk of LPIPS (csrc/vgg_bf16.hip) against torch convolutions on the same
+bf16-rounded data, and the whole LPIPS value / image gradient against the fp32 path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 16, 32, 32, 64, True), (2, 24, 40, 64, 128, False), (1, 9, 21, 128, 64, True)])
+def test_conv3x3_matches_torch(B, H, W, Cin, Cout, relu):
+    from gomavatar_amd import _lib
+    from gomavatar_amd.lpips import pack_conv_weight, pack_conv_weight_backward
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = _bf(torch.randn(B, H, W, Cin, generator=g)).cuda()
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+    xb, wp = x.to(torch.bfloat16).contiguous(), pack_conv_weight(w)
+    _lib.check(lib.gom_conv3x3_bf16(B, H, W, Cin, Cout, _lib.ptr(xb), _lib.ptr(wp), _lib.ptr(b), 0, _lib.ptr(out), 1 if relu else 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 6e-3, float(err)           # one bf16 rounding of the output
+    # backward-data = the same kernel on rotated / transposed weights, with the ReLU mask of the layer below fused
+    gy = _bf(torch.randn(B, H, W, Cout, generator=g)).cuda()
+    below = torch.randn(B, H, W, Cin, generator=g).cuda()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_()
+    F.conv2d(xr, w, None, padding=1).backward(gy.permute(0, 3, 1, 2))
+    ref_dx = xr.grad.permute(0, 2, 3, 1) * (below > 0)
+    dx = torch.empty(B, H, W, max(64, Cin), dtype=torch.bfloat16, device="cuda")
+    wb = pack_conv_weight_backward(w)
+    mask = torch.zeros(B, H, W, max(64, Cin), dtype=torch.bfloat16, device="cuda")
+    mask[..., :Cin] = below.to(torch.bfloat16)
+    gyb = gy.to(torch.bfloat16).contiguous()
+    _lib.check(lib.gom_conv3x3_bf16(B, H, W, Cout, max(64, Cin), _lib.ptr(gyb), _lib.ptr(wb), 0, _lib.ptr(mask), _lib.ptr(dx), 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (dx.float()[..., :Cin] - ref_dx).abs().max() / ref_dx.abs().max()
+    assert float(err) < 6e-3, float(err)
+
+
+def test_maxpool_forward_backward():
+    from gomavatar_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(2, 8, 12, 64, generator=g)).cuda()
+    x[0, :2, :2, :] = -x[0, :2, :2, :].abs()          # one all-negative window: its routed gradient is masked ([x > 0])
+    xb = x.to(torch.bfloat16).contiguous()
+    y = torch.empty(2, 4, 6, 64, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.gom_maxpool2x2_bf16(2, 8, 12, 64, _lib.ptr(xb), _lib.ptr(y), _lib.stream_ptr()))
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_()
+    ref = F.max_pool2d(xr, 2, 2)
+    assert torch.equal(y.float(), ref.detach().permute(0, 2, 3, 1))
+    dy = _bf(torch.randn(2, 4, 6, 64, generator=g)).cuda()
+    ref.backward(dy.permute(0, 3, 1, 2))
+    base = _bf(torch.randn(2, 8, 12, 64, generator=g)).cuda()
+    dx = base.to(torch.bfloat16).contiguous()
+    dyb = dy.to(torch.bfloat16).contiguous()
+    _lib.check(lib.gom_maxpool2x2_backward_bf16(2, 8, 12, 64, _lib.ptr(xb), _lib.ptr(dyb), _lib.ptr(dx), 1, _lib.stream_ptr()))
+    want = _bf(base + xr.grad.permute(0, 2, 3, 1) * (x > 0))
+    assert torch.allclose(dx.float(), want, atol=2e-2, rtol=1e-2)
+
+
+def test_lpips_matrix_core_matches_fp32_path():
+    from gomavatar_amd.lpips import LPIPS, LPIPSMatrixCore, lpips_loss
+    g = torch.Generator().manual_seed(11)
+    pred = torch.rand(2, 64, 96, 3, generator=g).cuda()
+    gt = (pred.cpu() + 0.2 * torch.randn(2, 64, 96, 3, generator=g)).clamp(0, 1).cuda()
+    ref_model = LPIPS(trunk_seed=5)
+    p = pred.clone().requires_grad_()
+    ref = lpips_loss(ref_model, p, gt)
+    ref.backward()
+    mc = LPIPSMatrixCore(trunk_seed=5)
+    val, grad = mc.value_and_grad(pred, gt)
+    torch.cuda.synchronize()
+    assert abs(float(val) - float(ref.detach())) <= 0.03 * float(ref.detach()), (float(val), float(ref.detach()))      # bf16 activations
+    a, b = grad.flatten().double(), p.grad.flatten().double()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    assert cos > 0.98, cos
+    assert abs(float(a.norm() / b.norm()) - 1.0) < 0.05
+    # autograd wrapper: same value, gradient scaled by the upstream factor
+    q = pred.clone().requires_grad_()
+    (3.0 * mc.loss(q, gt)).backward()
+    assert torch.allclose(q.grad, 3.0 * grad, rtol=1e-6, atol=0)
+    v2, none = mc.value_and_grad(pred, gt, want_grad=False)
+    assert none is None and float(v2) == float(val)
