@@ -26,9 +26,22 @@ struct GomLpipsVgg {
     float *splitk = nullptr;
     float *go = nullptr;                         // [B] d value / d value_b
     size_t splitk_elems = 0;
+    // captured launch sequence (GOM_LPIPS_USE_GRAPH), valid for exactly these arguments
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const float *g_pred = nullptr, *g_gt = nullptr;
+    float *g_partials = nullptr, *g_dpred = nullptr;
+    float g_scale = 0.f;
 };
 
+static void lp_drop_graph(GomLpipsVgg *h) {
+    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->exec = nullptr; h->graph = nullptr;
+}
+
 static void lp_free(GomLpipsVgg *h) {
+    lp_drop_graph(h);
     void *ptrs[] = {h->x[0], h->x[1], h->grad[0], h->grad[1], h->gtap, h->splitk, h->go};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++)
@@ -98,12 +111,37 @@ __global__ void k_fill(float *p, int n, float v) {
     if (i < n) p[i] = v;
 }
 
+static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials, float grad_scale,
+                      float *d_pred, void *stream);
+
 extern "C" int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
-                                            float grad_scale, float *d_pred, void *stream) {
+                                            float grad_scale, float *d_pred, uint32_t flags, void *stream) {
     if (!h || !pred || !gt || !value_partials) { gom_set_error("gom_lpips_vgg_value_and_grad: null argument"); return -1; }
     if (B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) { gom_set_error("gom_lpips_vgg_value_and_grad: H and W must be multiples of 16"); return -1; }
     int rc;
+    const bool same_size = h->B == B && h->H == H && h->W == W;
     if ((rc = lp_ensure(h, B, H, W))) return rc;
+    if (!(flags & GOM_LPIPS_USE_GRAPH) || stream == nullptr) return lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->exec && same_size && h->g_pred == pred && h->g_gt == gt && h->g_partials == value_partials && h->g_dpred == d_pred && h->g_scale == grad_scale) {
+        GOM_HIP_CHECK(hipGraphLaunch(h->exec, st));
+        return 0;
+    }
+    lp_drop_graph(h);
+    GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    rc = lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, stream);
+    hipError_t ce = hipStreamEndCapture(st, &h->graph);
+    if (rc) { lp_drop_graph(h); return rc; }
+    if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); h->graph = nullptr; return -2; }
+    GOM_HIP_CHECK(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
+    h->g_pred = pred; h->g_gt = gt; h->g_partials = value_partials; h->g_dpred = d_pred; h->g_scale = grad_scale;
+    GOM_HIP_CHECK(hipGraphLaunch(h->exec, st));
+    return 0;
+}
+
+static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials, float grad_scale,
+                      float *d_pred, void *stream) {
+    int rc;
     const float *img[2] = {pred, gt};
     for (int k = 0; k < 2; k++) {
         if ((rc = gom_lpips_prepare_bf16(B, H, W, img[k], h->x[k], stream))) return rc;

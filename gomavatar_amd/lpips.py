@@ -210,15 +210,21 @@ class LPIPSMatrixCore:
             self.lib.gom_lpips_vgg_destroy(self._h)
             self._h = None
 
-    def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True):
-        """(mean_b LPIPS_b, d/d pred of it): ~75 kernel launches from one `gom_lpips_vgg_value_and_grad` call."""
+    def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True, out=None):
+        """(mean_b LPIPS_b, d/d pred of it): ~75 kernel launches from one `gom_lpips_vgg_value_and_grad` call.
+        `out=(partials, d_pred)` persistent buffers + contiguous fp32 `pred`/`gt` at stable addresses on a non-default
+        stream make the call replay a captured hipGraph."""
         assert pred.is_cuda and pred.dim() == 4 and pred.shape[-1] == 3 and pred.shape == gt.shape
         B, H, W, _ = pred.shape
         p32, g32 = pred.detach().float().contiguous(), gt.detach().float().contiguous()
-        partials = torch.empty((5, B, _lib.GOM_LOSS_BLOCKS), dtype=torch.float32, device=pred.device)
-        d_pred = torch.empty((B, H, W, 3), dtype=torch.float32, device=pred.device) if want_grad else None
+        if out is None:
+            partials = torch.empty((5, B, _lib.GOM_LOSS_BLOCKS), dtype=torch.float32, device=pred.device)
+            d_pred = torch.empty((B, H, W, 3), dtype=torch.float32, device=pred.device) if want_grad else None
+        else:
+            partials, d_pred = out
+        flags = 1 if (out is not None and _lib.stream_ptr() != 0) else 0
         _lib.check(self.lib.gom_lpips_vgg_value_and_grad(self._handle(), B, H, W, _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(partials), 1.0 / B,
-                                                         _lib.ptr(d_pred), _lib.stream_ptr()))
+                                                         _lib.ptr(d_pred), flags, _lib.stream_ptr()))
         return partials.sum(2).sum(0).mean(), d_pred
 
     def loss(self, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:

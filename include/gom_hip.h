@@ -219,8 +219,9 @@ typedef struct GomLpipsVgg GomLpipsVgg;
 GomLpipsVgg *gom_lpips_vgg_create(const void *const *w_fwd, const void *const *w_bwd, const float *const *bias, const float *const *lin,
                                   const int32_t *cin, const int32_t *cout);
 void gom_lpips_vgg_destroy(GomLpipsVgg *h);
+#define GOM_LPIPS_USE_GRAPH 1u   /* capture the ~75 launches once per (sizes, pointers) and replay them as one hipGraph */
 int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
-                                 float grad_scale, float *d_pred, void *stream);
+                                 float grad_scale, float *d_pred, uint32_t flags, void *stream);
 
 /* ---- SSIM (evaluation metric; eval.py:106-108,157) --------------------------------------------
  * img0, img1 [H][W][C] fp32; weights [win][win] fp64 window (sums to 1; win odd); the SSIM map is evaluated where the

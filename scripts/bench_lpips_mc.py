@@ -16,7 +16,11 @@ def timeit(fn, n=20, warm=3):
 H = W = int(os.environ.get("IMG", 512))
 pred = torch.rand(1, H, W, 3, device="cuda"); gt = torch.rand(1, H, W, 3, device="cuda")
 mc = LPIPSMatrixCore(trunk_seed=0)
-out = {"matrix_core_value_and_grad_ms": round(timeit(lambda: mc.value_and_grad(pred, gt)), 3),
+bufs = (torch.empty((5, 1, _lib.GOM_LOSS_BLOCKS), device="cuda"), torch.empty((1, H, W, 3), device="cuda"))
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    graph_ms = round(timeit(lambda: mc.value_and_grad(pred, gt, out=bufs)), 3)
+out = {"matrix_core_value_and_grad_graph_ms": graph_ms, "matrix_core_value_and_grad_ms": round(timeit(lambda: mc.value_and_grad(pred, gt)), 3),
        "matrix_core_value_only_ms": round(timeit(lambda: mc.value_and_grad(pred, gt, want_grad=False)), 3)}
 for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
     m = LPIPS(trunk_seed=0, trunk_dtype=dt)
