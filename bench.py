@@ -243,7 +243,7 @@ def main():
                           "all_kernels_us": {k: round(iso[k] * 1e3, 2) for k in _lib.KERNEL_NAMES}}}
 
     out = {
-        "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians",
+        "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians; PSNR vs ref",
         "value": round(world * B * args.steps / elapsed, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -272,6 +272,8 @@ def main():
         orast.set_threads(threads)
         pc = {k: v.detach().cpu() for k, v in params.items()}
         times = []
+        check = RenderStep(faces, N, (img, img), w25, device=dev)   # single-frame HIP render of the same frames: PSNR vs the oracle
+        mse_sum, mse_n = 0.0, 0
         for i in range(args.cpu_frames + 1):
             fr = {k: torch.from_numpy(v) for k, v in syn.make_frame(i, img).items()}
             po = {k: v.clone().requires_grad_() for k, v in pc.items()}
@@ -281,7 +283,16 @@ def main():
             l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt["gt_rgb"].cpu()[None], gt["gt_mask"].cpu()[None])
             (l1 + 5.0 * l2).backward()
             times.append(time.perf_counter() - t1)
+            fd = frames[i % len(frames)]
+            if i < len(frames):   # frames[i] was generated from make_frame(i) on rank 0: identical inputs on both sides
+                check.set_camera(fd["K"], fd["E"])
+                check.forward_backward(params, fd, fd["gt_rgb"], fd["gt_mask"], fd["bg"], backward=False)
+                h_rgb, h_mask = check.rgb_mask()
+                d = torch.cat([h_rgb[0].cpu() - o_rgb[0].detach(), (h_mask[0].cpu() - o_mask[0].detach())[..., None]], -1).double()
+                mse_sum += float((d ** 2).mean()); mse_n += 1
         times = times[1:]  # first frame warms caches / page-faults
+        if mse_n:
+            out["psnr_vs_oracle_db"] = round(-10.0 * math.log10(max(mse_sum / mse_n, 1e-30)), 2)   # "PSNR vs ref" of BASELINE.json's metric
         out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "frames/s", "cores": threads, "kind": "port",
                                "sample": f"{len(times)} frames of the same workload (fwd+bwd) through the CPU oracle, "
                                          f"{threads} threads (torch + OpenMP), host has {cores} logical cores"}
