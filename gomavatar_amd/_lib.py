@@ -77,6 +77,11 @@ SIGNATURES = {
     "gom_lpips_vgg_create": (c_void_p, [c_void_p] * 6),
     "gom_lpips_vgg_destroy": (None, [c_void_p]),
     "gom_lpips_vgg_value_and_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint32, c_void_p]),
+    "gom_mesh_raster_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gom_mesh_raster_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
+    "gom_mesh_pix_to_face": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gom_vertex_normals_forward": (c_int, [c_int, c_int] + [c_void_p] * 7),
+    "gom_vertex_normals_backward": (c_int, [c_int, c_int] + [c_void_p] * 9),
     "gom_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "gom_lpips_layer_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

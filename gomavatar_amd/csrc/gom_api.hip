@@ -48,7 +48,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,
-                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->batch_grads};
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->batch_grads, s->mesh_face};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -85,7 +85,10 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
 
 // Make sure the scratch fits (P, H, W).  Reallocation synchronises the device
 // (hipFree); it only happens when a dimension grows.
-static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B = 1) {
+static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B = 1);
+int gom_ensure_capacity(GomState *s, int P_frame, int H, int W, int B) { return ensure_capacity(s, P_frame, H, W, B); }
+
+static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int gx = (W + GOM_TILE - 1) / GOM_TILE, gy = (H + GOM_TILE - 1) / GOM_TILE;
     if ((int64_t)P_frame * B > 0x7fffffffLL || (int64_t)gy * B > 65535 || (int64_t)H * W * B > 0x7fffffffLL) {
         gom_set_error("batch of %d frames too large (P=%d, %dx%d)", B, P_frame, H, W);

@@ -48,6 +48,11 @@ struct GomState {
     int B = 1;
     const GomCamera *cams = nullptr;  // device array of B cameras for a batched launch; nullptr: the by-value camera
     bool haveForward = false;
+    // mesh normal / silhouette rasterizer (mesh_raster.hip) on this state: per-face geometry + per-face gradients
+    float *mesh_face = nullptr;
+    size_t capMeshFace = 0;
+    float meshBlurRadius = 0.f, meshSigma = 1e-4f;
+    bool meshForward = false;
     // per-frame parameter gradients of a batched frame call, summed by k_sum_frames
     float *batch_grads = nullptr;
     size_t capBatchGrads = 0;
@@ -128,6 +133,8 @@ void gom_set_error(const char *fmt, ...);
             return -3;                                                                            \
         }                                                                                         \
     } while (0)
+
+int gom_ensure_capacity(GomState *s, int P_frame, int H, int W, int B);
 
 // ---- launchers (one per kernel family; defined in the .hip files) ----------
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,

@@ -1,0 +1,450 @@
+// Mesh normal map + soft silhouette of the posed mesh: replaces the PyTorch3D MeshRasterizer
+// (naive O(pixels x faces) path, bin_size=0) + NormalShader / hard_rgb_blend and MeshRenderer(SoftSilhouetteShader)
+// that the reference runs every frame at models/modules/renderer/mesh.py:65-128 (called from models/model.py:270-273).
+//
+//   normal(p)  = n0 + n1 + n2 of the nearest (smallest interpolated z) face covering pixel p, 0 where none
+//                (phong_normal_shading with barycentrics = 1, hard_rgb_blend, x alpha: mesh.py:23-30,57-61,121-124)
+//   alpha(p)   = 1 - prod_k (1 - sigmoid(-sdist_k / 1e-4)) over the faces whose blurred footprint reaches p
+//                (blur_radius = ln(1/1e-4 - 1) * sigma_cfg, faces_per_pixel = 50: mesh.py:99-112,127)
+//
+// MI355X design: faces are tile-binned exactly like the Gaussians (count -> scan -> emit -> per-tile sort by face index
+// = the GomState machinery of raster_pre.hip / raster_render.hip, which also yields the (face, tile) -> list position
+// table for the backward); one workgroup per 16x16 tile walks its LDS-staged face list once for both outputs.
+// faces_per_pixel: every qualifying face has sigmoid(-sdist/1e-4) >= 0.285 (sdist < blur_radius = 9.2e-5), so with 50
+// or more of them the product is < 6e-8 whichever 50 are kept: alpha is computed over ALL qualifying faces and
+// differs from the K = 50 truncation by less than one fp32 ulp of 1.0.
+// Backward: one thread per (tile, face) list entry re-walks the few pixels of the face's footprint in that tile and
+// writes one record; a per-face gather and a per-vertex CSR gather follow.  No float atomics: bitwise reproducible.
+#include "gom_internal.h"
+
+namespace {
+
+constexpr float kEpsArea = 1e-8f;
+constexpr int kFaceStride = 12;  // x0 y0 z0 x1 y1 z1 x2 y2 z2 area . .
+
+struct MeshGrid {
+    int H, W, gx, gy;
+    float rngx, offx, rngy, offy;  // pix_to_non_square_ndc
+};
+
+__device__ __forceinline__ float pix_x(const MeshGrid &g, int xi) { return -g.offx + (g.rngx * (float)(g.W - 1 - xi) + g.offx) / (float)g.W; }
+__device__ __forceinline__ float pix_y(const MeshGrid &g, int yi) { return -g.offy + (g.rngy * (float)(g.H - 1 - yi) + g.offy) / (float)g.H; }
+// continuous pixel coordinate of an NDC value (inverse of the above)
+__device__ __forceinline__ float ndc_to_px(const MeshGrid &g, float x) { return (float)(g.W - 1) - ((x + g.offx) * (float)g.W - g.offx) / g.rngx; }
+__device__ __forceinline__ float ndc_to_py(const MeshGrid &g, float y) { return (float)(g.H - 1) - ((y + g.offy) * (float)g.H - g.offy) / g.rngy; }
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+// squared distance from p to segment ab; t_out: clamped parameter, degenerate: the edge is (nearly) a point
+__device__ __forceinline__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by, float &t_out, bool &degenerate) {
+    const float dx = bx - ax, dy = by - ay;
+    const float l2 = dx * dx + dy * dy;
+    degenerate = !(l2 > kEpsArea);
+    if (degenerate) { t_out = 1.f; return (px - bx) * (px - bx) + (py - by) * (py - by); }
+    float t = ((px - ax) * dx + (py - ay) * dy) / l2;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    t_out = t;
+    const float qx = ax + t * dx, qy = ay + t * dy;
+    return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+}
+
+struct FaceEval {
+    bool hard, soft, inside;
+    float z_hard, prob;
+    int edge;       // nearest edge 0: v0v1, 1: v1v2, 2: v2v0
+    float t;        // clamped parameter on it
+    bool degenerate;
+};
+
+__device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py, float blur, float blur_radius, float inv_sigma) {
+    FaceEval r;
+    r.hard = r.soft = r.inside = false;
+    r.z_hard = 0.f; r.prob = 0.f; r.edge = 0; r.t = 0.f; r.degenerate = false;
+    const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8], area = f[9];
+    const float xmin = fminf(fminf(x0, x1), x2), xmax = fmaxf(fmaxf(x0, x1), x2);
+    const float ymin = fminf(fminf(y0, y1), y2), ymax = fmaxf(fmaxf(y0, y1), y2);
+    if (px > xmax + blur || px < xmin - blur || py > ymax + blur || py < ymin - blur) return r;
+    const float den = area + kEpsArea;
+    const float w0 = edge_fn(px, py, x1, y1, x2, y2) / den, w1 = edge_fn(px, py, x2, y2, x0, y0) / den, w2 = edge_fn(px, py, x0, y0, x1, y1) / den;
+    r.inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+    if (r.inside) {
+        const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+        r.hard = pz >= 0.f;
+        r.z_hard = pz;
+    }
+    // soft pass: clipped barycentrics for the depth test
+    const float c0 = fminf(fmaxf(w0, 0.f), 1.f), c1 = fminf(fmaxf(w1, 0.f), 1.f), c2 = fminf(fmaxf(w2, 0.f), 1.f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    const float pzs = (c0 / s) * z0 + (c1 / s) * z1 + (c2 / s) * z2;
+    if (!(pzs >= 0.f)) return r;
+    float t0, t1, t2;
+    bool g0, g1, g2;
+    const float d0 = seg_dist2(px, py, x0, y0, x1, y1, t0, g0), d1 = seg_dist2(px, py, x1, y1, x2, y2, t1, g1), d2 = seg_dist2(px, py, x2, y2, x0, y0, t2, g2);
+    float d = d0; r.edge = 0; r.t = t0; r.degenerate = g0;
+    if (d1 < d) { d = d1; r.edge = 1; r.t = t1; r.degenerate = g1; }
+    if (d2 < d) { d = d2; r.edge = 2; r.t = t2; r.degenerate = g2; }
+    if (!r.inside && !(d < blur_radius)) return r;
+    r.soft = true;
+    const float sd = r.inside ? -d : d;
+    r.prob = 1.f / (1.f + __expf(sd * inv_sigma));   // sigmoid(-sd / sigma)
+    return r;
+}
+
+// ---- per face: projected geometry, conservative tile rect, tile counts (feeds k_scan_tiles / k_emit / k_sort) --------
+__global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, const float *__restrict__ verts, const int32_t *__restrict__ faces, float blur,
+                                                         float *__restrict__ face_geo, float *__restrict__ depth, float2 *__restrict__ xy,
+                                                         float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
+                                                         ushort4 *__restrict__ rect, int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count,
+                                                         uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status) {
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_blockbase;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (f < F) {
+        const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[k] = verts[3 * (size_t)i0 + k]; v[3 + k] = verts[3 * (size_t)i1 + k]; v[6 + k] = verts[3 * (size_t)i2 + k]; }
+        const float area = edge_fn(v[6], v[7], v[0], v[1], v[3], v[4]);
+        float *dst = face_geo + (size_t)f * kFaceStride;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k] = v[k];
+        dst[9] = area;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        const bool finite = isfinite(v[0]) && isfinite(v[1]) && isfinite(v[3]) && isfinite(v[4]) && isfinite(v[6]) && isfinite(v[7]);
+        if (finite && fabsf(area) > kEpsArea && fmaxf(fmaxf(v[2], v[5]), v[8]) >= 0.f) {
+            const float xmin = fminf(fminf(v[0], v[3]), v[6]) - blur, xmax = fmaxf(fmaxf(v[0], v[3]), v[6]) + blur;
+            const float ymin = fminf(fminf(v[1], v[4]), v[7]) - blur, ymax = fmaxf(fmaxf(v[1], v[4]), v[7]) + blur;
+            // +X is left / +Y is up: the largest NDC value maps to the smallest pixel index; one pixel of safety margin
+            const float pxa = fminf(fmaxf(ndc_to_px(g, xmax) - 1.f, -1.f), (float)g.W), pxb = fminf(fmaxf(ndc_to_px(g, xmin) + 1.f, -1.f), (float)g.W);
+            const float pya = fminf(fmaxf(ndc_to_py(g, ymax) - 1.f, -1.f), (float)g.H), pyb = fminf(fmaxf(ndc_to_py(g, ymin) + 1.f, -1.f), (float)g.H);
+            const int ixa = max(0, (int)floorf(pxa)), ixb = min(g.W - 1, (int)ceilf(pxb));
+            const int iya = max(0, (int)floorf(pya)), iyb = min(g.H - 1, (int)ceilf(pyb));
+            if (ixa <= ixb && iya <= iyb) {
+                x0 = ixa / GOM_TILE; x1 = ixb / GOM_TILE + 1; y0 = iya / GOM_TILE; y1 = iyb / GOM_TILE + 1;
+            }
+        }
+        my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+        depth[f] = 0.f;                               // the sort key is the face index alone
+        xy[f] = make_float2(0.f, 0.f);
+        conic_opacity[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        radii[f] = my_tiles ? 1 : 0;
+        tiles_touched[f] = my_tiles;
+        rect[f] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * g.gx + x], 1u);
+    }
+    // private range of this face in pair_pos (same scheme as k_preprocess)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = my_tiles;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wid] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        s_blockbase = tot ? atomicAdd(&status->pair_cursor, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += s_wsum[w];
+    if (f < F) pair_off[f] = s_blockbase + woff + (x - my_tiles);
+}
+
+// ---- forward: one workgroup per tile, thread = pixel ---------------------------------------------------------------------
+constexpr int kChunk = 128;
+__global__ void __launch_bounds__(256) k_mesh_forward(MeshGrid g, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ point_list,
+                                                      const float *__restrict__ face_geo, const int32_t *__restrict__ faces,
+                                                      const float *__restrict__ vnormals, float blur, float blur_radius, float inv_sigma,
+                                                      float *__restrict__ normal_map, float *__restrict__ alpha, uint32_t *__restrict__ pix_to_face,
+                                                      float *__restrict__ prodQ, const GomDevStatus *__restrict__ status) {
+    __shared__ float s_f[kChunk][10];
+    __shared__ uint32_t s_id[kChunk];
+    const int tile = blockIdx.x;
+    const int xi = (tile % g.gx) * GOM_TILE + (threadIdx.x & 15), yi = (tile / g.gx) * GOM_TILE + (threadIdx.x >> 4);
+    const bool inside_img = xi < g.W && yi < g.H;
+    const float px = pix_x(g, xi), py = pix_y(g, yi);
+    const uint32_t base = tile_base[tile], n = status->overflow ? 0u : tile_base[tile + 1] - base;
+    float best_z = 3.0e38f, Q = 1.f;
+    uint32_t best = 0xffffffffu;
+    for (uint32_t e0 = 0; e0 < n; e0 += kChunk) {
+        const uint32_t cn = min((uint32_t)kChunk, n - e0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cn * 10; i += 256) {
+            const uint32_t j = i / 10, k = i % 10;
+            s_f[j][k] = face_geo[(size_t)point_list[base + e0 + j] * kFaceStride + k];
+        }
+        if (threadIdx.x < cn) s_id[threadIdx.x] = point_list[base + e0 + threadIdx.x];
+        __syncthreads();
+        if (!inside_img) continue;
+        for (uint32_t j = 0; j < cn; j++) {
+            const FaceEval r = eval_face(s_f[j], px, py, blur, blur_radius, inv_sigma);
+            if (r.hard && r.z_hard < best_z) { best_z = r.z_hard; best = s_id[j]; }   // list is sorted by face index: first wins ties
+            if (r.soft) Q *= (1.f - r.prob);
+        }
+    }
+    if (!inside_img) return;
+    const size_t p = (size_t)yi * g.W + xi;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (best != 0xffffffffu) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int v = faces[3 * (size_t)best + c];
+            nx += vnormals[3 * (size_t)v]; ny += vnormals[3 * (size_t)v + 1]; nz += vnormals[3 * (size_t)v + 2];
+        }
+    }
+    normal_map[3 * p] = nx; normal_map[3 * p + 1] = ny; normal_map[3 * p + 2] = nz;
+    pix_to_face[p] = best;
+    prodQ[p] = Q;
+    if (alpha) alpha[p] = 1.f - Q;
+}
+
+// ---- backward, step 1: one thread per (tile, face) entry -> 9-float record at the entry's list position --------------
+//   [0..5] d/d(x0,y0,x1,y1,x2,y2) from the silhouette, [6..8] d/d(n0+n1+n2) from the normal map
+__global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ point_list,
+                                                               const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
+                                                               const uint32_t *__restrict__ pix_to_face, const float *__restrict__ prodQ,
+                                                               const float *__restrict__ d_normal, const float *__restrict__ d_alpha,
+                                                               float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
+    if (status->overflow) return;
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % g.gx) * GOM_TILE, ty0 = (tile / g.gx) * GOM_TILE;
+    const uint32_t base = tile_base[tile], n = tile_base[tile + 1] - base;
+    for (uint32_t e = threadIdx.x; e < n; e += 256) {
+        const uint32_t f = point_list[base + e];
+        float fg[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) fg[k] = face_geo[(size_t)f * kFaceStride + k];
+        const float xmin = fminf(fminf(fg[0], fg[3]), fg[6]) - blur, xmax = fmaxf(fmaxf(fg[0], fg[3]), fg[6]) + blur;
+        const float ymin = fminf(fminf(fg[1], fg[4]), fg[7]) - blur, ymax = fmaxf(fmaxf(fg[1], fg[4]), fg[7]) + blur;
+        const int ixa = max(tx0, (int)floorf(ndc_to_px(g, xmax) - 1.f)), ixb = min(min(tx0 + GOM_TILE, g.W) - 1, (int)ceilf(ndc_to_px(g, xmin) + 1.f));
+        const int iya = max(ty0, (int)floorf(ndc_to_py(g, ymax) - 1.f)), iyb = min(min(ty0 + GOM_TILE, g.H) - 1, (int)ceilf(ndc_to_py(g, ymin) + 1.f));
+        float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+        for (int yi = iya; yi <= iyb; yi++)
+            for (int xi = ixa; xi <= ixb; xi++) {
+                const size_t p = (size_t)yi * g.W + xi;
+                if (pix_to_face[p] == f) { gn[0] += d_normal[3 * p]; gn[1] += d_normal[3 * p + 1]; gn[2] += d_normal[3 * p + 2]; }
+                if (!d_alpha) continue;
+                const float px = pix_x(g, xi), py = pix_y(g, yi);
+                const FaceEval r = eval_face(fg, px, py, blur, blur_radius, inv_sigma);
+                if (!r.soft) continue;
+                // alpha = 1 - prod(1 - p_j), p = sigmoid(-sd/sigma):  d alpha / d sd_k = -(Q / (1 - p_k)) p_k (1 - p_k) / sigma
+                const float others = prodQ[p] / fmaxf(1.f - r.prob, 1e-30f);
+                float gd = -d_alpha[p] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
+                if (r.inside) gd = -gd;                                                    // sd = -dist inside
+                const int ia = r.edge, ib = (r.edge + 1) % 3;
+                const float ax = fg[3 * ia], ay = fg[3 * ia + 1], bx = fg[3 * ib], by = fg[3 * ib + 1];
+                if (r.degenerate) {
+                    gv[2 * ib] += gd * -2.f * (px - bx); gv[2 * ib + 1] += gd * -2.f * (py - by);
+                } else {
+                    const float qx = ax + r.t * (bx - ax), qy = ay + r.t * (by - ay);
+                    const float rx = px - qx, ry = py - qy;
+                    // dist = |p - q|^2, q = a + t (b - a): for 0 < t < 1 the residual is normal to the edge, so only q's
+                    // explicit dependence on a, b counts; at the clamps q is the end point itself
+                    gv[2 * ia] += gd * -2.f * rx * (1.f - r.t); gv[2 * ia + 1] += gd * -2.f * ry * (1.f - r.t);
+                    gv[2 * ib] += gd * -2.f * rx * r.t;         gv[2 * ib + 1] += gd * -2.f * ry * r.t;
+                }
+            }
+        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(base + e) * GOM_PARTIAL_STRIDE);
+        rec[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        rec[1] = make_float4(gv[4], gv[5], gn[0], gn[1]);
+        rec[2] = make_float4(gn[2], 0.f, 0.f, 0.f);
+    }
+}
+
+// ---- backward, step 2: per face, sum the records of its tiles (fixed order) ------------------------------------------------
+__global__ void __launch_bounds__(256) k_mesh_face_gather(int F, const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ pair_off,
+                                                          const uint32_t *__restrict__ pair_pos, const float *__restrict__ partial,
+                                                          float *__restrict__ d_face, const GomDevStatus *__restrict__ status) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = status->overflow ? __uint_as_float(0x7fc00000u) : 0.f;
+    const uint32_t nt = status->overflow ? 0u : tiles_touched[f];
+    const uint32_t *pp = pair_pos + pair_off[f];
+    for (uint32_t k = 0; k < nt; k++) {
+        const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[k] * GOM_PARTIAL_STRIDE);
+        const float4 a = rec[0], b = rec[1], c = rec[2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) d_face[(size_t)f * 9 + k] = acc[k];
+}
+
+// ---- backward, step 3: per vertex, CSR gather over incident (face, corner) pairs -------------------------------------------
+__global__ void __launch_bounds__(256) k_mesh_vertex_gather(int N, const int32_t *__restrict__ csr_off, const int32_t *__restrict__ csr_idx,
+                                                            const float *__restrict__ d_face, float *__restrict__ d_verts, float *__restrict__ d_vnormals) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    float gx = 0.f, gy = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
+        const int fc = csr_idx[k], f = fc / 3, c = fc % 3;
+        const float *r = d_face + (size_t)f * 9;
+        gx += r[2 * c]; gy += r[2 * c + 1];
+        n0 += r[6]; n1 += r[7]; n2 += r[8];
+    }
+    d_verts[3 * (size_t)v] = gx; d_verts[3 * (size_t)v + 1] = gy; d_verts[3 * (size_t)v + 2] = 0.f;   // z only orders the faces
+    d_vnormals[3 * (size_t)v] = n0; d_vnormals[3 * (size_t)v + 1] = n1; d_vnormals[3 * (size_t)v + 2] = n2;
+}
+
+// ---- vertex normals (PyTorch3D Meshes.verts_normals_packed: area-weighted face normals summed on the corners, then
+// normalize(eps = 1e-6)); CSR gather instead of three index_add scatters: no atomics, fixed summation order ---------------
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__global__ void __launch_bounds__(256) k_vnormal_fwd(int N, const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                     const int32_t *__restrict__ csr_off, const int32_t *__restrict__ csr_idx,
+                                                     float *__restrict__ sums, float *__restrict__ normals) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
+        const int fc = csr_idx[k], f = fc / 3, c = fc % 3;
+        // corner c: cross(v[c+1] - v[c], v[c+2] - v[c]) -- the three per-corner expressions of the reference framework
+        const int ia = faces[3 * f + c], ib = faces[3 * f + (c + 1) % 3], ic = faces[3 * f + (c + 2) % 3];
+        float e1[3], e2[3], n[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { e1[d] = verts[3 * (size_t)ib + d] - verts[3 * (size_t)ia + d]; e2[d] = verts[3 * (size_t)ic + d] - verts[3 * (size_t)ia + d]; }
+        cross3(e1, e2, n);
+        acc[0] += n[0]; acc[1] += n[1]; acc[2] += n[2];
+    }
+    const float len = fmaxf(sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]), 1e-6f);
+#pragma unroll
+    for (int d = 0; d < 3; d++) { sums[3 * (size_t)v + d] = acc[d]; normals[3 * (size_t)v + d] = acc[d] / len; }
+}
+// per face: g = sum over its corners of d L / d sums[corner vertex]; n = (v1 - v0) x (v2 - v0):
+// dL/dv1 = (v2 - v0) x g, dL/dv2 = g x (v1 - v0), dL/dv0 = -(dL/dv1 + dL/dv2)   -> d_corner [F][3][3]
+__global__ void __launch_bounds__(256) k_vnormal_bwd_face(int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                          const float *__restrict__ sums, const float *__restrict__ d_normals,
+                                                          float *__restrict__ d_corner) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    int idx[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+    float g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *sv = sums + 3 * (size_t)idx[c], *dn = d_normals + 3 * (size_t)idx[c];
+        const float l = sqrtf(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
+        if (l > 1e-6f) {   // y = s / |s|: dL/ds = (dn - y (y . dn)) / |s|
+            const float y[3] = {sv[0] / l, sv[1] / l, sv[2] / l};
+            const float dot = y[0] * dn[0] + y[1] * dn[1] + y[2] * dn[2];
+#pragma unroll
+            for (int d = 0; d < 3; d++) g[d] += (dn[d] - y[d] * dot) / l;
+        } else {           // y = s / 1e-6
+#pragma unroll
+            for (int d = 0; d < 3; d++) g[d] += dn[d] / 1e-6f;
+        }
+    }
+    float e1[3], e2[3], d1[3], d2[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { e1[d] = verts[3 * (size_t)idx[1] + d] - verts[3 * (size_t)idx[0] + d]; e2[d] = verts[3 * (size_t)idx[2] + d] - verts[3 * (size_t)idx[0] + d]; }
+    cross3(e2, g, d1);
+    cross3(g, e1, d2);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        d_corner[9 * (size_t)f + d] = -(d1[d] + d2[d]);
+        d_corner[9 * (size_t)f + 3 + d] = d1[d];
+        d_corner[9 * (size_t)f + 6 + d] = d2[d];
+    }
+}
+__global__ void __launch_bounds__(256) k_corner_gather(int N, const int32_t *__restrict__ csr_off, const int32_t *__restrict__ csr_idx,
+                                                       const float *__restrict__ d_corner, float *__restrict__ d_verts) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
+        const float *r = d_corner + 3 * (size_t)csr_idx[k];
+        a0 += r[0]; a1 += r[1]; a2 += r[2];
+    }
+    d_verts[3 * (size_t)v] = a0; d_verts[3 * (size_t)v + 1] = a1; d_verts[3 * (size_t)v + 2] = a2;
+}
+
+MeshGrid make_grid(int H, int W) {
+    MeshGrid g;
+    g.H = H; g.W = W;
+    g.gx = (W + GOM_TILE - 1) / GOM_TILE; g.gy = (H + GOM_TILE - 1) / GOM_TILE;
+    g.rngx = W > H ? 2.f * (float)W / (float)H : 2.f; g.offx = g.rngx / 2.f;
+    g.rngy = H > W ? 2.f * (float)H / (float)W : 2.f; g.offy = g.rngy / 2.f;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, const float *verts_ndc, const int32_t *faces, const float *vnormals,
+                                       float blur_radius, float sigma, float *normal_map, float *alpha, void *stream) {
+    if (!s) { gom_set_error("null state"); return -1; }
+    if (N <= 0 || F <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f) || blur_radius < 0.f) { gom_set_error("gom_mesh_raster_forward: bad sizes"); return -1; }
+    if (!verts_ndc || !faces || !vnormals || !normal_map) { gom_set_error("gom_mesh_raster_forward: null pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = gom_ensure_capacity(s, F, H, W, 1)) return rc;
+    if ((size_t)F * kFaceStride > s->capMeshFace) {
+        if (s->mesh_face) GOM_HIP_CHECK(hipFree(s->mesh_face));
+        s->mesh_face = nullptr;
+        GOM_HIP_CHECK(hipMalloc((void **)&s->mesh_face, (size_t)F * kFaceStride * sizeof(float) * 2));   // geometry + per-face gradient
+        s->capMeshFace = (size_t)F * kFaceStride;
+    }
+    s->P = F; s->H = H; s->W = W; s->C = 3; s->cams = nullptr; s->haveForward = false;
+    const MeshGrid g = make_grid(H, W);
+    const float blur = sqrtf(blur_radius);
+    hipLaunchKernelGGL(k_mesh_preprocess, dim3((F + 255) / 256), dim3(256), 0, st, g, F, verts_ndc, faces, blur, s->mesh_face, s->depth, s->xy,
+                       s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->pair_off, s->status);
+    GOM_LAUNCH_CHECK();
+    if (int rc = gom_launch_scan_emit(s, F, st)) return rc;
+    if (int rc = gom_launch_sort(s, st)) return rc;
+    hipLaunchKernelGGL(k_mesh_forward, dim3(g.gx * g.gy), dim3(256), 0, st, g, s->tile_base, s->point_list, s->mesh_face, faces, vnormals, blur,
+                       blur_radius, 1.0f / sigma, normal_map, alpha, s->n_contrib, s->final_T, s->status);
+    GOM_LAUNCH_CHECK();
+    s->meshBlurRadius = blur_radius; s->meshSigma = sigma; s->meshForward = true;
+    return 0;
+}
+
+extern "C" int gom_mesh_raster_backward(GomState *s, int N, int F, int H, int W, const int32_t *csr_off, const int32_t *csr_idx,
+                                        const float *d_normal_map, const float *d_alpha, float *d_verts_ndc, float *d_vnormals, void *stream) {
+    if (!s || !s->meshForward || s->P != F || s->H != H || s->W != W) { gom_set_error("gom_mesh_raster_backward without a matching forward on this state"); return -1; }
+    if (!csr_off || !csr_idx || !d_normal_map || !d_verts_ndc || !d_vnormals) { gom_set_error("gom_mesh_raster_backward: null pointer"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const MeshGrid g = make_grid(H, W);
+    float *d_face = s->mesh_face + s->capMeshFace;
+    hipLaunchKernelGGL(k_mesh_backward_entries, dim3(g.gx * g.gy), dim3(256), 0, st, g, s->tile_base, s->point_list, s->mesh_face, sqrtf(s->meshBlurRadius),
+                       s->meshBlurRadius, 1.0f / s->meshSigma, s->n_contrib, s->final_T, d_normal_map, d_alpha, s->partial, s->status);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mesh_face_gather, dim3((F + 255) / 256), dim3(256), 0, st, F, s->tiles_touched, s->pair_off, s->pair_pos, s->partial, d_face,
+                       s->status);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mesh_vertex_gather, dim3((N + 255) / 256), dim3(256), 0, st, N, csr_off, csr_idx, d_face, d_verts_ndc, d_vnormals);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_mesh_pix_to_face(GomState *s, int32_t *dst, void *stream) {
+    if (!s || !s->meshForward || !dst) { gom_set_error("gom_mesh_pix_to_face without a forward"); return -1; }
+    GOM_HIP_CHECK(hipMemcpyAsync(dst, s->n_contrib, (size_t)s->H * s->W * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gom_vertex_normals_forward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
+                                          float *sums, float *normals, void *stream) {
+    (void)F;
+    if (N <= 0 || !verts || !faces || !csr_off || !csr_idx || !sums || !normals) { gom_set_error("gom_vertex_normals_forward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_vnormal_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, verts, faces, csr_off, csr_idx, sums, normals);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_vertex_normals_backward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
+                                           const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts, void *stream) {
+    if (N <= 0 || F <= 0 || !verts || !faces || !csr_off || !csr_idx || !sums || !d_normals || !d_corner_scratch || !d_verts) {
+        gom_set_error("gom_vertex_normals_backward: bad arguments");
+        return -1;
+    }
+    hipLaunchKernelGGL(k_vnormal_bwd_face, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, F, verts, faces, sums, d_normals, d_corner_scratch);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_corner_gather, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, csr_off, csr_idx, d_corner_scratch, d_verts);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

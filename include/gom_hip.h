@@ -28,6 +28,8 @@
  *       autograd backward.
  *   gom_conv3x3_bf16, gom_maxpool2x2_*, gom_lpips_prepare_bf16, gom_lpips_layer_*_nhwc_bf16
  *       utils/lpips/pretrained_networks.py:96-134 (VGG16 trunk) + utils/lpips/lpips.py:81-133 on the matrix cores.
+ *   gom_mesh_raster_forward / gom_mesh_raster_backward
+ *       models/modules/renderer/mesh.py:65-128 (PyTorch3D MeshRasterizer + NormalShader + SoftSilhouetteShader).
  *   gom_ssim
  *       eval.py:106-108 (skimage structural_similarity, multichannel) and eval.py:157 (torchmetrics SSIM).
  *   gom_lpips_layer_forward / gom_lpips_layer_backward
@@ -222,6 +224,28 @@ void gom_lpips_vgg_destroy(GomLpipsVgg *h);
 #define GOM_LPIPS_USE_GRAPH 1u   /* capture the ~75 launches once per (sizes, pointers) and replay them as one hipGraph */
 int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
                                  float grad_scale, float *d_pred, uint32_t flags, void *stream);
+
+/* ---- mesh normal map + soft silhouette (models/modules/renderer/mesh.py:65-128, called at models/model.py:270-273) -----
+ * verts_ndc [N][3]: what utils/pc_util.py:30-46 `ndc_T_world` returns (x, y negated NDC with the shorter image side in
+ * [-1,1], z = camera depth); faces [F][3]; vnormals [N][3] (already rotated into the camera frame, model.py:271-273).
+ * normal_map [H][W][3] = n0 + n1 + n2 of the nearest face under the pixel, 0 where none (NormalShader + hard_rgb_blend,
+ * then x alpha: mesh.py:23-30,121-124).  alpha [H][W] (NULL: evaluation mode) = soft silhouette of
+ * MeshRenderer(SoftSilhouetteShader) with blur_radius = ln(1/1e-4 - 1) * cfg.sigma and blend sigma 1e-4 (mesh.py:99-112,127).
+ * The state keeps binning, pix_to_face and the per-pixel product for the backward; it is a GomState used for nothing else.
+ * backward: d_normal_map [H][W][3], d_alpha [H][W] or NULL -> d_verts_ndc [N][3] (z = 0: depth only orders the faces),
+ * d_vnormals [N][3]; csr_off [N+1] / csr_idx [3F] = vertex -> (face*3 + corner). */
+int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, const float *verts_ndc, const int32_t *faces, const float *vnormals,
+                            float blur_radius, float sigma, float *normal_map, float *alpha, void *stream);
+int gom_mesh_raster_backward(GomState *s, int N, int F, int H, int W, const int32_t *csr_off, const int32_t *csr_idx, const float *d_normal_map,
+                             const float *d_alpha, float *d_verts_ndc, float *d_vnormals, void *stream);
+int gom_mesh_pix_to_face(GomState *s, int32_t *dst /*[H][W], -1 = background*/, void *stream);
+/* vertex normals of a mesh (PyTorch3D Meshes.verts_normals_padded, models/model.py:271): verts [N][3], faces [F][3];
+ * sums [N][3] = un-normalised sums (kept for the backward), normals [N][3] = sums / max(|sums|, 1e-6).
+ * backward: d_normals [N][3] -> d_verts [N][3]; d_corner_scratch [F][9]. */
+int gom_vertex_normals_forward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
+                               float *sums, float *normals, void *stream);
+int gom_vertex_normals_backward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
+                                const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts, void *stream);
 
 /* ---- SSIM (evaluation metric; eval.py:106-108,157) --------------------------------------------
  * img0, img1 [H][W][C] fp32; weights [win][win] fp64 window (sums to 1; win odd); the SSIM map is evaluated where the

@@ -1,0 +1,80 @@
+"""Mesh normal map / soft silhouette rasterizer (csrc/mesh_raster.hip) against the brute-force torch restatement of
+the reference's PyTorch3D renderer (oracle/mesh.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gomavatar_amd import synthetic as syn
+from oracle import mesh as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(img, body=None, frame=1):
+    body = body or syn.icosphere_body(3)
+    fr = syn.make_frame(frame, img)
+    v = torch.from_numpy(body["canonical_vertex"]).T.contiguous()[None]
+    faces = torch.from_numpy(body["faces"]).long()
+    return v, faces, torch.from_numpy(fr["K"]), torch.from_numpy(fr["E"])
+
+
+@pytest.mark.parametrize("img,zoom", [(64, 1.0), (96, 3.0)])
+def test_forward_and_backward_match_oracle(img, zoom):
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, ndc_T_world, vertex_normals
+    v, faces, K, E = _scene(img)
+    K = K.clone(); K[:, 0, 0] *= zoom; K[:, 1, 1] *= zoom      # zoom: faces of several pixels (real footprints, blur band < face)
+    # --- oracle (fp64) ---
+    vo = v.double().requires_grad_()
+    ndc_o = om.ndc_T_world(vo, K.double(), E.double(), img, img)[0]
+    vn_o = om.vertex_normals(vo[0].T, faces)
+    n_o, a_o, p2f_o = om.render(ndc_o, faces, vn_o, img, img, sigma_cfg=1e-5)
+    g = torch.Generator().manual_seed(0)
+    wn, wa = torch.randn(img, img, 3, generator=g).double(), torch.randn(img, img, generator=g).double()
+    ((n_o * wn).sum() + (a_o * wa).sum()).backward()
+    # --- HIP ---
+    r = MeshNormalRenderer(img_size=(img, img), sigma=1e-5).cuda().train()
+    vh = v.cuda().requires_grad_()
+    fc = faces.cuda()
+    vn_h = vertex_normals(vh[0].T, r.topology(fc, vh.shape[2]))
+    assert torch.allclose(vn_h.detach().cpu().double(), vn_o.detach(), atol=2e-6)
+    normal, mask = r(vh, vn_h[None], K.cuda(), E.cuda(), fc)
+    assert normal.shape == (1, img, img, 3) and mask.shape == (1, img, img, 1)
+    ((normal[0] * wn.float().cuda()).sum() + (mask[0, ..., 0] * wa.float().cuda()).sum()).backward()
+    p2f = torch.empty(img, img, dtype=torch.int32, device="cuda")
+    from gomavatar_amd import _lib
+    _lib.check(_lib.load().gom_mesh_pix_to_face(r.state.handle, _lib.ptr(p2f), _lib.stream_ptr()))
+    same = (p2f.cpu().long() == p2f_o)
+    assert same.float().mean() > 0.999, same.float().mean()                # pixels exactly on an edge may pick the neighbour
+    assert (p2f_o >= 0).float().mean() > 0.03
+    dn = (normal[0].detach().cpu().double() - n_o.detach()).abs().amax(-1)
+    assert float(dn[same].max()) < 1e-5
+    da = (mask[0, ..., 0].detach().cpu().double() - a_o.detach()).abs()
+    assert float(da.max()) < 2e-5, float(da.max())
+    # ndc_T_world mirror
+    assert torch.allclose(ndc_T_world(v, K, E, img, img), om.ndc_T_world(v, K, E, img, img), atol=1e-6)
+    gr, gg = vo.grad[0].numpy(), vh.grad[0].cpu().numpy().astype(np.float64)
+    scale = np.abs(gr).max()
+    err = np.abs(gg - gr)
+    assert np.quantile(err, 0.99) <= 2e-3 * scale and np.median(err) <= 1e-5 * scale, (np.quantile(err, 0.99), np.median(err), scale)
+
+
+def test_eval_mode_and_reproducibility():
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, vertex_normals
+    img = 128
+    v, faces, K, E = _scene(img, body=syn.make_body(0), frame=2)
+    r = MeshNormalRenderer(img_size=(img, img), sigma=1e-5).cuda()
+    vc, fc = v.cuda(), faces.cuda()
+    topo = r.topology(fc, vc.shape[2])
+    vn = vertex_normals(vc[0].T, topo)
+    r.eval()
+    n_eval, m_eval = r(vc, vn[None], K.cuda(), E.cuda(), fc)
+    assert m_eval is None
+    r.train()
+    outs = []
+    for _ in range(2):
+        x = vc.clone().requires_grad_()
+        n, m = r(x, vertex_normals(x[0].T, topo)[None], K.cuda(), E.cuda(), fc)
+        (n.square().sum() + m.sum()).backward()
+        outs.append((n.clone(), m.clone(), x.grad.clone()))
+    assert torch.equal(outs[0][0], n_eval) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert float(outs[0][1].max()) > 0.99 and float(outs[0][1].min()) == 0.0
