@@ -1,0 +1,253 @@
+"""`Model` -- mirror of the reference's `models/model.py::Model` (constructor arguments, `forward` signature and
+outputs, `get_param_groups`, `subdivide`) with the per-frame hot path running through the HIP library:
+
+    FK + LBS + per-face Gaussians   geometry.posed_face_gaussians           (model.py:213-234)
+    albedo / mask splat             rasterizer.rasterize, one 4-channel pass (model.py:236-250, gaussian.py:22-100)
+    vertex normals, normal map,
+    soft silhouette                 mesh_renderer                            (model.py:270-273, mesh.py:65-128)
+    pseudo shading                  ShadowModule (plain MLP, torch)          (model.py:279-287, shadow_module.py:66-117)
+
+`model_cfg` is the reference's yacs node or anything with the same attributes; missing attributes fall back to the
+values of configs/default.yaml + exps/zju-mocap_377.yaml.  The optional non-rigid and pose-refinement MLPs are taken as
+ready-made modules (the reference's own classes are plain torch and can be passed in unchanged)."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .geometry import MeshTopology, apply_lbs, face_gaussians, get_global_RTs, posed_face_gaussians
+from .mesh_renderer import MeshNormalRenderer, vertex_normals
+from .rasterizer import rasterize
+from . import synthetic as _syn
+
+
+def _get(cfg, path: str, default):
+    cur = cfg
+    for part in path.split("."):
+        if cur is None or not hasattr(cur, part):
+            return default
+        cur = getattr(cur, part)
+    return cur
+
+
+class SimpleMesh:
+    """What the reference's loss code reads from a PyTorch3D `Meshes` (one mesh): packed verts / faces / edges."""
+
+    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor):
+        self._v, self._f, self._e = verts, faces, edges
+
+    def verts_packed(self): return self._v
+    def faces_packed(self): return self._f
+    def edges_packed(self): return self._e
+    def verts_padded(self): return self._v[None]
+    def faces_padded(self): return self._f[None]
+
+
+def mesh_edges(faces: torch.Tensor, n_verts: int):
+    """PyTorch3D edge conventions: unique undirected edges sorted by (v0 * V + v1) with v0 < v1, and per face the
+    indices of its edges (v1v2, v2v0, v0v1)."""
+    f = faces.detach().cpu().numpy().astype(np.int64)
+    e = np.concatenate([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)
+    e.sort(1)
+    key = e[:, 0] * n_verts + e[:, 1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    edges = np.stack([uniq // n_verts, uniq % n_verts], 1)
+    F = f.shape[0]
+    f2e = np.stack([inv[:F], inv[F:2 * F], inv[2 * F:]], 1)
+    return torch.from_numpy(edges), torch.from_numpy(f2e)
+
+
+class ShadowModule(nn.Module):
+    """shadow_module.py:66-117: positional encoding of the normal (multires frequencies, sin/cos, input included) ->
+    MLP (width, depth, optional skip) -> sigmoid.  The last layer starts at U(-1e-5, 1e-5) / zero bias."""
+
+    def __init__(self, multires: int = 6, mlp_width: int = 128, mlp_depth: int = 3, skips=(4,), init_scale: float = 1e-5):
+        super().__init__()
+        self.multires, self.skips = int(multires), tuple(skips)
+        embed = 3 + 3 * 2 * self.multires
+        layers = [nn.Linear(embed, mlp_width), nn.ReLU()]
+        self.layers_to_cat_inputs = []
+        for i in range(1, mlp_depth):
+            if i in self.skips:
+                self.layers_to_cat_inputs.append(len(layers))
+                layers += [nn.Linear(mlp_width + embed, mlp_width), nn.ReLU()]
+            else:
+                layers += [nn.Linear(mlp_width, mlp_width), nn.ReLU()]
+        layers += [nn.Linear(mlp_width, 1)]
+        self.block_mlps = nn.ModuleList(layers)
+        for m in self.block_mlps:   # initseq (network_util): xavier weights, zero bias
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+        last = self.block_mlps[-1]
+        last.weight.data.uniform_(-init_scale, init_scale)
+        last.bias.data.zero_()
+
+    def embed(self, x):
+        freqs = 2.0 ** torch.linspace(0.0, self.multires - 1, self.multires, device=x.device, dtype=x.dtype)
+        out = [x]
+        for f in freqs:
+            out += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(out, -1)
+
+    def forward(self, normals, **kwargs):
+        pe = self.embed(normals)
+        h = pe
+        for i, layer in enumerate(self.block_mlps):
+            if i in self.layers_to_cat_inputs:
+                h = torch.cat([h, pe], -1)
+            h = layer(h)
+        return torch.sigmoid(h)
+
+
+class Model(nn.Module):
+    def __init__(self, model_cfg, canonical_info, non_rigid_module: Optional[nn.Module] = None,
+                 pose_refinement_module: Optional[nn.Module] = None, device=None):
+        super().__init__()
+        self.cfg = model_cfg
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.img_size = tuple(_get(model_cfg, "img_size", (512, 512)))     # (W, H) like the reference
+        faces = torch.as_tensor(np.asarray(canonical_info["faces"]).astype(np.int64))
+        verts = torch.as_tensor(np.asarray(canonical_info["canonical_vertex"])).float()
+        self.register_buffer("faces", faces.to(dev))
+        lbs = torch.as_tensor(np.asarray(canonical_info["canonical_lbs_weights"])).float().T   # (24, N)
+        if _get(model_cfg, "lbs_weights.refine", False):
+            raise NotImplementedError("lbs_weights.refine: the HIP LBS kernel treats the weights as constants")
+        self.register_buffer("lbs_weights", torch.cat([lbs, torch.zeros_like(lbs[:1])], 0).contiguous().to(dev))
+        self.vertices = nn.Parameter(verts.T.contiguous().to(dev))
+        F = faces.shape[0]
+        radius_scale = float(_get(model_cfg, "canonical_geometry.radius_scale", 1.0))
+        self.so3 = nn.Parameter(torch.zeros(3, F, device=dev), requires_grad=bool(_get(model_cfg, "canonical_geometry.deform_so3", True)))
+        self.scale = nn.Parameter(torch.ones(3, F, device=dev) * radius_scale, requires_grad=bool(_get(model_cfg, "canonical_geometry.deform_scale", True)))
+        self.sigma = float(_get(model_cfg, "canonical_geometry.sigma", 1e-3))
+        self.appearance = nn.Parameter(torch.ones(3, F, device=dev) * float(_get(model_cfg, "appearance.color_init", 0.5)))   # AppearanceModule
+        self.register_buffer("bg_col", torch.zeros(3, device=dev))
+        self.non_rigid_module, self.pose_refinement_module = non_rigid_module, pose_refinement_module
+        self.normal_renderer = MeshNormalRenderer(self.img_size, sigma=_get(model_cfg, "normal_renderer.sigma", None),
+                                                  soft_mask=_get(model_cfg, "normal_renderer.soft_mask", True))
+        if _get(model_cfg, "shadow_module.name", "basic") != "none":
+            self.shadow_module = ShadowModule(_get(model_cfg, "shadow_module.multires", 6), _get(model_cfg, "shadow_module.mlp_width", 128),
+                                              _get(model_cfg, "shadow_module.mlp_depth", 3), tuple(_get(model_cfg, "shadow_module.skips", (4,)))).to(dev)
+        else:
+            self.shadow_module = None
+        self._rebuild_topology()
+
+    # -- topology-dependent, rebuilt by subdivide() ---------------------------------------------------------------------
+    def _rebuild_topology(self):
+        N = self.vertices.shape[1]
+        self.topo = MeshTopology(self.faces, N, device=self.vertices.device)
+        edges, f2e = mesh_edges(self.faces, N)
+        self.edges = edges.to(self.vertices.device)
+        # get_face_connectivity (model.py:115-125): faces sharing edge i, for i in range(max_edge_id) -- the last edge id is
+        # skipped by the reference's loop bound and therefore here
+        f2e_np = f2e.numpy()
+        order = np.argsort(f2e_np.reshape(-1), kind="stable")
+        eid = f2e_np.reshape(-1)[order]
+        fid = order // 3
+        starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
+        counts = np.diff(np.r_[starts, len(eid)])
+        keep = (counts == 2) & (eid[starts] < f2e_np.max())
+        pairs = np.stack([fid[starts[keep]], fid[starts[keep] + 1]], 1)
+        pairs.sort(1)
+        self.face_connectivity = torch.from_numpy(pairs).to(self.vertices.device)
+        v = self.vertices.detach().T
+        self.target_edge_length = (v[self.edges[:, 0]] - v[self.edges[:, 1]]).norm(dim=1)     # get_init_edge_length (model.py:127-134)
+
+    def subdivide(self, need_face_connectivity: bool = True):
+        """model.py:136-179: midpoint subdivision; per-face parameters are inherited by the four children."""
+        v, f, attrs = _syn.subdivide(self.vertices.detach().T.cpu().numpy(), self.faces.cpu().numpy(),
+                                     {"weights": self.lbs_weights.T.detach().cpu().numpy()})
+        dev = self.vertices.device
+        rep = lambda t: t.detach()[..., None].repeat(1, 1, 4).reshape(t.shape[0], -1).contiguous()
+        self.vertices = nn.Parameter(torch.from_numpy(v).float().T.contiguous().to(dev))
+        self.faces = torch.from_numpy(f).to(dev)
+        self.lbs_weights = torch.from_numpy(attrs["weights"]).float().T.contiguous().to(dev)
+        self.appearance = nn.Parameter(rep(self.appearance))
+        self.so3 = nn.Parameter(rep(self.so3), requires_grad=self.so3.requires_grad)
+        self.scale = nn.Parameter(rep(self.scale), requires_grad=self.scale.requires_grad)
+        self._rebuild_topology()
+
+    def get_param_groups(self, cfg):
+        """model.py:305-327 (lr names of configs/default.yaml)."""
+        lr = cfg.lr
+        groups = [{"name": "appearance", "params": [self.appearance], "lr": lr.appearance},
+                  {"name": "canonical_geometry_xyz", "params": [self.vertices], "lr": lr.canonical_geometry_xyz},
+                  {"name": "canonical_geometry", "params": [self.scale], "lr": lr.canonical_geometry},
+                  {"name": "canonical_geometry", "params": [self.so3], "lr": lr.canonical_geometry}]
+        if self.non_rigid_module is not None:
+            groups.append({"name": "non_rigid", "params": self.non_rigid_module.parameters(), "lr": lr.non_rigid})
+        if self.pose_refinement_module is not None:
+            groups.append({"name": "pose_refinement", "params": self.pose_refinement_module.parameters(), "lr": lr.pose_refinement})
+        if self.shadow_module is not None:
+            groups.append({"name": "shadow", "params": self.shadow_module.parameters(), "lr": lr.shadow})
+        return groups
+
+    # -- the per-frame forward (model.py:184-303) -------------------------------------------------------------------------
+    def _camera(self, K, E, bg4):
+        W, H = self.img_size
+        Kc, Ec = K[0].detach().cpu().numpy(), E[0].detach().cpu().numpy()
+        fx, fy, px, py = float(Kc[0, 0]), float(Kc[1, 1]), float(Kc[0, 2]), float(Kc[1, 2])
+        tanfovx, tanfovy = math.tan(math.atan(W / (2 * fx))), math.tan(math.atan(H / (2 * fy)))
+        znear, zfar = 0.001, 100
+        K_ndc = np.array([[2 * fx / W, 0, (2 * px - W) / W, 0], [0, 2 * fy / H, (2 * py - H) / H, 0],
+                          [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]], dtype=np.float32)
+        view = np.ascontiguousarray(Ec.T.astype(np.float32))
+        proj = (Ec.T.astype(np.float32) @ K_ndc.T).astype(np.float32)
+        return _lib.make_camera(H, W, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
+
+    def forward(self, K, E, cnl_gtfms, dst_Rs, dst_Ts, dst_posevec=None, canonical_joints=None, i_iter=1e7, bgcolor=None,
+                global_R=None, global_T=None, tb=None):
+        B = dst_Rs.shape[0]
+        assert B == 1, "batch size 1, like the reference renderer (gaussian.py:24)"
+        F = self.faces.shape[0]
+        if self.pose_refinement_module is not None and i_iter >= _get(self.cfg, "pose_refinement.kick_in_iter", 0):
+            delta_Rs = self.pose_refinement_module(dst_posevec)
+            nb = dst_Rs.shape[1]
+            dst_Rs = torch.matmul(dst_Rs.reshape(B * nb, 3, 3), delta_Rs.reshape(B * nb, 3, 3)).reshape(B, nb, 3, 3)
+        vertices_canonical = self.vertices
+        if self.non_rigid_module is not None and i_iter >= _get(self.cfg, "non_rigid.kick_in_iter", 0):
+            vertices_pose = self.non_rigid_module(vertices_canonical.unsqueeze(0), dst_posevec, i_iter, R=None, S=None)[0][0]
+        else:
+            vertices_pose = vertices_canonical
+        if global_R is None:
+            xyz, cov6, vertices_observation = posed_face_gaussians(vertices_pose, self.so3, self.scale, dst_Rs[0], dst_Ts[0], cnl_gtfms[0],
+                                                                   self.lbs_weights, self.topo, self.sigma)
+        else:   # PeopleSnapshot test-time pose optimisation (model.py:218-221): a rigid transform after the skinning
+            from .geometry import get_global_RTs as _g
+            vertices_observation = apply_lbs(vertices_pose.unsqueeze(0), *_g(cnl_gtfms, dst_Rs, dst_Ts), self.lbs_weights)[0]
+            th = global_R.norm().clamp_min(1e-8)
+            k = global_R / th
+            Kx = torch.zeros(3, 3, device=k.device, dtype=k.dtype)
+            Kx[0, 1], Kx[0, 2], Kx[1, 0], Kx[1, 2], Kx[2, 0], Kx[2, 1] = -k[2], k[1], k[2], -k[0], -k[1], k[0]
+            Rg = torch.eye(3, device=k.device) + torch.sin(th) * Kx + (1 - torch.cos(th)) * (Kx @ Kx)
+            vertices_observation = Rg @ vertices_observation + global_T[:, None]
+            xyz, cov6 = face_gaussians(vertices_observation, self.so3, self.scale, self.topo, self.sigma)
+        # pseudo albedo + mask: one 4-channel pass (the reference pads to 6 channels and rasterizes twice)
+        feat = torch.cat([self.appearance.T, torch.ones(F, 1, device=xyz.device)], 1)
+        opacity = torch.ones(F, device=xyz.device)
+        cam = self._camera(K, E, (0.0, 0.0, 0.0, 0.0))        # bg_col = [bg_feat (zeros), 0] (model.py:243)
+        img, _ = rasterize(xyz, cov6, feat, opacity, cam)
+        albedos, masks = img[:3].permute(1, 2, 0)[None], img[3][None]
+        # normals, normal map, silhouette (model.py:270-273)
+        vn = vertex_normals(vertices_observation.T, self.topo)
+        vn = (E[0, :3, :3] @ vn.T).T
+        normal, normal_mask = self.normal_renderer(vertices_observation.unsqueeze(0), vn[None], K, E, faces=self.faces)
+        if self.shadow_module is not None:
+            Bn, H, W, _ = normal.shape
+            shadings = self.shadow_module(normal.reshape(-1, H * W, 3)).reshape(Bn, H, W, 1) * 2
+            rgbs = albedos * shadings
+        else:
+            shadings, rgbs = None, albedos
+        outputs = {}
+        if self.training:
+            vo, vc = vertices_observation.T, vertices_canonical.T
+            outputs.update(colors=self.appearance.T, face_connectivity=self.face_connectivity, mesh=SimpleMesh(vo, self.faces, self.edges),
+                           mesh_canonical=SimpleMesh(vc, self.faces, self.edges), target_edge_length=self.target_edge_length, albedo=albedos[0],
+                           normal=normal, normal_mask=normal_mask[..., 0] if normal_mask is not None else None, shadow=shadings)
+        return rgbs, masks, outputs

@@ -1,0 +1,70 @@
+"""`unpack` and `compute_loss` of the reference's training loop (train.py:53-55, 98-163) on top of the HIP path, plus
+the three mesh regularisers it calls (PyTorch3D `mesh_laplacian_smoothing(method="uniform")`,
+`mesh_normal_consistency`, utils/network_util.py `mesh_color_consistency`) written against `model.SimpleMesh`."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .model import _get
+
+
+def unpack(rgbs, masks, bgcolors):
+    """train.py:53-55."""
+    return rgbs * masks.unsqueeze(-1) + bgcolors[:, None, None, :] * (1 - masks).unsqueeze(-1)
+
+
+def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
+    """Uniform Laplacian: mean over vertices of || (1/deg) sum_neighbours v_j - v_i ||."""
+    v, e = mesh.verts_packed(), mesh.edges_packed()
+    N = v.shape[0]
+    deg = torch.zeros(N, device=v.device, dtype=v.dtype).index_add(0, e[:, 0], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
+    deg = deg.index_add(0, e[:, 1], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
+    s = torch.zeros_like(v).index_add(0, e[:, 0], v[e[:, 1]]).index_add(0, e[:, 1], v[e[:, 0]])
+    lap = s / deg.clamp_min(1.0)[:, None] - v
+    return lap.norm(dim=1).mean()
+
+
+def mesh_normal_consistency(mesh, face_connectivity) -> torch.Tensor:
+    """1 - cos between the normals of faces sharing an edge, averaged over those edges."""
+    v, f = mesh.verts_packed(), mesh.faces_packed()
+    n = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
+    n = F.normalize(n, dim=1, eps=1e-6)
+    return (1.0 - (n[face_connectivity[:, 0]] * n[face_connectivity[:, 1]]).sum(1)).mean()
+
+
+def mesh_color_consistency(colors, face_connectivity) -> torch.Tensor:
+    """network_util.py: mean absolute colour difference of edge-adjacent faces."""
+    return (colors[face_connectivity[:, 0]] - colors[face_connectivity[:, 1]]).abs().mean()
+
+
+def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=None, i_iter=0, tb=None, lpips_func=None, **kwargs):
+    """train.py:98-163.  `lpips_func(pred_nchw_pm1, gt_nchw_pm1)` as in the reference, or an object with `.loss(pred_nhwc01,
+    gt_nhwc01)` (gomavatar_amd.lpips.LPIPSMatrixCore)."""
+    losses = {}
+
+    def put(name, value, coeff):
+        losses[name] = {"unscaled": value, "scaled": value * coeff}
+
+    put("rgb", torch.mean(torch.abs(rgb_pred - rgb_gt)), _get(loss_cfg, "rgb.coeff", 1.0))
+    put("mask", torch.mean(torch.abs(mask_pred - mask_gt)), _get(loss_cfg, "mask.coeff", 5.0))
+    if lpips_func is not None and _get(loss_cfg, "lpips.coeff", 1.0) > 0:
+        if hasattr(lpips_func, "loss"):
+            lp = lpips_func.loss(rgb_pred, rgb_gt)
+        else:
+            lp = torch.mean(lpips_func(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1))
+        put("lpips", lp, _get(loss_cfg, "lpips.coeff", 1.0))
+    if _get(loss_cfg, "laplacian.coeff_canonical", 0.0) > 0:
+        put("laplacian_canoincal", mesh_laplacian_smoothing(outputs["mesh_canonical"]), loss_cfg.laplacian.coeff_canonical)
+    if _get(loss_cfg, "laplacian.coeff_observation", 0.0) > 0:
+        put("laplacian_observation", mesh_laplacian_smoothing(outputs["mesh"]), loss_cfg.laplacian.coeff_observation)
+    if _get(loss_cfg, "normal.coeff_mask", 0.0) > 0 and outputs.get("normal_mask") is not None:
+        k = int(_get(loss_cfg, "normal.kernel_size", 5))
+        dil = F.max_pool2d(mask_gt.unsqueeze(1), kernel_size=k, stride=1, padding=k // 2).squeeze(1)
+        put("normal_mask", torch.mean(torch.abs(outputs["normal_mask"] - dil)), loss_cfg.normal.coeff_mask)
+    if _get(loss_cfg, "normal.coeff_consist", 0.0) > 0:
+        put("normal_consist", mesh_normal_consistency(outputs["mesh"], outputs["face_connectivity"]), loss_cfg.normal.coeff_consist)
+    if _get(loss_cfg, "color_consist.coeff", 0.0) > 0:
+        put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"]), loss_cfg.color_consist.coeff)
+    total = sum(item["scaled"] for item in losses.values())
+    return total, losses

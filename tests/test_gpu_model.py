@@ -1,0 +1,112 @@
+"""`gomavatar_amd.model.Model` (mirror of models/model.py::Model.forward) against the CPU oracles composed the way the
+reference composes them: FK/LBS/face Gaussians + splat (oracle/geometry.py, oracle/raster), vertex normals + mesh
+normal map + soft silhouette (oracle/mesh.py), shadow MLP (same torch weights on the CPU)."""
+from types import SimpleNamespace as NS
+
+import copy
+import numpy as np
+import pytest
+import torch
+
+from gomavatar_amd import synthetic as syn
+from oracle import geometry as og, mesh as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(img):
+    return NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True),
+              appearance=NS(color_init=0.5), normal_renderer=NS(sigma=1e-5, soft_mask=True),
+              shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)), lbs_weights=NS(refine=False))
+
+
+def _frame(i, img):
+    fr = syn.make_frame(i, img)
+    return {k: torch.from_numpy(v) for k, v in fr.items()}
+
+
+def test_forward_matches_oracle_composition():
+    from gomavatar_amd.model import Model
+    img = 96
+    body = syn.icosphere_body(3)
+    m = Model(_cfg(img), body).train()
+    F = m.faces.shape[0]
+    gp = syn.make_gaussian_params(F)
+    with torch.no_grad():
+        m.so3.copy_(torch.from_numpy(gp["so3"])); m.scale.copy_(torch.from_numpy(gp["scale"]) * 3.0); m.appearance.copy_(torch.from_numpy(gp["appearance"]))
+        m.shadow_module.block_mlps[-1].weight.normal_(0, 0.3)          # a shading that actually varies
+    fr = _frame(1, img)
+    dv = {k: v.cuda() for k, v in fr.items() if torch.is_tensor(v)}
+    rgbs, masks, out = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"], bgcolor=dv["bgcolor"])
+    assert rgbs.shape == (1, img, img, 3) and masks.shape == (1, img, img)
+    for key in ("colors", "face_connectivity", "mesh", "mesh_canonical", "target_edge_length", "albedo", "normal", "normal_mask", "shadow"):
+        assert key in out
+    # ---- oracle ----
+    params = dict(vertices=m.vertices.detach().cpu(), so3=m.so3.detach().cpu(), scale=m.scale.detach().cpu(), appearance=m.appearance.detach().cpu())
+    faces, w25 = m.faces.cpu(), m.lbs_weights.cpu()
+    o_rgb, o_mask, aux = og.render_path(params, fr, faces, w25, img)
+    Rs, Ts = og.fk_global_RTs(fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+    v_obs = og.lbs(params["vertices"].unsqueeze(0), Rs, Ts, w25)      # (1,3,N)
+    vn = om.vertex_normals(v_obs[0].T, faces)
+    vn = (fr["E"][0, :3, :3] @ vn.T).T
+    ndc = om.ndc_T_world(v_obs, fr["K"], fr["E"], img, img)[0]
+    o_normal, o_alpha, _ = om.render(ndc, faces, vn, img, img, sigma_cfg=1e-5)
+    sh = copy.deepcopy(m.shadow_module).cpu()
+    o_shade = sh(o_normal.reshape(1, -1, 3)).reshape(1, img, img, 1) * 2
+    o_rgbs = o_rgb * o_shade
+    def close(a, b, mean_tol, frac_tol=2e-3, tol=1e-4):
+        d = (a.detach().cpu() - b.detach()).abs()
+        assert float(d.mean()) <= mean_tol and float((d > tol).float().mean()) <= frac_tol, (float(d.mean()), float((d > tol).float().mean()), float(d.max()))
+    close(out["albedo"][None], o_rgb, 2e-6)
+    close(masks, o_mask, 2e-6)
+    close(out["normal"], o_normal[None], 1e-5)
+    close(out["normal_mask"], o_alpha[None], 5e-5)   # fp32 on both sides: a face exactly at the blur radius may flip
+    close(rgbs, o_rgbs, 2e-5)
+    # edges / connectivity follow the PyTorch3D conventions: closed manifold -> every edge has two faces, E = 3F/2
+    assert m.edges.shape[0] == 3 * F // 2 and m.face_connectivity.shape == (3 * F // 2 - 1, 2)     # (the reference skips the last edge id)
+    assert m.target_edge_length.shape[0] == m.edges.shape[0]
+
+
+def test_training_steps_reduce_the_loss_and_subdivide_keeps_going():
+    from gomavatar_amd.model import Model
+    from gomavatar_amd.train_util import compute_loss, unpack
+    img = 64
+    body = syn.icosphere_body(2)
+    teacher = Model(_cfg(img), body).train()
+    with torch.no_grad():
+        teacher.appearance.copy_(torch.rand_like(teacher.appearance))
+        teacher.scale.mul_(2.0)
+    student = Model(_cfg(img), body).train()
+    with torch.no_grad():
+        student.scale.mul_(2.0)
+    loss_cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                  normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05))
+    lr_cfg = NS(lr=NS(appearance=5e-3, canonical_geometry=5e-4, canonical_geometry_xyz=5e-5, shadow=5e-4))
+    frames = []
+    for i in range(4):
+        fr = {k: v.cuda() for k, v in _frame(i, img).items()}
+        with torch.no_grad():
+            rgbs, masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            fr["gt_rgb"], fr["gt_mask"] = unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
+        frames.append(fr)
+
+    def run(model, iters):
+        opt = torch.optim.Adam(model.get_param_groups(lr_cfg))
+        hist = []
+        for it in range(iters):
+            fr = frames[it % len(frames)]
+            opt.zero_grad(set_to_none=True)
+            rgbs, masks, out = model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
+            total, losses = compute_loss(unpack(rgbs, masks, fr["bgcolor"]), masks, out, fr["gt_rgb"], fr["gt_mask"], loss_cfg)
+            total.backward()
+            opt.step()
+            hist.append(float(losses["rgb"]["unscaled"].detach()))
+            assert all(torch.isfinite(p.grad).all() for g in opt.param_groups for p in g["params"] if p.grad is not None)
+        return hist
+    h1 = run(student, 40)
+    assert np.mean(h1[-4:]) < 0.85 * np.mean(h1[:4]), (h1[:4], h1[-4:])
+    F0 = student.faces.shape[0]
+    student.subdivide()
+    assert student.faces.shape[0] == 4 * F0 and student.appearance.shape[1] == 4 * F0 and student.lbs_weights.shape[1] == student.vertices.shape[1]
+    h2 = run(student, 8)
+    assert np.isfinite(h2).all() and np.mean(h2) < 0.1     # 4x smaller triangles change the render (as in the reference); training goes on
