@@ -9,7 +9,9 @@
 //
 // MI355X design: faces are tile-binned exactly like the Gaussians (count -> scan -> emit -> per-tile sort by face index
 // = the GomState machinery of raster_pre.hip / raster_render.hip, which also yields the (face, tile) -> list position
-// table for the backward); one workgroup per 16x16 tile walks its LDS-staged face list once for both outputs.
+// table for the backward), but on 8x8-pixel tiles: a face plus its blur band covers ~7x7 pixels, so 16x16 bins would make
+// every pixel wade through ~5x more candidates.  One wave per tile walks its LDS-staged face list once for both outputs;
+// a face none of the wave's 64 pixels can reach is skipped wave-uniformly before any per-pixel math.
 // faces_per_pixel: every qualifying face has sigmoid(-sdist/1e-4) >= 0.285 (sdist < blur_radius = 9.2e-5), so with 50
 // or more of them the product is < 6e-8 whichever 50 are kept: alpha is computed over ALL qualifying faces and
 // differs from the K = 50 truncation by less than one fp32 ulp of 1.0.
@@ -21,6 +23,7 @@ namespace {
 
 constexpr float kEpsArea = 1e-8f;
 constexpr int kFaceStride = 12;  // x0 y0 z0 x1 y1 z1 x2 y2 z2 area . .
+constexpr int kMeshTile = 8;     // pixels per side of a mesh-raster bin (the GomState tile grid is built for 2H x 2W / 16)
 
 struct MeshGrid {
     int H, W, gx, gy;
@@ -96,9 +99,15 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
                                                          float *__restrict__ face_geo, float *__restrict__ depth, float2 *__restrict__ xy,
                                                          float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
                                                          ushort4 *__restrict__ rect, int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count,
-                                                         uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status) {
+                                                         uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status, int lds_hist) {
+    extern __shared__ uint32_t s_hist[];   // per-block tile histogram (gx * gy entries; 0 bytes = count straight in global memory)
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_blockbase;
+    const int n_tiles = g.gx * g.gy;
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
+        __syncthreads();
+    }
     const int f = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
     if (f < F) {
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
             const int ixa = max(0, (int)floorf(pxa)), ixb = min(g.W - 1, (int)ceilf(pxb));
             const int iya = max(0, (int)floorf(pya)), iyb = min(g.H - 1, (int)ceilf(pyb));
             if (ixa <= ixb && iya <= iyb) {
-                x0 = ixa / GOM_TILE; x1 = ixb / GOM_TILE + 1; y0 = iya / GOM_TILE; y1 = iyb / GOM_TILE + 1;
+                x0 = ixa / kMeshTile; x1 = ixb / kMeshTile + 1; y0 = iya / kMeshTile; y1 = iyb / kMeshTile + 1;
             }
         }
         my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
@@ -133,7 +142,7 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
         tiles_touched[f] = my_tiles;
         rect[f] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * g.gx + x], 1u);
+            for (int x = x0; x < x1; x++) atomicAdd(lds_hist ? &s_hist[y * g.gx + x] : &tile_count[y * g.gx + x], 1u);
     }
     // private range of this face in pair_pos (same scheme as k_preprocess)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -153,41 +162,87 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
     uint32_t woff = 0;
     for (int w = 0; w < wid; w++) woff += s_wsum[w];
     if (f < F) pair_off[f] = s_blockbase + woff + (x - my_tiles);
-}
-
-// ---- forward: one workgroup per tile, thread = pixel ---------------------------------------------------------------------
-constexpr int kChunk = 128;
-__global__ void __launch_bounds__(256) k_mesh_forward(MeshGrid g, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ point_list,
-                                                      const float *__restrict__ face_geo, const int32_t *__restrict__ faces,
-                                                      const float *__restrict__ vnormals, float blur, float blur_radius, float inv_sigma,
-                                                      float *__restrict__ normal_map, float *__restrict__ alpha, uint32_t *__restrict__ pix_to_face,
-                                                      float *__restrict__ prodQ, const GomDevStatus *__restrict__ status) {
-    __shared__ float s_f[kChunk][10];
-    __shared__ uint32_t s_id[kChunk];
-    const int tile = blockIdx.x;
-    const int xi = (tile % g.gx) * GOM_TILE + (threadIdx.x & 15), yi = (tile / g.gx) * GOM_TILE + (threadIdx.x >> 4);
-    const bool inside_img = xi < g.W && yi < g.H;
-    const float px = pix_x(g, xi), py = pix_y(g, yi);
-    const uint32_t base = tile_base[tile], n = status->overflow ? 0u : tile_base[tile + 1] - base;
-    float best_z = 3.0e38f, Q = 1.f;
-    uint32_t best = 0xffffffffu;
-    for (uint32_t e0 = 0; e0 < n; e0 += kChunk) {
-        const uint32_t cn = min((uint32_t)kChunk, n - e0);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cn * 10; i += 256) {
-            const uint32_t j = i / 10, k = i % 10;
-            s_f[j][k] = face_geo[(size_t)point_list[base + e0 + j] * kFaceStride + k];
-        }
-        if (threadIdx.x < cn) s_id[threadIdx.x] = point_list[base + e0 + threadIdx.x];
-        __syncthreads();
-        if (!inside_img) continue;
-        for (uint32_t j = 0; j < cn; j++) {
-            const FaceEval r = eval_face(s_f[j], px, py, blur, blur_radius, inv_sigma);
-            if (r.hard && r.z_hard < best_z) { best_z = r.z_hard; best = s_id[j]; }   // list is sorted by face index: first wins ties
-            if (r.soft) Q *= (1.f - r.prob);
+    if (lds_hist) {
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const uint32_t c = s_hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
         }
     }
-    if (!inside_img) return;
+}
+
+// ---- forward, pass 1: one wave per (8x8 tile, 128-face segment of its list), lane = pixel ----------------------------------
+// A UV-sphere pole or a crumpled region puts thousands of faces into one tile; min-z and the product over faces are
+// associative, so the lists are cut into the same 128-entry segments as the splat lists (seg_desc of k_sort) and every
+// segment is an independent wave.  Partial results: product of (1 - p), nearest depth and its face per pixel.
+constexpr int kChunk = 64;
+__global__ void __launch_bounds__(64) k_mesh_forward_seg(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+                                                         const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
+                                                         float *__restrict__ seg_Q, float *__restrict__ seg_z, uint32_t *__restrict__ seg_face,
+                                                         const GomDevStatus *__restrict__ status) {
+    __shared__ float s_f[kChunk][10];
+    __shared__ uint32_t s_id[kChunk];
+    if (status->overflow) return;
+    const uint32_t nsegs = status->num_segs;
+    const int lane = threadIdx.x;
+    for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
+        const uint4 d = seg_desc[seg];
+        const int tile = (int)d.x;
+        const uint32_t start = d.y, n = d.z;
+        const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
+        const float px = pix_x(g, tx0 + (lane & 7)), py = pix_y(g, ty0 + (lane >> 3));
+        // the wave's pixel rectangle in NDC (+X left / +Y up: the first pixel has the largest coordinate)
+        const float wx_hi = pix_x(g, tx0), wx_lo = pix_x(g, min(tx0 + kMeshTile, g.W) - 1), wy_hi = pix_y(g, ty0), wy_lo = pix_y(g, min(ty0 + kMeshTile, g.H) - 1);
+        float best_z = 3.0e38f, Q = 1.f;
+        uint32_t best = 0xffffffffu;
+        for (uint32_t e0 = 0; e0 < n; e0 += kChunk) {
+            const uint32_t cn = min((uint32_t)kChunk, n - e0);
+            __syncthreads();
+            bool reach = false;
+            if ((uint32_t)lane < cn) {   // lane = face: stage it and test its blurred box against the wave's rectangle
+                const uint32_t f = point_list[start + e0 + lane];
+                const float *src = face_geo + (size_t)f * kFaceStride;
+                float v[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) { v[k] = src[k]; s_f[lane][k] = v[k]; }
+                s_id[lane] = f;
+                const float xmin = fminf(fminf(v[0], v[3]), v[6]) - blur, xmax = fmaxf(fmaxf(v[0], v[3]), v[6]) + blur;
+                const float ymin = fminf(fminf(v[1], v[4]), v[7]) - blur, ymax = fmaxf(fmaxf(v[1], v[4]), v[7]) + blur;
+                reach = !(wx_lo > xmax || wx_hi < xmin || wy_lo > ymax || wy_hi < ymin);
+            }
+            unsigned long long todo = __ballot(reach);
+            __syncthreads();
+            while (todo) {   // wave-uniform loop over the faces that can touch this tile at all
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const FaceEval r = eval_face(s_f[j], px, py, blur, blur_radius, inv_sigma);
+                if (r.hard && r.z_hard < best_z) { best_z = r.z_hard; best = s_id[j]; }   // ascending face index: first wins ties
+                if (r.soft) Q *= (1.f - r.prob);
+            }
+        }
+        seg_Q[(size_t)seg * 64 + lane] = Q;
+        seg_z[(size_t)seg * 64 + lane] = best_z;
+        seg_face[(size_t)seg * 64 + lane] = best;
+    }
+}
+
+// ---- forward, pass 2: per tile, fold its segments in list order ---------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_mesh_combine(MeshGrid g, const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_Q,
+                                                     const float *__restrict__ seg_z, const uint32_t *__restrict__ seg_face,
+                                                     const int32_t *__restrict__ faces, const float *__restrict__ vnormals,
+                                                     float *__restrict__ normal_map, float *__restrict__ alpha, uint32_t *__restrict__ pix_to_face,
+                                                     float *__restrict__ prodQ, const GomDevStatus *__restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int xi = (tile % g.gx) * kMeshTile + (lane & 7), yi = (tile / g.gx) * kMeshTile + (lane >> 3);
+    if (xi >= g.W || yi >= g.H) return;
+    const uint32_t sb = seg_base[tile], ns = status->overflow ? 0u : seg_base[tile + 1] - sb;
+    float best_z = 3.0e38f, Q = 1.f;
+    uint32_t best = 0xffffffffu;
+    for (uint32_t k = 0; k < ns; k++) {
+        const size_t o = (size_t)(sb + k) * 64 + lane;
+        Q *= seg_Q[o];
+        const float z = seg_z[o];
+        if (z < best_z) { best_z = z; best = seg_face[o]; }
+    }
     const size_t p = (size_t)yi * g.W + xi;
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (best != 0xffffffffu) {
@@ -205,24 +260,27 @@ __global__ void __launch_bounds__(256) k_mesh_forward(MeshGrid g, const uint32_t
 
 // ---- backward, step 1: one thread per (tile, face) entry -> 9-float record at the entry's list position --------------
 //   [0..5] d/d(x0,y0,x1,y1,x2,y2) from the silhouette, [6..8] d/d(n0+n1+n2) from the normal map
-__global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(64) k_mesh_backward_entries(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                                const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
                                                                const uint32_t *__restrict__ pix_to_face, const float *__restrict__ prodQ,
                                                                const float *__restrict__ d_normal, const float *__restrict__ d_alpha,
                                                                float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
     if (status->overflow) return;
-    const int tile = blockIdx.x;
-    const int tx0 = (tile % g.gx) * GOM_TILE, ty0 = (tile / g.gx) * GOM_TILE;
-    const uint32_t base = tile_base[tile], n = tile_base[tile + 1] - base;
-    for (uint32_t e = threadIdx.x; e < n; e += 256) {
+    const uint32_t nsegs = status->num_segs;
+    for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
+    const uint4 sd = seg_desc[seg];
+    const int tile = (int)sd.x;
+    const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
+    const uint32_t base = sd.y, n = sd.z;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         const uint32_t f = point_list[base + e];
         float fg[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) fg[k] = face_geo[(size_t)f * kFaceStride + k];
         const float xmin = fminf(fminf(fg[0], fg[3]), fg[6]) - blur, xmax = fmaxf(fmaxf(fg[0], fg[3]), fg[6]) + blur;
         const float ymin = fminf(fminf(fg[1], fg[4]), fg[7]) - blur, ymax = fmaxf(fmaxf(fg[1], fg[4]), fg[7]) + blur;
-        const int ixa = max(tx0, (int)floorf(ndc_to_px(g, xmax) - 1.f)), ixb = min(min(tx0 + GOM_TILE, g.W) - 1, (int)ceilf(ndc_to_px(g, xmin) + 1.f));
-        const int iya = max(ty0, (int)floorf(ndc_to_py(g, ymax) - 1.f)), iyb = min(min(ty0 + GOM_TILE, g.H) - 1, (int)ceilf(ndc_to_py(g, ymin) + 1.f));
+        const int ixa = max(tx0, (int)floorf(ndc_to_px(g, xmax) - 1.f)), ixb = min(min(tx0 + kMeshTile, g.W) - 1, (int)ceilf(ndc_to_px(g, xmin) + 1.f));
+        const int iya = max(ty0, (int)floorf(ndc_to_py(g, ymax) - 1.f)), iyb = min(min(ty0 + kMeshTile, g.H) - 1, (int)ceilf(ndc_to_py(g, ymin) + 1.f));
         float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
         for (int yi = iya; yi <= iyb; yi++)
             for (int xi = ixa; xi <= ixb; xi++) {
@@ -253,6 +311,7 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
         rec[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
         rec[1] = make_float4(gv[4], gv[5], gn[0], gn[1]);
         rec[2] = make_float4(gn[2], 0.f, 0.f, 0.f);
+    }
     }
 }
 
@@ -367,7 +426,7 @@ __global__ void __launch_bounds__(256) k_corner_gather(int N, const int32_t *__r
 MeshGrid make_grid(int H, int W) {
     MeshGrid g;
     g.H = H; g.W = W;
-    g.gx = (W + GOM_TILE - 1) / GOM_TILE; g.gy = (H + GOM_TILE - 1) / GOM_TILE;
+    g.gx = (W + kMeshTile - 1) / kMeshTile; g.gy = (H + kMeshTile - 1) / kMeshTile;
     g.rngx = W > H ? 2.f * (float)W / (float)H : 2.f; g.offx = g.rngx / 2.f;
     g.rngy = H > W ? 2.f * (float)H / (float)W : 2.f; g.offy = g.rngy / 2.f;
     return g;
@@ -381,7 +440,8 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
     if (N <= 0 || F <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f) || blur_radius < 0.f) { gom_set_error("gom_mesh_raster_forward: bad sizes"); return -1; }
     if (!verts_ndc || !faces || !vnormals || !normal_map) { gom_set_error("gom_mesh_raster_forward: null pointer"); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = gom_ensure_capacity(s, F, H, W, 1)) return rc;
+    // the shared binning machinery thinks in 16-pixel tiles: give it the doubled image so that its grid is ours (8-pixel tiles)
+    if (int rc = gom_ensure_capacity(s, F, 2 * H, 2 * W, 1)) return rc;
     if ((size_t)F * kFaceStride > s->capMeshFace) {
         if (s->mesh_face) GOM_HIP_CHECK(hipFree(s->mesh_face));
         s->mesh_face = nullptr;
@@ -391,13 +451,17 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
     s->P = F; s->H = H; s->W = W; s->C = 3; s->cams = nullptr; s->haveForward = false;
     const MeshGrid g = make_grid(H, W);
     const float blur = sqrtf(blur_radius);
-    hipLaunchKernelGGL(k_mesh_preprocess, dim3((F + 255) / 256), dim3(256), 0, st, g, F, verts_ndc, faces, blur, s->mesh_face, s->depth, s->xy,
-                       s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->pair_off, s->status);
+    const int lds_hist = g.gx * g.gy <= 8192 ? 1 : 0;
+    hipLaunchKernelGGL(k_mesh_preprocess, dim3((F + 255) / 256), dim3(256), lds_hist ? g.gx * g.gy * sizeof(uint32_t) : 0, st, g, F, verts_ndc, faces, blur,
+                       s->mesh_face, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->pair_off, s->status, lds_hist);
     GOM_LAUNCH_CHECK();
     if (int rc = gom_launch_scan_emit(s, F, st)) return rc;
     if (int rc = gom_launch_sort(s, st)) return rc;
-    hipLaunchKernelGGL(k_mesh_forward, dim3(g.gx * g.gy), dim3(256), 0, st, g, s->tile_base, s->point_list, s->mesh_face, faces, vnormals, blur,
-                       blur_radius, 1.0f / sigma, normal_map, alpha, s->n_contrib, s->final_T, s->status);
+    hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(64), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
+                       s->seg_T, s->seg_Tend, s->seg_last, s->status);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mesh_combine, dim3(g.gx * g.gy), dim3(64), 0, st, g, s->seg_base, s->seg_T, s->seg_Tend, s->seg_last, faces, vnormals,
+                       normal_map, alpha, s->n_contrib, s->final_T, s->status);
     GOM_LAUNCH_CHECK();
     s->meshBlurRadius = blur_radius; s->meshSigma = sigma; s->meshForward = true;
     return 0;
@@ -410,7 +474,7 @@ extern "C" int gom_mesh_raster_backward(GomState *s, int N, int F, int H, int W,
     hipStream_t st = (hipStream_t)stream;
     const MeshGrid g = make_grid(H, W);
     float *d_face = s->mesh_face + s->capMeshFace;
-    hipLaunchKernelGGL(k_mesh_backward_entries, dim3(g.gx * g.gy), dim3(256), 0, st, g, s->tile_base, s->point_list, s->mesh_face, sqrtf(s->meshBlurRadius),
+    hipLaunchKernelGGL(k_mesh_backward_entries, dim3(8192), dim3(64), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, sqrtf(s->meshBlurRadius),
                        s->meshBlurRadius, 1.0f / s->meshSigma, s->n_contrib, s->final_T, d_normal_map, d_alpha, s->partial, s->status);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mesh_face_gather, dim3((F + 255) / 256), dim3(256), 0, st, F, s->tiles_touched, s->pair_off, s->pair_pos, s->partial, d_face,

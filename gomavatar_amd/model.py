@@ -240,7 +240,15 @@ class Model(nn.Module):
         normal, normal_mask = self.normal_renderer(vertices_observation.unsqueeze(0), vn[None], K, E, faces=self.faces)
         if self.shadow_module is not None:
             Bn, H, W, _ = normal.shape
-            shadings = self.shadow_module(normal.reshape(-1, H * W, 3)).reshape(Bn, H, W, 1) * 2
+            # shadow_module(normal) for every pixel (model.py:279-282).  The normal map is exactly 0 outside the mesh, where
+            # the MLP output is one constant: evaluate it once there and per pixel only under the mesh (~15 % of the image).
+            flat = normal.reshape(-1, 3)
+            idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
+            s_bg = self.shadow_module(torch.zeros(1, 1, 3, device=flat.device, dtype=flat.dtype)).reshape(1, 1)
+            s_all = s_bg.expand(flat.shape[0], 1).clone()
+            if idx.numel():
+                s_all = s_all.index_put((idx,), self.shadow_module(flat[idx][None]).reshape(-1, 1))
+            shadings = s_all.reshape(Bn, H, W, 1) * 2
             rgbs = albedos * shadings
         else:
             shadings, rgbs = None, albedos
