@@ -1,0 +1,183 @@
+"""On-disk formats of the reference, so that its checkpoints and prepared datasets load unchanged.
+
+Checkpoints (train.py:269-295,370-377): `torch.save({'iter', 'network': model.state_dict(), 'optimizer': ...})`; a run that
+subdivided the mesh is resumed by subdividing as often as `cfg.model.subdivide_iters` says before loading.  The only
+name that differs from `gomavatar_amd.model.Model` is the colour parameter (`appearance_module.appearance` /
+`appearance_module.bg_col` in the reference).
+
+Datasets (dataset/train.py:75-126,209-287; scripts/prepare_zju-mocap/prepare_dataset.py): `cameras.pkl`
+{frame: {'intrinsics', 'extrinsics'[, 'distortions']}}, `mesh_infos.pkl` {frame: {'Rh', 'Th', 'poses', 'joints',
+'tpose_joints'}}, `canonical_joints.pkl` {'joints', 'vertex', 'weights'[, 'edges', 'faces']}, `images/*.png`, `masks/*.png`."""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import synthetic as _syn
+
+_RENAME = {"appearance_module.appearance": "appearance", "appearance_module.bg_col": "bg_col"}
+_RENAME_BACK = {v: k for k, v in _RENAME.items()}
+
+
+def to_reference_state_dict(model) -> Dict[str, torch.Tensor]:
+    """`model.state_dict()` with the reference's key names (plus the buffers it registers: faces, target_edge_length)."""
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.startswith("normal_renderer."):
+            continue
+        sd[_RENAME_BACK.get(k, k)] = v.detach().clone()
+    sd["faces"] = model.faces.detach().clone()
+    sd["target_edge_length"] = model.target_edge_length.detach().clone()
+    return sd
+
+
+def load_reference_state_dict(model, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+    """Load a reference `network` state dict; subdivides the model first when the checkpoint's mesh is a subdivision of it."""
+    n_faces = int(sd["faces"].shape[0]) if "faces" in sd else int(sd["so3"].shape[1])
+    while model.faces.shape[0] < n_faces:
+        model.subdivide()
+    if model.faces.shape[0] != n_faces:
+        raise ValueError(f"checkpoint has {n_faces} faces, the model {model.faces.shape[0]} (not a midpoint subdivision of each other)")
+    own = dict(model.named_parameters())
+    own.update(dict(model.named_buffers()))
+    used = set()
+    with torch.no_grad():
+        for k, v in sd.items():
+            name = _RENAME.get(k, k)
+            if name in ("faces", "target_edge_length"):
+                if name == "faces" and not torch.equal(model.faces.cpu(), v.cpu().to(model.faces.dtype)):
+                    raise ValueError("checkpoint faces differ from the subdivided canonical mesh")
+                used.add(name)
+                continue
+            if name == "lbs_weights":
+                model.lbs_weights = v.to(model.vertices.device, torch.float32).contiguous()
+                used.add(name)
+                continue
+            if name not in own:
+                if strict:
+                    raise KeyError(f"unexpected key in checkpoint: {k}")
+                continue
+            own[name].copy_(v.to(own[name].device, own[name].dtype))
+            used.add(name)
+    missing = [k for k in own if k not in used and not k.startswith("normal_renderer.")]
+    if strict and missing:
+        raise KeyError(f"keys missing from checkpoint: {missing}")
+    model._rebuild_topology()
+    if "target_edge_length" in sd:   # a buffer of the reference model: the edge lengths at (the last) subdivision, not today's
+        model.target_edge_length = sd["target_edge_length"].to(model.vertices.device, torch.float32)
+
+
+def save_checkpoint(path: str, n_iter: int, model, optimizer) -> None:
+    """train.py:370-377."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save({"iter": n_iter, "network": to_reference_state_dict(model), "optimizer": optimizer.state_dict()}, path)
+
+
+def load_checkpoint(path: str, model, optimizer=None, subdivide_iters: Iterable[int] = ()) -> int:
+    """train.py:276-291: returns the iteration to continue from."""
+    ckpt = torch.load(path, map_location="cpu")
+    max_iter = int(ckpt["iter"])
+    for i in subdivide_iters:
+        if max_iter >= i:
+            model.subdivide()
+    load_reference_state_dict(model, ckpt["network"])
+    if optimizer is not None and "optimizer" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer"])
+    return max_iter + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def apply_global_tfm_to_camera(E: np.ndarray, Rh: np.ndarray, Th: np.ndarray):
+    """utils/camera_util.py:111-131: fold the body's global rotation / translation into the extrinsics."""
+    g = np.eye(4)
+    rot = _syn.rodrigues(np.asarray(Rh, dtype=np.float64).reshape(3)).T
+    g[:3, :3] = rot
+    g[:3, 3] = -rot.dot(np.asarray(Th, dtype=np.float64).reshape(3))
+    return E.dot(np.linalg.inv(g)), g
+
+
+class ReferenceDataset:
+    """Frames of a dataset directory prepared by the reference's scripts, as the dict `dataset/train.py:209-287` returns
+    (without the random crop; images need Pillow and are optional)."""
+
+    def __init__(self, dataset_path: str, bgcolor=None, load_images: bool = True):
+        self.path = dataset_path
+        with open(os.path.join(dataset_path, "canonical_joints.pkl"), "rb") as f:
+            cj = pickle.load(f)
+        self.canonical_joints = cj["joints"].astype("float32")
+        self.canonical_vertex = cj["vertex"].astype("float32")
+        self.canonical_lbs_weights = cj["weights"].astype("float32")
+        self.faces = cj.get("faces")
+        self.edges = cj["edges"].astype(int) if "edges" in cj else None
+        with open(os.path.join(dataset_path, "cameras.pkl"), "rb") as f:
+            self.cameras = pickle.load(f)
+        with open(os.path.join(dataset_path, "mesh_infos.pkl"), "rb") as f:
+            self.mesh_infos = pickle.load(f)
+        img_dir = os.path.join(dataset_path, "images")
+        if os.path.isdir(img_dir):
+            self.framelist = sorted(os.path.splitext(n)[0] for n in os.listdir(img_dir) if n.endswith(".png"))
+        else:
+            self.framelist = sorted(self.mesh_infos.keys())
+        self.bgcolor = bgcolor
+        self.load_images = load_images and os.path.isdir(img_dir)
+
+    def get_canonical_info(self):
+        return {"canonical_joints": self.canonical_joints, "canonical_vertex": self.canonical_vertex,
+                "canonical_lbs_weights": self.canonical_lbs_weights, "edges": self.edges, "faces": self.faces}
+
+    def __len__(self):
+        return len(self.framelist)
+
+    def __getitem__(self, idx: int) -> Dict[str, np.ndarray]:
+        name = self.framelist[idx]
+        mi, cam = self.mesh_infos[name], self.cameras[name]
+        if "distortions" in cam and np.any(np.asarray(cam["distortions"]) != 0):
+            raise NotImplementedError("lens undistortion needs OpenCV (dataset/train.py:151-155)")
+        bg = (np.random.rand(3) * 255.0).astype("float32") if self.bgcolor is None else np.asarray(self.bgcolor, dtype="float32")
+        poses, tpose = mi["poses"].astype("float32"), mi["tpose_joints"].astype("float32")
+        E, gt = apply_global_tfm_to_camera(cam["extrinsics"], mi["Rh"].astype("float32"), mi["Th"].astype("float32"))
+        dst_Rs, dst_Ts = _syn.pose_to_body_RTs(poses.reshape(-1), tpose)
+        out = {"frame_name": name, "bgcolor": bg / 255.0, "K": cam["intrinsics"][:3, :3].astype(np.float32), "E": E.astype(np.float32),
+               "global_tfms": gt, "dst_poses": poses, "dst_Rs": dst_Rs, "dst_Ts": dst_Ts,
+               "cnl_gtfms": _syn.canonical_global_tfms(self.canonical_joints), "dst_posevec": poses.reshape(-1)[3:] + 1e-2,
+               "dst_tpose_joints": tpose}
+        if self.load_images:
+            from PIL import Image
+            img = np.asarray(Image.open(os.path.join(self.path, "images", name + ".png")).convert("RGB"), dtype=np.float32)
+            alpha = np.asarray(Image.open(os.path.join(self.path, "masks", name + ".png")).convert("RGB"), dtype=np.float32) / 255.0
+            out["target_rgbs"] = ((alpha * img + (1.0 - alpha) * bg[None, None, :]) / 255.0).astype(np.float32)
+            out["target_masks"] = alpha[:, :, 0].astype(np.float32)
+        return out
+
+
+def write_synthetic_dataset(path: str, n_frames: int = 4, img: int = 64, level: int = 2) -> None:
+    """A dataset directory in the reference's layout from the synthetic body (tests, demos)."""
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    os.makedirs(os.path.join(path, "masks"), exist_ok=True)
+    body = _syn.icosphere_body(level)
+    joints = _syn.TPOSE_JOINTS
+    with open(os.path.join(path, "canonical_joints.pkl"), "wb") as f:
+        pickle.dump({"joints": joints, "vertex": body["canonical_vertex"], "weights": body["canonical_lbs_weights"], "faces": body["faces"]}, f)
+    cams, infos = {}, {}
+    for i in range(n_frames):
+        name = f"frame_{i:06d}"
+        K, E = _syn.look_at_camera(img, yaw=2 * np.pi * i / max(n_frames, 1))
+        cams[name] = {"intrinsics": K, "extrinsics": E}
+        pose = _syn.random_pose(i)
+        infos[name] = {"Rh": np.zeros(3, np.float32), "Th": np.zeros(3, np.float32), "poses": pose, "joints": joints, "tpose_joints": joints}
+        try:
+            from PIL import Image
+            rng = np.random.default_rng(i)
+            Image.fromarray((rng.uniform(0, 255, (img, img, 3))).astype(np.uint8)).save(os.path.join(path, "images", name + ".png"))
+            m = np.zeros((img, img, 3), np.uint8); m[img // 4: 3 * img // 4, img // 3: 2 * img // 3] = 255
+            Image.fromarray(m).save(os.path.join(path, "masks", name + ".png"))
+        except ImportError:
+            pass
+    with open(os.path.join(path, "cameras.pkl"), "wb") as f:
+        pickle.dump(cams, f)
+    with open(os.path.join(path, "mesh_infos.pkl"), "wb") as f:
+        pickle.dump(infos, f)

@@ -107,9 +107,15 @@ class MeshNormalRenderer(torch.nn.Module):
         self.sigma = 1e-4 if sigma is None else float(sigma)
         self.soft_mask = soft_mask
         self.blur_radius = math.log(1.0 / 1e-4 - 1.0) * self.sigma
-        self.state = RasterState()
+        self._state = None      # created on first use: constructing a Model for checkpoint IO needs no HIP device
         self._topo = None
         self._topo_key = None
+
+    @property
+    def state(self) -> RasterState:
+        if self._state is None:
+            self._state = RasterState()
+        return self._state
 
     def topology(self, faces: torch.Tensor, n_verts: int) -> MeshTopology:
         key = (faces.data_ptr(), int(faces.shape[0]), n_verts)
