@@ -30,20 +30,24 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
-constexpr int kTileH = 8, kTileW = 16, kBN = 64, kKC = 32;
-constexpr int kPatchW = kTileW + 2, kPatchPx = (kTileH + 2) * kPatchW;  // 18, 180
+constexpr int kTileW = 16, kBN = 64, kKC = 32;
+constexpr int kPatchW = kTileW + 2;  // 18
+// TH = pixel rows per workgroup (2 per wave): 8 rows / 4 waves for the small deep layers, 16 rows / 8 waves for the large
+// ones -- the 36 KB weight block is re-read from L2 by every workgroup, so twice the pixels per workgroup halves that traffic
+// (the large layers are L2-bandwidth-bound at 8 rows: 100 flop per byte staged).
 
 // in  [B][H][W][Cin]  bf16 (Cin multiple of 32);  wt [Cin/32][9][Cout][32] bf16 (Cout multiple of 64)
 // out [B][H][W][Cout] bf16;  bias fp32 [Cout] or null;  mask (same shape as out) or null: out *= (mask > 0)
 // SPLITK: blockIdx.z = image * splits + s; this block sums only its share of the input-channel chunks and stores raw fp32
 // partial sums to `partial` [splits][B][H][W][Cout]; k_splitk_epilogue adds them up and applies bias / ReLU / mask.  Used
 // for the deep layers (64x64 and 32x32 pixels: 8-32 pixel tiles), which would otherwise leave most of the 256 CUs idle.
-template <bool RELU, bool SPLITK>
-__global__ void __launch_bounds__(256) k_conv3x3_bf16(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
+template <bool RELU, bool SPLITK, int TH>
+__global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
                                                       const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                       const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
                                                       float *__restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) bf16_t s_in[kPatchPx * kKC];   // 11 520 B
+    constexpr int kTileH = TH, kPatchPx = (TH + 2) * kPatchW, NT = TH * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t s_in[kPatchPx * kKC];   // 11 520 B (TH = 8) / 20 736 B (TH = 16)
     __shared__ __attribute__((aligned(16))) bf16_t s_w[9 * kBN * kKC];      // 36 864 B
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * kTileH;
@@ -60,9 +64,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_bf16(int H, int W, int Cin, int
 
     const int nchunk = Cin / kKC;
     const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
+    // (A register-prefetch software pipeline -- next chunk's global loads in flight during the MFMA loop -- was measured
+    //  25 % SLOWER: +50 VGPRs, spills and one wave less per SIMD; latency is hidden by the 2-3 co-resident workgroups instead.)
     for (int cc = cc_lo; cc < cc_hi; cc++) {
         __syncthreads();  // the previous chunk's MFMA reads are done
-        for (int idx = tid; idx < kPatchPx * 4; idx += 256) {
+        for (int idx = tid; idx < kPatchPx * 4; idx += NT) {
             const int px = idx >> 2, part = idx & 3;
             const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -72,7 +78,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_bf16(int H, int W, int Cin, int
         }
         {
             const bf16_t *wsrc = wt + ((size_t)cc * 9 * Cout + co0) * kKC;
-            for (int idx = tid; idx < 9 * kBN * 4; idx += 256) {
+            for (int idx = tid; idx < 9 * kBN * 4; idx += NT) {
                 const int tap = idx >> 8, r = idx & 255;  // 256 16-byte units per tap (64 co x 32 ci)
                 *reinterpret_cast<uint4 *>(s_w + tap * kBN * kKC + r * 8) =
                     *reinterpret_cast<const uint4 *>(wsrc + (size_t)tap * Cout * kKC + r * 8);
@@ -332,7 +338,7 @@ extern "C" int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const vo
 }
 
 extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
-    const long blocks = (long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH) * (Cout / kBN) * B;
+    const long blocks = (long)((W + kTileW - 1) / kTileW) * ((H + 7) / 8) * (Cout / kBN) * B;
     int s = 1;
     while (s < 16 && blocks * s < 512 && (Cin / kKC) % (2 * s) == 0) s *= 2;   // >= 2 workgroups per CU, equal shares of the chunks
     // (measured on MI355X: 512 plain workgroups beat 2 x 512 split ones -- the fp32 partials and the second launch cost more)
@@ -345,19 +351,28 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
     if (!in || !wt || !out) { gom_set_error("gom_conv3x3_bf16: null pointer"); return -1; }
     if (splits < 1 || (splits > 1 && (!workspace || (Cin / kKC) % splits))) { gom_set_error("gom_conv3x3_bf16: bad split-K arguments"); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH), Cout / kBN, B * splits);
+    // 16 pixel rows per workgroup when that still leaves >= 2 workgroups per CU
+    const long blocks16 = (long)((W + kTileW - 1) / kTileW) * ((H + 15) / 16) * (Cout / kBN) * B * splits;
+    const int TH = (blocks16 >= 512 && H >= 16) ? 16 : 8;
+    const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + TH - 1) / TH), Cout / kBN, B * splits);
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
+#define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
+    do {                                                                                                                              \
+        if (TH == 16) hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 16>), grid, dim3(512), 0, st, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                            \
+    } while (0)
     if (splits > 1) {
-        hipLaunchKernelGGL((k_conv3x3_bf16<false, true>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace);
+        GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace);
         GOM_LAUNCH_CHECK();
         const size_t n4 = (size_t)B * H * W * Cout / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, n4, Cout, splits, workspace,
                            bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0);
     } else if (flags & GOM_CONV_RELU) {
-        hipLaunchKernelGGL((k_conv3x3_bf16<true, false>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+        GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
     } else {
-        hipLaunchKernelGGL((k_conv3x3_bf16<false, false>), grid, dim3(256), 0, st, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+        GOM_CONV_LAUNCH(false, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
     }
+#undef GOM_CONV_LAUNCH
     GOM_LAUNCH_CHECK();
     return 0;
 }
