@@ -78,3 +78,26 @@ def test_eval_mode_and_reproducibility():
         outs.append((n.clone(), m.clone(), x.grad.clone()))
     assert torch.equal(outs[0][0], n_eval) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     assert float(outs[0][1].max()) > 0.99 and float(outs[0][1].min()) == 0.0
+
+
+def test_non_square_image_ndc_convention():
+    """H != W: the shorter side spans [-1, 1] (pc_util.py:38-43 and PyTorch3D's pix_to_non_square_ndc)."""
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, vertex_normals
+    H, W = 64, 96
+    body = syn.icosphere_body(2)
+    fr = syn.make_frame(0, 64)
+    K = torch.from_numpy(fr["K"]).clone(); K[:, 0, 2] = W / 2; K[:, 0, 0] *= 2.0; K[:, 1, 1] *= 2.0
+    E = torch.from_numpy(fr["E"])
+    v = torch.from_numpy(body["canonical_vertex"]).T.contiguous()[None]
+    faces = torch.from_numpy(body["faces"]).long()
+    ndc_o = om.ndc_T_world(v.double(), K.double(), E.double(), H, W)[0]
+    vn_o = om.vertex_normals(v[0].T.double(), faces)
+    n_o, a_o, p2f_o = om.render(ndc_o, faces, vn_o, H, W, sigma_cfg=1e-5)
+    r = MeshNormalRenderer(img_size=(W, H), sigma=1e-5).cuda().train()
+    vc, fc = v.cuda(), faces.cuda()
+    normal, mask = r(vc, vertex_normals(vc[0].T, r.topology(fc, vc.shape[2]))[None], K.cuda(), E.cuda(), fc)
+    assert normal.shape == (1, H, W, 3) and mask.shape == (1, H, W, 1)
+    assert (p2f_o >= 0).float().mean() > 0.02
+    assert float((mask[0, ..., 0].cpu().double() - a_o).abs().max()) < 2e-5
+    d = (normal[0].cpu().double() - n_o).abs().amax(-1)
+    assert float((d > 1e-5).float().mean()) < 1e-3
