@@ -82,6 +82,12 @@ SIGNATURES = {
     "gom_mesh_pix_to_face": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gom_vertex_normals_forward": (c_int, [c_int, c_int] + [c_void_p] * 7),
     "gom_vertex_normals_backward": (c_int, [c_int, c_int] + [c_void_p] * 9),
+    "gom_mesh_laplacian": (c_int, [c_int] + [c_void_p] * 6),
+    "gom_mesh_laplacian_backward": (c_int, [c_int] + [c_void_p] * 6),
+    "gom_mesh_normal_consistency": (c_int, [c_int] + [c_void_p] * 6),
+    "gom_mesh_normal_consistency_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 11),
+    "gom_mesh_color_consistency": (c_int, [c_int, c_int] + [c_void_p] * 5),
+    "gom_mesh_color_consistency_backward": (c_int, [c_int, c_int] + [c_void_p] * 6),
     "gom_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "gom_lpips_layer_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -27,6 +27,7 @@ SOURCES = [
     ("vgg_bf16.hip", []),
     ("lpips_vgg_api.hip", []),
     ("mesh_raster.hip", []),
+    ("mesh_losses.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           f"-I{_INC}", f"-I{_CSRC}"]

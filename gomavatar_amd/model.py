@@ -39,8 +39,9 @@ def _get(cfg, path: str, default):
 class SimpleMesh:
     """What the reference's loss code reads from a PyTorch3D `Meshes` (one mesh): packed verts / faces / edges."""
 
-    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor):
+    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor, topo=None, loss_topo=None):
         self._v, self._f, self._e = verts, faces, edges
+        self.topo, self.loss_topo = topo, loss_topo          # device CSR adjacency for the HIP regularisers
 
     def verts_packed(self): return self._v
     def faces_packed(self): return self._f
@@ -156,6 +157,8 @@ class Model(nn.Module):
         pairs = np.stack([fid[starts[keep]], fid[starts[keep] + 1]], 1)
         pairs.sort(1)
         self.face_connectivity = torch.from_numpy(pairs).to(self.vertices.device)
+        from .mesh_losses import MeshLossTopology
+        self.loss_topo = MeshLossTopology(self.edges, self.face_connectivity, N, self.faces.shape[0], self.vertices.device)
         v = self.vertices.detach().T
         self.target_edge_length = (v[self.edges[:, 0]] - v[self.edges[:, 1]]).norm(dim=1)     # get_init_edge_length (model.py:127-134)
 
@@ -255,7 +258,9 @@ class Model(nn.Module):
         outputs = {}
         if self.training:
             vo, vc = vertices_observation.T, vertices_canonical.T
-            outputs.update(colors=self.appearance.T, face_connectivity=self.face_connectivity, mesh=SimpleMesh(vo, self.faces, self.edges),
-                           mesh_canonical=SimpleMesh(vc, self.faces, self.edges), target_edge_length=self.target_edge_length, albedo=albedos[0],
+            outputs.update(colors=self.appearance.T, face_connectivity=self.face_connectivity,
+                           mesh=SimpleMesh(vo, self.faces, self.edges, self.topo, self.loss_topo),
+                           mesh_canonical=SimpleMesh(vc, self.faces, self.edges, self.topo, self.loss_topo), target_edge_length=self.target_edge_length,
+                           albedo=albedos[0],
                            normal=normal, normal_mask=normal_mask[..., 0] if normal_mask is not None else None, shadow=shadings)
         return rgbs, masks, outputs

@@ -17,6 +17,9 @@ def unpack(rgbs, masks, bgcolors):
 def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
     """Uniform Laplacian: mean over vertices of || (1/deg) sum_neighbours v_j - v_i ||."""
     v, e = mesh.verts_packed(), mesh.edges_packed()
+    if v.is_cuda and getattr(mesh, "loss_topo", None) is not None:
+        from .mesh_losses import laplacian_smoothing
+        return laplacian_smoothing(v, mesh.loss_topo)
     N = v.shape[0]
     deg = torch.zeros(N, device=v.device, dtype=v.dtype).index_add(0, e[:, 0], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
     deg = deg.index_add(0, e[:, 1], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
@@ -28,13 +31,19 @@ def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
 def mesh_normal_consistency(mesh, face_connectivity) -> torch.Tensor:
     """1 - cos between the normals of faces sharing an edge, averaged over those edges."""
     v, f = mesh.verts_packed(), mesh.faces_packed()
+    if v.is_cuda and getattr(mesh, "loss_topo", None) is not None:
+        from .mesh_losses import normal_consistency
+        return normal_consistency(v, mesh.topo, mesh.loss_topo)
     n = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
     n = F.normalize(n, dim=1, eps=1e-6)
     return (1.0 - (n[face_connectivity[:, 0]] * n[face_connectivity[:, 1]]).sum(1)).mean()
 
 
-def mesh_color_consistency(colors, face_connectivity) -> torch.Tensor:
-    """network_util.py: mean absolute colour difference of edge-adjacent faces."""
+def mesh_color_consistency(colors, face_connectivity, loss_topo=None) -> torch.Tensor:
+    """network_util.py:795-799: mean absolute colour difference of edge-adjacent faces."""
+    if colors.is_cuda and loss_topo is not None:
+        from .mesh_losses import color_consistency
+        return color_consistency(colors.T, loss_topo)      # (F,3) view of the (3,F) parameter -> its own layout
     return (colors[face_connectivity[:, 0]] - colors[face_connectivity[:, 1]]).abs().mean()
 
 
@@ -65,6 +74,7 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
     if _get(loss_cfg, "normal.coeff_consist", 0.0) > 0:
         put("normal_consist", mesh_normal_consistency(outputs["mesh"], outputs["face_connectivity"]), loss_cfg.normal.coeff_consist)
     if _get(loss_cfg, "color_consist.coeff", 0.0) > 0:
-        put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"]), loss_cfg.color_consist.coeff)
+        put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"], getattr(outputs.get("mesh"), "loss_topo", None)),
+            loss_cfg.color_consist.coeff)
     total = sum(item["scaled"] for item in losses.values())
     return total, losses

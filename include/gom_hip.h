@@ -30,6 +30,8 @@
  *       utils/lpips/pretrained_networks.py:96-134 (VGG16 trunk) + utils/lpips/lpips.py:81-133 on the matrix cores.
  *   gom_mesh_raster_forward / gom_mesh_raster_backward
  *       models/modules/renderer/mesh.py:65-128 (PyTorch3D MeshRasterizer + NormalShader + SoftSilhouetteShader).
+ *   gom_mesh_laplacian, gom_mesh_normal_consistency, gom_mesh_color_consistency (+ _backward)
+ *       train.py:123-160 (PyTorch3D mesh_laplacian_smoothing / mesh_normal_consistency, network_util.py:795-799).
  *   gom_ssim
  *       eval.py:106-108 (skimage structural_similarity, multichannel) and eval.py:157 (torchmetrics SSIM).
  *   gom_lpips_layer_forward / gom_lpips_layer_backward
@@ -246,6 +248,25 @@ int gom_vertex_normals_forward(int N, int F, const float *verts, const int32_t *
                                float *sums, float *normals, void *stream);
 int gom_vertex_normals_backward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
                                 const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts, void *stream);
+
+/* ---- mesh regularisers (train.py:123-160) ------------------------------------------------------------------------------
+ * verts [N][3]; nbr_off [N+1] / nbr_idx [2E]: vertex -> neighbouring vertices; pairs [P][2]: faces sharing an edge
+ * (models/model.py:115-125); fp_off [F+1] / fp_idx: face -> (pair*2 + side); csr_off / csr_idx: vertex -> face*3 + corner.
+ * Forward calls write GOM_LOSS_BLOCKS partial sums (loss = their sum) and the per-element data the backward needs;
+ * grad_out is a 1-element DEVICE array (the upstream gradient of the scalar loss).
+ *   laplacian:           mean_i || mean_{j in N(i)} v_j - v_i ||     (PyTorch3D mesh_laplacian_smoothing, method="uniform")
+ *   normal consistency:  mean_pairs 1 - cos(n_a, n_b)                (PyTorch3D mesh_normal_consistency, oriented manifold mesh)
+ *   colour consistency:  mean |c_a - c_b|, colours [3][F]            (utils/network_util.py:795-799) */
+int gom_mesh_laplacian(int N, const float *verts, const int32_t *nbr_off, const int32_t *nbr_idx, float *dir /*[N][3]*/, float *partials, void *stream);
+int gom_mesh_laplacian_backward(int N, const float *dir, const int32_t *nbr_off, const int32_t *nbr_idx, const float *grad_out, float *d_verts, void *stream);
+int gom_mesh_normal_consistency(int P, const int32_t *pairs, const float *verts, const int32_t *faces, float *pair_grad /*[P][2][3]*/, float *partials,
+                                void *stream);
+int gom_mesh_normal_consistency_backward(int N, int F, int P, const int32_t *fp_off, const int32_t *fp_idx, const float *pair_grad, const float *verts,
+                                         const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx, const float *grad_out,
+                                         float *d_corner_scratch /*[F][9]*/, float *d_verts, void *stream);
+int gom_mesh_color_consistency(int P, int F, const int32_t *pairs, const float *colors, float *pair_sign /*[P][3]*/, float *partials, void *stream);
+int gom_mesh_color_consistency_backward(int F, int P, const int32_t *fp_off, const int32_t *fp_idx, const float *pair_sign, const float *grad_out,
+                                        float *d_colors /*[3][F]*/, void *stream);
 
 /* ---- SSIM (evaluation metric; eval.py:106-108,157) --------------------------------------------
  * img0, img1 [H][W][C] fp32; weights [win][win] fp64 window (sums to 1; win odd); the SSIM map is evaluated where the
