@@ -422,6 +422,21 @@ __global__ void __launch_bounds__(256) k_gather_colors(const uint32_t *__restric
     }
 }
 
+// Per-pixel colour checkpoints (seg_C, seg_Sbehind, sub_C) are rows of 256 float4 (one 16-byte load or store per lane,
+// 1 KiB contiguous per wave) rather than 4 planes of 256 floats: the backward reads up to 16 of them per lane and task.
+template <int C>
+__device__ __forceinline__ void st4(float *base, size_t row, int pxi, const float (&v)[C]) {
+    float4 o = make_float4(v[0], v[1], v[2], 0.f);
+    if (C == 4) o.w = v[C - 1];
+    reinterpret_cast<float4 *>(base)[row * GOM_TPX + pxi] = o;
+}
+template <int C>
+__device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, float (&v)[C]) {
+    const float4 o = reinterpret_cast<const float4 *>(base)[row * GOM_TPX + pxi];
+    v[0] = o.x; v[1] = o.y; v[2] = o.z;
+    if (C == 4) v[C - 1] = o.w;
+}
+
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
@@ -544,8 +559,8 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__
                 const size_t o = (size_t)seg * GOM_TPX + pxi;
                 seg_Tend[o] = 0.f;
                 seg_last[o] = 0;
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) seg_C[((size_t)seg * 4 + ch) * GOM_TPX + pxi] = 0.f;
+                const float zero[C] = {};
+                st4<C>(seg_C, seg, pxi, zero);
             }
             continue;
         }
@@ -611,15 +626,15 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__
                 }
                 // checkpoints for the backward: what this piece really added, and T behind it
                 sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
+                float cu[C];
 #pragma unroll
-                for (int ch = 0; ch < C; ch++)
-                    sub_C[(((size_t)seg * GOM_NSUB + u) * 4 + ch) * GOM_TPX + pxi] = counts ? s_c[u][ch][lane] : 0.f;
+                for (int ch = 0; ch < C; ch++) cu[ch] = counts ? s_c[u][ch][lane] : 0.f;
+                st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu);
             }
             const size_t o = (size_t)seg * GOM_TPX + pxi;
             seg_Tend[o] = !any ? 0.f : (stopped ? -Tc : Tc);
             seg_last[o] = lastc;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) seg_C[((size_t)seg * 4 + ch) * GOM_TPX + pxi] = tot[ch];
+            st4<C>(seg_C, seg, pxi, tot);
         }
     }
 }
@@ -679,8 +694,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
             const size_t o = (size_t)(sb + sl) * GOM_TPX + threadIdx.x;
             te[u] = seg_Tend[o];
             ll[u] = seg_last[o];
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) cs[u][ch] = seg_C[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x];
+            ld4<C>(seg_C, sb + sl, threadIdx.x, cs[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -716,18 +730,16 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int sl = max(s1 - 1 - u, 0);
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) cs[u][ch] = seg_C[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x];
+                ld4<C>(seg_C, (size_t)(sb + sl), threadIdx.x, cs[u]);
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int sl = s1 - 1 - u;
                 if (sl >= 0) {
+                    st4<C>(seg_Sbehind, (size_t)(sb + sl), threadIdx.x, S);
 #pragma unroll
-                    for (int ch = 0; ch < C; ch++) {
-                        seg_Sbehind[((size_t)(sb + sl) * 4 + ch) * GOM_TPX + threadIdx.x] = S[ch];
+                    for (int ch = 0; ch < C; ch++)
                         if (sl <= s_stop) S[ch] += cs[u][ch];
-                    }
                 }
             }
         }
@@ -813,14 +825,23 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
             float T = sub_Tend[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi];
             float accum_rec[C], last_color[C], last_alpha = 0.f;
             const float invT = T > 0.f ? 1.f / T : 0.f;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                float S = seg_Sbehind[((size_t)seg * 4 + ch) * GOM_TPX + pxi];
+            {
+                float S[C], cu[GOM_NSUB][C];
+                ld4<C>(seg_Sbehind, seg, pxi, S);
 #pragma unroll
                 for (int u = GOM_NSUB - 1; u > 0; u--)
-                    if (u > sub) S += sub_C[(((size_t)seg * GOM_NSUB + u) * 4 + ch) * GOM_TPX + pxi];
-                accum_rec[ch] = S * invT;
-                last_color[ch] = 0.f;
+                    if (u > sub) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu[u]);   // (wave-uniform condition)
+#pragma unroll
+                for (int u = GOM_NSUB - 1; u > 0; u--)
+                    if (u > sub) {
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) S[ch] += cu[u][ch];
+                    }
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    accum_rec[ch] = S[ch] * invT;
+                    last_color[ch] = 0.f;
+                }
             }
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
             const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1);
