@@ -71,6 +71,10 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value < 0 || value > 0xffffffffLL) { gom_set_error("pair capacity out of range"); return -1; }
             s->wantPairs = value;
             return 0;
+        case GOM_OPT_SEG_SHIFT:
+            if (value != 0 && value != 7 && value != 8) { gom_set_error("segment shift must be 0 (auto), 7 or 8"); return -1; }
+            s->wantSegShift = (int)value;
+            return 0;
         case GOM_OPT_PROFILE:
             if (value && !s->ev[0]) {
                 for (int i = 0; i < 2 * GOM_NUM_KERNELS; i++) GOM_HIP_CHECK(hipEventCreate(&s->ev[i]));
@@ -142,6 +146,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     s->gx = gx;
     s->gy = gy;
     s->B = B;
+    s->segShift = s->wantSegShift ? s->wantSegShift : (B > 1 ? 8 : 7);   // (capSegs above is sized for the 128-entry case)
     return 0;
 }
 

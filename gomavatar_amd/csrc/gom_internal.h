@@ -12,7 +12,7 @@
 #define GOM_SORT_SMALL 2048         // lists up to this length are sorted by the 256-thread instantiation of k_sort
 #define GOM_PARTIAL_STRIDE 12       // floats per (tile, gaussian) partial-gradient record (10 used)
 #ifndef GOM_SEG
-#define GOM_SEG 128                 // tile-list entries per segment (the unit of parallel compositing), <= 256
+#define GOM_SEG 128                 // smallest tile-list segment (the unit of parallel compositing); GomState::segShift picks 128 or 256
 #endif
 #define GOM_TPX 256                 // pixels per tile = threads of the per-tile / per-segment workgroups
 #ifndef GOM_SEG_GRID
@@ -46,6 +46,8 @@ struct GomState {
     // last forward (P, H, W, gx, gy are PER FRAME; a batched launch stacks B frames: B*P Gaussians on a gx x B*gy tile grid)
     int P = 0, H = 0, W = 0, C = 0, gx = 0, gy = 0;
     int B = 1;
+    int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
+    int segShift = 7;                 // log2 of the segment size of the current binning: 7 for one frame, 8 for a batch
     const GomCamera *cams = nullptr;  // device array of B cameras for a batched launch; nullptr: the by-value camera
     bool haveForward = false;
     // mesh normal / silhouette rasterizer (mesh_raster.hip) on this state: per-face geometry + per-face gradients

@@ -253,7 +253,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
 __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
                                                      uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ seg_base,
                                                      uint32_t *__restrict__ tile_nmax, int n_tiles,
-                                                     GomDevStatus *__restrict__ status, uint32_t cap_pairs) {
+                                                     GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
     uint32_t carry = 0, seg_carry = 0;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
         uint32_t tot, stot;
         const uint32_t excl = carry + block_excl_scan_1024(v, s_wave, tot);
-        const uint32_t sexcl = seg_carry + block_excl_scan_1024((v + GOM_SEG - 1) / GOM_SEG, s_wave, stot);
+        const uint32_t sexcl = seg_carry + block_excl_scan_1024((v + (1u << seg_shift) - 1) >> seg_shift, s_wave, stot);
         if (i < n_tiles) {
             tile_base[i] = excl;
             tile_cursor[i] = excl;
@@ -512,7 +512,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st) {
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
-                           s->tile_nmax, n_tiles * s->B, s->status, cap);
+                           s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;

@@ -9,7 +9,7 @@
 // A GoMAvatar frame touches only ~170 of 1024 tiles and a few of them hold
 // >5 000 Gaussians; "one workgroup per tile walks its list" leaves the chip idle
 // behind those tiles.  Alpha compositing is associative, so the list of every
-// tile is cut into segments of GOM_SEG = 128 entries, every segment into 4
+// tile is cut into segments of 128 entries (256 in a batched launch), every segment into 4
 // sub-ranges of 32, and the unit of work is one wave = (segment, 8x8 pixel
 // quadrant, sub-range): ~19 000 independent waves per frame, x B for a batched
 // launch (B frames stacked into one tall tile grid, see raster_pre.hip).
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
                                                float2 *__restrict__ ent_geo, uint64_t *__restrict__ scratch,
-                                               const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max) {
+                                               const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max, uint32_t seg_shift) {
     __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * NT];
     if (status->overflow) return;
     const int tile = blockIdx.x;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
     // one 16-byte descriptor per segment: the segment kernels start from a single load
     for (uint32_t i = threadIdx.x; i < nseg; i += NT)
-        seg_desc[sb + i] = make_uint4((uint32_t)tile, base + i * GOM_SEG, min((uint32_t)GOM_SEG, n - i * GOM_SEG), i);
+        seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t t = threadIdx.x;
     const uint32_t CH = 1u << log_chunk;
@@ -368,25 +368,27 @@ struct EntryRegs {
     bool keep;
 };
 
-// The unit of work is one wave = (segment, quadrant q of 8x8 pixels, sub-range j of GOM_SUB = 32 list entries).
+// The unit of work is one wave = (segment, quadrant q of 8x8 pixels, sub-range j of 32 (or 64) list entries).
 // A single wave issues at most one VALU instruction every ~5 cycles on gfx950 (measured,
 // scripts/ubench/dpp_bench.hip) and most of a wave's life here is load latency, so the lists are cut into many
 // short independent pieces that the CU interleaves 8 per SIMD.  Workgroups are 4 waves: the four sub-ranges of a
 // (segment, quadrant) in the forward (they fold their results in LDS), the four quadrants of a (segment,
 // sub-range) in the backward (they sum their per-entry reductions in LDS).
-#define GOM_SUB 32
-#define GOM_NSUB (GOM_SEG / GOM_SUB)
-static_assert(GOM_SEG == 128 && GOM_NSUB == 4, "the segment kernels are written for 4 sub-ranges of 32 entries");
+// Segment size is a launch parameter (seg_shift = 7 or 8): 128-entry segments / 32-entry sub-ranges give a single frame the
+// most independent waves; a batched launch has parallelism to spare and halves the per-task fixed cost (checkpoint loads,
+// cull, LDS fold, stores -- measured at 40-60 % of these kernels) with 256 / 64.
+#define GOM_NSUB 4
+#define GOM_SUB_MAX 64
 
 // The <=32 entries of this wave's sub-range, read straight from the list-ordered records the sort left behind
 // (contiguous 24-byte geometry + 16-byte colour rows: coalesced, no LDS staging, no barrier): lanes 0..31 load
 // one entry each and test it against the wave's 8x8 rectangle.
 template <int C>
 __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col, uint32_t start,
-                                                 uint32_t cnt, int sub, int lane, float qx0, float qy0, float qx1, float qy1) {
+                                                 uint32_t cnt, int sub, int lane, float qx0, float qy0, float qx1, float qy1, uint32_t sub_sz) {
     EntryRegs<C> r;
-    const uint32_t e = (uint32_t)sub * GOM_SUB + (uint32_t)lane;
-    const bool valid = lane < GOM_SUB && e < cnt;
+    const uint32_t e = (uint32_t)sub * sub_sz + (uint32_t)lane;
+    const bool valid = (uint32_t)lane < sub_sz && e < cnt;
     r.x = r.y = r.a = r.b = r.c = r.o = 0.f;
 #pragma unroll
     for (int ch = 0; ch < (C > 0 ? C : 1); ch++) r.col[ch] = 0.f;
@@ -442,11 +444,12 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
 // starts without walking the list serially.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                 const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
                                                 float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
                                                 const GomDevStatus *__restrict__ status) {
     __shared__ float s_P[GOM_NSUB][64];
+    const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
@@ -470,7 +473,7 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__re
         }
         float T = 1.f;
         {
-            const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
+            const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             unsigned long long mask = __ballot(r.keep);
             while (mask) {
                 float al[4];
@@ -500,7 +503,7 @@ __global__ void __launch_bounds__(256) k_seg_T(int gx, int gy, const uint4 *__re
 // contribution, T after it (negated if the stop rule fired inside) and the last contributor; the per-sub-range
 // pieces are kept as checkpoints for the backward.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+__global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
@@ -508,6 +511,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__
     __shared__ float s_c[GOM_NSUB][C][64];
     __shared__ float s_t[GOM_NSUB][64];
     __shared__ uint32_t s_l[GOM_NSUB][64];
+    const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
@@ -517,13 +521,13 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__
         const int pxi = q * 64 + lane;
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z, sb = seg - d.w;
-        const uint32_t e0 = d.w * GOM_SEG;
+        const uint32_t e0 = d.w << seg_shift;
         const int tx = tile % gx, ty = (tile / gx) % gy;  // row inside the tile's own frame (batched launches stack the frames)
         const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
         // issued early: the entry loads overlap the transmittance prefix below
-        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1);
+        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
         // transmittance at the start of this sub-range; 0 = the pixel has certainly stopped earlier.
         // (In the 1e-5-wide borderline band the pixel stays alive; the fold below / the combine pass honour
         //  the exact stop flag of the earlier piece.)
@@ -594,7 +598,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(int gx, int gy, const uint4 *__
                     for (int ch = 0; ch < C; ch++) acc[ch] += ecol[u][ch] * w;
                     T = cont ? test_T : T;
                     wl = cont ? wl : 0.f;
-                    last = (w > 0.f) ? (e0 + (uint32_t)sub * GOM_SUB + (uint32_t)kk[u] + 1u) : last;
+                    last = (w > 0.f) ? (e0 + (uint32_t)sub * sub_sz + (uint32_t)kk[u] + 1u) : last;
                 }
                 if (__ballot(wl != 0.f) == 0ull) break;
             }
@@ -758,7 +762,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 
 // ---------------------------------------------------------------- backward -
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ tile_nmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
@@ -767,7 +771,8 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
     constexpr int NV = 6 + C;  // values reduced per entry
-    __shared__ float s_acc[4][GOM_SUB][10];  // [quadrant][entry of the sub-range][value]
+    __shared__ float s_acc[4][GOM_SUB_MAX][10];  // [quadrant][entry of the sub-range][value]
+    const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 quadrants of one (segment, sub-range)
@@ -778,11 +783,11 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
         const int sub = (int)(task & 3);
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
-        const uint32_t e0 = d.w * GOM_SEG;
-        if ((uint32_t)sub * GOM_SUB >= cnt) continue;  // no entries in this sub-range
-        const uint32_t scnt = min((uint32_t)GOM_SUB, cnt - (uint32_t)sub * GOM_SUB);
-        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * GOM_SUB + threadIdx.x) * GOM_PARTIAL_STRIDE);
-        if (e0 + (uint32_t)sub * GOM_SUB >= tile_nmax[tile]) {  // every pixel of the tile stopped before this sub-range: all-zero records
+        const uint32_t e0 = d.w << seg_shift;
+        if ((uint32_t)sub * sub_sz >= cnt) continue;  // no entries in this sub-range
+        const uint32_t scnt = min(sub_sz, cnt - (uint32_t)sub * sub_sz);
+        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * sub_sz + threadIdx.x) * GOM_PARTIAL_STRIDE);
+        if (e0 + (uint32_t)sub * sub_sz >= tile_nmax[tile]) {  // every pixel of the tile stopped before this sub-range: all-zero records
             if (threadIdx.x < scnt) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 rec[0] = z; rec[1] = z; rec[2] = z;
@@ -790,7 +795,10 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
             continue;
         }
         __syncthreads();  // the previous segment's flush is done
-        for (int i = threadIdx.x; i < 4 * GOM_SUB * 10; i += 256) (&s_acc[0][0][0])[i] = 0.f;
+        for (int i = threadIdx.x; i < 4 * (int)sub_sz * 10; i += 256) {
+            const int qq = i / ((int)sub_sz * 10);
+            (&s_acc[qq][0][0])[i - qq * (int)sub_sz * 10] = 0.f;
+        }
         __syncthreads();
 
         const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
@@ -804,7 +812,7 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
         const uint32_t wmax = wave_max_u32(my_last);
-        const uint32_t s0 = e0 + (uint32_t)sub * GOM_SUB;  // list index of this wave's first entry
+        const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;  // list index of this wave's first entry
         if (wmax > s0) {
             const float T_final = final_T[inside ? fpix : 0];
             float dpix[C], bg_dot = 0.f;
@@ -844,7 +852,7 @@ __global__ void __launch_bounds__(256) k_seg_bwd(int H, int W, int gx, int gy, f
                 }
             }
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
-            const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1);
+            const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             unsigned long long mask = __ballot(r.keep);
             // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
             // T / accum_rec recurrences, then interleaved DPP reductions.
@@ -939,12 +947,12 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     if (small_max) {
         hipLaunchKernelGGL(k_sort<256>, dim3(n_tiles), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
                            s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial),
-                           s->status, lc < 11u ? lc : 11u, small_max);
+                           s->status, lc < 11u ? lc : 11u, small_max, (uint32_t)s->segShift);
         GOM_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_sort<1024>, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
                        s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial), s->status,
-                       lc, small_max);
+                       lc, small_max, (uint32_t)s->segShift);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -957,10 +965,10 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         GomKernelTimer timer(s, GOM_K_SEG_T, st);
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
             if (C == 3)
-                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
+                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
                                    s->ent_col, s->seg_T, s->sub_T, s->status);
             else
-                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
+                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
                                    s->ent_col, s->seg_T, s->sub_T, s->status);
         } else {  // only the colours changed: bring them into list order
             if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
@@ -971,7 +979,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     {
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
+    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
                        s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
@@ -997,7 +1005,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #define GOM_SB(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
                        s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status)
     if (C == 3) GOM_SB(3); else GOM_SB(4);

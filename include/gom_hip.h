@@ -87,7 +87,9 @@ enum {
     GOM_OPT_SORT_CAP = 0,   /* tile-list length sorted in one register/LDS chunk (64..8192, rounded down to a power of
                                two; default 8192); longer lists take the chunked merge path -- lowered by tests */
     GOM_OPT_PAIR_CAPACITY = 1, /* capacity (entries) of the (tile, gaussian) pair buffers */
-    GOM_OPT_PROFILE = 2        /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
+    GOM_OPT_PROFILE = 2,       /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
+    GOM_OPT_SEG_SHIFT = 3      /* log2 of the tile-list segment size: 7 (128 entries), 8 (256) or 0 = auto (7 for one frame,
+                                  8 for a batched launch).  Results for different sizes agree to fp32 round-off, not bitwise. */
 };
 
 /* kernel ids for gom_state_kernel_times */

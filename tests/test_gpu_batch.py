@@ -38,7 +38,9 @@ def test_batch_equals_single_frames_bitwise(B, img, graph, smpl_like):
     bg_b = stack("bgcolor")
     bg4 = (0.1, 0.2, 0.3, 0.0)
 
+    from gomavatar_amd import _lib
     single = RenderStep(faces, N, (img, img), w25)
+    single.state.set_option(_lib.OPT_SEG_SHIFT, 8)      # a batch uses 256-entry segments: bitwise equality needs the same split
     imgs, losses, grads, radii = [], [], [], []
     for b in range(B):
         single.set_camera(frames[b]["K"][0], frames[b]["E"][0], bg4)
@@ -61,8 +63,13 @@ def test_batch_equals_single_frames_bitwise(B, img, graph, smpl_like):
     assert torch.equal(batch.radii, torch.stack(radii))
     D, overflow = batch.state.poll()
     assert not overflow and D > 0
+    # default single-frame segment size (128): same images up to fp32 association
+    auto = RenderStep(faces, N, (img, img), w25)
+    auto.set_camera(frames[0]["K"][0], frames[0]["E"][0], bg4)
+    auto.forward_backward(params, {k: fr_b[k][0].contiguous() for k in fr_b}, gt_rgb[0].contiguous(), gt_mask[0].contiguous(), bg_b[0].contiguous())
+    torch.cuda.synchronize()
+    assert float((auto.image - imgs[0]).abs().max()) < 2e-6
     if smpl_like:
-        from gomavatar_amd import _lib
         tb = batch.state.export(_lib.BUF_TILE_BASE, torch.empty(B * (img // 16) ** 2 + 1, dtype=torch.int32, device="cuda")).cpu().numpy()
         cnt = np.diff(tb.astype(np.int64))
         assert cnt.max() > 2048 and (cnt[cnt > 0] <= 2048).any()
