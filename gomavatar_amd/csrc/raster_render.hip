@@ -119,13 +119,14 @@ __device__ __forceinline__ bool cull_entry(float cx, float cy, float a, float b,
     const float Y = cy < y0 ? (y0 - cy) : (cy > y1 ? (y1 - cy) : 0.f);
     if (X == 0.f && Y == 0.f) return false;
     float q = 3.0e38f;
+    // (v_rcp_f32, 1 ulp: the bound below carries a 1e-5 relative + 1e-2 absolute margin, and dx / dy are clamped anyway)
     if (X != 0.f) {
-        float dy = -b * X / cz;
+        float dy = -b * X * __builtin_amdgcn_rcpf(cz);
         dy = fminf(fmaxf(dy, y0 - cy), y1 - cy);
         q = fminf(q, a * X * X + 2.f * b * X * dy + cz * dy * dy);
     }
     if (Y != 0.f) {
-        float dx = -b * Y / a;
+        float dx = -b * Y * __builtin_amdgcn_rcpf(a);
         dx = fminf(fmaxf(dx, x0 - cx), x1 - cx);
         q = fminf(q, a * dx * dx + 2.f * b * dx * Y + cz * Y * Y);
     }
