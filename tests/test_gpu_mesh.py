@@ -101,3 +101,28 @@ def test_non_square_image_ndc_convention():
     assert float((mask[0, ..., 0].cpu().double() - a_o).abs().max()) < 2e-5
     d = (normal[0].cpu().double() - n_o).abs().amax(-1)
     assert float((d > 1e-5).float().mean()) < 1e-3
+
+
+def test_degenerate_and_offscreen_faces_are_harmless():
+    """Zero-area faces are skipped (PyTorch3D kEpsilon rule), faces outside the image or behind the camera touch nothing,
+    and gradients stay finite."""
+    from gomavatar_amd.mesh_renderer import _MeshRaster, vertex_normals
+    from gomavatar_amd.geometry import MeshTopology
+    from gomavatar_amd.rasterizer import RasterState
+    H = W = 48
+    verts = torch.tensor([[0.3, 0.3, 5.0], [-0.3, 0.3, 5.0], [0.0, -0.3, 5.0],      # a visible triangle
+                          [0.1, 0.1, 4.0], [0.1, 0.1, 4.0], [0.1, 0.1, 4.0],        # three coincident points: zero area
+                          [5.0, 5.0, 5.0], [5.2, 5.0, 5.0], [5.0, 5.2, 5.0],        # far outside the image
+                          [0.2, 0.0, -1.0], [-0.2, 0.0, -1.0], [0.0, 0.2, -1.0]],   # behind the camera
+                         dtype=torch.float32)
+    faces = torch.arange(12).reshape(4, 3)
+    v = verts.cuda().requires_grad_()
+    topo = MeshTopology(faces.cuda(), 12)
+    vn = vertex_normals(v, topo)
+    normal, alpha = _MeshRaster.apply(v, vn, topo, RasterState(), H, W, 9.21e-5, 1e-4, True)
+    (normal.sum() + alpha.sum()).backward()
+    assert torch.isfinite(normal).all() and torch.isfinite(alpha).all() and torch.isfinite(v.grad).all()
+    n_o, a_o, p2f = om.render(verts.double(), faces, om.vertex_normals(verts.double(), faces), H, W, sigma_cfg=1e-5)
+    assert set(p2f.unique().tolist()) <= {-1, 0}                       # only the first face is ever on top
+    assert float((alpha.detach().cpu().double() - a_o).abs().max()) < 2e-5
+    assert float(v.grad[3:].abs().max()) == 0.0                        # nothing reaches the other three faces' vertices
