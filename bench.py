@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
                          "1 = strictly one step after the other")
+    ap.add_argument("--seg-shift", type=int, default=0, help="log2 of the tile-list segment size (0 = library default)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the 17 kernels of a frame one by one instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -159,6 +160,10 @@ def main():
         for name in ("vertices", "so3", "scale", "appearance"):
             st_k.grads[name] = fp_k.grads[name]
         slots.append(dict(step=st_k, fp=fp_k, stream=torch.cuda.Stream(device=dev)))
+
+    if args.seg_shift:
+        for sl in slots:
+            sl["step"].state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
 
     def run_step(i):
         bt = batches[i % len(batches)]

@@ -236,3 +236,28 @@ def test_body_frame_large_configs(subdiv, img):
         err = np.abs(got - ref)
         assert np.quantile(err, 0.999) <= 2e-4 * scale, (name, np.quantile(err, 0.999), scale)
         assert np.median(err) <= 1e-6 * scale, (name, np.median(err), scale)
+
+
+@pytest.mark.parametrize("shift", [7, 8])
+def test_segment_size_option_matches_oracle(shift):
+    """GOM_OPT_SEG_SHIFT: 128-entry (single frame) and 256-entry (batched launch) segments on a single frame."""
+    from gpu_util import hip_forward
+    from gomavatar_amd import _lib, rasterizer as R
+    cam, means, cov6, colors, op = small_scene(seed=41, P=5000, H=64, W=64, spread=0.15, scale=0.03, opacity=(0.2, 0.9))
+    cam["bg"] = np.array([0.3, 0.1, 0.6, 0.2], np.float32)
+    st = R.RasterState()
+    st.set_option(_lib.OPT_SEG_SHIFT, shift)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, state=st, requires_grad=True)
+    f = orast.forward(cam, means, cov6, colors, op)
+    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 700          # several segments per tile
+    assert_image_parity(out.detach().cpu().numpy(), f["color"])
+    rng = np.random.default_rng(2)
+    wimg = rng.normal(size=(4, 64, 64)).astype(np.float32)
+    (out * torch.from_numpy(wimg).cuda()).sum().backward()
+    g = orast.backward(orast.forward(cam, means, cov6, colors, op, dtype=np.float64), wimg.astype(np.float64))
+    for name, got, ref in (("means3D", t[0].grad, g["dL_dmeans3D"]), ("cov6", t[1].grad, g["dL_dcov6"]), ("colors", t[2].grad, g["dL_dcolors"]),
+                           ("opacity", t[3].grad, g["dL_dopacity"])):
+        got = got.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref)
+        assert np.quantile(err, 0.999) <= 2e-4 * scale and np.median(err) <= 1e-6 * scale, (name, np.quantile(err, 0.999), scale)
