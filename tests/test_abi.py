@@ -64,3 +64,27 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle/" not in txt.replace("under oracle/", "") or f in ("_lib.py",), f
+
+
+def test_header_is_plain_c_and_links(tmp_path, lib_path):
+    """include/gom_hip.h must be consumable by a C compiler (no C++ / torch types at the boundary) and the library must link
+    into a plain C program -- what a cgo / JNI / ctypes-free host would do."""
+    import subprocess
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include "gom_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  GomCamera cam; GomFrame fr; (void)cam; (void)fr;\n'
+                   '  printf("%d %d\\n", gom_abi_version(), (int)sizeof(GomCamera));\n'
+                   '  /* NULL state: every entry point must fail with an error code, not crash */\n'
+                   '  return gom_raster_forward(0, &cam, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0) != 0 && gom_last_error()[0] ? 0 : 1;\n'
+                   '}\n')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(lib_path)
+    exe = tmp_path / "use_abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{inc}", str(src), "-o", str(exe), f"-L{libdir}", "-lgom_hip",
+                        f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    ver, size = run.stdout.split()
+    assert int(ver) >= 2 and int(size) == 160
