@@ -72,17 +72,22 @@ class RenderStep:
             "appearance": torch.empty((3, F), **f32)}
         self.cam = None
         self._frame = None
+        self._cams_copied = None
 
     # -- inputs ---------------------------------------------------------------
     def set_cameras(self, Ks, Es, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
         """One (K, E) per frame of the batch -> device camera array (async copy on the current stream)."""
         assert len(Ks) == self.B and len(Es) == self.B
+        if self._cams_copied is not None:
+            self._cams_copied.synchronize()   # the previous async copy still reads the pinned staging buffer
         for b in range(self.B):
             cam = self._make_camera(Ks[b], Es[b], bg4)
             self._cams_host[b] = torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8)
             if b == 0:
                 self.cam = cam
         self.cams_dev.copy_(self._cams_host, non_blocking=True)
+        self._cams_copied = torch.cuda.Event()
+        self._cams_copied.record()
 
     def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
         """K (3,3), E (4,4) host arrays/tensors -> rasterizer camera, as
