@@ -353,7 +353,7 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
     hipStream_t st = (hipStream_t)stream;
     // 16 pixel rows per workgroup when that still leaves >= 2 workgroups per CU
     const long blocks16 = (long)((W + kTileW - 1) / kTileW) * ((H + 15) / 16) * (Cout / kBN) * B * splits;
-    const int TH = (blocks16 >= 512 && H >= 16) ? 16 : 8;
+    const int TH = (blocks16 >= 256 && H >= 16) ? 16 : 8;
     const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + TH - 1) / TH), Cout / kBN, B * splits);
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
