@@ -29,6 +29,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (needed by RCCL across processes)
+
 import numpy as np
 import torch
 
