@@ -261,3 +261,28 @@ def test_segment_size_option_matches_oracle(shift):
         scale = np.abs(ref).max()
         err = np.abs(got - ref)
         assert np.quantile(err, 0.999) <= 2e-4 * scale and np.median(err) <= 1e-6 * scale, (name, np.quantile(err, 0.999), scale)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_shapes_scales_and_depths(seed):
+    """Random image sizes (not multiples of the tile), Gaussian counts, footprints from sub-pixel to a quarter of the image,
+    points close to / behind the 0.2 near cut and far off screen: bit-exact binning + image parity + backward sanity."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(17, 120)), int(rng.integers(17, 120))
+    P = int(rng.integers(1, 3000))
+    C = int(rng.choice([3, 4]))
+    cam, means, cov6, colors, op = small_scene(seed=2000 + seed, P=P, H=H, W=W, C=C, opacity=(0.05, 1.0), spread=float(rng.uniform(0.2, 1.5)),
+                                               scale=float(10 ** rng.uniform(-3, -0.7)), z=float(rng.uniform(0.5, 4.0)))
+    cam["bg"] = rng.uniform(0, 1, 4).astype(np.float32)
+    img, f, e = _compare_forward(cam, means, cov6, colors, op)
+    from gpu_util import hip_forward
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True)
+    wimg = rng.normal(size=(C, H, W)).astype(np.float32)
+    (out * torch.from_numpy(wimg).cuda()).sum().backward()
+    g = orast.backward(orast.forward(cam, means, cov6, colors, op, dtype=np.float64), wimg.astype(np.float64))
+    for name, got, ref in (("means3D", t[0].grad, g["dL_dmeans3D"]), ("cov6", t[1].grad, g["dL_dcov6"]), ("colors", t[2].grad, g["dL_dcolors"])):
+        got = got.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), name
+        scale = max(np.abs(ref).max(), 1e-30)
+        err = np.abs(got - ref)
+        assert np.quantile(err, 0.995) <= 1e-3 * scale, (name, np.quantile(err, 0.995), scale)
