@@ -191,6 +191,22 @@ def main():
         val, res = ref(in0, in1, retPerLayer=True)
     np.savez_compressed(os.path.join(OUT, "lpips_vgg.npz"), in0=in0.numpy(), in1=in1.numpy(), trunk_seed=np.int64(0),
                         val=val.numpy(), **{f"res{k}": res[k].numpy() for k in range(5)})
+    # ---------------- shadow MLP + colour consistency (pure torch modules of the reference) ----------------
+    from models.modules.shadow_module import ShadowModule as RefShadow  # noqa: E402
+    from utils.network_util import mesh_color_consistency as ref_cc  # noqa: E402
+    torch.manual_seed(3)
+    scfg = types.SimpleNamespace(condition_code_size=162, mlp_width=128, mlp_depth=3, skips=[4], multires=6, i_embed=0)
+    rs = RefShadow(scfg)
+    with torch.no_grad():
+        rs.block_mlps[-1].weight.normal_(0, 0.3)
+    gs = torch.Generator().manual_seed(4)
+    nrm = torch.randn(1, 50, 3, generator=gs)
+    with torch.no_grad():
+        sh_out = rs(nrm)
+    col = torch.rand(40, 3, generator=gs)
+    conn = torch.randint(0, 40, (60, 2), generator=gs)
+    np.savez_compressed(os.path.join(OUT, "shadow_color.npz"), normals=nrm.numpy(), shadow=sh_out.numpy(), colors=col.numpy(), pairs=conn.numpy(),
+                        color_consistency=ref_cc(col, conn).numpy(), **{"w_" + k: v.numpy() for k, v in rs.state_dict().items()})
     print("goldens written to", OUT, sorted(os.listdir(OUT)))
 
 

@@ -59,3 +59,19 @@ def test_dataset_directory_round_trip(tmp_path):
     # Rh / Th are folded into the extrinsics (camera_util.py:111-131)
     E2, g = formats.apply_global_tfm_to_camera(np.eye(4), np.array([0.0, 0.3, 0.0]), np.array([0.1, 0.0, 0.0]))
     np.testing.assert_allclose(E2 @ g, np.eye(4), atol=1e-12)
+
+
+def test_shadow_module_and_color_consistency_match_reference_goldens(golden_dir):
+    """ShadowModule (positional encoding order, layer layout, state-dict names) and the colour-consistency formula against
+    outputs of the reference's own classes (scripts/make_goldens.py)."""
+    from gomavatar_amd.model import ShadowModule
+    from gomavatar_amd import train_util as tu
+    g = np.load(os.path.join(golden_dir, "shadow_color.npz"))
+    m = ShadowModule(multires=6, mlp_width=128, mlp_depth=3, skips=(4,))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")}
+    m.load_state_dict(sd)                                   # same key names as the reference module
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["normals"]))
+    np.testing.assert_allclose(out.numpy(), g["shadow"], rtol=1e-5, atol=1e-6)
+    cc = tu.mesh_color_consistency(torch.from_numpy(g["colors"]), torch.from_numpy(g["pairs"]))
+    np.testing.assert_allclose(float(cc), float(g["color_consistency"]), rtol=1e-6)
