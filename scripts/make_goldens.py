@@ -207,6 +207,14 @@ def main():
     conn = torch.randint(0, 40, (60, 2), generator=gs)
     np.savez_compressed(os.path.join(OUT, "shadow_color.npz"), normals=nrm.numpy(), shadow=sh_out.numpy(), colors=col.numpy(), pairs=conn.numpy(),
                         color_consistency=ref_cc(col, conn).numpy(), **{"w_" + k: v.numpy() for k, v in rs.state_dict().items()})
+    # ---------------- ndc_T_world (utils/pc_util.py:30-46): square and both non-square cases ----------------
+    from utils import pc_util as ref_pc  # noqa: E402
+    gn = torch.Generator().manual_seed(6)
+    pts = torch.randn(1, 3, 40, generator=gn) * 0.5 + torch.tensor([0.0, 1.2, 0.0]).view(1, 3, 1)
+    nd = {"pts": pts.numpy(), "K": Ks, "E": Es}
+    for (h, w) in ((512, 512), (384, 512), (512, 384)):
+        nd[f"ndc_{h}x{w}"] = ref_pc.ndc_T_world(pts, torch.from_numpy(Ks)[None], torch.from_numpy(Es)[None], h, w).numpy()
+    np.savez_compressed(os.path.join(OUT, "ndc_T_world.npz"), **nd)
     print("goldens written to", OUT, sorted(os.listdir(OUT)))
 
 

@@ -75,3 +75,13 @@ def test_shadow_module_and_color_consistency_match_reference_goldens(golden_dir)
     np.testing.assert_allclose(out.numpy(), g["shadow"], rtol=1e-5, atol=1e-6)
     cc = tu.mesh_color_consistency(torch.from_numpy(g["colors"]), torch.from_numpy(g["pairs"]))
     np.testing.assert_allclose(float(cc), float(g["color_consistency"]), rtol=1e-6)
+
+
+def test_ndc_T_world_matches_reference_golden(golden_dir):
+    from gomavatar_amd.mesh_renderer import ndc_T_world
+    from oracle import mesh as om
+    g = np.load(os.path.join(golden_dir, "ndc_T_world.npz"))
+    pts, K, E = torch.from_numpy(g["pts"]), torch.from_numpy(g["K"])[None], torch.from_numpy(g["E"])[None]
+    for (h, w) in ((512, 512), (384, 512), (512, 384)):
+        np.testing.assert_allclose(ndc_T_world(pts, K, E, h, w).numpy(), g[f"ndc_{h}x{w}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(om.ndc_T_world(pts, K, E, h, w).numpy(), g[f"ndc_{h}x{w}"], rtol=1e-6, atol=1e-6)
