@@ -99,6 +99,33 @@ __device__ __forceinline__ void wave_sum_lane63_n(float (&v)[NV]) {
 #undef GOM_DPP_STEP
 }
 
+// Transposed variant for 10 values: v_permlane32_swap / v_permlane16_swap exchange halves (rows) of two registers, so
+// one swap + one add folds a level of the tree for TWO values and halves the number of live registers
+// (10 -> 5 -> 3); only the four in-row steps remain as DPP adds on 3 registers.  34 wave instructions instead of
+// 60 (scripts/ubench: ~130 issue cycles instead of ~265).  Totals land in lane 15 of each 16-lane row:
+//   s0: rows 0..3 = values 0, 2, 1, 3     s1: rows 0..3 = values 4, 6, 5, 7     s2: row 1 = value 8, row 3 = value 9
+// (layout checked on the hardware by scripts/ubench/permlane_probe.hip).
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void wave_sum10_rows(const float (&w)[10], float &s0, float &s1, float &s2) {
+    const float p0 = swap_add32(w[0], w[1]), p1 = swap_add32(w[2], w[3]), p2 = swap_add32(w[4], w[5]), p3 = swap_add32(w[6], w[7]);
+    s2 = swap_add32(w[8], w[9]);
+    s0 = swap_add16(p0, p1);
+    s1 = swap_add16(p2, p3);
+#define GOM_ROW_STEP(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL "\n v_add_f32_dpp %1, %1, %1 " CTRL "\n v_add_f32_dpp %2, %2, %2 " CTRL "\n"
+    asm volatile("s_nop 1\n" GOM_ROW_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") GOM_ROW_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 GOM_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") GOM_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 "s_nop 1\n v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                 : "+v"(s0), "+v"(s1), "+v"(s2));
+#undef GOM_ROW_STEP
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -778,6 +805,7 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 quadrants of one (segment, sub-range)
     const int pxi = q * 64 + lane;
+    const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);  // which value the row's total of s0 / s1 is: rows 0..3 -> 0, 2, 1, 3
     const size_t HW = (size_t)H * W;
     for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
         const uint32_t seg = task >> 2;
@@ -911,13 +939,17 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
                     v[C + 3] = Q * dx * dx;
                     v[C + 4] = Q * dx * dy;
                     v[C + 5] = Q * dy * dy;
-                    wave_sum_lane63_n<NV>(v);
-                    if (lane == 63) {
+                    float w10[10], r0, r1, r2;  // record layout: colour gradients in 0..3 (3 stays 0 for C = 3), geometry in 4..9
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
+                    wave_sum10_rows(w10, r0, r1, r2);
+                    if ((lane & 15) == 15) {  // lane 15 of every row holds totals (see wave_sum10_rows)
                         float *dst = &s_acc[q][kk[u]][0];
-#pragma unroll
-                        for (int ch = 0; ch < C; ch++) dst[ch] = v[ch];
-#pragma unroll
-                        for (int qq = 0; qq < 6; qq++) dst[4 + qq] = v[C + qq];
+                        dst[row_slot] = r0;
+                        dst[4 + row_slot] = r1;
+                        if (lane & 16) dst[8 + (lane >> 5)] = r2;
                     }
                 }
             }
