@@ -36,7 +36,8 @@ extern "C" GomState *gom_state_create(void) {
         return nullptr;
     }
     if (hipMalloc((void **)&s->status, sizeof(GomDevStatus)) != hipSuccess ||
-        hipMemset(s->status, 0, sizeof(GomDevStatus)) != hipSuccess) {
+        hipMemset(s->status, 0, sizeof(GomDevStatus)) != hipSuccess ||
+        hipMalloc((void **)&s->task_ctr, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess || hipMemset(s->task_ctr, 0, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess) {
         gom_set_error("hipMalloc(status) failed");
         delete s;
         return nullptr;
@@ -48,7 +49,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,
-                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->batch_grads, s->mesh_face};
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)

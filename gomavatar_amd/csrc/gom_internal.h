@@ -19,6 +19,8 @@
 #define GOM_SEG_GRID 1024           // workgroups launched for the segment kernels (grid-stride over segments)
 #endif
 
+#define GOM_TASK_CTR_WORDS (3 * (32 * 8 + 32))   // three sharded task queues (raster_render.hip: TaskQueue)
+
 struct GomDevStatus {
     uint32_t num_pairs;
     uint32_t overflow;
@@ -97,6 +99,7 @@ struct GomState {
     uint32_t *n_contrib = nullptr;
     float *scratch_img = nullptr;     // [4][capPix] image sink when the backward has to re-create its checkpoints
     GomDevStatus *status = nullptr;
+    uint32_t *task_ctr = nullptr;     // heads of the task queues of k_seg_T / k_seg_fwd / k_seg_bwd
     // optional per-kernel HIP-event timing (GOM_OPT_PROFILE); events bracket each launch on the caller's stream
     bool profile = false;
     hipEvent_t ev[2 * GOM_NUM_KERNELS] = {};

@@ -44,6 +44,35 @@
 // loop is branch-free and keeps its state in VGPRs (float masks) so that the
 // serial T chain never round-trips through SALU/VCC logic.
 #include "gom_internal.h"
+#include <cstdlib>
+
+#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py ... -DGOM_PHASE_PROF): cycles per phase of k_seg_bwd
+__device__ unsigned long long g_phase[16];
+__device__ unsigned long long g_wg_busy[GOM_SEG_GRID * 4];
+extern "C" int gom_debug_phase_counters(unsigned long long *out, unsigned long long *wg, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
+    if (wg) (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_wg_busy), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
+    if (reset) {
+        static unsigned long long z[GOM_SEG_GRID * 4];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(unsigned long long) * 16);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_busy), z, sizeof(z));
+    }
+    return 0;
+}
+__device__ unsigned long long g_wg_t0[GOM_SEG_GRID * 4], g_wg_t1[GOM_SEG_GRID * 4];
+extern "C" int gom_debug_wg_timeline(unsigned long long *t0, unsigned long long *t1) {
+    (void)hipMemcpyFromSymbol(t0, HIP_SYMBOL(g_wg_t0), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
+    (void)hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_wg_t1), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
+    return 0;
+}
+#endif
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
+#define PH_T() __builtin_readcyclecounter()
+#define PH_ADD(i, v) do { ph_acc[i] += (unsigned long long)(v); } while (0)
+#else
+#define PH_T() 0ull
+#define PH_ADD(i, v) do { } while (0)
+#endif
 
 namespace {
 
@@ -467,6 +496,66 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
     if (C == 4) v[C - 1] = o.w;
 }
 
+
+// Dynamic distribution of the (segment, piece) tasks of the segment kernels.  A static grid-stride assignment left a
+// third of the chip idle behind the last workgroups to start (timeline: scripts/phase_prof.py); instead exactly as
+// many workgroups as the chip holds are launched and each draws tasks from a queue until they run out, so all of
+// them finish within one task of each other.
+//   * One device-scope counter saturates at ~88 dequeues/us (MI355X_MICROARCH.md "dequeue"): the queue is sharded 8
+//     ways (one head per XCD, 128 bytes apart).  Shard x owns the segments with seg % 8 == x; a workgroup starts on
+//     shard blockIdx % 8 (the XCD it normally runs on, so a segment's four pieces share an L2) and moves on to the
+//     next shard when its own is empty -- placement is only an affinity, any workgroup may take any task.
+//   * The first task of every workgroup is implied by its index (no atomic); head values count from there.
+//   * request() is issued AFTER the task's own loads (returns are in order: a load behind the atomic would wait for
+//     it), publish() hands the result to the other waves through LDS before the task's last __syncthreads() --
+//     every path through a task must call both and then pass a barrier.
+//   * The last workgroup to leave zeroes the heads for the next launch (graph replays included).
+// ctr layout: head of shard x at ctr[32 * x], workgroups that have left at ctr[32 * 8].
+#define GOM_TQ_SHARDS 8
+#define GOM_TQ_WORDS (32 * GOM_TQ_SHARDS + 32)
+struct TaskQueue {
+    uint32_t *ctr;
+    uint32_t nsegs, per_shard_wgs, shard, tried, pend, it;
+    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? 4u * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
+    __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const { return (((j >> 2) * GOM_TQ_SHARDS + x) << 2) | (j & 3u); }
+    // thread 0 only: local index j on the current shard -> task, moving to the next shards while the current one is empty
+    __device__ __forceinline__ uint32_t resolve(uint32_t j) {
+        while (j >= shard_tasks(shard)) {
+            if (++tried >= GOM_TQ_SHARDS) return 0xffffffffu;
+            shard = (shard + 1) % GOM_TQ_SHARDS;
+            j = per_shard_wgs + atomicAdd(ctr + 32 * shard, 1u);
+        }
+        return task_of(shard, j);
+    }
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task) {
+        ctr = c; nsegs = n_segs; it = 0; tried = 0; pend = 0;
+        if (!ctr) return;  // static mode: plain grid-stride (single-frame launches, see the launchers)
+        per_shard_wgs = gridDim.x / GOM_TQ_SHARDS;  // the launchers round the grid to a multiple of the shard count
+        shard = blockIdx.x % GOM_TQ_SHARDS;
+        if (threadIdx.x == 0) s_task[0] = resolve(blockIdx.x / GOM_TQ_SHARDS);
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
+        if (!ctr) {
+            const uint32_t t = blockIdx.x + it * gridDim.x;
+            return t < nsegs * 4u ? t : 0xffffffffu;
+        }
+        return s_task[it & 1];
+    }
+    __device__ __forceinline__ void request() {
+        if (ctr && threadIdx.x == 0) pend = atomicAdd(ctr + 32 * shard, 1u);
+    }
+    __device__ __forceinline__ void publish(uint32_t *s_task) {
+        if (ctr && threadIdx.x == 0) s_task[(it + 1) & 1] = resolve(per_shard_wgs + pend);
+    }
+    __device__ __forceinline__ void advance() { it++; }
+    __device__ __forceinline__ void finish() {
+        if (ctr && threadIdx.x == 0 && atomicAdd(ctr + 32 * GOM_TQ_SHARDS, 1u) == gridDim.x - 1) {
+            for (int x = 0; x <= GOM_TQ_SHARDS; x++) ctr[32 * x] = 0;
+        }
+    }
+};
+
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
@@ -475,13 +564,17 @@ template <int C>
 __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                 const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
                                                 float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
-                                                const GomDevStatus *__restrict__ status) {
-    __shared__ float s_P[GOM_NSUB][64];
+                                                const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr) {
+    __shared__ float s_P[2][GOM_NSUB][64];
+    __shared__ uint32_t s_task[2];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
-    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+    TaskQueue tq;
+    for (tq.init(task_ctr, nsegs, s_task);; tq.advance()) {
+        const uint32_t task = tq.current(s_task);
+        if (task == 0xffffffffu) break;
         const uint32_t seg = task >> 2;
         const int q = (int)(task & 3);
         const int pxi = q * 64 + lane;
@@ -502,6 +595,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         float T = 1.f;
         {
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
+            tq.request();
             unsigned long long mask = __ballot(r.keep);
             while (mask) {
                 float al[4];
@@ -517,11 +611,13 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             }
         }
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
-        __syncthreads();  // previous iteration's readers of s_P are done
-        s_P[sub][lane] = T;
+        float(*sp)[64] = s_P[tq.it & 1];  // double-buffered: the readers of the previous task use the other half
+        sp[sub][lane] = T;
+        tq.publish(s_task);
         __syncthreads();
-        if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((s_P[0][lane] * s_P[1][lane]) * s_P[2][lane]) * s_P[3][lane];
+        if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
     }
+    tq.finish();
 }
 
 // ---------------------------------------- forward, pass B (exact, per segment)
@@ -535,15 +631,19 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
-                                                  const GomDevStatus *__restrict__ status) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr) {
     __shared__ float s_c[GOM_NSUB][C][64];
     __shared__ float s_t[GOM_NSUB][64];
     __shared__ uint32_t s_l[GOM_NSUB][64];
+    __shared__ uint32_t s_task[2];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
-    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+    TaskQueue tq;
+    for (tq.init(task_ctr ? task_ctr + GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
+        const uint32_t task = tq.current(s_task);
+        if (task == 0xffffffffu) break;
         const uint32_t seg = task >> 2;
         const int q = (int)(task & 3);
         const int pxi = q * 64 + lane;
@@ -585,6 +685,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
             }
         }
         float wl = T > 0.f ? 1.f : 0.f;  // lane still compositing (float mask: no SALU in the chain)
+        tq.request();  // (behind every load of this task)
         const bool any_alive = __syncthreads_or(wl != 0.f ? 1 : 0) != 0;  // also fences the LDS of the previous segment
         if (!any_alive) {  // every pixel of the quadrant stopped before this segment
             if (sub == 0) {
@@ -594,6 +695,8 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
                 const float zero[C] = {};
                 st4<C>(seg_C, seg, pxi, zero);
             }
+            tq.publish(s_task);
+            __syncthreads();
             continue;
         }
         float acc[C];
@@ -636,6 +739,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
         s_l[sub][lane] = last;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) s_c[sub][ch][lane] = acc[ch];
+        tq.publish(s_task);
         __syncthreads();
         if (sub == 0) {  // fold the four pieces of this segment for pixel pxi
             float Tc = 0.f, tot[C];
@@ -669,6 +773,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
             st4<C>(seg_C, seg, pxi, tot);
         }
     }
+    tq.finish();
 }
 
 // ----------------------------------------------- forward, pass C (assembly) -
@@ -797,9 +902,11 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
-                                                  float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
+                                                  float *__restrict__ partial, const GomDevStatus *__restrict__ status,
+                                                  uint32_t *__restrict__ task_ctr) {
     constexpr int NV = 6 + C;  // values reduced per entry
     __shared__ float s_acc[4][GOM_SUB_MAX][10];  // [quadrant][entry of the sub-range][value]
+    __shared__ uint32_t s_task[2];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
@@ -807,13 +914,28 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
     const int pxi = q * 64 + lane;
     const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);  // which value the row's total of s0 / s1 is: rows 0..3 -> 0, 2, 1, 3
     const size_t HW = (size_t)H * W;
-    for (uint32_t task = blockIdx.x; task < nsegs * 4; task += gridDim.x) {
+#ifdef GOM_PHASE_PROF
+    const unsigned long long ph_k0 = __builtin_readcyclecounter(), ph_w0 = wall_clock64();
+#if GOM_PHASE_PROF >= 2
+    unsigned long long ph_acc[16] = {};
+#endif
+#endif
+    TaskQueue tq;
+    for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
+        const uint32_t task = tq.current(s_task);
+        if (task == 0xffffffffu) break;
+        [[maybe_unused]] const unsigned long long ph_t0 = PH_T();
         const uint32_t seg = task >> 2;
         const int sub = (int)(task & 3);
         const uint4 d = seg_desc[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
         const uint32_t e0 = d.w << seg_shift;
-        if ((uint32_t)sub * sub_sz >= cnt) continue;  // no entries in this sub-range
+        if ((uint32_t)sub * sub_sz >= cnt) {  // no entries in this sub-range
+            tq.request();
+            tq.publish(s_task);
+            __syncthreads();
+            continue;
+        }
         const uint32_t scnt = min(sub_sz, cnt - (uint32_t)sub * sub_sz);
         float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * sub_sz + threadIdx.x) * GOM_PARTIAL_STRIDE);
         if (e0 + (uint32_t)sub * sub_sz >= tile_nmax[tile]) {  // every pixel of the tile stopped before this sub-range: all-zero records
@@ -821,6 +943,10 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 rec[0] = z; rec[1] = z; rec[2] = z;
             }
+            PH_ADD(0, PH_T() - ph_t0); PH_ADD(8, 1);
+            tq.request();
+            tq.publish(s_task);
+            __syncthreads();
             continue;
         }
         __syncthreads();  // the previous segment's flush is done
@@ -842,6 +968,9 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
         const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
         const uint32_t wmax = wave_max_u32(my_last);
         const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;  // list index of this wave's first entry
+        [[maybe_unused]] const unsigned long long ph_t1 = PH_T();
+        PH_ADD(1, ph_t1 - ph_t0); PH_ADD(9, 1);
+        bool requested = false;
         if (wmax > s0) {
             const float T_final = final_T[inside ? fpix : 0];
             float dpix[C], bg_dot = 0.f;
@@ -883,6 +1012,15 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
             const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             unsigned long long mask = __ballot(r.keep);
+            tq.request();  // (behind every load of this task)
+            requested = true;
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
+            {   // wait for everything loaded so far, so that the loop phase is the loop alone
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                PH_ADD(2, PH_T() - ph_t1); PH_ADD(10, 1); PH_ADD(11, __builtin_popcountll(mask));
+            }
+            [[maybe_unused]] const unsigned long long ph_t2 = PH_T();
+#endif
             // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
             // T / accum_rec recurrences, then interleaved DPP reductions.
             while (mask) {
@@ -914,6 +1052,7 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;  // wave-uniform
+                    PH_ADD(12, 1); PH_ADD(13, __builtin_popcountll(__ballot(al[u] > 0.f)));
                     // An entry with a == 0 is replayed as a zero-alpha layer: the recurrences below then
                     // leave T / accum_rec exactly as skipping would (App. A.4), without divergent branches.
                     const float a = al[u];
@@ -953,8 +1092,16 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
                     }
                 }
             }
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
+            PH_ADD(3, PH_T() - ph_t2);
+#endif
         }
+        [[maybe_unused]] const unsigned long long ph_t3 = PH_T();
+        if (!requested) tq.request();
+        tq.publish(s_task);
         __syncthreads();
+        PH_ADD(4, PH_T() - ph_t3);
+        [[maybe_unused]] const unsigned long long ph_t4 = PH_T();
         if (threadIdx.x < scnt) {  // one 48-byte record per entry, quadrants summed in a fixed order
             float rr[10];
 #pragma unroll
@@ -964,7 +1111,22 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
             rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
             rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
         }
+        PH_ADD(5, PH_T() - ph_t4);
     }
+    tq.finish();
+#ifdef GOM_PHASE_PROF
+    if (threadIdx.x == 0) {
+        const unsigned long long ph_k1 = __builtin_readcyclecounter();
+        g_wg_busy[blockIdx.x] += ph_k1 - ph_k0;
+        g_wg_t0[blockIdx.x] = ph_w0;   // timeline of the last launch (100 MHz wall clock, common to all XCDs)
+        g_wg_t1[blockIdx.x] = wall_clock64();
+    }
+#if GOM_PHASE_PROF >= 2
+    PH_ADD(6, PH_T() - ph_k0);
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_phase[i], ph_acc[i]);
+#endif
+#endif
 }
 
 }  // namespace
@@ -990,6 +1152,21 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     return 0;
 }
 
+// Workgroups the chip holds at once for a segment kernel (the task queue needs no more than that).
+template <typename K>
+static int resident_grid(K kernel, int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    int g = per_cu * cus;
+    if (const char *e = getenv("GOM_TQ_GRID_PCT")) g = (int)((long long)g * atoi(e) / 100);  // development knob
+    return g < GOM_TQ_SHARDS ? GOM_TQ_SHARDS : g / GOM_TQ_SHARDS * GOM_TQ_SHARDS;
+}
+// A batched launch (tens of thousands of tasks) uses the task queue on a grid that just fills the chip; a single frame
+// has fewer tasks than two rounds of that grid, where one task per workgroup and no queue is the shorter path.
+#define GOM_RESIDENT(KERNEL) (s->B > 1 ? ([&]() { static const int g = resident_grid(KERNEL, s->device); return g; }()) : GOM_SEG_GRID * 4)
+#define GOM_TASK_CTR (s->B > 1 ? s->task_ctr : nullptr)
+
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st) {
     const int n_tiles = s->gx * s->gy * s->B;
@@ -998,11 +1175,11 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         GomKernelTimer timer(s, GOM_K_SEG_T, st);
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
             if (C == 3)
-                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status);
+                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_RESIDENT(k_seg_T<3>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR);
             else
-                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status);
+                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_RESIDENT(k_seg_T<4>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR);
         } else {  // only the colours changed: bring them into list order
             if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
             else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
@@ -1012,8 +1189,8 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     {
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
-                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status)
+    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_RESIDENT(k_seg_fwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
     }
@@ -1038,9 +1215,9 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #define GOM_SB(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_SEG_GRID * 4), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_RESIDENT(k_seg_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status)
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status, GOM_TASK_CTR)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB
     GOM_LAUNCH_CHECK();
