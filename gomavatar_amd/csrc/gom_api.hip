@@ -48,7 +48,7 @@ extern "C" GomState *gom_state_create(void) {
 extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
-                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,
+                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -138,7 +138,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow(&s->seg_desc, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
+        if (grow(&s->seg_desc, n) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
             grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX) || grow(&s->sub_T, n * 4 * GOM_TPX) ||
             grow(&s->sub_C, n * 16 * GOM_TPX) || grow(&s->sub_Tend, n * 4 * GOM_TPX))
             return -2;

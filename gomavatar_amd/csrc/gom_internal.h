@@ -82,6 +82,7 @@ struct GomState {
     float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE]
     // per segment (x 256 pixels of the tile, quadrant-major)
     int64_t capSegs = 0;
+    uint4 *seg_qmax = nullptr;        // [capSegs] max n_contrib over each 8x8 quadrant of the segment's tile (combine pass, for the backward)
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
     float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
     float *ent_col = nullptr;         // [capPairs][4] list-ordered colours

@@ -66,14 +66,6 @@ extern "C" int gom_debug_wg_timeline(unsigned long long *t0, unsigned long long 
     return 0;
 }
 #endif
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
-#define PH_T() __builtin_readcyclecounter()
-#define PH_ADD(i, v) do { ph_acc[i] += (unsigned long long)(v); } while (0)
-#else
-#define PH_T() 0ull
-#define PH_ADD(i, v) do { } while (0)
-#endif
-
 namespace {
 
 constexpr float kStopT = 0.0001f;          // App. A.3: stop when T(1-alpha) < 1e-4
@@ -784,7 +776,8 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      const uint32_t *__restrict__ seg_last, float *__restrict__ seg_Tend,
                                                      float *__restrict__ seg_Sbehind, float *__restrict__ out_color,
                                                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                     uint32_t *__restrict__ tile_nmax, const GomDevStatus *__restrict__ status) {
+                                                     uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
+                                                     const GomDevStatus *__restrict__ status) {
     __shared__ uint32_t s_nmax[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
@@ -891,13 +884,15 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
     if (lane == 0) s_nmax[wave] = wmax;
     __syncthreads();
     if (threadIdx.x == 0) tile_nmax[tile] = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
+    // the four quadrant maxima once per SEGMENT of the tile: the backward finds them with the segment index alone
+    for (uint32_t i = threadIdx.x; i < nseg; i += 256) seg_qmax[sb + i] = make_uint4(s_nmax[0], s_nmax[1], s_nmax[2], s_nmax[3]);
 }
 
 // ---------------------------------------------------------------- backward -
 template <int C>
 __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
-                                                  const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ tile_nmax,
+                                                  const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
@@ -905,7 +900,11 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
                                                   float *__restrict__ partial, const GomDevStatus *__restrict__ status,
                                                   uint32_t *__restrict__ task_ctr) {
     constexpr int NV = 6 + C;  // values reduced per entry
-    __shared__ float s_acc[4][GOM_SUB_MAX][10];  // [quadrant][entry of the sub-range][value]
+    // [task parity][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote.
+    // Double-buffered by task parity and never cleared: the flush reads only the rows s_done names, and the next task
+    // writes the other half, so one barrier per task (before the flush) is all the synchronisation there is.
+    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
+    __shared__ unsigned long long s_done[2][4];
     __shared__ uint32_t s_task[2];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
@@ -916,62 +915,50 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
     const size_t HW = (size_t)H * W;
 #ifdef GOM_PHASE_PROF
     const unsigned long long ph_k0 = __builtin_readcyclecounter(), ph_w0 = wall_clock64();
-#if GOM_PHASE_PROF >= 2
-    unsigned long long ph_acc[16] = {};
-#endif
 #endif
     TaskQueue tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
         if (task == 0xffffffffu) break;
-        [[maybe_unused]] const unsigned long long ph_t0 = PH_T();
         const uint32_t seg = task >> 2;
         const int sub = (int)(task & 3);
+        const int buf = (int)(tq.it & 1u);
+        // Both per-segment records are indexed by the segment alone: one memory round trip tells the workgroup whether
+        // the sub-range is dead (every pixel of the tile finished before it) and each wave whether its quadrant is.
         const uint4 d = seg_desc[seg];
+        const uint4 qm4 = seg_qmax[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
         const uint32_t e0 = d.w << seg_shift;
-        if ((uint32_t)sub * sub_sz >= cnt) {  // no entries in this sub-range
-            tq.request();
-            tq.publish(s_task);
-            __syncthreads();
-            continue;
-        }
-        const uint32_t scnt = min(sub_sz, cnt - (uint32_t)sub * sub_sz);
+        const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;  // list index of the first entry of the sub-range
+        const bool empty = (uint32_t)sub * sub_sz >= cnt;
+        const uint32_t scnt = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
         float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * sub_sz + threadIdx.x) * GOM_PARTIAL_STRIDE);
-        if (e0 + (uint32_t)sub * sub_sz >= tile_nmax[tile]) {  // every pixel of the tile stopped before this sub-range: all-zero records
+        const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
+        if (empty || s0 >= tmax) {  // no entries, or every pixel of the tile stopped before this sub-range: all-zero records
             if (threadIdx.x < scnt) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 rec[0] = z; rec[1] = z; rec[2] = z;
             }
-            PH_ADD(0, PH_T() - ph_t0); PH_ADD(8, 1);
             tq.request();
             tq.publish(s_task);
             __syncthreads();
             continue;
         }
-        __syncthreads();  // the previous segment's flush is done
-        for (int i = threadIdx.x; i < 4 * (int)sub_sz * 10; i += 256) {
-            const int qq = i / ((int)sub_sz * 10);
-            (&s_acc[qq][0][0])[i - qq * (int)sub_sz * 10] = 0.f;
-        }
-        __syncthreads();
-
-        const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
-        const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
-        const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
-        const bool inside = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        const size_t fpix = (size_t)fr * HW + pix;  // per-pixel state of the stacked frames
-        const float pfx = (float)px, pfy = (float)py;
-        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
-        const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
-        const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
-        const uint32_t wmax = wave_max_u32(my_last);
-        const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;  // list index of this wave's first entry
-        [[maybe_unused]] const unsigned long long ph_t1 = PH_T();
-        PH_ADD(1, ph_t1 - ph_t0); PH_ADD(9, 1);
+        const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));  // max n_contrib over this wave's 8x8 pixels
+        unsigned long long done = 0ull;
         bool requested = false;
         if (wmax > s0) {
+            const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
+            const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
+            const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
+            const bool inside = px < W && py < H;
+            const size_t pix = (size_t)py * W + px;
+            const size_t fpix = (size_t)fr * HW + pix;  // per-pixel state of the stacked frames
+            const float pfx = (float)px, pfy = (float)py;
+            const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+            const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
+            // every load of the task is issued here, back to back
+            const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
             const float T_final = final_T[inside ? fpix : 0];
             float dpix[C], bg_dot = 0.f;
             {
@@ -990,39 +977,30 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
             // + the later pieces of this segment, smallest terms first)
             float T = sub_Tend[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi];
             float accum_rec[C], last_color[C], last_alpha = 0.f;
-            const float invT = T > 0.f ? 1.f / T : 0.f;
-            {
-                float S[C], cu[GOM_NSUB][C];
-                ld4<C>(seg_Sbehind, seg, pxi, S);
+            float S[C], cu[GOM_NSUB][C];
+            ld4<C>(seg_Sbehind, seg, pxi, S);
 #pragma unroll
-                for (int u = GOM_NSUB - 1; u > 0; u--)
-                    if (u > sub) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu[u]);   // (wave-uniform condition)
-#pragma unroll
-                for (int u = GOM_NSUB - 1; u > 0; u--)
-                    if (u > sub) {
-#pragma unroll
-                        for (int ch = 0; ch < C; ch++) S[ch] += cu[u][ch];
-                    }
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) {
-                    accum_rec[ch] = S[ch] * invT;
-                    last_color[ch] = 0.f;
-                }
-            }
+            for (int u = GOM_NSUB - 1; u > 0; u--)
+                if (u > sub) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu[u]);   // (wave-uniform condition)
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
             const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
-            unsigned long long mask = __ballot(r.keep);
             tq.request();  // (behind every load of this task)
             requested = true;
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
-            {   // wait for everything loaded so far, so that the loop phase is the loop alone
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                PH_ADD(2, PH_T() - ph_t1); PH_ADD(10, 1); PH_ADD(11, __builtin_popcountll(mask));
+            const float invT = T > 0.f ? 1.f / T : 0.f;
+#pragma unroll
+            for (int u = GOM_NSUB - 1; u > 0; u--)
+                if (u > sub) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) S[ch] += cu[u][ch];
+                }
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                accum_rec[ch] = S[ch] * invT;
+                last_color[ch] = 0.f;
             }
-            [[maybe_unused]] const unsigned long long ph_t2 = PH_T();
-#endif
+            unsigned long long mask = __ballot(r.keep);
             // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
-            // T / accum_rec recurrences, then interleaved DPP reductions.
+            // T / accum_rec recurrences, then the transposed reductions.
             while (mask) {
                 int kk[4];
                 bool kv[4];
@@ -1052,7 +1030,6 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;  // wave-uniform
-                    PH_ADD(12, 1); PH_ADD(13, __builtin_popcountll(__ballot(al[u] > 0.f)));
                     // An entry with a == 0 is replayed as a zero-alpha layer: the recurrences below then
                     // leave T / accum_rec exactly as skipping would (App. A.4), without divergent branches.
                     const float a = al[u];
@@ -1084,48 +1061,42 @@ __global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int 
 #pragma unroll
                     for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
                     wave_sum10_rows(w10, r0, r1, r2);
+                    done |= 1ull << kk[u];
                     if ((lane & 15) == 15) {  // lane 15 of every row holds totals (see wave_sum10_rows)
-                        float *dst = &s_acc[q][kk[u]][0];
+                        float *dst = &s_acc[buf][q][kk[u]][0];
                         dst[row_slot] = r0;
                         dst[4 + row_slot] = r1;
                         if (lane & 16) dst[8 + (lane >> 5)] = r2;
                     }
                 }
             }
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF >= 2
-            PH_ADD(3, PH_T() - ph_t2);
-#endif
         }
-        [[maybe_unused]] const unsigned long long ph_t3 = PH_T();
+        if (lane == 0) s_done[buf][q] = done;
         if (!requested) tq.request();
         tq.publish(s_task);
         __syncthreads();
-        PH_ADD(4, PH_T() - ph_t3);
-        [[maybe_unused]] const unsigned long long ph_t4 = PH_T();
         if (threadIdx.x < scnt) {  // one 48-byte record per entry, quadrants summed in a fixed order
             float rr[10];
 #pragma unroll
-            for (int qq = 0; qq < 10; qq++)
-                rr[qq] = ((s_acc[0][threadIdx.x][qq] + s_acc[1][threadIdx.x][qq]) + s_acc[2][threadIdx.x][qq]) + s_acc[3][threadIdx.x][qq];
+            for (int qq = 0; qq < 10; qq++) rr[qq] = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+                const bool have = (s_done[buf][w4] >> threadIdx.x) & 1ull;
+#pragma unroll
+                for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][threadIdx.x][qq] : 0.f;
+            }
             rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
             rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
             rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
         }
-        PH_ADD(5, PH_T() - ph_t4);
     }
     tq.finish();
 #ifdef GOM_PHASE_PROF
     if (threadIdx.x == 0) {
-        const unsigned long long ph_k1 = __builtin_readcyclecounter();
-        g_wg_busy[blockIdx.x] += ph_k1 - ph_k0;
+        g_wg_busy[blockIdx.x] += __builtin_readcyclecounter() - ph_k0;
         g_wg_t0[blockIdx.x] = ph_w0;   // timeline of the last launch (100 MHz wall clock, common to all XCDs)
         g_wg_t1[blockIdx.x] = wall_clock64();
     }
-#if GOM_PHASE_PROF >= 2
-    PH_ADD(6, PH_T() - ph_k0);
-    if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_phase[i], ph_acc[i]);
-#endif
 #endif
 }
 
@@ -1200,7 +1171,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 #define GOM_CF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
-                       s->n_contrib, s->tile_nmax, s->status)
+                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status)
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }
@@ -1216,7 +1187,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #define GOM_SB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_RESIDENT(k_seg_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
-                       cam.bg[3], s->cams, s->seg_desc, s->tile_nmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+                       cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
                        s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status, GOM_TASK_CTR)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB
