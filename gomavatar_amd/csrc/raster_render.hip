@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 
 // ---------------------------------------------------------------- backward -
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
