@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 2
+GOM_ABI_VERSION = 3
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
@@ -57,6 +57,10 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_raster_backward": (c_int, [c_void_p, POINTER(GomCamera), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "gom_raster_forward_dcam": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_uint32, c_void_p]),
+    "gom_raster_backward_dcam": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_fk_forward": (c_int, [c_void_p] * 6),
     "gom_fk_backward": (c_int, [c_void_p] * 7),
     "gom_lbs_forward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

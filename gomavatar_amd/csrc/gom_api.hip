@@ -225,6 +225,31 @@ extern "C" int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int
                                 dL_dopacity, dL_dmeans2D, flags, stream);
 }
 
+static bool dcam_stub(int H, int W, const GomCamera *cam_device, GomCamera *stub) {
+    if (!cam_device) { gom_set_error("null device camera"); return false; }
+    *stub = GomCamera{};
+    stub->H = H; stub->W = W;
+    return true;
+}
+
+extern "C" int gom_raster_forward_dcam(GomState *s, int H, int W, const GomCamera *cam_device, int P, int C, const float *means3D,
+                                       const float *cov6, const float *colors, const float *opacity, float *out_color, int32_t *radii,
+                                       uint32_t flags, void *stream) {
+    GomCamera stub;
+    if (!dcam_stub(H, W, cam_device, &stub)) return -1;
+    return raster_forward_impl(s, &stub, cam_device, 1, P, C, means3D, cov6, colors, opacity, out_color, radii, flags, stream);
+}
+
+extern "C" int gom_raster_backward_dcam(GomState *s, int H, int W, const GomCamera *cam_device, int P, int C, const float *means3D,
+                                        const float *cov6, const float *colors, const float *opacity, const float *dL_dcolor,
+                                        float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
+                                        uint32_t flags, void *stream) {
+    GomCamera stub;
+    if (!dcam_stub(H, W, cam_device, &stub)) return -1;
+    return raster_backward_impl(s, &stub, cam_device, 1, P, C, means3D, cov6, colors, opacity, dL_dcolor, dL_dmeans3D, dL_dcov6,
+                                dL_dcolors, dL_dopacity, dL_dmeans2D, flags, stream);
+}
+
 extern "C" int gom_state_poll(GomState *s, int64_t *num_pairs, int32_t *overflow, void *stream) {
     if (!s) { gom_set_error("null state"); return -1; }
     GomDevStatus h;

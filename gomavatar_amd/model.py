@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import _lib
 from .geometry import MeshTopology, apply_lbs, face_gaussians, get_global_RTs, posed_face_gaussians
 from .mesh_renderer import MeshNormalRenderer, vertex_normals
-from .rasterizer import rasterize
+from .rasterizer import DeviceCamera, rasterize
 from . import synthetic as _syn
 
 
@@ -129,6 +129,12 @@ class Model(nn.Module):
         self.sigma = float(_get(model_cfg, "canonical_geometry.sigma", 1e-3))
         self.appearance = nn.Parameter(torch.ones(3, F, device=dev) * float(_get(model_cfg, "appearance.color_init", 0.5)))   # AppearanceModule
         self.register_buffer("bg_col", torch.zeros(3, device=dev))
+        # capture_safe: no host read of device data anywhere in forward() (camera kept in device memory, shadow MLP on a
+        # fixed-capacity pixel list), so that a whole training iteration can be captured in one HIP graph and replayed for
+        # other frames (train_util.GraphedTrainStep).  Off: the reference's own behaviour (host camera, exact pixel list).
+        self.capture_safe = False
+        self.shadow_capacity = None          # pixels the shadow MLP is evaluated on in capture_safe mode (default H*W/3)
+        self._dcam = None
         self.non_rigid_module, self.pose_refinement_module = non_rigid_module, pose_refinement_module
         self.normal_renderer = MeshNormalRenderer(self.img_size, sigma=_get(model_cfg, "normal_renderer.sigma", None),
                                                   soft_mask=_get(model_cfg, "normal_renderer.soft_mask", True))
@@ -234,7 +240,12 @@ class Model(nn.Module):
         # pseudo albedo + mask: one 4-channel pass (the reference pads to 6 channels and rasterizes twice)
         feat = torch.cat([self.appearance.T, torch.ones(F, 1, device=xyz.device)], 1)
         opacity = torch.ones(F, device=xyz.device)
-        cam = self._camera(K, E, (0.0, 0.0, 0.0, 0.0))        # bg_col = [bg_feat (zeros), 0] (model.py:243)
+        if self.capture_safe:
+            if self._dcam is None or (self._dcam.H, self._dcam.W) != (self.img_size[1], self.img_size[0]):
+                self._dcam = DeviceCamera(self.img_size[1], self.img_size[0], xyz.device)
+            cam = self._dcam.update(K[0], E[0])               # 160 bytes rewritten on the device
+        else:
+            cam = self._camera(K, E, (0.0, 0.0, 0.0, 0.0))    # bg_col = [bg_feat (zeros), 0] (model.py:243)
         img, _ = rasterize(xyz, cov6, feat, opacity, cam)
         albedos, masks = img[:3].permute(1, 2, 0)[None], img[3][None]
         # normals, normal map, silhouette (model.py:270-273)
@@ -246,11 +257,26 @@ class Model(nn.Module):
             # shadow_module(normal) for every pixel (model.py:279-282).  The normal map is exactly 0 outside the mesh, where
             # the MLP output is one constant: evaluate it once there and per pixel only under the mesh (~15 % of the image).
             flat = normal.reshape(-1, 3)
-            idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
             s_bg = self.shadow_module(torch.zeros(1, 1, 3, device=flat.device, dtype=flat.dtype)).reshape(1, 1)
-            s_all = s_bg.expand(flat.shape[0], 1).clone()
-            if idx.numel():
-                s_all = s_all.index_put((idx,), self.shadow_module(flat[idx][None]).reshape(-1, 1))
+            if self.capture_safe:
+                # same result with static shapes: the pixels under the mesh are compacted into a list of fixed capacity
+                # (prefix sum, no nonzero()); every unused slot points at its own dummy row (duplicate indices would send
+                # the gather's backward down a serial path); more mesh pixels than slots -> NaN, loudly
+                n = flat.shape[0]
+                cap = int(self.shadow_capacity or n // 3)
+                under = (flat != 0).any(-1)
+                pos = torch.cumsum(under, 0) - 1
+                slot = torch.where(under & (pos < cap), pos, torch.full_like(pos, cap))
+                idx = torch.cat([n + torch.arange(cap, device=flat.device), pos[:1]]).scatter(0, slot, torch.arange(n, device=flat.device))[:cap]
+                flat1 = torch.cat([flat, flat.new_zeros(cap, 3)], 0)
+                s_sel = self.shadow_module(flat1[idx][None]).reshape(-1, 1)
+                s_all = s_bg.expand(n + cap, 1).clone().index_put((idx,), s_sel)[:n]
+                s_all = torch.where(pos[-1] >= cap, torch.full_like(s_all, float("nan")), s_all)
+            else:
+                idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
+                s_all = s_bg.expand(flat.shape[0], 1).clone()
+                if idx.numel():
+                    s_all = s_all.index_put((idx,), self.shadow_module(flat[idx][None]).reshape(-1, 1))
             shadings = s_all.reshape(Bn, H, W, 1) * 2
             rgbs = albedos * shadings
         else:

@@ -149,6 +149,44 @@ def camera_from_settings(rs: GaussianRasterizationSettings) -> _lib.GomCamera:
     return _lib.make_camera(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, view, proj, bg)
 
 
+class DeviceCamera:
+    """A GomCamera that lives in device memory (`data`: 40 x 4 bytes in the struct's layout) and is read by the kernels
+    themselves.  Nothing of it is baked into the launches, so a rasterizer call made with it can be part of a captured
+    HIP graph that is replayed for other frames: `update(K, E)` rewrites the same 160 bytes with device-side tensor
+    ops (no host read of K / E, unlike gaussian.py:30-31)."""
+
+    def __init__(self, H: int, W: int, device):
+        self.H, self.W = int(H), int(W)
+        self.data = torch.zeros(40, dtype=torch.float32, device=device)
+        self.data[:2] = torch.tensor([self.H, self.W], dtype=torch.int32).view(torch.float32).to(device)
+        self._bg_host = (0.0, 0.0, 0.0, 0.0)     # what data[36:40] currently holds, when it came from a host tuple
+
+    def update(self, K: torch.Tensor, E: torch.Tensor, bg=(0.0, 0.0, 0.0, 0.0), znear: float = 0.001, zfar: float = 100.0) -> "DeviceCamera":
+        """K (3,3), E (4,4) device tensors -> tanfov, viewmatrix = E^T, projmatrix = E^T K_ndc^T (gaussian.py:28-51)."""
+        H, W = self.H, self.W
+        K, E = K.detach().float(), E.detach().float()
+        fx, fy, px, py = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        zero, one = torch.zeros((), device=K.device), torch.ones((), device=K.device)
+        K_ndc = torch.stack([torch.stack([2 * fx / W, zero, (2 * px - W) / W, zero]),
+                             torch.stack([zero, 2 * fy / H, (2 * py - H) / H, zero]),
+                             torch.stack([zero, zero, one * (zfar / (zfar - znear)), one * (-zfar * znear / (zfar - znear))]),
+                             torch.stack([zero, zero, one, zero])])
+        view = E.T.contiguous()
+        proj = view @ K_ndc.T
+        # tan(atan(x)) written out like the host path (Model._camera) so both agree to the last bit
+        tanfov = torch.stack([torch.tan(torch.atan(W / (2 * fx))), torch.tan(torch.atan(H / (2 * fy)))])
+        self.data[2:4] = tanfov
+        self.data[4:20] = view.reshape(-1)
+        self.data[20:36] = proj.reshape(-1)
+        if torch.is_tensor(bg):
+            self.data[36:40] = bg.detach().float().reshape(-1)
+            self._bg_host = None
+        elif tuple(float(b) for b in bg) != self._bg_host:   # host -> device copy: only when the value really changes (never inside a capture)
+            self._bg_host = tuple(float(b) for b in bg)
+            self.data[36:40] = torch.tensor(self._bg_host, dtype=torch.float32).to(K.device)
+        return self
+
+
 class _Rasterize(torch.autograd.Function):
     _next_id = 0
 
@@ -163,9 +201,14 @@ class _Rasterize(torch.autograd.Function):
         cov_c = cov6.contiguous()
         out = torch.empty((C, H, W), dtype=torch.float32, device=means3D.device)
         radii = torch.empty((P,), dtype=torch.int32, device=means3D.device)
-        _lib.check(lib.gom_raster_forward(lease.st.handle, ctypes.byref(cam), P, C, _lib.ptr(means3D_c), _lib.ptr(cov_c),
-                                          _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(out), _lib.ptr(radii),
-                                          _lib.GOM_FWD_REUSE_BINNING if reuse else 0, _lib.stream_ptr()))
+        if isinstance(cam, DeviceCamera):
+            _lib.check(lib.gom_raster_forward_dcam(lease.st.handle, H, W, _lib.ptr(cam.data), P, C, _lib.ptr(means3D_c), _lib.ptr(cov_c),
+                                                   _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(out), _lib.ptr(radii),
+                                                   _lib.GOM_FWD_REUSE_BINNING if reuse else 0, _lib.stream_ptr()))
+        else:
+            _lib.check(lib.gom_raster_forward(lease.st.handle, ctypes.byref(cam), P, C, _lib.ptr(means3D_c), _lib.ptr(cov_c),
+                                              _lib.ptr(colors_c), _lib.ptr(opac_c), _lib.ptr(out), _lib.ptr(radii),
+                                              _lib.GOM_FWD_REUSE_BINNING if reuse else 0, _lib.stream_ptr()))
         _Rasterize._next_id += 1
         ctx.fid = _Rasterize._next_id
         lease.st.owner = ctx.fid
@@ -187,10 +230,15 @@ class _Rasterize(torch.autograd.Function):
         d_col = torch.empty_like(colors)
         d_op = torch.empty_like(opac)
         d_m2d = torch.empty((P, 3), dtype=torch.float32, device=means3D.device)
-        _lib.check(lib.gom_raster_backward(ctx.lease.st.handle, ctypes.byref(ctx.cam), P, C, _lib.ptr(means3D), _lib.ptr(cov6),
-                                           _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(g), _lib.ptr(d_means), _lib.ptr(d_cov),
-                                           _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_m2d),
-                                           _lib.GOM_BWD_RECOMPUTE_FORWARD if ctx.lease.st.owner != ctx.fid else 0, _lib.stream_ptr()))
+        flags = _lib.GOM_BWD_RECOMPUTE_FORWARD if ctx.lease.st.owner != ctx.fid else 0
+        if isinstance(ctx.cam, DeviceCamera):
+            _lib.check(lib.gom_raster_backward_dcam(ctx.lease.st.handle, ctx.cam.H, ctx.cam.W, _lib.ptr(ctx.cam.data), P, C, _lib.ptr(means3D),
+                                                    _lib.ptr(cov6), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(g), _lib.ptr(d_means), _lib.ptr(d_cov),
+                                                    _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_m2d), flags, _lib.stream_ptr()))
+        else:
+            _lib.check(lib.gom_raster_backward(ctx.lease.st.handle, ctypes.byref(ctx.cam), P, C, _lib.ptr(means3D), _lib.ptr(cov6),
+                                               _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(g), _lib.ptr(d_means), _lib.ptr(d_cov),
+                                               _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_m2d), flags, _lib.stream_ptr()))
         ctx.lease.st.owner = ctx.fid
         ctx.lease.finish()
         return d_means, d_m2d, d_col, d_op.reshape(ctx.opac_shape), d_cov, None, None, None

@@ -78,3 +78,64 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
             loss_cfg.color_consist.coeff)
     total = sum(item["scaled"] for item in losses.values())
     return total, losses
+
+
+class GraphedTrainStep:
+    """The reference's training iteration (train.py:309-349: zero_grad -> forward -> unpack -> compute_loss -> backward ->
+    optimizer step) captured ONCE in a HIP graph and replayed per frame.  An iteration is ~350 kernel launches of a few
+    microseconds each; launched one by one from Python the host, not the GPU, sets the pace (~10 ms per iteration against
+    ~5 ms of kernels).  Everything per-frame lives in static device buffers that `step(frame)` overwrites before the replay.
+
+        step = GraphedTrainStep(model, optimizer, loss_cfg, lpips_func)    # optimizer: capturable=True
+        for frame in loader:
+            total = step(frame)            # frame: K, E, cnl_gtfms, dst_Rs, dst_Ts, bgcolor, target_rgbs, target_masks (+ dst_posevec)
+
+    Python-level decisions are frozen at capture (i_iter thresholds such as kick_in_iter, loss coefficients, mesh
+    topology): call `invalidate()` when one of them changes (e.g. after `model.subdivide()`), the next step re-captures."""
+
+    FRAME_KEYS = ("K", "E", "cnl_gtfms", "dst_Rs", "dst_Ts", "dst_posevec", "bgcolor", "target_rgbs", "target_masks")
+
+    def __init__(self, model, optimizer, loss_cfg, lpips_func=None, warmup: int = 3):
+        self.model, self.opt, self.loss_cfg, self.lpips = model, optimizer, loss_cfg, lpips_func
+        self.warmup, self.graph, self.static, self.total, self.i_iter = warmup, None, None, None, 0
+        model.capture_safe = True
+
+    def invalidate(self):
+        self.graph = None
+
+    def _iteration(self):
+        fr = self.static
+        self.opt.zero_grad(set_to_none=True)
+        rgbs, masks, out = self.model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], dst_posevec=fr.get("dst_posevec"),
+                                      i_iter=self.i_iter)
+        total, _ = compute_loss(unpack(rgbs, masks, fr["bgcolor"]), masks, out, fr["target_rgbs"], fr["target_masks"], self.loss_cfg,
+                                i_iter=self.i_iter, lpips_func=self.lpips)
+        total.backward()
+        self.opt.step()
+        return total.detach()
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # allocations (library scratch, optimizer state) happen here, outside the graph
+            for _ in range(self.warmup):
+                first = self._iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):         # (records the launches, executes nothing)
+            self.total = self._iteration()
+        self.total.copy_(first)
+
+    def __call__(self, frame, i_iter=None):
+        if i_iter is not None:
+            self.i_iter = i_iter
+        if self.static is None:
+            self.static = {k: frame[k].clone() for k in self.FRAME_KEYS if k in frame and frame[k] is not None}
+        else:
+            for k, v in self.static.items():
+                v.copy_(frame[k], non_blocking=True)
+        if self.graph is None:
+            self._capture()                        # (this call = `warmup` ordinary iterations on this frame, then the capture)
+        else:
+            self.graph.replay()
+        return self.total

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 2
+#define GOM_ABI_VERSION 3
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -135,6 +135,20 @@ int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C,
                         const float *dL_dcolor,
                         float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
                         uint32_t flags, void *stream);
+
+/* gom_raster_forward / gom_raster_backward with the camera read from DEVICE memory by the kernels: nothing of
+ * tanfov / view / proj / bg is baked into the launches, so the calls can sit inside a captured hipGraph (the caller's,
+ * e.g. a whole training iteration) that is replayed for other cameras -- overwrite *cam_device before the replay.
+ * H and W are launch geometry and stay host values; cam_device->H / W must hold the same numbers.
+ * (The reference reads its camera back to the host with .item() every frame, gaussian.py:30-31.) */
+int gom_raster_forward_dcam(GomState *s, int H, int W, const GomCamera *cam_device, int P, int C,
+                            const float *means3D, const float *cov6, const float *colors, const float *opacity,
+                            float *out_color, int32_t *radii, uint32_t flags, void *stream);
+int gom_raster_backward_dcam(GomState *s, int H, int W, const GomCamera *cam_device, int P, int C,
+                             const float *means3D, const float *cov6, const float *colors, const float *opacity,
+                             const float *dL_dcolor,
+                             float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
+                             uint32_t flags, void *stream);
 
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gomavatar_amd import synthetic as syn
 from gomavatar_amd.model import Model
-from gomavatar_amd.train_util import compute_loss, unpack
+from gomavatar_amd.train_util import GraphedTrainStep, compute_loss, unpack
 from gomavatar_amd.lpips import LPIPSMatrixCore
 from gomavatar_amd import metrics as M
 
@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300); ap.add_argument("--img", type=int, default=256)
 ap.add_argument("--level", type=int, default=0, help="SMPL-like body subdivisions (0: 13 776 faces)")
 ap.add_argument("--subdivide-at", type=int, default=-1); ap.add_argument("--no-lpips", action="store_true")
+ap.add_argument("--graph", action="store_true", help="capture the whole iteration in one HIP graph (train_util.GraphedTrainStep)")
 a = ap.parse_args()
 img = a.img
 cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
@@ -41,17 +42,28 @@ for i in range(8):
         fr["gt_rgb"], fr["gt_mask"] = unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
     frames.append(fr)
 lp = None if a.no_lpips else LPIPSMatrixCore(trunk_seed=0)
-opt = torch.optim.Adam(student.get_param_groups(lr))
+opt = torch.optim.Adam(student.get_param_groups(lr), capturable=a.graph)
+for fr in frames:
+    fr["target_rgbs"], fr["target_masks"] = fr["gt_rgb"], fr["gt_mask"]                  # the reference's key names (dataset/train.py:272-275)
+gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None
 log, t0 = [], time.perf_counter()
 for it in range(a.iters):
     if it == a.subdivide_at:
-        student.subdivide(); opt = torch.optim.Adam(student.get_param_groups(lr))        # train.py:330-340 rebuilds the optimizer
+        student.subdivide(); opt = torch.optim.Adam(student.get_param_groups(lr), capturable=a.graph)   # train.py:330-340 rebuilds the optimizer
+        gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None        # new topology: new capture
     fr = frames[it % 8]
-    opt.zero_grad(set_to_none=True)
-    rgbs, masks, out = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
-    pred = unpack(rgbs, masks, fr["bgcolor"])
-    total, losses = compute_loss(pred, masks, out, fr["gt_rgb"], fr["gt_mask"], loss_cfg, lpips_func=lp)
-    total.backward(); opt.step()
+    if gstep is not None:
+        total = gstep(fr, i_iter=it)
+        if it % 50 == 0 or it == a.iters - 1:
+            with torch.no_grad():
+                rgbs, masks, _ = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
+                pred = unpack(rgbs, masks, fr["bgcolor"])
+    else:
+        opt.zero_grad(set_to_none=True)
+        rgbs, masks, out = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
+        pred = unpack(rgbs, masks, fr["bgcolor"])
+        total, losses = compute_loss(pred, masks, out, fr["gt_rgb"], fr["gt_mask"], loss_cfg, lpips_func=lp)
+        total.backward(); opt.step()
     if it % 50 == 0 or it == a.iters - 1:
         with torch.no_grad():
             p8, g8 = M.from_8b(M.to_8b(pred[0])), M.from_8b(M.to_8b(fr["gt_rgb"][0]))

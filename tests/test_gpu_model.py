@@ -110,3 +110,80 @@ def test_training_steps_reduce_the_loss_and_subdivide_keeps_going():
     assert student.faces.shape[0] == 4 * F0 and student.appearance.shape[1] == 4 * F0 and student.lbs_weights.shape[1] == student.vertices.shape[1]
     h2 = run(student, 8)
     assert np.isfinite(h2).all() and np.mean(h2) < 0.1     # 4x smaller triangles change the render (as in the reference); training goes on
+
+
+def _small_model(img=96, seed_shadow=True):
+    from gomavatar_amd.model import Model
+    m = Model(_cfg(img), syn.icosphere_body(3)).train()
+    gp = syn.make_gaussian_params(m.faces.shape[0])
+    with torch.no_grad():
+        m.so3.copy_(torch.from_numpy(gp["so3"])); m.scale.copy_(torch.from_numpy(gp["scale"]) * 3.0); m.appearance.copy_(torch.from_numpy(gp["appearance"]))
+        if seed_shadow:
+            m.shadow_module.block_mlps[-1].weight.normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(3))
+    return m
+
+
+def test_capture_safe_forward_equals_the_host_camera_path():
+    """Device-resident camera (gom_raster_*_dcam) + fixed-capacity shadow pixel list = the regular forward, values and gradients."""
+    img = 96
+    m = _small_model(img)
+    dv = {k: v.cuda() for k, v in _frame(2, img).items() if torch.is_tensor(v)}
+    res = []
+    for safe in (False, True):
+        m.capture_safe = safe
+        m.zero_grad(set_to_none=True)
+        rgbs, masks, out = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"])
+        w = torch.linspace(0.5, 1.5, img * img * 3, device="cuda").reshape(1, img, img, 3)
+        ((rgbs * w).sum() + 2.0 * masks.sum() + out["normal_mask"].sum()).backward()
+        res.append((rgbs.detach().clone(), masks.detach().clone(), out["albedo"].detach().clone(),
+                    [p.grad.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)] + [p.grad.detach().clone() for p in m.shadow_module.parameters()]))
+    # same kernels; the camera matrices are products formed on the device instead of in numpy (last-bit differences)
+    for k in (0, 1, 2):
+        d = (res[0][k] - res[1][k]).abs()
+        assert float(d.mean()) < 1e-6 and float(d.max()) < 1e-3, (k, float(d.mean()), float(d.max()))
+    for a, b in zip(res[0][3], res[1][3]):
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()), (tuple(a.shape), float((a - b).norm()), float(a.norm()))   # (last-bit camera differences)
+    m.shadow_capacity = 16                                                                 # too few slots: loud, not silently wrong
+    rgbs, _, _ = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"])
+    assert torch.isnan(rgbs).all()
+
+
+def test_graphed_train_step_matches_the_eager_iterations():
+    """One HIP graph per training iteration (train_util.GraphedTrainStep) = the same iterations launched one by one."""
+    from gomavatar_amd.train_util import GraphedTrainStep, compute_loss, unpack
+    img = 96
+    loss_cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                  normal=NS(coeff_mask=1.0, kernel_size=5, coeff_consist=0.1), color_consist=NS(coeff=0.05))
+    lr = NS(lr=NS(appearance=5e-3, canonical_geometry=5e-4, canonical_geometry_xyz=5e-5, shadow=5e-4))
+    teacher = _small_model(img)
+    frames = []
+    for i in range(4):
+        fr = {k: v.cuda() for k, v in _frame(i, img).items() if torch.is_tensor(v)}
+        with torch.no_grad():
+            rgbs, masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            fr["target_rgbs"], fr["target_masks"] = unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
+        frames.append(fr)
+    finals = []
+    for graphed in (False, True):
+        from gomavatar_amd.model import Model
+        m = Model(_cfg(img), syn.icosphere_body(3)).train()
+        m.capture_safe = True
+        opt = torch.optim.Adam(m.get_param_groups(lr), capturable=True)
+        step = GraphedTrainStep(m, opt, loss_cfg, None, warmup=2) if graphed else None
+        if graphed:   # the first call runs its 2 warm-up iterations on its frame (the capture itself executes nothing)
+            for it in range(8):
+                total = step(frames[it % 4])
+        else:
+            for fi in [0, 0] + [it % 4 for it in range(1, 8)]:
+                f2 = frames[fi]
+                opt.zero_grad(set_to_none=True)
+                rgbs, masks, out = m(f2["K"], f2["E"], f2["cnl_gtfms"], f2["dst_Rs"], f2["dst_Ts"])
+                total, _ = compute_loss(unpack(rgbs, masks, f2["bgcolor"]), masks, out, f2["target_rgbs"], f2["target_masks"], loss_cfg)
+                total.backward(); opt.step()
+        torch.cuda.synchronize()
+        finals.append((float(total.detach()), [p.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)]))
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * max(1.0, abs(finals[0][0])), (finals[0][0], finals[1][0])
+    # Two eager runs differ by as much: the torch ops around the kernels (index_put backward) sum with atomics, and Adam turns a
+    # last-bit gradient difference on a near-zero gradient into a +-lr step.  So: within a few steps of each parameter's lr.
+    for (a, b), step_size in zip(zip(finals[0][1], finals[1][1]), (5e-5, 5e-4, 5e-4, 5e-3)):
+        assert float((a - b).abs().max()) <= 4 * step_size, (tuple(a.shape), float((a - b).abs().max()))
