@@ -286,3 +286,27 @@ def test_fuzz_shapes_scales_and_depths(seed):
         scale = max(np.abs(ref).max(), 1e-30)
         err = np.abs(got - ref)
         assert np.quantile(err, 0.995) <= 1e-3 * scale, (name, np.quantile(err, 0.995), scale)
+
+
+def test_device_camera_entry_points_are_bitwise_the_host_camera_path():
+    """gom_raster_forward_dcam / gom_raster_backward_dcam read the same 160 camera bytes from device memory instead of the
+    launch arguments: identical image, radii and gradients."""
+    import ctypes
+    from gpu_util import hip_forward, gom_camera, dev
+    from gomavatar_amd import rasterizer as R
+    cam, means, cov6, colors, op = small_scene(seed=77, P=3000, H=80, W=112, opacity=(0.3, 1.0), scale=0.05, C=4)
+    cam["bg"] = np.array([0.3, 0.1, 0.6, 0.2], np.float32)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True)
+    w = torch.linspace(-1.0, 1.0, out.numel(), device="cuda").reshape(out.shape)
+    (out * w).sum().backward()
+    host = gom_camera(cam)
+    dcam = R.DeviceCamera(cam["H"], cam["W"], "cuda")
+    raw = np.frombuffer(ctypes.string_at(ctypes.addressof(host), ctypes.sizeof(host)), dtype=np.float32).copy()
+    assert raw.size == 40
+    dcam.data.copy_(torch.from_numpy(raw))
+    t2 = [dev(means).requires_grad_(), dev(cov6).requires_grad_(), dev(colors).requires_grad_(), dev(op).requires_grad_()]
+    out2, radii2 = R.rasterize(t2[0], t2[1], t2[2], t2[3], dcam)
+    (out2 * w).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(radii, radii2)
+    for a, b in zip(t, t2):
+        assert torch.equal(a.grad, b.grad)
