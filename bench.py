@@ -229,7 +229,10 @@ def main():
     kt = {k: acc[k] / n_prof for k in _lib.KERNEL_NAMES}
     D_avg = acc["D"] / n_prof
     abytes = algorithmic_bytes(F * B, D_avg, img * img * B, 4)   # per launch: B frames (D_avg already counts all B)
-    dom = max(kt, key=kt.get)
+    # Dominant kernel = the one that costs most when it owns the chip.  (With several steps in flight a kernel's duration also
+    # counts the time it spends sharing CUs with the other steps' kernels -- a property of the mix, not of the kernel; the
+    # few long tile lists of k_sort, two launches under one event pair, stretch most that way.)  Both durations are reported.
+    dom = max(iso, key=iso.get)
     achieved = abytes[dom] / (kt[dom] * 1e-3) / 1e9
     # HBM traffic of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, FETCH doubled per
     # MI355X_MICROARCH.md), recorded by scripts/collect_profiles.sh into profiles/<round>_traffic.json
