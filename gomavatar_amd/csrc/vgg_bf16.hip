@@ -16,6 +16,7 @@
 //   k_lpips_prepare     (B,H,W,3) fp32 image in [0,1] -> ScalingLayer(2x-1) -> NHWC bf16 padded to 32 channels
 //   k_lpips_head_nhwc_* the LPIPS head of lpips.hip for NHWC bf16 taps (one wave per pixel group)
 #include "gom_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -102,6 +103,157 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
         }
     }
     // D[i = co][j = px]: lane holds co = 4*kg + r (r = 0..3) of pixel column l15
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int gy = ty0 + 2 * wave + m, gx = tx0 + l15;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
+        if (SPLITK) {
+            float *dst = partial + (size_t)zs * (gridDim.z / splits) * H * W * Cout + pix;   // [splits][B][H][W][Cout]
+#pragma unroll
+            for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + co0 + n * 16 + kg * 4) = acc[m][n];
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int co = co0 + n * 16 + kg * 4;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+            }
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (mask) {
+                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
+                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
+            }
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(out + pix + co) = o;
+        }
+    }
+}
+
+// ---- pipelined variant: global -> LDS by LDS-DMA (global_load_lds_dwordx4), three stages in flight ---------------------
+// Same tile (16 x 16 pixels x 64 output channels, 8 waves of 2 rows), same MFMA / epilogue as k_conv3x3_bf16<.., 16>; what
+// changes is how the operands reach LDS.  v1 stages a whole 32-channel chunk (halo patch + 9 taps of weights, 57 KB) through
+// VGPRs between two barriers and relies on a second co-resident workgroup to keep the matrix cores busy meanwhile.  Here a
+// STAGE is one kernel row (ky) of one chunk: 3 taps of weights (12 KB) and, for ky = 0, the chunk's halo patch (20 KB).  Every
+// wave issues the loads of stage s + 2 as `global_load_lds` (no VGPRs, no ds_write pass: lane i's 16 bytes land at
+// base + 16 i, so the LDS images are laid out in exactly the order the lanes enumerate them), waits with a COUNTED
+// `s_waitcnt vmcnt(N)` that leaves the younger stages' loads in flight, crosses ONE barrier and runs the 24 MFMAs of stage
+// s.  Weights are triple-buffered, patches double-buffered: 78 KB, two workgroups per CU.
+//   * Halo pixels outside the image read 16 zero bytes from a global constant instead of being masked: every wave issues
+//     the same number of loads in every stage, which is what makes the counted waits exact.
+//   * RAW: a wave reads a buffer only after its own vmcnt wait AND the barrier every other wave reaches after theirs.
+//     WAR: the loads that overwrite a buffer are issued after the barrier that follows its last reader's MFMAs.
+//   * No ordinary global load may sit inside the loop (hipcc would drain the DMA queue with vmcnt(0) at its first use).
+__device__ uint4 g_zero16[4];   // zero-initialised: source of the halo's out-of-image pixels
+
+constexpr int kV2PatchUnits = 18 * 18 * 4;            // 16-byte units of a halo patch (1 296)
+constexpr int kV2PatchBytes = kV2PatchUnits * 16;     // 20 736
+constexpr int kV2WBytes = 3 * kBN * kKC * 2;          // 12 288: three taps
+constexpr int kV2Lds = 2 * kV2PatchBytes + 3 * kV2WBytes;   // 78 336
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <bool RELU, bool SPLITK>
+__global__ void __launch_bounds__(512, 2) k_conv3x3_bf16_v2(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
+                                                         const bf16_t *__restrict__ wt, const float *__restrict__ bias,
+                                                         const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
+                                                         float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TH = 16;
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int co0 = blockIdx.y * kBN;
+    const int zb = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, zs = SPLITK ? (int)blockIdx.z % splits : 0;
+    const size_t img = (size_t)zb * H * W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int nchunk = Cin / kKC;
+    const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
+    const int NS = 3 * (cc_hi - cc_lo);   // stages
+
+    // this wave's share of a patch: units [162 w, 162 w + 162) as 64 + 64 + 34 lanes; of a weight stage: [96 w, 96 w + 96) as 64 + 32
+    const unsigned char *zero = reinterpret_cast<const unsigned char *>(g_zero16);
+    const unsigned char *psrc[3];   // element 0 of the pixel's 32-channel row in chunk 0 (or the zero block)
+    bool pin[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int u = 162 * wave + 64 * j + lane;
+        const int px = u >> 2, part = u & 3;
+        const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
+        pin[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        psrc[j] = pin[j] ? reinterpret_cast<const unsigned char *>(in + (img + (size_t)gy * W + gx) * Cin + part * 8) : zero;
+    }
+    // weight units of a stage: v = 96 w + 64 j + lane -> tap v >> 8 (of the row), r = v & 255
+    size_t woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int v = 96 * wave + 64 * j + lane;
+        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)(v & 255) * 8) * 2;   // bytes inside the (chunk, ky) row block
+    }
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wt + (size_t)co0 * kKC);
+
+    auto issue = [&](int s) {   // loads of stage s (s < NS): 2 weight instructions, + 3 patch instructions when ky == 0
+        const int cc = cc_lo + s / 3, ky = s % 3;
+        unsigned char *wb = smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes + (96 * wave) * 16;
+        const unsigned char *wsrc = wbase + ((size_t)(cc * 9 + ky * 3) * Cout * kKC) * 2;
+        glds16(wsrc + woff[0], wb);
+        if (lane < 32) glds16(wsrc + woff[1], wb + 64 * 16);
+        if (ky == 0) {
+            unsigned char *pb = smem + ((s / 3) & 1) * kV2PatchBytes + (162 * wave) * 16;
+            const size_t coff = (size_t)cc * kKC * 2;
+            glds16(pin[0] ? psrc[0] + coff : psrc[0], pb);
+            glds16(pin[1] ? psrc[1] + coff : psrc[1], pb + 64 * 16);
+            if (lane < 34) glds16(pin[2] ? psrc[2] + coff : psrc[2], pb + 128 * 16);
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (NS > 1) issue(1);
+    for (int s = 0; s < NS; s++) {
+        // stage s has landed when at most the loads of stage s + 1 are still in flight (2, or 5 when it carries a patch)
+        if (s + 1 >= NS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if ((s + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < NS) issue(s + 2);
+        const int ky = s % 3;
+        const bf16_t *pb = reinterpret_cast<const bf16_t *>(smem + ((s / 3) & 1) * kV2PatchBytes);
+        const bf16_t *wb = reinterpret_cast<const bf16_t *>(smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes);
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            bf16x8 bfrag[2], afrag[4];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + ((2 * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+                afrag[n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + kg * 8);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
+        }
+    }
+    // epilogue: identical to k_conv3x3_bf16
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         const int gy = ty0 + 2 * wave + m, gx = tx0 + l15;
@@ -356,9 +508,15 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
     const int TH = (blocks16 >= 256 && H >= 16) ? 16 : 8;
     const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + TH - 1) / TH), Cout / kBN, B * splits);
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
+    static const bool use_v2 = !(getenv("GOM_CONV_V2") && atoi(getenv("GOM_CONV_V2")) == 0);   // development switch
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \
-        if (TH == 16) hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 16>), grid, dim3(512), 0, st, __VA_ARGS__);                  \
+        if (TH == 16 && use_v2) {                                                                                                     \
+            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_>),     \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                   \
+            if (attr_ != hipSuccess) { gom_set_error("hipFuncSetAttribute(k_conv3x3_bf16_v2): %s", hipGetErrorString(attr_)); return -1; } \
+            hipLaunchKernelGGL((k_conv3x3_bf16_v2<RELU_, SPLIT_>), grid, dim3(512), kV2Lds, st, __VA_ARGS__);                         \
+        } else if (TH == 16) hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 16>), grid, dim3(512), 0, st, __VA_ARGS__);           \
         else hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                            \
     } while (0)
     if (splits > 1) {

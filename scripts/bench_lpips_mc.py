@@ -22,7 +22,7 @@ with torch.cuda.stream(stream):
     graph_ms = round(timeit(lambda: mc.value_and_grad(pred, gt, out=bufs)), 3)
 out = {"matrix_core_value_and_grad_graph_ms": graph_ms, "matrix_core_value_and_grad_ms": round(timeit(lambda: mc.value_and_grad(pred, gt)), 3),
        "matrix_core_value_only_ms": round(timeit(lambda: mc.value_and_grad(pred, gt, want_grad=False)), 3)}
-for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+for name, dt in (() if os.environ.get("NO_LIBRARY") else (("fp32", torch.float32), ("bf16", torch.bfloat16))):
     m = LPIPS(trunk_seed=0, trunk_dtype=dt)
     def f():
         p = pred.clone().requires_grad_(); lpips_loss(m, p, gt).backward()
