@@ -165,13 +165,16 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <bool RELU, bool SPLITK>
-__global__ void __launch_bounds__(512, 2) k_conv3x3_bf16_v2(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
-                                                         const bf16_t *__restrict__ wt, const float *__restrict__ bias,
-                                                         const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
-                                                         float *__restrict__ partial) {
+template <bool RELU, bool SPLITK, int RPW>
+__global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
+                                                                const bf16_t *__restrict__ wt, const float *__restrict__ bias,
+                                                                const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
+                                                                float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TH = 16;
+    constexpr int TH = 16, NW = TH / RPW;                                  // RPW pixel rows per wave, NW waves
+    constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: patch (162 / 324), weights (96 / 192)
+    constexpr int PI = (PU + 63) / 64, WI = (WU + 63) / 64;                // load instructions per wave
+    static_assert(kV2PatchUnits % NW == 0 && (3 * kBN * 4) % NW == 0, "even shares");
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * TH;
     const int co0 = blockIdx.y * kBN;
@@ -184,55 +187,56 @@ __global__ void __launch_bounds__(512, 2) k_conv3x3_bf16_v2(int H, int W, int Ci
     const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
     const int NS = 3 * (cc_hi - cc_lo);   // stages
 
-    // this wave's share of a patch: units [162 w, 162 w + 162) as 64 + 64 + 34 lanes; of a weight stage: [96 w, 96 w + 96) as 64 + 32
+    // this wave's share of a patch: units [PU w, PU w + PU); of a weight stage: [WU w, WU w + WU); 64 lanes per instruction
     const unsigned char *zero = reinterpret_cast<const unsigned char *>(g_zero16);
-    const unsigned char *psrc[3];   // element 0 of the pixel's 32-channel row in chunk 0 (or the zero block)
-    bool pin[3];
+    const unsigned char *psrc[PI];   // element 0 of the pixel's 32-channel row in chunk 0 (or the zero block)
+    bool pin[PI];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int u = 162 * wave + 64 * j + lane;
+    for (int j = 0; j < PI; j++) {
+        const int u = min(PU * wave + 64 * j + lane, kV2PatchUnits - 1);
         const int px = u >> 2, part = u & 3;
         const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
         pin[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
         psrc[j] = pin[j] ? reinterpret_cast<const unsigned char *>(in + (img + (size_t)gy * W + gx) * Cin + part * 8) : zero;
     }
-    // weight units of a stage: v = 96 w + 64 j + lane -> tap v >> 8 (of the row), r = v & 255
-    size_t woff[2];
+    // weight units of a stage: v = WU w + 64 j + lane -> tap v >> 8 (of the row), r = v & 255
+    size_t woff[WI];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int v = 96 * wave + 64 * j + lane;
+    for (int j = 0; j < WI; j++) {
+        const int v = min(WU * wave + 64 * j + lane, 3 * kBN * 4 - 1);
         woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)(v & 255) * 8) * 2;   // bytes inside the (chunk, ky) row block
     }
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wt + (size_t)co0 * kKC);
 
-    auto issue = [&](int s) {   // loads of stage s (s < NS): 2 weight instructions, + 3 patch instructions when ky == 0
+    auto issue = [&](int s) {   // loads of stage s (s < NS): WI weight instructions, + PI patch instructions when ky == 0
         const int cc = cc_lo + s / 3, ky = s % 3;
-        unsigned char *wb = smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes + (96 * wave) * 16;
+        unsigned char *wb = smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes + (WU * wave) * 16;
         const unsigned char *wsrc = wbase + ((size_t)(cc * 9 + ky * 3) * Cout * kKC) * 2;
-        glds16(wsrc + woff[0], wb);
-        if (lane < 32) glds16(wsrc + woff[1], wb + 64 * 16);
+#pragma unroll
+        for (int j = 0; j < WI; j++)
+            if (64 * j + lane < WU) glds16(wsrc + woff[j], wb + 64 * j * 16);
         if (ky == 0) {
-            unsigned char *pb = smem + ((s / 3) & 1) * kV2PatchBytes + (162 * wave) * 16;
+            unsigned char *pb = smem + ((s / 3) & 1) * kV2PatchBytes + (PU * wave) * 16;
             const size_t coff = (size_t)cc * kKC * 2;
-            glds16(pin[0] ? psrc[0] + coff : psrc[0], pb);
-            glds16(pin[1] ? psrc[1] + coff : psrc[1], pb + 64 * 16);
-            if (lane < 34) glds16(pin[2] ? psrc[2] + coff : psrc[2], pb + 128 * 16);
+#pragma unroll
+            for (int j = 0; j < PI; j++)
+                if (64 * j + lane < PU) glds16(pin[j] ? psrc[j] + coff : psrc[j], pb + 64 * j * 16);
         }
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[RPW][4];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < RPW; m++)
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     issue(0);
     if (NS > 1) issue(1);
     for (int s = 0; s < NS; s++) {
-        // stage s has landed when at most the loads of stage s + 1 are still in flight (2, or 5 when it carries a patch)
+        // stage s has landed when at most the loads of stage s + 1 are still in flight (WI, or WI + PI when it carries a patch)
         if (s + 1 >= NS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if ((s + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if ((s + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WI + PI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WI) : "memory");
         __builtin_amdgcn_s_barrier();
         if (s + 2 < NS) issue(s + 2);
         const int ky = s % 3;
@@ -240,23 +244,23 @@ __global__ void __launch_bounds__(512, 2) k_conv3x3_bf16_v2(int H, int W, int Ci
         const bf16_t *wb = reinterpret_cast<const bf16_t *>(smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
-            bf16x8 bfrag[2], afrag[4];
+            bf16x8 bfrag[RPW], afrag[4];
 #pragma unroll
-            for (int m = 0; m < 2; m++)
-                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + ((2 * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
+            for (int m = 0; m < RPW; m++)
+                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + ((RPW * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
 #pragma unroll
             for (int n = 0; n < 4; n++)
                 afrag[n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + kg * 8);
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < RPW; m++)
 #pragma unroll
                 for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
         }
     }
     // epilogue: identical to k_conv3x3_bf16
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int gy = ty0 + 2 * wave + m, gx = tx0 + l15;
+    for (int m = 0; m < RPW; m++) {
+        const int gy = ty0 + RPW * wave + m, gx = tx0 + l15;
         if (gy >= H || gx >= W) continue;
         const size_t pix = (img + (size_t)gy * W + gx) * Cout;
         if (SPLITK) {
@@ -508,14 +512,18 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
     const int TH = (blocks16 >= 256 && H >= 16) ? 16 : 8;
     const dim3 grid(((W + kTileW - 1) / kTileW) * ((H + TH - 1) / TH), Cout / kBN, B * splits);
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
-    static const bool use_v2 = !(getenv("GOM_CONV_V2") && atoi(getenv("GOM_CONV_V2")) == 0);   // development switch
+    static const bool use_v2 = !(getenv("GOM_CONV_V2") && atoi(getenv("GOM_CONV_V2")) == 0);   // development switches
+    static const int v2_rpw = getenv("GOM_CONV_RPW") ? atoi(getenv("GOM_CONV_RPW")) : 2;
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \
         if (TH == 16 && use_v2) {                                                                                                     \
-            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_>),     \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                   \
-            if (attr_ != hipSuccess) { gom_set_error("hipFuncSetAttribute(k_conv3x3_bf16_v2): %s", hipGetErrorString(attr_)); return -1; } \
-            hipLaunchKernelGGL((k_conv3x3_bf16_v2<RELU_, SPLIT_>), grid, dim3(512), kV2Lds, st, __VA_ARGS__);                         \
+            static const hipError_t attr2_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_, 2>),   \
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                  \
+            static const hipError_t attr4_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_, 4>),   \
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                  \
+            if (attr2_ != hipSuccess || attr4_ != hipSuccess) { gom_set_error("hipFuncSetAttribute(k_conv3x3_bf16_v2) failed"); return -1; } \
+            if (v2_rpw == 4) hipLaunchKernelGGL((k_conv3x3_bf16_v2<RELU_, SPLIT_, 4>), grid, dim3(256), kV2Lds, st, __VA_ARGS__);     \
+            else hipLaunchKernelGGL((k_conv3x3_bf16_v2<RELU_, SPLIT_, 2>), grid, dim3(512), kV2Lds, st, __VA_ARGS__);                 \
         } else if (TH == 16) hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 16>), grid, dim3(512), 0, st, __VA_ARGS__);           \
         else hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                            \
     } while (0)

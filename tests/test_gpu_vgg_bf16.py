@@ -12,7 +12,10 @@ def _bf(x):
     return x.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 16, 32, 32, 64, True), (2, 24, 40, 64, 128, False), (1, 9, 21, 128, 64, True)])
+# small shapes run the 8-row kernel; (2, 200, 136, ...) is large enough for the pipelined 16-row kernel (LDS-DMA staging) with
+# ragged right / bottom tiles; (1, 64, 64, 256, 256) takes its split-K form
+@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 16, 32, 32, 64, True), (2, 24, 40, 64, 128, False), (1, 9, 21, 128, 64, True),
+                                                 (2, 200, 136, 64, 128, True), (1, 64, 64, 256, 256, False), (1, 129, 257, 32, 64, True)])
 def test_conv3x3_matches_torch(B, H, W, Cin, Cout, relu):
     from gomavatar_amd import _lib
     from gomavatar_amd.lpips import pack_conv_weight, pack_conv_weight_backward
@@ -25,7 +28,10 @@ def test_conv3x3_matches_torch(B, H, W, Cin, Cout, relu):
     ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
     out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device="cuda")
     xb, wp = x.to(torch.bfloat16).contiguous(), pack_conv_weight(w)
-    _lib.check(lib.gom_conv3x3_bf16(B, H, W, Cin, Cout, _lib.ptr(xb), _lib.ptr(wp), _lib.ptr(b), 0, _lib.ptr(out), 1 if relu else 0, _lib.stream_ptr()))
+    sp = lib.gom_conv3x3_splits(B, H, W, Cin, Cout)
+    ws = torch.empty(sp * B * H * W * Cout, device="cuda") if sp > 1 else None
+    _lib.check(lib.gom_conv3x3_bf16_splitk(B, H, W, Cin, Cout, _lib.ptr(xb), _lib.ptr(wp), _lib.ptr(b), 0, _lib.ptr(out), 1 if relu else 0, sp,
+                                           _lib.ptr(ws), _lib.stream_ptr()))
     torch.cuda.synchronize()
     err = (out.float() - ref).abs().max() / ref.abs().max()
     assert float(err) < 6e-3, float(err)           # one bf16 rounding of the output
@@ -91,3 +97,32 @@ def test_lpips_matrix_core_matches_fp32_path():
     assert torch.allclose(q.grad, 3.0 * grad, rtol=1e-6, atol=0)
     v2, none = mc.value_and_grad(pred, gt, want_grad=False)
     assert none is None and float(v2) == float(val)
+
+
+def test_pipelined_conv_is_race_free_over_many_launches():
+    """The 16-row kernel orders its LDS-DMA staging by counted vmcnt waits and one barrier per stage: a misplaced wait would show
+    up as rare, timing-dependent wrong tiles.  300 back-to-back launches (other launches in between to perturb timing) must
+    reproduce the first result bit for bit."""
+    from gomavatar_amd import _lib
+    from gomavatar_amd.lpips import pack_conv_weight
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for (B, H, W, Cin, Cout) in ((1, 256, 256, 128, 128), (2, 200, 136, 64, 128), (1, 64, 64, 256, 256)):
+        x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
+        w = pack_conv_weight(_bf(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).cuda())
+        b = torch.randn(Cout, generator=g).cuda()
+        sp = lib.gom_conv3x3_splits(B, H, W, Cin, Cout)
+        ws = torch.empty(sp * B * H * W * Cout, device="cuda") if sp > 1 else None
+        outs = [torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        junk = torch.empty(1 << 22, device="cuda")
+        def run(o):
+            _lib.check(lib.gom_conv3x3_bf16_splitk(B, H, W, Cin, Cout, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), 0, _lib.ptr(o), 1, sp, _lib.ptr(ws),
+                                                   _lib.stream_ptr()))
+        run(outs[0])
+        for it in range(100):
+            if it % 3 == 0:
+                junk.normal_()          # a bandwidth-heavy neighbour now and then
+            run(outs[1])
+            if it % 10 == 9:
+                assert torch.equal(outs[0], outs[1]), (B, H, W, Cin, Cout, it)
+                outs[1].zero_()
