@@ -42,14 +42,13 @@ static void lp_drop_graph(GomLpipsVgg *h) {
 
 static void lp_free(GomLpipsVgg *h) {
     lp_drop_graph(h);
-    void *ptrs[] = {h->x[0], h->x[1], h->grad[0], h->grad[1], h->gtap, h->splitk, h->go};
+    void *ptrs[] = {h->x[0], h->grad[0], h->grad[1], h->gtap, h->splitk, h->go};   // (x[1], act[1][], pooled[1][] are the second halves of [0])
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int k = 0; k < 2; k++)
-        for (int i = 0; i < 13; i++) {
-            if (h->act[k][i]) (void)hipFree(h->act[k][i]);
-            if (h->pooled[k][i]) (void)hipFree(h->pooled[k][i]);
-            h->act[k][i] = h->pooled[k][i] = nullptr;
-        }
+    for (int i = 0; i < 13; i++) {
+        if (h->act[0][i]) (void)hipFree(h->act[0][i]);
+        if (h->pooled[0][i]) (void)hipFree(h->pooled[0][i]);
+        for (int k = 0; k < 2; k++) h->act[k][i] = h->pooled[k][i] = nullptr;
+    }
     h->x[0] = h->x[1] = h->grad[0] = h->grad[1] = h->gtap = nullptr;
     h->splitk = nullptr; h->go = nullptr;
     h->B = h->H = h->W = 0;
@@ -75,18 +74,25 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
     lp_free(h);
     size_t maxact = 0, maxsplit = 0;
     int hh = H, ww = W;
-    for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->x[k], (size_t)B * H * W * 32 * 2));
+    // prediction and target walk the trunk as ONE batch of 2B images (twice the workgroups per launch, half the launches):
+    // every forward buffer is [2][B][...], its second half is image set 1
+    auto alloc2 = [](void **p0, void **p1, size_t bytes) -> hipError_t {
+        const hipError_t e = hipMalloc(p0, 2 * bytes);
+        *p1 = e == hipSuccess ? (void *)((char *)*p0 + bytes) : nullptr;
+        return e;
+    };
+    GOM_HIP_CHECK(alloc2(&h->x[0], &h->x[1], (size_t)B * H * W * 32 * 2));
     for (int i = 0; i < 13; i++) {
         if (kPoolBefore[i]) {
             hh /= 2; ww /= 2;
-            for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->pooled[k][i], (size_t)B * hh * ww * h->cin[i] * 2));
+            GOM_HIP_CHECK(alloc2(&h->pooled[0][i], &h->pooled[1][i], (size_t)B * hh * ww * h->cin[i] * 2));
         }
         const size_t n = (size_t)B * hh * ww * h->cout[i];
-        for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->act[k][i], n * 2));
+        GOM_HIP_CHECK(alloc2(&h->act[0][i], &h->act[1][i], n * 2));
         maxact = n > maxact ? n : maxact;
         const size_t nin = (size_t)B * hh * ww * (h->cin[i] < 64 ? 64 : h->cin[i]);
         maxact = nin > maxact ? nin : maxact;
-        const size_t sf = (size_t)gom_conv3x3_splits(B, hh, ww, h->cin[i], h->cout[i]) * n;
+        const size_t sf = (size_t)gom_conv3x3_splits(2 * B, hh, ww, h->cin[i], h->cout[i]) * 2 * n;
         const size_t sb = (size_t)gom_conv3x3_splits(B, hh, ww, h->cout[i], h->cin[i] < 64 ? 64 : h->cin[i]) * nin;
         maxsplit = sf > maxsplit ? sf : maxsplit;
         maxsplit = sb > maxsplit ? sb : maxsplit;
@@ -143,18 +149,19 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
                       float *d_pred, void *stream) {
     int rc;
     const float *img[2] = {pred, gt};
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 2; k++)
         if ((rc = gom_lpips_prepare_bf16(B, H, W, img[k], h->x[k], stream))) return rc;
+    {
         int hh = H, ww = W;
-        const void *cur = h->x[k];
+        const void *cur = h->x[0];
         for (int i = 0; i < 13; i++) {
             if (kPoolBefore[i]) {
-                if ((rc = gom_maxpool2x2_bf16(B, hh, ww, h->cin[i], cur, h->pooled[k][i], stream))) return rc;
+                if ((rc = gom_maxpool2x2_bf16(2 * B, hh, ww, h->cin[i], cur, h->pooled[0][i], stream))) return rc;
                 hh /= 2; ww /= 2;
-                cur = h->pooled[k][i];
+                cur = h->pooled[0][i];
             }
-            if ((rc = lp_conv(h, B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k][i], GOM_CONV_RELU, stream))) return rc;
-            cur = h->act[k][i];
+            if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, stream))) return rc;
+            cur = h->act[0][i];
         }
     }
     {   // heads

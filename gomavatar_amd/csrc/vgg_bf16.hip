@@ -37,6 +37,14 @@ constexpr int kPatchW = kTileW + 2;  // 18
 // ones -- the 36 KB weight block is re-read from L2 by every workgroup, so twice the pixels per workgroup halves that traffic
 // (the large layers are L2-bandwidth-bound at 8 rows: 100 flop per byte staged).
 
+// LDS rows are 64 bytes (32 channels of one pixel / one output channel) and a fragment read is one 16-byte k-group of 16
+// consecutive rows per 16 lanes.  ds_read_b128 is served in four 16-lane groups over a 256-byte bank row, so with a 64-byte
+// row stride the rows r and r + 4 of a group collide: 8 LDS cycles instead of 4 per instruction.  XOR-ing the k-group with 2
+// for the rows whose bit 2 is set spreads every group over all 16 slots for ANY start row (the nine taps are shifted windows
+// of the same patch; checked exhaustively over the lane groups of MI355X_MICROARCH.md).  LDS unit (row, slot) holds channel
+// group slot ^ 2 * bit2(row): the writers apply it to the source (LDS-DMA writes linearly), the readers to the address.
+__device__ __forceinline__ int swz_part(int part, int row) { return part ^ (((row >> 2) & 1) << 1); }
+
 // in  [B][H][W][Cin]  bf16 (Cin multiple of 32);  wt [Cin/32][9][Cout][32] bf16 (Cout multiple of 64)
 // out [B][H][W][Cout] bf16;  bias fp32 [Cout] or null;  mask (same shape as out) or null: out *= (mask > 0)
 // SPLITK: blockIdx.z = image * splits + s; this block sums only its share of the input-channel chunks and stores raw fp32
@@ -75,13 +83,13 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = *reinterpret_cast<const uint4 *>(in + (img + (size_t)gy * W + gx) * Cin + cc * kKC + part * 8);
-            *reinterpret_cast<uint4 *>(s_in + px * kKC + part * 8) = v;
+            *reinterpret_cast<uint4 *>(s_in + px * kKC + swz_part(part, px) * 8) = v;
         }
         {
             const bf16_t *wsrc = wt + ((size_t)cc * 9 * Cout + co0) * kKC;
             for (int idx = tid; idx < 9 * kBN * 4; idx += NT) {
                 const int tap = idx >> 8, r = idx & 255;  // 256 16-byte units per tap (64 co x 32 ci)
-                *reinterpret_cast<uint4 *>(s_w + tap * kBN * kKC + r * 8) =
+                *reinterpret_cast<uint4 *>(s_w + tap * kBN * kKC + (r >> 2) * kKC + swz_part(r & 3, r >> 2) * 8) =
                     *reinterpret_cast<const uint4 *>(wsrc + (size_t)tap * Cout * kKC + r * 8);
             }
         }
@@ -91,11 +99,13 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
             const int ky = tap / 3, kx = tap % 3;
             bf16x8 bfrag[2], afrag[4];
 #pragma unroll
-            for (int m = 0; m < 2; m++)
-                bfrag[m] = *reinterpret_cast<const bf16x8 *>(s_in + ((2 * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
+            for (int m = 0; m < 2; m++) {
+                const int px = (2 * wave + m + ky) * kPatchW + l15 + kx;
+                bfrag[m] = *reinterpret_cast<const bf16x8 *>(s_in + px * kKC + swz_part(kg, px) * 8);
+            }
 #pragma unroll
             for (int n = 0; n < 4; n++)
-                afrag[n] = *reinterpret_cast<const bf16x8 *>(s_w + (tap * kBN + n * 16 + l15) * kKC + kg * 8);
+                afrag[n] = *reinterpret_cast<const bf16x8 *>(s_w + (tap * kBN + n * 16 + l15) * kKC + swz_part(kg, l15) * 8);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 #pragma unroll
     for (int j = 0; j < PI; j++) {
         const int u = min(PU * wave + 64 * j + lane, kV2PatchUnits - 1);
-        const int px = u >> 2, part = u & 3;
+        const int px = u >> 2, part = swz_part(u & 3, px);   // LDS unit u holds channel group `part` of its pixel (see swz_part)
         const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
         pin[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
         psrc[j] = pin[j] ? reinterpret_cast<const unsigned char *>(in + (img + (size_t)gy * W + gx) * Cin + part * 8) : zero;
@@ -204,7 +214,8 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 #pragma unroll
     for (int j = 0; j < WI; j++) {
         const int v = min(WU * wave + 64 * j + lane, 3 * kBN * 4 - 1);
-        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)(v & 255) * 8) * 2;   // bytes inside the (chunk, ky) row block
+        const int row = (v & 255) >> 2;                                           // output channel of the unit
+        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)row * kKC + (size_t)swz_part(v & 3, row) * 8) * 2;   // bytes inside the (chunk, ky) row block
     }
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wt + (size_t)co0 * kKC);
 
@@ -247,10 +258,13 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
             bf16x8 bfrag[RPW], afrag[4];
 #pragma unroll
             for (int m = 0; m < RPW; m++)
-                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + ((RPW * wave + m + ky) * kPatchW + l15 + kx) * kKC + kg * 8);
+            {
+                const int px = (RPW * wave + m + ky) * kPatchW + l15 + kx;
+                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + px * kKC + swz_part(kg, px) * 8);
+            }
 #pragma unroll
             for (int n = 0; n < 4; n++)
-                afrag[n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + kg * 8);
+                afrag[n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + swz_part(kg, l15) * 8);
 #pragma unroll
             for (int m = 0; m < RPW; m++)
 #pragma unroll
