@@ -500,6 +500,72 @@ __global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const
     }
 }
 
+// Single-pass variant for the tap widths of VGG16 (C = 64 .. 512): LPP = C / 8 lanes per pixel, every lane keeps its 8 channels
+// of both feature maps in registers across the three phases (norms, weighted difference, gradient), so each feature is read
+// from memory once (the generic kernel above reads it two / three times and idles half its lanes at C = 64).
+template <bool BWD, int LPP>
+__global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
+                                                                        const float *__restrict__ w, const float *__restrict__ grad_out,
+                                                                        float *__restrict__ partials, bf16_t *__restrict__ d_f0) {
+    constexpr int C = 8 * LPP;
+    __shared__ float s_red[16];
+    const size_t b = blockIdx.y;
+    f0 += b * HW * C; f1 += b * HW * C;
+    if (BWD) d_f0 += b * HW * C;
+    const int sub = threadIdx.x & (LPP - 1);
+    const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LPP, ngrp = ((size_t)gridDim.x * blockDim.x) / LPP;
+    const float go = BWD ? grad_out[b] * (2.0f / (float)HW) : 0.f;
+    float wl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) wl[k] = w[sub * 8 + k];
+    float acc = 0.f;
+    for (size_t p = grp; p < HW; p += ngrp) {
+        float x[8], y[8];
+        unpack8(*reinterpret_cast<const uint4 *>(f0 + p * C + sub * 8), x);
+        unpack8(*reinterpret_cast<const uint4 *>(f1 + p * C + sub * 8), y);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s0 += x[k] * x[k]; s1 += y[k] * y[k]; }
+#pragma unroll
+        for (int d = LPP / 2; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+        const float n0 = sqrtf(s0 + kEps);
+        const float i0 = 1.f / (n0 + kEps), i1 = 1.f / (sqrtf(s1 + kEps) + kEps);
+        float v = 0.f;   // forward: sum w d^2 ; backward: sum w d f0
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float d = x[k] * i0 - y[k] * i1;
+            v += BWD ? wl[k] * d * x[k] : wl[k] * d * d;
+        }
+#pragma unroll
+        for (int d = LPP / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (!BWD) {
+            acc += (sub == 0) ? v : 0.f;
+        } else {
+            const float kk = v * i0 * i0 / n0;
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // times the ReLU derivative of the tap's own layer (x = 0 <=> the pre-activation was clipped)
+                const float g0 = x[2 * k] > 0.f ? go * (wl[2 * k] * (x[2 * k] * i0 - y[2 * k] * i1) * i0 - x[2 * k] * kk) : 0.f;
+                const float g1 = x[2 * k + 1] > 0.f ? go * (wl[2 * k + 1] * (x[2 * k + 1] * i0 - y[2 * k + 1] * i1) * i0 - x[2 * k + 1] * kk) : 0.f;
+                o[k] = (uint32_t)f2bf(g0) | ((uint32_t)f2bf(g1) << 16);
+            }
+            *reinterpret_cast<uint4 *>(d_f0 + p * C + sub * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += s_red[k];
+            partials[b * gridDim.x + blockIdx.x] = t / (float)HW;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
@@ -595,6 +661,13 @@ extern "C" int gom_lpips_unprepare_bf16(int B, int H, int W, int Cpad, const voi
 
 extern "C" int gom_lpips_layer_forward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, void *stream) {
     if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_forward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
+#define GOM_HEAD1P(BWD_, LPP_, GRID_, NT_, ...) hipLaunchKernelGGL((k_lpips_head_nhwc_1p<BWD_, LPP_>), GRID_, dim3(NT_), 0, (hipStream_t)stream, __VA_ARGS__)
+    const dim3 grid(GOM_LOSS_BLOCKS, B);
+    if (C == 64) GOM_HEAD1P(false, 8, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
+    else if (C == 128) GOM_HEAD1P(false, 16, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
+    else if (C == 256) GOM_HEAD1P(false, 32, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
+    else if (C == 512) GOM_HEAD1P(false, 64, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
+    else
     hipLaunchKernelGGL(k_lpips_head_nhwc<false>, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w,
                        nullptr, partials, nullptr);
     GOM_LAUNCH_CHECK();
@@ -605,6 +678,12 @@ extern "C" int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const vo
                                                   void *stream) {
     if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_backward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
     const size_t groups = ((size_t)HW + 15) / 16;
+    const dim3 gridb((unsigned)(groups < 4096 ? groups : 4096), B);
+    if (C == 64) GOM_HEAD1P(true, 8, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    else if (C == 128) GOM_HEAD1P(true, 16, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    else if (C == 256) GOM_HEAD1P(true, 32, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    else if (C == 512) GOM_HEAD1P(true, 64, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    else
     hipLaunchKernelGGL(k_lpips_head_nhwc<true>, dim3((unsigned)(groups < 4096 ? groups : 4096), B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0,
                        (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
     GOM_LAUNCH_CHECK();
