@@ -21,6 +21,8 @@ ap.add_argument("--iters", type=int, default=300); ap.add_argument("--img", type
 ap.add_argument("--level", type=int, default=0, help="SMPL-like body subdivisions (0: 13 776 faces)")
 ap.add_argument("--subdivide-at", type=int, default=-1); ap.add_argument("--no-lpips", action="store_true")
 ap.add_argument("--graph", action="store_true", help="capture the whole iteration in one HIP graph (train_util.GraphedTrainStep)")
+ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one kernel per step instead of ~40")
+ap.add_argument("--no-host-sync", action="store_true", help="Model.capture_safe without a graph: no device->host read per iteration, the host runs ahead")
 a = ap.parse_args()
 img = a.img
 cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
@@ -42,14 +44,16 @@ for i in range(8):
         fr["gt_rgb"], fr["gt_mask"] = unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
     frames.append(fr)
 lp = None if a.no_lpips else LPIPSMatrixCore(trunk_seed=0)
-opt = torch.optim.Adam(student.get_param_groups(lr), capturable=a.graph)
+adam_kw = dict(fused=True, capturable=a.graph) if a.fused_adam else dict(capturable=a.graph)
+opt = torch.optim.Adam(student.get_param_groups(lr), **adam_kw)
 for fr in frames:
     fr["target_rgbs"], fr["target_masks"] = fr["gt_rgb"], fr["gt_mask"]                  # the reference's key names (dataset/train.py:272-275)
+student.capture_safe = a.no_host_sync or a.graph
 gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None
 log, t0 = [], time.perf_counter()
 for it in range(a.iters):
     if it == a.subdivide_at:
-        student.subdivide(); opt = torch.optim.Adam(student.get_param_groups(lr), capturable=a.graph)   # train.py:330-340 rebuilds the optimizer
+        student.subdivide(); opt = torch.optim.Adam(student.get_param_groups(lr), **adam_kw)   # train.py:330-340 rebuilds the optimizer
         gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None        # new topology: new capture
     fr = frames[it % 8]
     if gstep is not None:
