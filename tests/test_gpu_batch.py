@@ -106,3 +106,42 @@ def test_batch_new_cameras_need_no_recapture():
         outs.append(batch.image.clone())
     assert torch.equal(outs[0][1], outs[1][1])          # frame 1 unchanged
     assert not torch.equal(outs[0][0], outs[1][0])      # frame 0 got the new pose + camera
+
+
+def test_batch_with_nothing_in_view_and_then_a_normal_one():
+    """No (tile, Gaussian) pair at all: the task queues of the segment kernels find zero tasks, every image is the background,
+    every gradient zero -- and the same state then renders a normal batch (queue heads were reset)."""
+    from gomavatar_amd.pipeline import RenderStep
+    B, img = 2, 96
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    batch = RenderStep(faces, N, (img, img), w25, batch=B)
+    far = []
+    for f in frames:
+        E = f["E"][0].copy()
+        E[2, 3] = -50.0                      # the whole body behind the camera
+        far.append(E)
+    batch.set_cameras([f["K"][0] for f in frames], far, (0.1, 0.2, 0.3, 0.0))
+    batch.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b)
+    torch.cuda.synchronize()
+    D, overflow = batch.state.poll()
+    assert D == 0 and not overflow
+    assert torch.equal(batch.image[:, 3], torch.zeros_like(batch.image[:, 3]))
+    for c, v in enumerate((0.1, 0.2, 0.3)):
+        assert float((batch.image[:, c] - v).abs().max()) == 0.0
+    for k in ("vertices", "so3", "scale", "appearance"):
+        assert float(batch.grads[k].abs().max()) == 0.0
+    batch.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames], (0.1, 0.2, 0.3, 0.0))
+    batch.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b)
+    torch.cuda.synchronize()
+    D, overflow = batch.state.poll()
+    assert D > 0 and not overflow and float(batch.image[:, 3].max()) > 0.9
+    single = RenderStep(faces, N, (img, img), w25)
+    from gomavatar_amd import _lib
+    single.state.set_option(_lib.OPT_SEG_SHIFT, 8)
+    single.set_camera(frames[1]["K"][0], frames[1]["E"][0], (0.1, 0.2, 0.3, 0.0))
+    single.forward_backward(params, {k: fr_b[k][1].contiguous() for k in fr_b}, gt_rgb[1].contiguous(), gt_mask[1].contiguous(), bg_b[1].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(batch.image[1], single.image)
