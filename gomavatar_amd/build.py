@@ -28,6 +28,7 @@ SOURCES = [
     ("lpips_vgg_api.hip", []),
     ("mesh_raster.hip", []),
     ("mesh_losses.hip", []),
+    ("posenc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           f"-I{_INC}", f"-I{_CSRC}"]

@@ -64,6 +64,28 @@ def mesh_edges(faces: torch.Tensor, n_verts: int):
     return torch.from_numpy(edges), torch.from_numpy(f2e)
 
 
+class _PosEnc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, L):
+        lib = _lib.load()
+        x32 = x.detach().float().contiguous()
+        n = x32.numel() // 3
+        out = torch.empty(x32.shape[:-1] + (3 + 6 * L,), dtype=torch.float32, device=x.device)
+        _lib.check(lib.gom_posenc_forward(n, L, _lib.ptr(x32), _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(x32)
+        ctx.L, ctx.dtype = L, x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x32,) = ctx.saved_tensors
+        lib = _lib.load()
+        g32 = g.float().contiguous()
+        dx = torch.empty_like(x32)
+        _lib.check(lib.gom_posenc_backward(x32.numel() // 3, ctx.L, _lib.ptr(x32), _lib.ptr(g32), _lib.ptr(dx), _lib.stream_ptr()))
+        return dx.to(ctx.dtype), None
+
+
 class ShadowModule(nn.Module):
     """shadow_module.py:66-117: positional encoding of the normal (multires frequencies, sin/cos, input included) ->
     MLP (width, depth, optional skip) -> sigmoid.  The last layer starts at U(-1e-5, 1e-5) / zero bias."""
@@ -91,6 +113,8 @@ class ShadowModule(nn.Module):
         last.bias.data.zero_()
 
     def embed(self, x):
+        if x.is_cuda:   # one HIP kernel forward, one backward (csrc/posenc.hip); the torch formula below serves host tensors
+            return _PosEnc.apply(x, self.multires)
         freqs = 2.0 ** torch.linspace(0.0, self.multires - 1, self.multires, device=x.device, dtype=x.dtype)
         out = [x]
         for f in freqs:

@@ -150,6 +150,11 @@ int gom_raster_backward_dcam(GomState *s, int H, int W, const GomCamera *cam_dev
                              float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
                              uint32_t flags, void *stream);
 
+/* ---- positional encoding of the shadow MLP's input (models/modules/shadow_module.py:96-97, utils/network_util.py get_embedder) --
+ * x [n][3] -> out [n][3 + 6 L] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)];  backward: g_out -> dx [n][3]. */
+int gom_posenc_forward(int64_t n, int L, const float *x, float *out, void *stream);
+int gom_posenc_backward(int64_t n, int L, const float *x, const float *g_out, float *dx, void *stream);
+
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]
  * (row-major 3x3 R then T).  fk_save [24][32] keeps the chain for backward. */

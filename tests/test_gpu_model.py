@@ -187,3 +187,17 @@ def test_graphed_train_step_matches_the_eager_iterations():
     # last-bit gradient difference on a near-zero gradient into a +-lr step.  So: within a few steps of each parameter's lr.
     for (a, b), step_size in zip(zip(finals[0][1], finals[1][1]), (5e-5, 5e-4, 5e-4, 5e-3)):
         assert float((a - b).abs().max()) <= 4 * step_size, (tuple(a.shape), float((a - b).abs().max()))
+
+
+def test_fused_positional_encoding_matches_the_torch_formula():
+    """csrc/posenc.hip against ShadowModule.embed's torch path (shadow_module.py:96-97), values and input gradient."""
+    from gomavatar_amd.model import ShadowModule
+    sm = ShadowModule(multires=6)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(1, 5000, 3, generator=g) * 2 - 1)
+    w = torch.randn(1, 5000, 39, generator=g)
+    xc = x.clone().requires_grad_(); (sm.embed(xc) * w).sum().backward()                      # host tensors: the torch formula
+    xg = x.cuda().requires_grad_(); out = sm.embed(xg); (out * w.cuda()).sum().backward()     # device tensors: the HIP kernels
+    assert out.shape == (1, 5000, 39)
+    assert float((out.cpu() - sm.embed(x)).abs().max()) < 2e-6
+    assert float((xg.grad.cpu() - xc.grad).abs().max()) < 1e-4 * float(xc.grad.abs().max())
