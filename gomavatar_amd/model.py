@@ -281,7 +281,8 @@ class Model(nn.Module):
             # shadow_module(normal) for every pixel (model.py:279-282).  The normal map is exactly 0 outside the mesh, where
             # the MLP output is one constant: evaluate it once there and per pixel only under the mesh (~15 % of the image).
             flat = normal.reshape(-1, 3)
-            s_bg = self.shadow_module(torch.zeros(1, 1, 3, device=flat.device, dtype=flat.dtype)).reshape(1, 1)
+            # The all-zero background normal rides along as one extra row of the same MLP call (a second call for that single
+            # row would double the ~25 GEMM launches of the module's forward + backward: the iteration is launch-bound).
             if self.capture_safe:
                 # same result with static shapes: the pixels under the mesh are compacted into a list of fixed capacity
                 # (prefix sum, no nonzero()); every unused slot points at its own dummy row (duplicate indices would send
@@ -292,15 +293,15 @@ class Model(nn.Module):
                 pos = torch.cumsum(under, 0) - 1
                 slot = torch.where(under & (pos < cap), pos, torch.full_like(pos, cap))
                 idx = torch.cat([n + torch.arange(cap, device=flat.device), pos[:1]]).scatter(0, slot, torch.arange(n, device=flat.device))[:cap]
-                flat1 = torch.cat([flat, flat.new_zeros(cap, 3)], 0)
-                s_sel = self.shadow_module(flat1[idx][None]).reshape(-1, 1)
-                s_all = s_bg.expand(n + cap, 1).clone().index_put((idx,), s_sel)[:n]
+                flat1 = torch.cat([flat, flat.new_zeros(cap + 1, 3)], 0)                       # row n + cap: the background normal
+                idx1 = torch.cat([idx, torch.full_like(idx[:1], n + cap)])
+                s_sel = self.shadow_module(flat1[idx1][None]).reshape(-1, 1)
+                s_all = s_sel[-1:].expand(n + cap, 1).clone().index_put((idx,), s_sel[:-1])[:n]
                 s_all = torch.where(pos[-1] >= cap, torch.full_like(s_all, float("nan")), s_all)
             else:
                 idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
-                s_all = s_bg.expand(flat.shape[0], 1).clone()
-                if idx.numel():
-                    s_all = s_all.index_put((idx,), self.shadow_module(flat[idx][None]).reshape(-1, 1))
+                s_sel = self.shadow_module(torch.cat([flat[idx], flat.new_zeros(1, 3)], 0)[None]).reshape(-1, 1)
+                s_all = s_sel[-1:].expand(flat.shape[0], 1).clone().index_put((idx,), s_sel[:-1])
             shadings = s_all.reshape(Bn, H, W, 1) * 2
             rgbs = albedos * shadings
         else:

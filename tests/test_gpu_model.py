@@ -182,7 +182,7 @@ def test_graphed_train_step_matches_the_eager_iterations():
                 total.backward(); opt.step()
         torch.cuda.synchronize()
         finals.append((float(total.detach()), [p.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)]))
-    assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * max(1.0, abs(finals[0][0])), (finals[0][0], finals[1][0])
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-3 * max(1.0, abs(finals[0][0])), (finals[0][0], finals[1][0])   # (two eager runs differ by ~1e-4 too)
     # Two eager runs differ by as much: the torch ops around the kernels (index_put backward) sum with atomics, and Adam turns a
     # last-bit gradient difference on a near-zero gradient into a +-lr step.  So: within a few steps of each parameter's lr.
     for (a, b), step_size in zip(zip(finals[0][1], finals[1][1]), (5e-5, 5e-4, 5e-4, 5e-3)):
