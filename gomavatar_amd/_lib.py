@@ -42,6 +42,7 @@ class GomFrame(ctypes.Structure):
 
 GOM_FRAME_FORWARD_ONLY = 1
 GOM_FRAME_USE_GRAPH = 2
+GOM_FRAME_BACKWARD_ONLY = 4
 
 # name -> (restype, argtypes); every symbol include/gom_hip.h declares
 SIGNATURES = {

@@ -369,17 +369,20 @@ extern "C" int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_
 static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream) {
     const int N = f->N, F = f->F, H = f->H, W = f->W, J = 24;
     int rc;
-    if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
-    if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
-    if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
-                                     f->work_feat, stream)))
-        return rc;
-    if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
-                                  f->work_radii, 0, stream)))
-        return rc;
-    if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
-                                nullptr, f->loss_partials, stream)))
-        return rc;
+    if ((flags & GOM_FRAME_FORWARD_ONLY) && (flags & GOM_FRAME_BACKWARD_ONLY)) { gom_set_error("FORWARD_ONLY and BACKWARD_ONLY together"); return -1; }
+    if (!(flags & GOM_FRAME_BACKWARD_ONLY)) {
+        if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
+        if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
+        if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
+                                         f->work_feat, stream)))
+            return rc;
+        if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
+                                      f->work_radii, 0, stream)))
+            return rc;
+        if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
+                                    nullptr, f->loss_partials, stream)))
+            return rc;
+    }
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
     if ((rc = raster_backward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage,
                                    f->work_dxyz, f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream)))

@@ -127,12 +127,15 @@ class RenderStep:
         return f
 
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
-                         target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False) -> None:
+                         target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False,
+                         image_grad_hook=None) -> None:
         """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 17 kernels.
         params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
         frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
         target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors.
-        With batch=B > 1 every frame/target tensor has a leading B dimension."""
+        With batch=B > 1 every frame/target tensor has a leading B dimension.
+        `image_grad_hook(step)`: called between the forward half (image + d(L1)/d(image) in `self.d_image`) and the backward
+        half of a split call; it may ADD any other image-space gradient to `self.d_image` ((B,)4,H,W) -- see `lpips_hook`."""
         P = _lib.ptr
         f = self._frame
         if f is None:
@@ -143,12 +146,37 @@ class RenderStep:
         f.gt_rgb, f.gt_mask, f.bgcolor = P(target_rgb), P(target_mask), P(bgcolor)
         g = self.grads
         f.g_vertices, f.g_so3, f.g_scale, f.g_appearance = P(g["vertices"]), P(g["so3"]), P(g["scale"]), P(g["appearance"])
-        flags = (0 if backward else _lib.GOM_FRAME_FORWARD_ONLY) | (_lib.GOM_FRAME_USE_GRAPH if graph else 0)
-        if self.B == 1:
-            _lib.check(self.lib.gom_frame_forward_backward(self.state.handle, ctypes.byref(f), flags, _lib.stream_ptr()))
+        gflag = _lib.GOM_FRAME_USE_GRAPH if graph else 0
+
+        def call(flags):
+            if self.B == 1:
+                _lib.check(self.lib.gom_frame_forward_backward(self.state.handle, ctypes.byref(f), flags | gflag, _lib.stream_ptr()))
+            else:
+                _lib.check(self.lib.gom_batch_forward_backward(self.state.handle, ctypes.byref(f), self.B, P(self.cams_dev), flags | gflag,
+                                                               _lib.stream_ptr()))
+        if image_grad_hook is None or not backward:
+            call(0 if backward else _lib.GOM_FRAME_FORWARD_ONLY)
         else:
-            _lib.check(self.lib.gom_batch_forward_backward(self.state.handle, ctypes.byref(f), self.B, P(self.cams_dev), flags,
-                                                           _lib.stream_ptr()))
+            call(_lib.GOM_FRAME_FORWARD_ONLY)
+            image_grad_hook(self)
+            call(_lib.GOM_FRAME_BACKWARD_ONLY)
+
+    def lpips_hook(self, lpips_model, target_rgb: torch.Tensor, bgcolor: torch.Tensor, coeff: float = 1.0):
+        """image_grad_hook adding coeff * sum_b LPIPS(unpack(render_b), target_b) (train.py:53-55, 113-121) to the step: LPIPS value +
+        image gradient from `LPIPSMatrixCore.value_and_grad`, chained through `unpack` into the 4-channel image gradient.
+        The value of the last call is kept in `self.lpips_value` (mean over the batch)."""
+        def hook(step):
+            img = step.image if step.B > 1 else step.image[None]                    # (B,4,H,W)
+            tgt = target_rgb if step.B > 1 else target_rgb[None]
+            bg = (bgcolor if step.B > 1 else bgcolor[None])[:, :, None, None]      # (B,3,1,1)
+            rgb, mask = img[:, :3], img[:, 3:4]
+            unpacked = (rgb * mask + bg * (1 - mask)).permute(0, 2, 3, 1).contiguous()
+            step.lpips_value, d_pred = lpips_model.value_and_grad(unpacked, tgt)    # d(mean_b)/d(pred): (B,H,W,3)
+            d = d_pred.permute(0, 3, 1, 2) * (coeff * step.B)                        # gradients of a batch are SUMMED over its frames
+            di = step.d_image if step.B > 1 else step.d_image[None]
+            di[:, :3] += d * mask
+            di[:, 3:4] += (d * (rgb - bg)).sum(1, keepdim=True)
+        return hook
 
     def losses(self):
         """(L_rgb, L_mask) of the last frame as 0-d device tensors ((B,) tensors when batched)."""

@@ -329,6 +329,10 @@ typedef struct GomFrame {
 } GomFrame;
 
 #define GOM_FRAME_FORWARD_ONLY 1u
+#define GOM_FRAME_BACKWARD_ONLY 4u  /* second half of a split call: the previous call on this state was the same frame with
+                                       GOM_FRAME_FORWARD_ONLY (which also leaves d(L1 losses)/d(image) in work_dimage).  In between the
+                                       caller may ADD any other image-space gradient to work_dimage -- that is how LPIPS
+                                       (gom_lpips_vgg_value_and_grad on the unpacked image, train.py:113-121) joins the native path. */
 #define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
                                        hipGraph on first use and replay it afterwards: one submission instead of 17 */
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);

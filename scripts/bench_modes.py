@@ -5,7 +5,7 @@ at a time (batch 1, the reference's own semantics) unless stated:
   (i)   raster only, fwd+bwd:  one fused 4-channel pass  |  the reference's pattern: two 3-channel calls (gaussian.py:77-94)
   (ii)  render path fwd+bwd = FK + LBS + face Gaussians + raster + L1 losses (bench.py's step), batch 1 and batch 8
   (iii) (ii) + LPIPS-VGG (library fp32 / bf16 trunk, hand-written bf16 MFMA trunk) + Adam on the four parameter tensors
-        [mesh/shadow branch: not built]
+        [the mesh / shadow branch of the whole Model step: scripts/train_synthetic.py]
 
 Prints one JSON object.  Not the graded benchmark (that is bench.py)."""
 import json
@@ -117,6 +117,19 @@ def main():
                 out[f"full_step_lpips_{name}_adam_fps"] = round(timeit(full, n=30, warm=5), 1)
             except Exception as e:  # report, do not hide
                 out[f"full_step_lpips_{name}_adam_fps"] = f"failed: {type(e).__name__}: {e}"
+        # (iii) at batch 8 through the native path: forward half -> LPIPS on 8 unpacked images -> backward half -> Adam on the summed
+        # gradients (RenderStep.lpips_hook); the same "one optimizer step on 8 frames" the 8-GPU frame-parallel run takes.
+        lp8 = LPIPSMatrixCore(trunk_seed=0, device=dev)
+        P8 = {k: v.clone() for k, v in params.items()}
+        for k, v in P8.items():
+            v.grad = stepB.grads[k]
+        opt8 = torch.optim.Adam(list(P8.values()), lr=1e-4)
+        hook8 = stepB.lpips_hook(lp8, gB, bB, coeff=1.0)
+
+        def full8():
+            stepB.forward_backward(P8, frB, gB, mB, bB, graph=True, image_grad_hook=hook8)
+            opt8.step()
+        out["full_step_lpips_bf16_matrix_core_adam_batch8_fps"] = round(B * timeit(full8, n=30, warm=5), 1)
     print(json.dumps(out))
 
 

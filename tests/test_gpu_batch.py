@@ -145,3 +145,61 @@ def test_batch_with_nothing_in_view_and_then_a_normal_one():
     single.forward_backward(params, {k: fr_b[k][1].contiguous() for k in fr_b}, gt_rgb[1].contiguous(), gt_mask[1].contiguous(), bg_b[1].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(batch.image[1], single.image)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_split_call_with_lpips_hook_matches_the_autograd_composition(B):
+    """RenderStep(forward half -> LPIPS value + image gradient chained through unpack -> backward half) against the same step
+    written with the autograd pieces (posed_face_gaussians -> rasterize -> compute_loss_l1 + LPIPSMatrixCore.loss), summed over
+    the frames of the batch."""
+    from gomavatar_amd.pipeline import RenderStep
+    from gomavatar_amd import rasterizer as R
+    from gomavatar_amd.geometry import MeshTopology, posed_face_gaussians
+    from gomavatar_amd.losses import compute_loss_l1
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    img = 96
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    lp = LPIPSMatrixCore(trunk_seed=0)
+    step = RenderStep(faces, N, (img, img), w25, batch=B)
+    sq = (lambda t: t) if B > 1 else (lambda t: t[0].contiguous())
+    if B > 1:
+        step.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames])
+    else:
+        step.set_camera(frames[0]["K"][0], frames[0]["E"][0])
+    step.forward_backward(params, {k: sq(v) for k, v in fr_b.items()}, sq(gt_rgb), sq(gt_mask), sq(bg_b),
+                          image_grad_hook=step.lpips_hook(lp, sq(gt_rgb), sq(bg_b), coeff=0.7))
+    torch.cuda.synchronize()
+    # reference composition, one frame at a time
+    topo = MeshTopology(faces, N, device="cuda")
+    F = faces.shape[0]
+    acc = {k: torch.zeros_like(v) for k, v in params.items()}
+    lp_vals = []
+    single = RenderStep(faces, N, (img, img), w25)
+    if B > 1:
+        from gomavatar_amd import _lib
+        single.state.set_option(_lib.OPT_SEG_SHIFT, 8)     # a batch uses 256-entry segments: same split -> bitwise the same render
+    for b in range(B):
+        P = {k: v.clone().requires_grad_() for k, v in params.items()}
+        single.set_camera(frames[b]["K"][0], frames[b]["E"][0])
+        x, c6, _ = posed_face_gaussians(P["vertices"], P["so3"], P["scale"], fr_b["dst_Rs"][b], fr_b["dst_Ts"][b], fr_b["cnl_gtfms"][b], w25.cuda(), topo, 1e-3)
+        f4 = torch.cat([P["appearance"].T, torch.ones(F, 1, device="cuda")], 1)
+        o, _ = R.rasterize(x, c6, f4, torch.ones(F, device="cuda"), single.cam, state=single.state)
+        total, _ = compute_loss_l1(o, gt_rgb[b], gt_mask[b], bg_b[b])
+        rgb, mask = o[:3].permute(1, 2, 0), o[3]
+        unpacked = rgb * mask[..., None] + bg_b[b] * (1 - mask[..., None])
+        ll = lp.loss(unpacked[None], gt_rgb[b][None])
+        (total + 0.7 * ll).backward()
+        lp_vals.append(float(ll.detach()))
+        for k in acc:
+            acc[k] += P[k].grad
+    assert abs(float(step.lpips_value) - np.mean(lp_vals)) <= 1e-4 * max(1.0, abs(np.mean(lp_vals)))
+    for k in acc:
+        d = float((step.grads[k] - acc[k]).norm()) / max(float(acc[k].norm()), 1e-20)
+        # Without the hook the two paths agree bitwise; with it the image gradients agree to 2e-8 (the order of three additions)
+        # and the geometry gradients -- sums of large cancelling terms under a noise-like LPIPS image gradient -- to 3e-3.
+        # (B = 2: the trunk picks other split-K factors for a 4-image batch, and bf16 activations turn a last-bit difference of a
+        #  partial sum into a flipped rounding somewhere downstream: 1e-3 on every gradient)
+        assert d < (1e-5 if k == "appearance" and B == 1 else 1e-2), (k, d)
