@@ -260,58 +260,90 @@ __global__ void __launch_bounds__(64) k_mesh_combine(MeshGrid g, const uint32_t 
 
 // ---- backward, step 1: one thread per (tile, face) entry -> 9-float record at the entry's list position --------------
 //   [0..5] d/d(x0,y0,x1,y1,x2,y2) from the silhouette, [6..8] d/d(n0+n1+n2) from the normal map
-__global__ void __launch_bounds__(64) k_mesh_backward_entries(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                                const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
                                                                const uint32_t *__restrict__ pix_to_face, const float *__restrict__ prodQ,
                                                                const float *__restrict__ d_normal, const float *__restrict__ d_alpha,
                                                                float *__restrict__ partial, const GomDevStatus *__restrict__ status) {
+    // One workgroup per (tile, <=128-face segment).  The 64 pixels of the tile are staged in LDS once (every entry walks a part of
+    // the same 8x8 pixels; four dependent global loads per visited pixel made the pixel loop a latency chain), and the pixel
+    // rows are split over the four waves: thread = (entry, pair of rows), <= 16 pixels each instead of <= 64, four times the
+    // waves in flight.  The four partial records of an entry are summed in row order (no atomics: reproducible).
+    __shared__ uint32_t s_p2f[64];
+    __shared__ float s_Q[64], s_da[64], s_dn[64][3];
+    __shared__ float s_rec[4][256][9];   // (a segment holds 128 faces, 256 if the state was switched to large segments)
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
-    const uint4 sd = seg_desc[seg];
-    const int tile = (int)sd.x;
-    const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
-    const uint32_t base = sd.y, n = sd.z;
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        const uint32_t f = point_list[base + e];
-        float fg[10];
+        const uint4 sd = seg_desc[seg];
+        const int tile = (int)sd.x;
+        const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
+        const uint32_t base = sd.y, n = sd.z;   // n <= 256
+        __syncthreads();   // the previous segment's readers are done
+        if (threadIdx.x < 64) {
+            const int xi = tx0 + (threadIdx.x & 7), yi = ty0 + (threadIdx.x >> 3);
+            const bool in = xi < g.W && yi < g.H;
+            const size_t p = in ? (size_t)yi * g.W + xi : 0;
+            s_p2f[threadIdx.x] = in ? pix_to_face[p] : 0xffffffffu;
+            s_Q[threadIdx.x] = in ? prodQ[p] : 1.f;
+            s_da[threadIdx.x] = (in && d_alpha) ? d_alpha[p] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; k++) fg[k] = face_geo[(size_t)f * kFaceStride + k];
-        const float xmin = fminf(fminf(fg[0], fg[3]), fg[6]) - blur, xmax = fmaxf(fmaxf(fg[0], fg[3]), fg[6]) + blur;
-        const float ymin = fminf(fminf(fg[1], fg[4]), fg[7]) - blur, ymax = fmaxf(fmaxf(fg[1], fg[4]), fg[7]) + blur;
-        const int ixa = max(tx0, (int)floorf(ndc_to_px(g, xmax) - 1.f)), ixb = min(min(tx0 + kMeshTile, g.W) - 1, (int)ceilf(ndc_to_px(g, xmin) + 1.f));
-        const int iya = max(ty0, (int)floorf(ndc_to_py(g, ymax) - 1.f)), iyb = min(min(ty0 + kMeshTile, g.H) - 1, (int)ceilf(ndc_to_py(g, ymin) + 1.f));
-        float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
-        for (int yi = iya; yi <= iyb; yi++)
-            for (int xi = ixa; xi <= ixb; xi++) {
-                const size_t p = (size_t)yi * g.W + xi;
-                if (pix_to_face[p] == f) { gn[0] += d_normal[3 * p]; gn[1] += d_normal[3 * p + 1]; gn[2] += d_normal[3 * p + 2]; }
-                if (!d_alpha) continue;
-                const float px = pix_x(g, xi), py = pix_y(g, yi);
-                const FaceEval r = eval_face(fg, px, py, blur, blur_radius, inv_sigma);
-                if (!r.soft) continue;
-                // alpha = 1 - prod(1 - p_j), p = sigmoid(-sd/sigma):  d alpha / d sd_k = -(Q / (1 - p_k)) p_k (1 - p_k) / sigma
-                const float others = prodQ[p] / fmaxf(1.f - r.prob, 1e-30f);
-                float gd = -d_alpha[p] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
-                if (r.inside) gd = -gd;                                                    // sd = -dist inside
-                const int ia = r.edge, ib = (r.edge + 1) % 3;
-                const float ax = fg[3 * ia], ay = fg[3 * ia + 1], bx = fg[3 * ib], by = fg[3 * ib + 1];
-                if (r.degenerate) {
-                    gv[2 * ib] += gd * -2.f * (px - bx); gv[2 * ib + 1] += gd * -2.f * (py - by);
-                } else {
-                    const float qx = ax + r.t * (bx - ax), qy = ay + r.t * (by - ay);
-                    const float rx = px - qx, ry = py - qy;
-                    // dist = |p - q|^2, q = a + t (b - a): for 0 < t < 1 the residual is normal to the edge, so only q's
-                    // explicit dependence on a, b counts; at the clamps q is the end point itself
-                    gv[2 * ia] += gd * -2.f * rx * (1.f - r.t); gv[2 * ia + 1] += gd * -2.f * ry * (1.f - r.t);
-                    gv[2 * ib] += gd * -2.f * rx * r.t;         gv[2 * ib + 1] += gd * -2.f * ry * r.t;
+            for (int c = 0; c < 3; c++) s_dn[threadIdx.x][c] = in ? d_normal[3 * p + c] : 0.f;
+        }
+        __syncthreads();
+        for (uint32_t e = lane; e < n; e += 64) {
+            const uint32_t f = point_list[base + e];
+            float fg[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) fg[k] = face_geo[(size_t)f * kFaceStride + k];
+            const float xmin = fminf(fminf(fg[0], fg[3]), fg[6]) - blur, xmax = fmaxf(fmaxf(fg[0], fg[3]), fg[6]) + blur;
+            const float ymin = fminf(fminf(fg[1], fg[4]), fg[7]) - blur, ymax = fmaxf(fmaxf(fg[1], fg[4]), fg[7]) + blur;
+            const int ixa = max(tx0, (int)floorf(ndc_to_px(g, xmax) - 1.f)), ixb = min(min(tx0 + kMeshTile, g.W) - 1, (int)ceilf(ndc_to_px(g, xmin) + 1.f));
+            int iya = max(ty0, (int)floorf(ndc_to_py(g, ymax) - 1.f)), iyb = min(min(ty0 + kMeshTile, g.H) - 1, (int)ceilf(ndc_to_py(g, ymin) + 1.f));
+            iya = max(iya, ty0 + 2 * part);          // this wave's two pixel rows
+            iyb = min(iyb, ty0 + 2 * part + 1);
+            float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+            for (int yi = iya; yi <= iyb; yi++)
+                for (int xi = ixa; xi <= ixb; xi++) {
+                    const int lp = (yi - ty0) * kMeshTile + (xi - tx0);
+                    if (s_p2f[lp] == f) { gn[0] += s_dn[lp][0]; gn[1] += s_dn[lp][1]; gn[2] += s_dn[lp][2]; }
+                    if (!d_alpha) continue;
+                    const float px = pix_x(g, xi), py = pix_y(g, yi);
+                    const FaceEval r = eval_face(fg, px, py, blur, blur_radius, inv_sigma);
+                    if (!r.soft) continue;
+                    // alpha = 1 - prod(1 - p_j), p = sigmoid(-sd/sigma):  d alpha / d sd_k = -(Q / (1 - p_k)) p_k (1 - p_k) / sigma
+                    const float others = s_Q[lp] / fmaxf(1.f - r.prob, 1e-30f);
+                    float gd = -s_da[lp] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
+                    if (r.inside) gd = -gd;                                                    // sd = -dist inside
+                    const int ia = r.edge, ib = (r.edge + 1) % 3;
+                    const float ax = fg[3 * ia], ay = fg[3 * ia + 1], bx = fg[3 * ib], by = fg[3 * ib + 1];
+                    if (r.degenerate) {
+                        gv[2 * ib] += gd * -2.f * (px - bx); gv[2 * ib + 1] += gd * -2.f * (py - by);
+                    } else {
+                        const float qx = ax + r.t * (bx - ax), qy = ay + r.t * (by - ay);
+                        const float rx = px - qx, ry = py - qy;
+                        // dist = |p - q|^2, q = a + t (b - a): for 0 < t < 1 the residual is normal to the edge, so only q's
+                        // explicit dependence on a, b counts; at the clamps q is the end point itself
+                        gv[2 * ia] += gd * -2.f * rx * (1.f - r.t); gv[2 * ia + 1] += gd * -2.f * ry * (1.f - r.t);
+                        gv[2 * ib] += gd * -2.f * rx * r.t;         gv[2 * ib + 1] += gd * -2.f * ry * r.t;
+                    }
                 }
-            }
-        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(base + e) * GOM_PARTIAL_STRIDE);
-        rec[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
-        rec[1] = make_float4(gv[4], gv[5], gn[0], gn[1]);
-        rec[2] = make_float4(gn[2], 0.f, 0.f, 0.f);
-    }
+#pragma unroll
+            for (int k = 0; k < 6; k++) s_rec[part][e][k] = gv[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) s_rec[part][e][6 + k] = gn[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < n) {
+            float r9[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) r9[k] = ((s_rec[0][threadIdx.x][k] + s_rec[1][threadIdx.x][k]) + s_rec[2][threadIdx.x][k]) + s_rec[3][threadIdx.x][k];
+            float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(base + threadIdx.x) * GOM_PARTIAL_STRIDE);
+            rec[0] = make_float4(r9[0], r9[1], r9[2], r9[3]);
+            rec[1] = make_float4(r9[4], r9[5], r9[6], r9[7]);
+            rec[2] = make_float4(r9[8], 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -474,7 +506,7 @@ extern "C" int gom_mesh_raster_backward(GomState *s, int N, int F, int H, int W,
     hipStream_t st = (hipStream_t)stream;
     const MeshGrid g = make_grid(H, W);
     float *d_face = s->mesh_face + s->capMeshFace;
-    hipLaunchKernelGGL(k_mesh_backward_entries, dim3(8192), dim3(64), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, sqrtf(s->meshBlurRadius),
+    hipLaunchKernelGGL(k_mesh_backward_entries, dim3(8192), dim3(256), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, sqrtf(s->meshBlurRadius),
                        s->meshBlurRadius, 1.0f / s->meshSigma, s->n_contrib, s->final_T, d_normal_map, d_alpha, s->partial, s->status);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mesh_face_gather, dim3((F + 255) / 256), dim3(256), 0, st, F, s->tiles_touched, s->pair_off, s->pair_pos, s->partial, d_face,
