@@ -174,54 +174,68 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
 // A UV-sphere pole or a crumpled region puts thousands of faces into one tile; min-z and the product over faces are
 // associative, so the lists are cut into the same 128-entry segments as the splat lists (seg_desc of k_sort) and every
 // segment is an independent wave.  Partial results: product of (1 - p), nearest depth and its face per pixel.
+// Four waves per segment: wave w takes the faces [w n/4, (w+1) n/4) of the segment for all 64 pixels (a lone wave per 128 faces
+// left ~2.7 waves per SIMD, each a ~9 000-instruction chain), the four partial (product, nearest z, face) triples are folded in
+// list order in LDS.
 constexpr int kChunk = 64;
-__global__ void __launch_bounds__(64) k_mesh_forward_seg(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
-                                                         const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
-                                                         float *__restrict__ seg_Q, float *__restrict__ seg_z, uint32_t *__restrict__ seg_face,
-                                                         const GomDevStatus *__restrict__ status) {
-    __shared__ float s_f[kChunk][10];
-    __shared__ uint32_t s_id[kChunk];
+__global__ void __launch_bounds__(256) k_mesh_forward_seg(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+                                                          const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
+                                                          float *__restrict__ seg_Q, float *__restrict__ seg_z, uint32_t *__restrict__ seg_face,
+                                                          const GomDevStatus *__restrict__ status) {
+    __shared__ float s_f[4][kChunk][10];
+    __shared__ uint32_t s_id[4][kChunk];
+    __shared__ float s_pQ[4][64], s_pz[4][64];
+    __shared__ uint32_t s_pf[4][64];
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
         const uint4 d = seg_desc[seg];
         const int tile = (int)d.x;
-        const uint32_t start = d.y, n = d.z;
+        const uint32_t n_all = d.z, per = (n_all + 3) / 4;
+        const uint32_t first = min((uint32_t)w * per, n_all), n = min(per, n_all - first), start = d.y + first;
         const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
         const float px = pix_x(g, tx0 + (lane & 7)), py = pix_y(g, ty0 + (lane >> 3));
         // the wave's pixel rectangle in NDC (+X left / +Y up: the first pixel has the largest coordinate)
         const float wx_hi = pix_x(g, tx0), wx_lo = pix_x(g, min(tx0 + kMeshTile, g.W) - 1), wy_hi = pix_y(g, ty0), wy_lo = pix_y(g, min(ty0 + kMeshTile, g.H) - 1);
         float best_z = 3.0e38f, Q = 1.f;
         uint32_t best = 0xffffffffu;
-        for (uint32_t e0 = 0; e0 < n; e0 += kChunk) {
+        for (uint32_t e0 = 0; e0 < n; e0 += kChunk) {   // (wave-private LDS slices: no workgroup barrier inside)
             const uint32_t cn = min((uint32_t)kChunk, n - e0);
-            __syncthreads();
             bool reach = false;
             if ((uint32_t)lane < cn) {   // lane = face: stage it and test its blurred box against the wave's rectangle
                 const uint32_t f = point_list[start + e0 + lane];
                 const float *src = face_geo + (size_t)f * kFaceStride;
                 float v[10];
 #pragma unroll
-                for (int k = 0; k < 10; k++) { v[k] = src[k]; s_f[lane][k] = v[k]; }
-                s_id[lane] = f;
+                for (int k = 0; k < 10; k++) { v[k] = src[k]; s_f[w][lane][k] = v[k]; }
+                s_id[w][lane] = f;
                 const float xmin = fminf(fminf(v[0], v[3]), v[6]) - blur, xmax = fmaxf(fmaxf(v[0], v[3]), v[6]) + blur;
                 const float ymin = fminf(fminf(v[1], v[4]), v[7]) - blur, ymax = fmaxf(fmaxf(v[1], v[4]), v[7]) + blur;
                 reach = !(wx_lo > xmax || wx_hi < xmin || wy_lo > ymax || wy_hi < ymin);
             }
             unsigned long long todo = __ballot(reach);
-            __syncthreads();
             while (todo) {   // wave-uniform loop over the faces that can touch this tile at all
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const FaceEval r = eval_face(s_f[j], px, py, blur, blur_radius, inv_sigma);
-                if (r.hard && r.z_hard < best_z) { best_z = r.z_hard; best = s_id[j]; }   // ascending face index: first wins ties
+                const FaceEval r = eval_face(s_f[w][j], px, py, blur, blur_radius, inv_sigma);
+                if (r.hard && r.z_hard < best_z) { best_z = r.z_hard; best = s_id[w][j]; }   // ascending face index: first wins ties
                 if (r.soft) Q *= (1.f - r.prob);
             }
         }
-        seg_Q[(size_t)seg * 64 + lane] = Q;
-        seg_z[(size_t)seg * 64 + lane] = best_z;
-        seg_face[(size_t)seg * 64 + lane] = best;
+        __syncthreads();   // the previous segment's fold is done
+        s_pQ[w][lane] = Q; s_pz[w][lane] = best_z; s_pf[w][lane] = best;
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                Q *= s_pQ[k][lane];
+                if (s_pz[k][lane] < best_z) { best_z = s_pz[k][lane]; best = s_pf[k][lane]; }
+            }
+            seg_Q[(size_t)seg * 64 + lane] = Q;
+            seg_z[(size_t)seg * 64 + lane] = best_z;
+            seg_face[(size_t)seg * 64 + lane] = best;
+        }
     }
 }
 
@@ -489,7 +503,7 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
     GOM_LAUNCH_CHECK();
     if (int rc = gom_launch_scan_emit(s, F, st)) return rc;
     if (int rc = gom_launch_sort(s, st)) return rc;
-    hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(64), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
+    hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(256), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
                        s->seg_T, s->seg_Tend, s->seg_last, s->status);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mesh_combine, dim3(g.gx * g.gy), dim3(64), 0, st, g, s->seg_base, s->seg_T, s->seg_Tend, s->seg_last, faces, vnormals,

@@ -26,3 +26,5 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 for e in sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)[:6]:
     print("%8.1f us  %s" % (e.self_device_time_total / 10, e.key[:70]))
+D, ov = r.state.poll()
+print("mesh pairs D =", D, "-> segments of 128 >=", D // 128)
