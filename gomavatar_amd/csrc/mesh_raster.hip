@@ -174,25 +174,28 @@ __global__ void __launch_bounds__(256) k_mesh_preprocess(MeshGrid g, int F, cons
 // A UV-sphere pole or a crumpled region puts thousands of faces into one tile; min-z and the product over faces are
 // associative, so the lists are cut into the same 128-entry segments as the splat lists (seg_desc of k_sort) and every
 // segment is an independent wave.  Partial results: product of (1 - p), nearest depth and its face per pixel.
-// Four waves per segment: wave w takes the faces [w n/4, (w+1) n/4) of the segment for all 64 pixels (a lone wave per 128 faces
+// MESH_FW waves per segment: wave w takes the faces [w n/MESH_FW, (w+1) n/MESH_FW) of the segment for all 64 pixels (a lone wave per 128 faces
 // left ~2.7 waves per SIMD, each a ~9 000-instruction chain), the four partial (product, nearest z, face) triples are folded in
 // list order in LDS.
+#ifndef MESH_FW
+#define MESH_FW 8   // waves per segment (2: 115 us, 4: 89 us, 8: 83 us at 55 104 faces, 512x512)
+#endif
 constexpr int kChunk = 64;
-__global__ void __launch_bounds__(256) k_mesh_forward_seg(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(64 * MESH_FW) k_mesh_forward_seg(MeshGrid g, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                           const float *__restrict__ face_geo, float blur, float blur_radius, float inv_sigma,
                                                           float *__restrict__ seg_Q, float *__restrict__ seg_z, uint32_t *__restrict__ seg_face,
                                                           const GomDevStatus *__restrict__ status) {
-    __shared__ float s_f[4][kChunk][10];
-    __shared__ uint32_t s_id[4][kChunk];
-    __shared__ float s_pQ[4][64], s_pz[4][64];
-    __shared__ uint32_t s_pf[4][64];
+    __shared__ float s_f[MESH_FW][kChunk][10];
+    __shared__ uint32_t s_id[MESH_FW][kChunk];
+    __shared__ float s_pQ[MESH_FW][64], s_pz[MESH_FW][64];
+    __shared__ uint32_t s_pf[MESH_FW][64];
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
         const uint4 d = seg_desc[seg];
         const int tile = (int)d.x;
-        const uint32_t n_all = d.z, per = (n_all + 3) / 4;
+        const uint32_t n_all = d.z, per = (n_all + MESH_FW - 1) / MESH_FW;
         const uint32_t first = min((uint32_t)w * per, n_all), n = min(per, n_all - first), start = d.y + first;
         const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
         const float px = pix_x(g, tx0 + (lane & 7)), py = pix_y(g, ty0 + (lane >> 3));
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256) k_mesh_forward_seg(MeshGrid g, const uint
         __syncthreads();
         if (w == 0) {
 #pragma unroll
-            for (int k = 1; k < 4; k++) {
+            for (int k = 1; k < MESH_FW; k++) {
                 Q *= s_pQ[k][lane];
                 if (s_pz[k][lane] < best_z) { best_z = s_pz[k][lane]; best = s_pf[k][lane]; }
             }
@@ -503,7 +506,7 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
     GOM_LAUNCH_CHECK();
     if (int rc = gom_launch_scan_emit(s, F, st)) return rc;
     if (int rc = gom_launch_sort(s, st)) return rc;
-    hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(256), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
+    hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(64 * MESH_FW), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
                        s->seg_T, s->seg_Tend, s->seg_last, s->status);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mesh_combine, dim3(g.gx * g.gy), dim3(64), 0, st, g, s->seg_base, s->seg_T, s->seg_Tend, s->seg_last, faces, vnormals,
