@@ -62,6 +62,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_raster_backward_dcam": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "gom_linear_wgrad_slices": (c_int, []),
+    "gom_linear_wgrad": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_posenc_forward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "gom_posenc_backward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_fk_forward": (c_int, [c_void_p] * 6),

@@ -29,6 +29,7 @@ SOURCES = [
     ("mesh_raster.hip", []),
     ("mesh_losses.hip", []),
     ("posenc.hip", []),
+    ("mlp.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           f"-I{_INC}", f"-I{_CSRC}"]

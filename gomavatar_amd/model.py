@@ -86,6 +86,31 @@ class _PosEnc(torch.autograd.Function):
         return dx.to(ctx.dtype), None
 
 
+class _LinearLongBatch(torch.autograd.Function):
+    """F.linear whose weight / bias gradients come from csrc/mlp.hip (rows split over the workgroups); the forward and the input
+    gradient are ordinary library GEMMs (their long dimension is M, which the library tiles well)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        lib = _lib.load()
+        out_dim, in_dim = weight.shape
+        g2 = g.reshape(-1, out_dim).float().contiguous()
+        x2 = x.reshape(-1, in_dim).float().contiguous()
+        dW = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty(out_dim, dtype=torch.float32, device=weight.device) if ctx.has_bias else None
+        ws = torch.empty(lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=weight.device)
+        _lib.check(lib.gom_linear_wgrad(x2.shape[0], in_dim, out_dim, _lib.ptr(x2), _lib.ptr(g2), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr()))
+        dx = (g2 @ weight.float()).reshape(x.shape).to(x.dtype) if ctx.needs_input_grad[0] else None
+        return dx, dW.to(weight.dtype), (db.to(weight.dtype) if ctx.has_bias else None)
+
+
 class ShadowModule(nn.Module):
     """shadow_module.py:66-117: positional encoding of the normal (multires frequencies, sin/cos, input included) ->
     MLP (width, depth, optional skip) -> sigmoid.  The last layer starts at U(-1e-5, 1e-5) / zero bias."""
@@ -127,7 +152,10 @@ class ShadowModule(nn.Module):
         for i, layer in enumerate(self.block_mlps):
             if i in self.layers_to_cat_inputs:
                 h = torch.cat([h, pe], -1)
-            h = layer(h)
+            if isinstance(layer, nn.Linear) and h.is_cuda and layer.in_features <= 128 and layer.out_features <= 128 and torch.is_grad_enabled():
+                h = _LinearLongBatch.apply(h, layer.weight, layer.bias)      # same values; the weight gradient takes the HIP kernel
+            else:
+                h = layer(h)
         return torch.sigmoid(h)
 
 

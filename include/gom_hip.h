@@ -155,6 +155,13 @@ int gom_raster_backward_dcam(GomState *s, int H, int W, const GomCamera *cam_dev
 int gom_posenc_forward(int64_t n, int L, const float *x, float *out, void *stream);
 int gom_posenc_backward(int64_t n, int L, const float *x, const float *g_out, float *dx, void *stream);
 
+/* ---- weight / bias gradient of a Linear layer with a long batch dimension (the shadow MLP, models/modules/shadow_module.py:66-117:
+ * one row per pixel under the mesh): dW [out][in] = dY^T X, db [out] = column sums of dY (may be NULL); X [n][in], dY [n][out],
+ * in, out <= 128.  workspace: gom_linear_wgrad_slices() * 129 * 128 floats.  Rows are split over the workgroups, partials summed
+ * in a fixed order. */
+int gom_linear_wgrad_slices(void);
+int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float *X, const float *dY, float *dW, float *db, float *workspace, void *stream);
+
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]
  * (row-major 3x3 R then T).  fk_save [24][32] keeps the chain for backward. */
