@@ -30,10 +30,13 @@
 //                  behind the segment, colour still to come) for the backward.
 //   k_seg_bwd      per (segment, sub-range), 4 quadrants per workgroup:
 //                  back-to-front replay from the checkpoint; the 6+C per-pixel
-//                  terms of every entry are reduced over the wave with fused
-//                  v_add_f32_dpp chains, the four quadrants are summed in LDS in
-//                  a fixed order and one 48-byte record per (tile, entry) is
-//                  written.  No float atomics anywhere.
+//                  terms of every entry are reduced over the wave with a
+//                  transposed tree (v_permlane32/16_swap halve the live registers,
+//                  four in-row v_add_f32_dpp steps finish), the four quadrants are
+//                  summed in LDS in a fixed order and one 48-byte record per
+//                  (tile, entry) is written.  No float atomics anywhere.
+// In a batched launch the three segment kernels run as exactly-resident grids that
+// draw their (segment, piece) tasks from a sharded queue (TaskQueue below).
 //
 // Inside a wave, lane = pixel.  Per sub-range lane = ENTRY first: every lane
 // tests one entry against the wave's 8x8 rectangle with a conservative bound on
