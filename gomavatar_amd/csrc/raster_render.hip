@@ -79,51 +79,7 @@ __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
-    return v + __int_as_float(m);
-}
-
-// Sum over the 64 lanes; the total lands in lane 63 (other lanes hold prefixes).
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);  // row_shr:8
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-// Sums NV registers over the 64 lanes (totals land in lane 63), one fused v_add_f32_dpp per value and step.
-// The NV chains are interleaved so that every DPP read is >= NV instructions behind the write it depends on
-// (the 2-wait-state VALU->DPP hazard is covered; the leading s_nop covers the producers of the inputs).
-template <int NV>
-__device__ __forceinline__ void wave_sum_lane63_n(float (&v)[NV]) {
-    static_assert(NV == 9 || NV == 10, "6 + C values");
-#define GOM_DPP_STEP(CTRL)                                                                                          \
-    "v_add_f32_dpp %0, %0, %0 " CTRL "\n v_add_f32_dpp %1, %1, %1 " CTRL "\n v_add_f32_dpp %2, %2, %2 " CTRL "\n"     \
-    "v_add_f32_dpp %3, %3, %3 " CTRL "\n v_add_f32_dpp %4, %4, %4 " CTRL "\n v_add_f32_dpp %5, %5, %5 " CTRL "\n"     \
-    "v_add_f32_dpp %6, %6, %6 " CTRL "\n v_add_f32_dpp %7, %7, %7 " CTRL "\n v_add_f32_dpp %8, %8, %8 " CTRL "\n"
-#define GOM_DPP_STEP10(CTRL) GOM_DPP_STEP(CTRL) "v_add_f32_dpp %9, %9, %9 " CTRL "\n"
-#define GOM_DPP_ALL(STEP)                                                                                           \
-    "s_nop 1\n" STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
-    STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")             \
-    STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-    if constexpr (NV == 10) {
-        asm volatile(GOM_DPP_ALL(GOM_DPP_STEP10)
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
-    } else {
-        asm volatile(GOM_DPP_ALL(GOM_DPP_STEP)
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
-    }
-#undef GOM_DPP_ALL
-#undef GOM_DPP_STEP10
-#undef GOM_DPP_STEP
-}
-
-// Transposed variant for 10 values: v_permlane32_swap / v_permlane16_swap exchange halves (rows) of two registers, so
+// Sum of 10 registers over the 64 lanes, transposed tree: v_permlane32_swap / v_permlane16_swap exchange halves (rows) of two registers, so
 // one swap + one add folds a level of the tree for TWO values and halves the number of live registers
 // (10 -> 5 -> 3); only the four in-row steps remain as DPP adds on 3 registers.  34 wave instructions instead of
 // 60 (scripts/ubench: ~130 issue cycles instead of ~265).  Totals land in lane 15 of each 16-lane row:
