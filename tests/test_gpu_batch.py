@@ -203,3 +203,29 @@ def test_split_call_with_lpips_hook_matches_the_autograd_composition(B):
         # (B = 2: the trunk picks other split-K factors for a 4-image batch, and bf16 activations turn a last-bit difference of a
         #  partial sum into a flipped rounding somewhere downstream: 1e-3 on every gradient)
         assert d < (1e-5 if k == "appearance" and B == 1 else 1e-2), (k, d)
+
+
+def test_batch_with_small_segments_equals_single_frames_bitwise():
+    """GOM_OPT_SEG_SHIFT = 7 in a batched launch: the task queue then hands out 128-entry segments / 32-entry sub-ranges."""
+    from gomavatar_amd.pipeline import RenderStep
+    from gomavatar_amd import _lib
+    B, img = 2, 128
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    single = RenderStep(faces, N, (img, img), w25)          # single frames default to 128-entry segments
+    imgs, grads = [], []
+    for b in range(B):
+        single.set_camera(frames[b]["K"][0], frames[b]["E"][0])
+        single.forward_backward(params, {k: fr_b[k][b].contiguous() for k in fr_b}, gt_rgb[b].contiguous(), gt_mask[b].contiguous(), bg_b[b].contiguous())
+        torch.cuda.synchronize()
+        imgs.append(single.image.clone()); grads.append({k: v.clone() for k, v in single.grads.items()})
+    batch = RenderStep(faces, N, (img, img), w25, batch=B)
+    batch.state.set_option(_lib.OPT_SEG_SHIFT, 7)
+    batch.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames])
+    batch.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b)
+    torch.cuda.synchronize()
+    assert torch.equal(batch.image, torch.stack(imgs))
+    for k in ("vertices", "so3", "scale", "appearance"):
+        assert torch.equal(batch.grads[k], grads[0][k] + grads[1][k]), k
