@@ -146,9 +146,17 @@ __device__ __forceinline__ bool cull_entry(float cx, float cy, float a, float b,
 
 // alpha of one entry at one pixel with the reference's skip rules folded in:
 // returns 0 when the reference would `continue` (power > 0 or alpha < 1/255).
+// power = -0.5 (a dx^2 + c dy^2) - b dx dy, written out operation by operation (no contraction left to the compiler): the
+// transmittance pre-pass, the compositing pass and the backward must see bit-identical alphas whether their operands arrive in
+// SGPRs (v_readlane) or VGPRs (LDS broadcast) -- sum_i alpha_i T_i + T_final = 1 only holds to 3e-6 if they do.
+__device__ __forceinline__ float gauss_power(float ea, float eb, float ec, float dx, float dy) {
+    const float q = __fmaf_rn(dx, __fmul_rn(ea, dx), __fmul_rn(dy, __fmul_rn(ec, dy)));
+    return __fsub_rn(__fmul_rn(-0.5f, q), __fmul_rn(dx, __fmul_rn(eb, dy)));
+}
+
 __device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float eb, float ec, float eo, float pfx, float pfy) {
     const float dx = ex - pfx, dy = ey - pfy;
-    const float power = -0.5f * (ea * dx * dx + ec * dy * dy) - eb * dx * dy;
+    const float power = gauss_power(ea, eb, ec, dx, dy);
     float a = fminf(kMaxAlpha, eo * __expf(power));
     a = (power <= 0.f) ? a : 0.f;
     a = (a >= kMinAlpha) ? a : 0.f;
@@ -975,7 +983,7 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
                     const float ea = rl(r.a, k), eb = rl(r.b, k), ec = rl(r.c, k);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
-                    const float power = -0.5f * (ea * dx * dx + ec * dy * dy) - eb * dx * dy;
+                    const float power = gauss_power(ea, eb, ec, dx, dy);
                     const float g = __expf(power);
                     float a = fminf(kMaxAlpha, eo * g);
                     a = (power <= 0.f) ? a : 0.f;
