@@ -895,6 +895,10 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
     __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
     __shared__ unsigned long long s_done[2][4];
     __shared__ uint32_t s_task[2];
+    // geometry of the survivors through wave-private LDS broadcast slabs (as in the forward kernels); the colours stay on
+    // v_readlane: with them the workgroup would no longer fit six times into a CU's LDS
+    __shared__ float4 s_e0[4][64];
+    __shared__ float2 s_e1[4][64];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
@@ -988,6 +992,8 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
                 last_color[ch] = 0.f;
             }
             unsigned long long mask = __ballot(r.keep);
+            s_e0[q][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
+            s_e1[q][lane] = make_float2(r.c, r.o);
             // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
             // T / accum_rec recurrences, then the transposed reductions.
             while (mask) {
@@ -1000,9 +1006,11 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
                     const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
                     mask &= ~(1ull << k);  // k = 0 when the mask is already empty: clearing bit 0 of 0 is a no-op
                     kk[u] = k;
-                    const float eo = kv[u] ? rl(r.o, k) : 0.f;
-                    const float dx = rl(r.x, k) - pfx, dy = rl(r.y, k) - pfy;
-                    const float ea = rl(r.a, k), eb = rl(r.b, k), ec = rl(r.c, k);
+                    const float4 g0 = s_e0[q][k];
+                    const float2 g1 = s_e1[q][k];
+                    const float eo = kv[u] ? g1.y : 0.f;
+                    const float dx = g0.x - pfx, dy = g0.y - pfy;
+                    const float ea = g0.z, eb = g0.w, ec = g1.x;
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
                     const float power = gauss_power(ea, eb, ec, dx, dy);
