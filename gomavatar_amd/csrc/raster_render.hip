@@ -394,6 +394,9 @@ struct EntryRegs {
 // most independent waves; a batched launch has parallelism to spare and halves the per-task fixed cost (checkpoint loads,
 // cull, LDS fold, stores -- measured at 40-60 % of these kernels) with 256 / 64.
 #define GOM_NSUB 4
+#ifndef GOM_FWD_EPT
+#define GOM_FWD_EPT 4   // entries evaluated per trip of the forward loops
+#endif
 #define GOM_SUB_MAX 64
 
 // The <=32 entries of this wave's sub-range, read straight from the list-ordered records the sort left behind
@@ -563,9 +566,9 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
             s_e1[sub][lane] = make_float2(r.c, r.o);
             while (mask) {
-                float al[4];
+                float al[GOM_FWD_EPT];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < GOM_FWD_EPT; u++) {
                     const bool kv = mask != 0ull;
                     const int k = kv ? __builtin_ctzll(mask) : 0;
                     mask &= mask - 1;
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
                     al[u] = entry_alpha(e0.x, e0.y, e0.z, e0.w, e1.x, kv ? e1.y : 0.f, pfx, pfy);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) T = T * (1.f - al[u]);
+                for (int u = 0; u < GOM_FWD_EPT; u++) T = T * (1.f - al[u]);
             }
         }
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
@@ -684,10 +687,10 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
                 s_e2[sub][lane] = cl;
             }
             while (mask) {
-                int kk[4];
-                float al[4], ecol[4][C];
+                int kk[GOM_FWD_EPT];
+                float al[GOM_FWD_EPT], ecol[GOM_FWD_EPT][C];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {  // independent alpha evaluations (ILP)
+                for (int u = 0; u < GOM_FWD_EPT; u++) {  // independent alpha evaluations (ILP)
                     const bool kv = mask != 0ull;
                     const int k = kv ? __builtin_ctzll(mask) : 0;
                     mask &= mask - 1;
@@ -701,7 +704,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
                     for (int ch = 0; ch < C; ch++) ecol[u][ch] = cv[ch];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {  // the serial chain: T -> test_T -> select
+                for (int u = 0; u < GOM_FWD_EPT; u++) {  // the serial chain: T -> test_T -> select
                     const float a = al[u] * wl;
                     const float test_T = T * (1.f - a);
                     const bool cont = test_T >= kStopT;  // reference: `test_T < 0.0001f -> done`
@@ -878,8 +881,14 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 }
 
 // ---------------------------------------------------------------- backward -
+#ifndef GOM_BWD_EPT
+#define GOM_BWD_EPT 2   // entries evaluated per trip of the backward loop (4: 8 VGPRs spilled at 6 waves per SIMD, 215 us; 3: 205; 2: 203)
+#endif
+#ifndef GOM_BWD_WAVES
+#define GOM_BWD_WAVES 6
+#endif
 template <int C>
-__global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
@@ -997,11 +1006,11 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
             // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
             // T / accum_rec recurrences, then the transposed reductions.
             while (mask) {
-                int kk[4];
-                bool kv[4];
-                float al[4], G0[4], dxs[4], dys[4], ecol[4][C];
+                int kk[GOM_BWD_EPT];
+                bool kv[GOM_BWD_EPT];
+                float al[GOM_BWD_EPT], G0[GOM_BWD_EPT], dxs[GOM_BWD_EPT], dys[GOM_BWD_EPT], ecol[GOM_BWD_EPT][C];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < GOM_BWD_EPT; u++) {
                     kv[u] = mask != 0ull;
                     const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
                     mask &= ~(1ull << k);  // k = 0 when the mask is already empty: clearing bit 0 of 0 is a no-op
@@ -1025,7 +1034,7 @@ __global__ void __launch_bounds__(256, 6) k_seg_bwd(uint32_t seg_shift, int H, i
                     dys[u] = dy;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < GOM_BWD_EPT; u++) {
                     if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;  // wave-uniform
                     // An entry with a == 0 is replayed as a zero-alpha layer: the recurrences below then
                     // leave T / accum_rec exactly as skipping would (App. A.4), without divergent branches.
