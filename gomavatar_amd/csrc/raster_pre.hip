@@ -257,21 +257,58 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
     uint32_t carry = 0, seg_carry = 0;
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + tid;
-        uint32_t v = 0;
-        if (i < n_tiles) {
-            v = tile_count[i];
-            tile_count[i] = 0;
-            tile_nmax[i] = 0;
+    // 8 consecutive tiles per thread and trip: a batched launch (8 192 tiles at 8 x 512x512) is ONE trip = one load latency and
+    // two block scans, where one tile per thread took eight dependent trips (20 us of a single workgroup's latency chain).
+    constexpr int kPer = 8;
+    for (int base = 0; base < n_tiles; base += 1024 * kPer) {
+        const int i0 = base + tid * kPer;
+        const bool full = i0 + kPer <= n_tiles;   // (arrays come from hipMalloc and i0 is a multiple of 8: 16-byte accesses are aligned)
+        uint32_t v[kPer];
+        if (full) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(tile_count + i0), b = *reinterpret_cast<const uint4 *>(tile_count + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; k++) v[k] = i0 + k < n_tiles ? tile_count[i0 + k] : 0u;
+        }
+        uint32_t tsum = 0, ssum = 0, sv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            sv[k] = (v[k] + (1u << seg_shift) - 1) >> seg_shift;
+            tsum += v[k];
+            ssum += sv[k];
         }
         uint32_t tot, stot;
-        const uint32_t excl = carry + block_excl_scan_1024(v, s_wave, tot);
-        const uint32_t sexcl = seg_carry + block_excl_scan_1024((v + (1u << seg_shift) - 1) >> seg_shift, s_wave, stot);
-        if (i < n_tiles) {
-            tile_base[i] = excl;
-            tile_cursor[i] = excl;
-            seg_base[i] = sexcl;
+        uint32_t excl = carry + block_excl_scan_1024(tsum, s_wave, tot);
+        uint32_t sexcl = seg_carry + block_excl_scan_1024(ssum, s_wave, stot);
+        uint32_t eb[kPer], sb2[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            eb[k] = excl; sb2[k] = sexcl;
+            excl += v[k];
+            sexcl += sv[k];
+        }
+        if (full) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint4 e4 = make_uint4(eb[4 * h], eb[4 * h + 1], eb[4 * h + 2], eb[4 * h + 3]);
+                *reinterpret_cast<uint4 *>(tile_count + i0 + 4 * h) = z;
+                *reinterpret_cast<uint4 *>(tile_nmax + i0 + 4 * h) = z;
+                *reinterpret_cast<uint4 *>(tile_base + i0 + 4 * h) = e4;
+                *reinterpret_cast<uint4 *>(tile_cursor + i0 + 4 * h) = e4;
+                *reinterpret_cast<uint4 *>(seg_base + i0 + 4 * h) = make_uint4(sb2[4 * h], sb2[4 * h + 1], sb2[4 * h + 2], sb2[4 * h + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if (i0 + k < n_tiles) {
+                    tile_count[i0 + k] = 0;
+                    tile_nmax[i0 + k] = 0;
+                    tile_base[i0 + k] = eb[k];
+                    tile_cursor[i0 + k] = eb[k];
+                    seg_base[i0 + k] = sb2[k];
+                }
         }
         carry += tot;
         seg_carry += stot;
