@@ -25,7 +25,12 @@ struct GomDevStatus {
     uint32_t num_pairs;
     uint32_t overflow;
     uint32_t num_segs;
-    uint32_t pair_cursor;   // allocator for the per-gaussian ranges of pair_pos (reset by the scan kernel)
+    uint32_t pair_cursor;   // allocator for the per-gaussian ranges of pair_pos (mesh rasterizer; reset by the scan kernel)
+    // The splat preprocess allocates from 8 cursors, one per eighth of pair_pos, 128 bytes apart: a single device-scope word takes
+    // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
+    uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
+    uint32_t pad_[27];
+    uint32_t shard_cursor[8][32];   // [shard][0] used
 };
 
 struct GomGraphEntry {

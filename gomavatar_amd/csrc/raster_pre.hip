@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
-                                                    int gx, int gy) {
+                                                    int gx, int gy, uint32_t cap_pairs) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_blockbase;
@@ -210,7 +210,13 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            s_blockbase = tot ? atomicAdd(&status->pair_cursor, tot) : 0u;
+            const uint32_t shard = (blockIdx.x + blockIdx.y) & 7u, shard_cap = cap_pairs >> 3;
+            uint32_t base = 0;
+            if (tot) {
+                base = atomicAdd(&status->shard_cursor[shard][0], tot);
+                if (base + tot > shard_cap) { atomicOr(&status->shard_overflow, 1u); base = 0; }   // poisoned frame: stay in bounds
+            }
+            s_blockbase = shard * shard_cap + base;
         }
         __syncthreads();
         uint32_t woff = 0;
@@ -316,10 +322,13 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
     if (tid == 0) {
         tile_base[n_tiles] = carry;
         seg_base[n_tiles] = seg_carry;
+        const bool over = carry > cap_pairs || status->shard_overflow != 0u;
         status->num_pairs = carry;
-        status->overflow = carry > cap_pairs ? 1u : 0u;
-        status->num_segs = carry > cap_pairs ? 0u : seg_carry;
+        status->overflow = over ? 1u : 0u;
+        status->num_segs = over ? 0u : seg_carry;
         status->pair_cursor = 0;
+        status->shard_overflow = 0;
+        for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
 
@@ -531,14 +540,15 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS, st);
     const dim3 grid(blocks, s->B);
+    const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
         hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), n_tiles * sizeof(uint32_t), st, cam, s->cams, P, means3D, cov6,
                            opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
-                           s->tile_count, s->pair_off, s->status, s->gx, s->gy);
+                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap);
     else
         hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, opacity, s->depth,
                            s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
-                           s->status, s->gx, s->gy);
+                           s->status, s->gx, s->gy, cap);
     GOM_LAUNCH_CHECK();
     return 0;
 }
