@@ -19,7 +19,10 @@
 #define GOM_SEG_GRID 1024           // workgroups launched for the segment kernels (grid-stride over segments)
 #endif
 
-#define GOM_TASK_CTR_WORDS (3 * (32 * 8 + 32))   // three sharded task queues (raster_render.hip: TaskQueue)
+#ifndef GOM_TQ_SHARDS
+#define GOM_TQ_SHARDS 8               // heads per task queue (raster_render.hip: TaskQueue)
+#endif
+#define GOM_TASK_CTR_WORDS (3 * (32 * GOM_TQ_SHARDS + 32))   // three sharded task queues
 
 struct GomDevStatus {
     uint32_t num_pairs;

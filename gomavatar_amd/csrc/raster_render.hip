@@ -473,7 +473,6 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 //     every path through a task must call both and then pass a barrier.
 //   * The last workgroup to leave zeroes the heads for the next launch (graph replays included).
 // ctr layout: head of shard x at ctr[32 * x], workgroups that have left at ctr[32 * 8].
-#define GOM_TQ_SHARDS 8
 #define GOM_TQ_WORDS (32 * GOM_TQ_SHARDS + 32)
 struct TaskQueue {
     uint32_t *ctr;
