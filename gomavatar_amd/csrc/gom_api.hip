@@ -76,6 +76,10 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value != 0 && value != 7 && value != 8) { gom_set_error("segment shift must be 0 (auto), 7 or 8"); return -1; }
             s->wantSegShift = (int)value;
             return 0;
+        case GOM_OPT_TASK_GRID_PCT:
+            if (value < 10 || value > 100) { gom_set_error("task grid share must be in [10, 100] percent"); return -1; }
+            s->taskGridPct = (int)value;
+            return 0;
         case GOM_OPT_PROFILE:
             if (value && !s->ev[0]) {
                 for (int i = 0; i < 2 * GOM_NUM_KERNELS; i++) GOM_HIP_CHECK(hipEventCreate(&s->ev[i]));

@@ -1134,13 +1134,15 @@ static int resident_grid(K kernel, int device) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-    int g = per_cu * cus;
-    if (const char *e = getenv("GOM_TQ_GRID_PCT")) g = (int)((long long)g * atoi(e) / 100);  // development knob
+    return per_cu * cus;
+}
+static int task_grid(int resident, int pct) {   // GOM_OPT_TASK_GRID_PCT of the resident grid, a multiple of the shard count
+    const int g = (int)((long long)resident * pct / 100);
     return g < GOM_TQ_SHARDS ? GOM_TQ_SHARDS : g / GOM_TQ_SHARDS * GOM_TQ_SHARDS;
 }
 // A batched launch (tens of thousands of tasks) uses the task queue on a grid that just fills the chip; a single frame
 // has fewer tasks than two rounds of that grid, where one task per workgroup and no queue is the shorter path.
-#define GOM_RESIDENT(KERNEL) (s->B > 1 ? ([&]() { static const int g = resident_grid(KERNEL, s->device); return g; }()) : GOM_SEG_GRID * 4)
+#define GOM_RESIDENT(KERNEL) (s->B > 1 ? task_grid([&]() { static const int g = resident_grid(KERNEL, s->device); return g; }(), s->taskGridPct) : GOM_SEG_GRID * 4)
 #define GOM_TASK_CTR (s->B > 1 ? s->task_ctr : nullptr)
 
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
