@@ -41,8 +41,9 @@
 // Inside a wave, lane = pixel.  Per sub-range lane = ENTRY first: every lane
 // tests one entry against the wave's 8x8 rectangle with a conservative bound on
 // the largest alpha it can reach there; a 64-bit ballot then drives a scalar
-// loop over the survivors only (~35 %), whose attributes are broadcast with
-// v_readlane (SGPR operands).  Entries skipped this way are exactly those the
+// loop over the survivors only (~35 %), whose attributes every lane fetches
+// with broadcast reads from a wave-private LDS slab (v_readlane, 6.6 issue cycles
+// per value, was the first version).  Entries skipped this way are exactly those the
 // reference skips for all 64 pixels (`alpha < 1/255 -> continue`).  The blend
 // loop is branch-free and keeps its state in VGPRs (float masks) so that the
 // serial T chain never round-trips through SALU/VCC logic.
