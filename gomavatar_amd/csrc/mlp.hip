@@ -102,3 +102,179 @@ extern "C" int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float 
     GOM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The shadow MLP itself (models/modules/shadow_module.py:66-117 at its default shape: D0 -> H -> H -> H -> 1, ReLU, sigmoid; no
+// skip connection inside depth 3), forward and input-gradient chain as ONE kernel each.  The layers are 0.9 GFLOP per frame: what
+// they cost through the BLAS library is launches (4 GEMMs + 4 activations forward, 3 GEMMs + 4 activation derivatives backward,
+// ~50 us of host time per GEMM call).  A workgroup takes 32 rows through all layers; activations live in LDS as [feature][row]
+// (a thread = one output feature x 16 rows reads 4 rows per ds_read_b128), weights stream through LDS 32 input features at a time.
+// Saved for the backward: the three hidden activations (post-ReLU) and the output; the backward writes dz of every layer for
+// gom_linear_wgrad and the gradient w.r.t. the input.
+namespace {
+
+constexpr int kTR = 32;     // rows per workgroup
+constexpr int kHW = 128;    // widest layer supported
+
+// out[o][rows] = act( b[o] + sum_i W[o][i] src[i][rows] ),  thread = (o = tid & 127, rows 16 (tid >> 7) .. +15)
+// W row-major [out_dim][in_dim] (nn.Linear).  TRANS = false: weights used as W[o][i] (forward);  TRANS = true: computes
+// out[i][rows] = sum_o W[o][i] src[o][rows] (backward through the layer), thread = (i, row half).
+template <bool TRANS>
+__device__ __forceinline__ void mlp_layer(int n_red, int n_out, int ld, const float *__restrict__ W, float (*s_w)[kHW], const float (*s_src)[kTR],
+                                          float (&acc)[16]) {
+    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    for (int rc = 0; rc < n_red; rc += 32) {
+        __syncthreads();   // previous chunk's readers are done
+        // stage a 32 x 128 block of weights as s_w[reduction index][output index]
+        if (!TRANS) {      // s_w[ii][o] = W[o][rc + ii]: thread (o = c, 16 consecutive ii)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int ii = 16 * rh + k;
+                s_w[ii][c] = (c < n_out && rc + ii < n_red) ? W[(size_t)c * ld + rc + ii] : 0.f;
+            }
+        } else {           // s_w[oo][i] = W[rc + oo][i]: rows of W are contiguous in i
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int oo = 16 * rh + k;
+                s_w[oo][c] = (c < n_out && rc + oo < n_red) ? W[(size_t)(rc + oo) * ld + c] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ii = 0; ii < 32; ii++) {
+            const float w = s_w[ii][c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 v = *reinterpret_cast<const float4 *>(&s_src[rc + ii][16 * rh + 4 * j]);
+                acc[4 * j] += w * v.x; acc[4 * j + 1] += w * v.y; acc[4 * j + 2] += w * v.z; acc[4 * j + 3] += w * v.w;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mlp3_fwd(int64_t n, int D0, int H, const float *__restrict__ x, const float *__restrict__ W1,
+                                                  const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+                                                  const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ w4,
+                                                  const float *__restrict__ b4, float *__restrict__ h1, float *__restrict__ h2,
+                                                  float *__restrict__ h3, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTR], s_b[kHW][kTR];
+    __shared__ float s_w[32][kHW];
+    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    const int64_t r0 = (int64_t)blockIdx.x * kTR;
+    for (int idx = tid; idx < kHW * kTR; idx += 256) {   // input rows -> s_a[feature][row] (zero padded)
+        const int rr = idx / kHW, i = idx % kHW;          // consecutive threads read consecutive features of one row
+        s_a[i][rr] = (r0 + rr < n && i < D0) ? x[(r0 + rr) * D0 + i] : 0.f;
+    }
+    float(*src)[kTR] = s_a;
+    float(*dst)[kTR] = s_b;
+    const float *Ws[3] = {W1, W2, W3}, *bs[3] = {b1, b2, b3};
+    float *hs[3] = {h1, h2, h3};
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const int in_dim = l == 0 ? D0 : H;
+        float acc[16];
+        const float bias = c < H ? bs[l][c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = bias;
+        mlp_layer<false>(in_dim, H, in_dim, Ws[l], s_w, src, acc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            acc[k] = c < H ? fmaxf(acc[k], 0.f) : 0.f;
+            const int64_t r = r0 + 16 * rh + k;
+            if (r < n && c < H) hs[l][r * H + c] = acc[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&dst[c][16 * rh + 4 * j]) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        float(*t)[kTR] = src; src = dst; dst = t;
+    }
+    __syncthreads();
+    if (tid < kTR && r0 + tid < n) {   // output layer: one thread per row
+        float s = b4[0];
+        for (int o = 0; o < H; o++) s += src[o][tid] * w4[o];
+        out[r0 + tid] = 1.f / (1.f + __expf(-s));
+    }
+}
+
+// g [n] = dL/d out  ->  dz4 [n], dz3 / dz2 / dz1 [n][H], dx [n][D0]
+__global__ void __launch_bounds__(256) k_mlp3_bwd(int64_t n, int D0, int H, const float *__restrict__ g, const float *__restrict__ out,
+                                                  const float *__restrict__ h1, const float *__restrict__ h2, const float *__restrict__ h3,
+                                                  const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
+                                                  const float *__restrict__ w4, float *__restrict__ dz4, float *__restrict__ dz3,
+                                                  float *__restrict__ dz2, float *__restrict__ dz1, float *__restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTR], s_b[kHW][kTR];
+    __shared__ float s_w[32][kHW];
+    __shared__ float s_d4[kTR];
+    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    const int64_t r0 = (int64_t)blockIdx.x * kTR;
+    if (tid < kTR) {
+        const int64_t r = r0 + tid;
+        float d = 0.f;
+        if (r < n) { const float o = out[r]; d = g[r] * o * (1.f - o); dz4[r] = d; }
+        s_d4[tid] = d;
+    }
+    __syncthreads();
+    {   // dz3 = dz4 w4^T (.) [h3 > 0]
+        const float w = c < H ? w4[c] : 0.f;
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t r = r0 + 16 * rh + k;
+            const bool on = r < n && c < H && h3[r * H + c] > 0.f;
+            v[k] = on ? s_d4[16 * rh + k] * w : 0.f;
+            if (r < n && c < H) dz3[r * H + c] = v[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&s_a[c][16 * rh + 4 * j]) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+    float(*src)[kTR] = s_a;
+    float(*dst)[kTR] = s_b;
+    const float *Ws[3] = {W3, W2, W1};
+    const float *hprev[3] = {h2, h1, nullptr};
+    float *dzs[3] = {dz2, dz1, dx};
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const int n_out = l == 2 ? D0 : H;   // width of the layer's INPUT side (what this step produces)
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0.f;
+        mlp_layer<true>(H, n_out, n_out, Ws[l], s_w, src, acc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t r = r0 + 16 * rh + k;
+            const bool live = r < n && c < n_out;
+            if (l < 2) acc[k] = (live && hprev[l][r * H + c] > 0.f) ? acc[k] : 0.f;
+            if (live) dzs[l][r * n_out + c] = acc[k];
+        }
+        if (l < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&dst[c][16 * rh + 4 * j]) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            float(*t)[kTR] = src; src = dst; dst = t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                                const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out,
+                                void *stream) {
+    if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_forward: widths must be in 1..128"); return -1; }
+    if (n == 0) return 0;
+    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !w4 || !b4 || !h1 || !h2 || !h3 || !out) { gom_set_error("gom_mlp3_forward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_mlp3_fwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2,
+                       h3, out);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
+                                 const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
+                                 float *dx, void *stream) {
+    if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_backward: widths must be in 1..128"); return -1; }
+    if (n == 0) return 0;
+    if (!g || !out || !h1 || !h2 || !h3 || !W1 || !W2 || !W3 || !w4 || !dz4 || !dz3 || !dz2 || !dz1 || !dx) { gom_set_error("gom_mlp3_backward: null pointer"); return -1; }
+    hipLaunchKernelGGL(k_mlp3_bwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4,
+                       dz3, dz2, dz1, dx);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -111,6 +111,51 @@ class _LinearLongBatch(torch.autograd.Function):
         return dx, dW.to(weight.dtype), (db.to(weight.dtype) if ctx.has_bias else None)
 
 
+class _ShadowMLP3(torch.autograd.Function):
+    """Linear-ReLU x 3 -> Linear -> sigmoid as one HIP kernel forward and one backward (csrc/mlp.hip: gom_mlp3_forward / _backward),
+    weight gradients through gom_linear_wgrad.  Same values as the nn.Sequential up to fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4):
+        lib = _lib.load()
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        n, D0 = x2.shape
+        H = W1.shape[0]
+        ps = [t.detach().float().contiguous() for t in (W1, b1, W2, b2, W3, b3, W4, b4)]
+        hs = torch.empty(3, n, H, dtype=torch.float32, device=x.device)
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gom_mlp3_forward(n, D0, H, _lib.ptr(x2), *[_lib.ptr(t) for t in ps], _lib.ptr(hs[0]), _lib.ptr(hs[1]), _lib.ptr(hs[2]),
+                                        _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(x2, hs, out, *ps)
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return out.reshape(*x.shape[:-1], 1).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, hs, out, W1, b1, W2, b2, W3, b3, W4, b4 = ctx.saved_tensors
+        lib = _lib.load()
+        n, D0 = x2.shape
+        H = W1.shape[0]
+        dev = x2.device
+        g2 = g.reshape(-1).float().contiguous()
+        dz = torch.empty(3, n, H, dtype=torch.float32, device=dev)     # dz1, dz2, dz3
+        dz4 = torch.empty(n, dtype=torch.float32, device=dev)
+        dx = torch.empty(n, D0, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr()
+        _lib.check(lib.gom_mlp3_backward(n, D0, H, _lib.ptr(g2), _lib.ptr(out), _lib.ptr(hs[0]), _lib.ptr(hs[1]), _lib.ptr(hs[2]), _lib.ptr(W1),
+                                         _lib.ptr(W2), _lib.ptr(W3), _lib.ptr(W4), _lib.ptr(dz4), _lib.ptr(dz[2]), _lib.ptr(dz[1]), _lib.ptr(dz[0]),
+                                         _lib.ptr(dx), st))
+        ws = torch.empty(lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=dev)
+        grads = []
+        for X, dY, W in ((x2, dz[0], W1), (hs[0], dz[1], W2), (hs[1], dz[2], W3), (hs[2], dz4, W4)):
+            out_dim, in_dim = W.shape
+            dW = torch.empty(out_dim, in_dim, dtype=torch.float32, device=dev)
+            db = torch.empty(out_dim, dtype=torch.float32, device=dev)
+            _lib.check(lib.gom_linear_wgrad(n, in_dim, out_dim, _lib.ptr(X), _lib.ptr(dY), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), st))
+            grads += [dW, db]
+        return (dx.reshape(ctx.shape).to(ctx.dtype) if ctx.needs_input_grad[0] else None, *grads)
+
+
 class ShadowModule(nn.Module):
     """shadow_module.py:66-117: positional encoding of the normal (multires frequencies, sin/cos, input included) ->
     MLP (width, depth, optional skip) -> sigmoid.  The last layer starts at U(-1e-5, 1e-5) / zero bias."""
@@ -148,6 +193,11 @@ class ShadowModule(nn.Module):
 
     def forward(self, normals, **kwargs):
         pe = self.embed(normals)
+        lin = [m for m in self.block_mlps if isinstance(m, nn.Linear)]
+        if (pe.is_cuda and len(lin) == 4 and not self.layers_to_cat_inputs and lin[0].out_features <= 128 and lin[0].in_features <= 128
+                and pe.dtype == torch.float32):
+            # the default shape (depth 3, the configured skip index lies beyond it): the whole MLP is one kernel each way
+            return _ShadowMLP3.apply(pe, *[p for m in lin for p in (m.weight, m.bias)])
         h = pe
         for i, layer in enumerate(self.block_mlps):
             if i in self.layers_to_cat_inputs:

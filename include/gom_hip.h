@@ -166,6 +166,16 @@ int gom_posenc_backward(int64_t n, int L, const float *x, const float *g_out, fl
 int gom_linear_wgrad_slices(void);
 int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float *X, const float *dY, float *dW, float *db, float *workspace, void *stream);
 
+/* ---- the shadow MLP at its default shape (shadow_module.py:66-117 with mlp_depth 3: D0 -> H -> H -> H -> 1, ReLU x 3, sigmoid),
+ * D0, H <= 128, nn.Linear weight layout [out][in].  forward: x [n][D0] -> h1, h2, h3 [n][H] (post-ReLU, kept for the backward) and
+ * out [n].  backward: g [n] = dL/d out -> dz4 [n], dz3, dz2, dz1 [n][H] (the dY of every layer: feed them to gom_linear_wgrad with
+ * X = h3, h2, h1, x) and dx [n][D0]. */
+int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out, void *stream);
+int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
+                      const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
+                      float *dx, void *stream);
+
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]
  * (row-major 3x3 R then T).  fk_save [24][32] keeps the chain for backward. */

@@ -232,3 +232,28 @@ def test_shadow_module_gradients_match_the_plain_torch_module():
     assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
     for p, q in zip(sm.parameters(), ref.parameters()):
         assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1e-6, float(q.grad.abs().max())), tuple(p.shape)
+
+
+@pytest.mark.parametrize("multires,width,depth,skips,n", [(6, 128, 3, (4,), 3000), (4, 64, 3, (4,), 1217), (6, 128, 3, (4,), 1),
+                                                          (6, 96, 5, (4,), 700), (2, 128, 3, (2,), 333)])
+def test_shadow_mlp_fused_kernels_vs_torch_cpu(multires, width, depth, skips, n):
+    """gom_mlp3_forward / _backward (the default depth-3 shape takes them; other depths or a skip inside the depth take the layer-wise
+    path) against the same module on the CPU: values, input gradient, every parameter gradient."""
+    from gomavatar_amd.model import ShadowModule
+    import copy
+    torch.manual_seed(multires * 100 + width + n)
+    sm = ShadowModule(multires=multires, mlp_width=width, mlp_depth=depth, skips=skips).cuda()
+    with torch.no_grad():
+        sm.block_mlps[-1].weight.normal_(0, 0.3)
+        for m in sm.block_mlps:
+            if hasattr(m, "bias"):
+                m.bias.normal_(0, 0.1)
+    ref = copy.deepcopy(sm).cpu()
+    x, w = torch.randn(n, 3), torch.randn(n, 1)
+    xr = x.clone().requires_grad_(); yr = ref(xr); (yr * w).sum().backward()
+    xg = x.cuda().requires_grad_(); yg = sm(xg); (yg * w.cuda()).sum().backward()
+    assert yg.shape == yr.shape
+    assert float((yg.detach().cpu() - yr.detach()).abs().max()) <= 2e-6
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    for p, q in zip(sm.parameters(), ref.parameters()):
+        assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1e-6, float(q.grad.abs().max())), tuple(p.shape)
