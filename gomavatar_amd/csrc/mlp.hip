@@ -105,93 +105,130 @@ extern "C" int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The shadow MLP itself (models/modules/shadow_module.py:66-117 at its default shape: D0 -> H -> H -> H -> 1, ReLU, sigmoid; no
-// skip connection inside depth 3), forward and input-gradient chain as ONE kernel each.  The layers are 0.9 GFLOP per frame: what
+// skip connection inside depth 3), forward and input-gradient chain as ONE kernel each.  The layers are 1.8 GFLOP per frame: what
 // they cost through the BLAS library is launches (4 GEMMs + 4 activations forward, 3 GEMMs + 4 activation derivatives backward,
-// ~50 us of host time per GEMM call).  A workgroup takes 32 rows through all layers; activations live in LDS as [feature][row]
-// (a thread = one output feature x 16 rows reads 4 rows per ds_read_b128), weights stream through LDS 32 input features at a time.
+// ~50 us of host time per GEMM call).  A workgroup takes 64 rows through all layers; the activations live in LDS as
+// [feature][row] and are overwritten in place layer by layer, the weights stream through LDS 32 reduction indices at a time.
+// A thread owns a 4 feature x 8 row register tile: per reduction index one ds_read_b128 of weights and two (wave-broadcast) of
+// rows feed 32 FMAs issued as 16 v_pk_fma_f32, which keeps the LDS return bus (8 clk per b128 per CU) under the VALU time.
 // Saved for the backward: the three hidden activations (post-ReLU) and the output; the backward writes dz of every layer for
 // gom_linear_wgrad and the gradient w.r.t. the input.
 namespace {
 
-constexpr int kTR = 32;     // rows per workgroup
-constexpr int kHW = 128;    // widest layer supported
+constexpr int kTR = 64;          // rows per workgroup
+constexpr int kTRP = kTR + 4;    // padded row stride (keeps 16-byte alignment, spreads the tile write-back over the banks)
+constexpr int kHW = 128;         // widest layer supported
+constexpr int kWP = kHW + 4;     // row stride of the staged weights: lets the forward's transposing write-in spread over the banks
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// out[o][rows] = act( b[o] + sum_i W[o][i] src[i][rows] ),  thread = (o = tid & 127, rows 16 (tid >> 7) .. +15)
-// W row-major [out_dim][in_dim] (nn.Linear).  TRANS = false: weights used as W[o][i] (forward);  TRANS = true: computes
-// out[i][rows] = sum_o W[o][i] src[o][rows] (backward through the layer), thread = (i, row half).
+// acc[j][k] += sum_red Wt[red][4 cg + j] * src[red][8 rg + k]   (cg = tid & 31, rg = tid >> 5)
+// TRANS = false: Wt[red][o] = W[o][red] (forward, W row-major [n_out][ld]);  TRANS = true: Wt[red][i] = W[red][i] (backward).
 template <bool TRANS>
-__device__ __forceinline__ void mlp_layer(int n_red, int n_out, int ld, const float *__restrict__ W, float (*s_w)[kHW], const float (*s_src)[kTR],
-                                          float (&acc)[16]) {
-    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
-    for (int rc = 0; rc < n_red; rc += 32) {
-        __syncthreads();   // previous chunk's readers are done
-        // stage a 32 x 128 block of weights as s_w[reduction index][output index]
-        if (!TRANS) {      // s_w[ii][o] = W[o][rc + ii]: thread (o = c, 16 consecutive ii)
+__device__ __forceinline__ void mlp_layer(int n_red, int n_out, int ld, const float *__restrict__ W, float (*s_w)[kWP], const float (*s_src)[kTRP],
+                                          f32x2 (&acc)[4][4]) {
+    const int tid = threadIdx.x, c = tid & 127, half = tid >> 7, cg = tid & 31, rg = tid >> 5;
+    float wn[16];   // the next 32 x 128 block of weights, in flight while the current one is being used
+    // forward: W[o][rc + ii] is contiguous in ii, so lanes run along ii (o = o0 + 8 k);  backward: W[rc + ii][i] is contiguous in i
+    const int f_ii = TRANS ? 16 * half : (tid & 31), f_c = TRANS ? c : (tid >> 5);
+    auto fetch = [&](int rc) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int ii = 16 * rh + k;
-                s_w[ii][c] = (c < n_out && rc + ii < n_red) ? W[(size_t)c * ld + rc + ii] : 0.f;
-            }
-        } else {           // s_w[oo][i] = W[rc + oo][i]: rows of W are contiguous in i
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int oo = 16 * rh + k;
-                s_w[oo][c] = (c < n_out && rc + oo < n_red) ? W[(size_t)(rc + oo) * ld + c] : 0.f;
-            }
+        for (int k = 0; k < 16; k++) {
+            const int ii = TRANS ? f_ii + k : f_ii, cc = TRANS ? f_c : f_c + 8 * k;
+            wn[k] = 0.f;
+            if (cc < n_out && rc + ii < n_red) wn[k] = TRANS ? W[(size_t)(rc + ii) * ld + cc] : W[(size_t)cc * ld + rc + ii];
         }
+    };
+    fetch(0);
+    for (int rc = 0; rc < n_red; rc += 32) {
+        __syncthreads();   // previous chunk's readers are done (and the activations written before the call are visible)
+#pragma unroll
+        for (int k = 0; k < 16; k++) s_w[TRANS ? f_ii + k : f_ii][TRANS ? f_c : f_c + 8 * k] = wn[k];
         __syncthreads();
-#pragma unroll 8
-        for (int ii = 0; ii < 32; ii++) {
-            const float w = s_w[ii][c];
+        if (rc + 32 < n_red) fetch(rc + 32);
+        const int lim = min(32, n_red - rc);
+#pragma unroll 4
+        for (int ii = 0; ii < lim; ii++) {
+            const float4 w = *reinterpret_cast<const float4 *>(&s_w[ii][4 * cg]);
+            const float4 va = *reinterpret_cast<const float4 *>(&s_src[rc + ii][8 * rg]);
+            const float4 vb = *reinterpret_cast<const float4 *>(&s_src[rc + ii][8 * rg + 4]);
+            const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+            const float wj[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float4 v = *reinterpret_cast<const float4 *>(&s_src[rc + ii][16 * rh + 4 * j]);
-                acc[4 * j] += w * v.x; acc[4 * j + 1] += w * v.y; acc[4 * j + 2] += w * v.z; acc[4 * j + 3] += w * v.w;
+                const f32x2 ww = {wj[j], wj[j]};
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[j][q] = __builtin_elementwise_fma(ww, v[q], acc[j][q]);
             }
         }
     }
 }
+
+__device__ __forceinline__ void tile_to_lds(float (*s)[kTRP], const f32x2 (&acc)[4][4]) {
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        *reinterpret_cast<float4 *>(&s[4 * cg + j][8 * rg]) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        *reinterpret_cast<float4 *>(&s[4 * cg + j][8 * rg + 4]) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
+    }
+}
+__device__ __forceinline__ float tile_get(const f32x2 (&acc)[4][4], int j, int k) { return (k & 1) ? acc[j][k >> 1].y : acc[j][k >> 1].x; }
+__device__ __forceinline__ void tile_set(f32x2 (&acc)[4][4], int j, int k, float v) { if (k & 1) acc[j][k >> 1].y = v; else acc[j][k >> 1].x = v; }
 
 __global__ void __launch_bounds__(256) k_mlp3_fwd(int64_t n, int D0, int H, const float *__restrict__ x, const float *__restrict__ W1,
                                                   const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
                                                   const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ w4,
                                                   const float *__restrict__ b4, float *__restrict__ h1, float *__restrict__ h2,
                                                   float *__restrict__ h3, float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTR], s_b[kHW][kTR];
-    __shared__ float s_w[32][kHW];
-    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTRP];
+    __shared__ __attribute__((aligned(16))) float s_w[32][kWP];
+    const int tid = threadIdx.x, cg = tid & 31, rg = tid >> 5;
     const int64_t r0 = (int64_t)blockIdx.x * kTR;
-    for (int idx = tid; idx < kHW * kTR; idx += 256) {   // input rows -> s_a[feature][row] (zero padded)
-        const int rr = idx / kHW, i = idx % kHW;          // consecutive threads read consecutive features of one row
-        s_a[i][rr] = (r0 + rr < n && i < D0) ? x[(r0 + rr) * D0 + i] : 0.f;
+    const int rows = (int)min<int64_t>(kTR, n - r0);
+    for (int idx = tid; idx < kTR * D0; idx += 256) {   // the workgroup's rows are one contiguous piece of x
+        const int rr = idx / D0, i = idx - rr * D0;
+        s_a[i][rr] = rr < rows ? x[r0 * D0 + idx] : 0.f;
     }
-    float(*src)[kTR] = s_a;
-    float(*dst)[kTR] = s_b;
     const float *Ws[3] = {W1, W2, W3}, *bs[3] = {b1, b2, b3};
     float *hs[3] = {h1, h2, h3};
+    const bool cols = 4 * cg < H;    // H % 4 == 0
 #pragma unroll
     for (int l = 0; l < 3; l++) {
         const int in_dim = l == 0 ? D0 : H;
-        float acc[16];
-        const float bias = c < H ? bs[l][c] : 0.f;
+        f32x2 acc[4][4];
+        const float4 bias = cols ? *reinterpret_cast<const float4 *>(bs[l] + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float bj[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = bias;
-        mlp_layer<false>(in_dim, H, in_dim, Ws[l], s_w, src, acc);
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            acc[k] = c < H ? fmaxf(acc[k], 0.f) : 0.f;
-            const int64_t r = r0 + 16 * rh + k;
-            if (r < n && c < H) hs[l][r * H + c] = acc[k];
+            for (int q = 0; q < 4; q++) acc[j][q] = f32x2{bj[j], bj[j]};
+        mlp_layer<false>(in_dim, H, in_dim, Ws[l], s_w, s_a, acc);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[j][q] = __builtin_elementwise_max(acc[j][q], f32x2{0.f, 0.f});
+        if (cols) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (8 * rg + k < rows)
+                    *reinterpret_cast<float4 *>(hs[l] + (r0 + 8 * rg + k) * H + 4 * cg) =
+                        make_float4(tile_get(acc, 0, k), tile_get(acc, 1, k), tile_get(acc, 2, k), tile_get(acc, 3, k));
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&dst[c][16 * rh + 4 * j]) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-        float(*t)[kTR] = src; src = dst; dst = t;
+        __syncthreads();   // every wave is done reading the layer's input
+        tile_to_lds(s_a, acc);
     }
     __syncthreads();
-    if (tid < kTR && r0 + tid < n) {   // output layer: one thread per row
-        float s = b4[0];
-        for (int o = 0; o < H; o++) s += src[o][tid] * w4[o];
-        out[r0 + tid] = 1.f / (1.f + __expf(-s));
+    {   // output layer: four threads per row, 32 features each
+        __shared__ float s_part[4][kTR];
+        const int row = tid & (kTR - 1), part = tid >> 6;
+        float s = 0.f;
+#pragma unroll 8
+        for (int o = 32 * part; o < min(H, 32 * part + 32); o++) s += s_a[o][row] * w4[o];
+        s_part[part][row] = s;
+        __syncthreads();
+        if (tid < rows) {
+            s = b4[0] + ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]));
+            out[r0 + tid] = 1.f / (1.f + __expf(-s));
+        }
     }
 }
 
@@ -201,54 +238,67 @@ __global__ void __launch_bounds__(256) k_mlp3_bwd(int64_t n, int D0, int H, cons
                                                   const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
                                                   const float *__restrict__ w4, float *__restrict__ dz4, float *__restrict__ dz3,
                                                   float *__restrict__ dz2, float *__restrict__ dz1, float *__restrict__ dx) {
-    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTR], s_b[kHW][kTR];
-    __shared__ float s_w[32][kHW];
+    __shared__ __attribute__((aligned(16))) float s_a[kHW][kTRP];
+    __shared__ __attribute__((aligned(16))) float s_w[32][kWP];
     __shared__ float s_d4[kTR];
-    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    const int tid = threadIdx.x, cg = tid & 31, rg = tid >> 5;
     const int64_t r0 = (int64_t)blockIdx.x * kTR;
+    const int rows = (int)min<int64_t>(kTR, n - r0);
+    const bool cols = 4 * cg < H;
     if (tid < kTR) {
-        const int64_t r = r0 + tid;
         float d = 0.f;
-        if (r < n) { const float o = out[r]; d = g[r] * o * (1.f - o); dz4[r] = d; }
+        if (tid < rows) { const float o = out[r0 + tid]; d = g[r0 + tid] * o * (1.f - o); dz4[r0 + tid] = d; }
         s_d4[tid] = d;
     }
     __syncthreads();
     {   // dz3 = dz4 w4^T (.) [h3 > 0]
-        const float w = c < H ? w4[c] : 0.f;
-        float v[16];
+        const float4 w = cols ? *reinterpret_cast<const float4 *>(w4 + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x2 acc[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int64_t r = r0 + 16 * rh + k;
-            const bool on = r < n && c < H && h3[r * H + c] > 0.f;
-            v[k] = on ? s_d4[16 * rh + k] * w : 0.f;
-            if (r < n && c < H) dz3[r * H + c] = v[k];
+        for (int k = 0; k < 8; k++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cols && 8 * rg + k < rows) {
+                const float4 h = *reinterpret_cast<const float4 *>(h3 + (r0 + 8 * rg + k) * H + 4 * cg);
+                const float d = s_d4[8 * rg + k];
+                v = make_float4(h.x > 0.f ? d * w.x : 0.f, h.y > 0.f ? d * w.y : 0.f, h.z > 0.f ? d * w.z : 0.f, h.w > 0.f ? d * w.w : 0.f);
+                *reinterpret_cast<float4 *>(dz3 + (r0 + 8 * rg + k) * H + 4 * cg) = v;
+            }
+            tile_set(acc, 0, k, v.x); tile_set(acc, 1, k, v.y); tile_set(acc, 2, k, v.z); tile_set(acc, 3, k, v.w);
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&s_a[c][16 * rh + 4 * j]) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        tile_to_lds(s_a, acc);
     }
-    float(*src)[kTR] = s_a;
-    float(*dst)[kTR] = s_b;
     const float *Ws[3] = {W3, W2, W1};
     const float *hprev[3] = {h2, h1, nullptr};
     float *dzs[3] = {dz2, dz1, dx};
 #pragma unroll
     for (int l = 0; l < 3; l++) {
         const int n_out = l == 2 ? D0 : H;   // width of the layer's INPUT side (what this step produces)
-        float acc[16];
+        f32x2 acc[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = 0.f;
-        mlp_layer<true>(H, n_out, n_out, Ws[l], s_w, src, acc);
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int64_t r = r0 + 16 * rh + k;
-            const bool live = r < n && c < n_out;
-            if (l < 2) acc[k] = (live && hprev[l][r * H + c] > 0.f) ? acc[k] : 0.f;
-            if (live) dzs[l][r * n_out + c] = acc[k];
-        }
+            for (int q = 0; q < 4; q++) acc[j][q] = f32x2{0.f, 0.f};
+        mlp_layer<true>(H, n_out, n_out, Ws[l], s_w, s_a, acc);
         if (l < 2) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&dst[c][16 * rh + 4 * j]) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-            float(*t)[kTR] = src; src = dst; dst = t;
+            for (int k = 0; k < 8; k++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cols && 8 * rg + k < rows) {
+                    const float4 h = *reinterpret_cast<const float4 *>(hprev[l] + (r0 + 8 * rg + k) * H + 4 * cg);
+                    v = make_float4(h.x > 0.f ? tile_get(acc, 0, k) : 0.f, h.y > 0.f ? tile_get(acc, 1, k) : 0.f, h.z > 0.f ? tile_get(acc, 2, k) : 0.f,
+                                    h.w > 0.f ? tile_get(acc, 3, k) : 0.f);
+                    *reinterpret_cast<float4 *>(dzs[l] + (r0 + 8 * rg + k) * H + 4 * cg) = v;
+                }
+                tile_set(acc, 0, k, v.x); tile_set(acc, 1, k, v.y); tile_set(acc, 2, k, v.z); tile_set(acc, 3, k, v.w);
+            }
+            __syncthreads();
+            tile_to_lds(s_a, acc);
+        } else {   // the input gradient: D0 need not be a multiple of 4
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (8 * rg + k < rows && 4 * cg + j < D0) dx[(r0 + 8 * rg + k) * D0 + 4 * cg + j] = tile_get(acc, j, k);
         }
     }
 }
@@ -259,6 +309,7 @@ extern "C" int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const 
                                 const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out,
                                 void *stream) {
     if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_forward: widths must be in 1..128"); return -1; }
+    if (H % 4) { gom_set_error("gom_mlp3_forward: the hidden width must be a multiple of 4"); return -1; }
     if (n == 0) return 0;
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !w4 || !b4 || !h1 || !h2 || !h3 || !out) { gom_set_error("gom_mlp3_forward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_mlp3_fwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2,
@@ -271,6 +322,7 @@ extern "C" int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const
                                  const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
                                  float *dx, void *stream) {
     if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_backward: widths must be in 1..128"); return -1; }
+    if (H % 4) { gom_set_error("gom_mlp3_backward: the hidden width must be a multiple of 4"); return -1; }
     if (n == 0) return 0;
     if (!g || !out || !h1 || !h2 || !h3 || !W1 || !W2 || !W3 || !w4 || !dz4 || !dz3 || !dz2 || !dz1 || !dx) { gom_set_error("gom_mlp3_backward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_mlp3_bwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4,

@@ -194,7 +194,7 @@ class ShadowModule(nn.Module):
     def forward(self, normals, **kwargs):
         pe = self.embed(normals)
         lin = [m for m in self.block_mlps if isinstance(m, nn.Linear)]
-        if (pe.is_cuda and len(lin) == 4 and not self.layers_to_cat_inputs and lin[0].out_features <= 128 and lin[0].in_features <= 128
+        if (pe.is_cuda and len(lin) == 4 and not self.layers_to_cat_inputs and lin[0].out_features <= 128 and lin[0].out_features % 4 == 0 and lin[0].in_features <= 128
                 and pe.dtype == torch.float32):
             # the default shape (depth 3, the configured skip index lies beyond it): the whole MLP is one kernel each way
             return _ShadowMLP3.apply(pe, *[p for m in lin for p in (m.weight, m.bias)])
