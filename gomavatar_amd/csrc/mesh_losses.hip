@@ -26,9 +26,16 @@ __global__ void __launch_bounds__(256) k_lap_fwd(int N, const float *__restrict_
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
         const int b = nbr_off[i], e = nbr_off[i + 1];
         float s[3] = {0.f, 0.f, 0.f};
-        for (int k = b; k < e; k++) {
-            const int j = nbr_idx[k];
-            s[0] += verts[3 * (size_t)j]; s[1] += verts[3 * (size_t)j + 1]; s[2] += verts[3 * (size_t)j + 2];
+        for (int k0 = b; k0 < e; k0 += 8) {   // 8 neighbours in flight per trip, summed in list order
+            float r[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float *q = verts + 3 * (size_t)nbr_idx[min(k0 + u, e - 1)];
+                r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < e) { s[0] += r[u][0]; s[1] += r[u][1]; s[2] += r[u][2]; }
         }
         const float inv = e > b ? 1.f / (float)(e - b) : 0.f;
         const float l[3] = {s[0] * inv - verts[3 * (size_t)i], s[1] * inv - verts[3 * (size_t)i + 1], s[2] * inv - verts[3 * (size_t)i + 2]};
@@ -46,10 +53,18 @@ __global__ void __launch_bounds__(256) k_lap_bwd(int N, const float *__restrict_
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     float g[3] = {-dir[3 * (size_t)i], -dir[3 * (size_t)i + 1], -dir[3 * (size_t)i + 2]};
-    for (int k = nbr_off[i]; k < nbr_off[i + 1]; k++) {
-        const int j = nbr_idx[k];
-        const float w = 1.f / (float)(nbr_off[j + 1] - nbr_off[j]);
-        g[0] += dir[3 * (size_t)j] * w; g[1] += dir[3 * (size_t)j + 1] * w; g[2] += dir[3 * (size_t)j + 2] * w;
+    const int kb = nbr_off[i], ke = nbr_off[i + 1];
+    for (int k0 = kb; k0 < ke; k0 += 8) {   // 8 neighbours in flight per trip, summed in list order
+        float r[8][3], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = nbr_idx[min(k0 + u, ke - 1)];
+            w[u] = 1.f / (float)(nbr_off[j + 1] - nbr_off[j]);
+            r[u][0] = dir[3 * (size_t)j]; r[u][1] = dir[3 * (size_t)j + 1]; r[u][2] = dir[3 * (size_t)j + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + u < ke) { g[0] += r[u][0] * w[u]; g[1] += r[u][1] * w[u]; g[2] += r[u][2] * w[u]; }
     }
     const float sc = grad_out[0] / (float)N;
     d_verts[3 * (size_t)i] = g[0] * sc; d_verts[3 * (size_t)i + 1] = g[1] * sc; d_verts[3 * (size_t)i + 2] = g[2] * sc;
@@ -117,9 +132,17 @@ __global__ void __launch_bounds__(256) k_corner_gather2(int N, const int32_t *__
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
-        const float *r = d_corner + 3 * (size_t)csr_idx[k];
-        a0 += r[0]; a1 += r[1]; a2 += r[2];
+    const int kb = csr_off[v], ke = csr_off[v + 1];
+    for (int k0 = kb; k0 < ke; k0 += 8) {   // 8 corners in flight per trip, summed in list order
+        float r[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float *q = d_corner + 3 * (size_t)csr_idx[min(k0 + u, ke - 1)];
+            r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + u < ke) { a0 += r[u][0]; a1 += r[u][1]; a2 += r[u][2]; }
     }
     d_verts[3 * (size_t)v] = a0; d_verts[3 * (size_t)v + 1] = a1; d_verts[3 * (size_t)v + 2] = a2;
 }

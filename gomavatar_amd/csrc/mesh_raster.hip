@@ -375,10 +375,19 @@ __global__ void __launch_bounds__(256) k_mesh_face_gather(int F, const uint32_t 
     for (int k = 0; k < 9; k++) acc[k] = status->overflow ? __uint_as_float(0x7fc00000u) : 0.f;
     const uint32_t nt = status->overflow ? 0u : tiles_touched[f];
     const uint32_t *pp = pair_pos + pair_off[f];
-    for (uint32_t k = 0; k < nt; k++) {
-        const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[k] * GOM_PARTIAL_STRIDE);
-        const float4 a = rec[0], b = rec[1], c = rec[2];
-        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x;
+    for (uint32_t k0 = 0; k0 < nt; k0 += 4) {   // 4 records in flight per trip (independent index -> record chains), summed in list order
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[min(k0 + u, nt - 1)] * GOM_PARTIAL_STRIDE);
+            a[u] = rec[0]; b[u] = rec[1]; c[u] = rec[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k0 + u < nt) {
+                acc[0] += a[u].x; acc[1] += a[u].y; acc[2] += a[u].z; acc[3] += a[u].w; acc[4] += b[u].x; acc[5] += b[u].y; acc[6] += b[u].z; acc[7] += b[u].w;
+                acc[8] += c[u].x;
+            }
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) d_face[(size_t)f * 9 + k] = acc[k];
@@ -390,11 +399,18 @@ __global__ void __launch_bounds__(256) k_mesh_vertex_gather(int N, const int32_t
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float gx = 0.f, gy = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
-        const int fc = csr_idx[k], f = fc / 3, c = fc % 3;
-        const float *r = d_face + (size_t)f * 9;
-        gx += r[2 * c]; gy += r[2 * c + 1];
-        n0 += r[6]; n1 += r[7]; n2 += r[8];
+    const int kb = csr_off[v], ke = csr_off[v + 1];
+    for (int k0 = kb; k0 < ke; k0 += 8) {   // 8 incident corners in flight per trip, summed in list order
+        float r[8][5];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int fc = csr_idx[min(k0 + u, ke - 1)], f = fc / 3, c = fc % 3;
+            const float *q = d_face + (size_t)f * 9;
+            r[u][0] = q[2 * c]; r[u][1] = q[2 * c + 1]; r[u][2] = q[6]; r[u][3] = q[7]; r[u][4] = q[8];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + u < ke) { gx += r[u][0]; gy += r[u][1]; n0 += r[u][2]; n1 += r[u][3]; n2 += r[u][4]; }
     }
     d_verts[3 * (size_t)v] = gx; d_verts[3 * (size_t)v + 1] = gy; d_verts[3 * (size_t)v + 2] = 0.f;   // z only orders the faces
     d_vnormals[3 * (size_t)v] = n0; d_vnormals[3 * (size_t)v + 1] = n1; d_vnormals[3 * (size_t)v + 2] = n2;
@@ -411,15 +427,30 @@ __global__ void __launch_bounds__(256) k_vnormal_fwd(int N, const float *__restr
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
-        const int fc = csr_idx[k], f = fc / 3, c = fc % 3;
-        // corner c: cross(v[c+1] - v[c], v[c+2] - v[c]) -- the three per-corner expressions of the reference framework
-        const int ia = faces[3 * f + c], ib = faces[3 * f + (c + 1) % 3], ic = faces[3 * f + (c + 2) % 3];
-        float e1[3], e2[3], n[3];
+    const int kb = csr_off[v], ke = csr_off[v + 1];
+    for (int k0 = kb; k0 < ke; k0 += 8) {   // 8 incident corners in flight per trip (index -> face -> 3 vertices is a 3-hop chain each)
+        int iv[8][3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) { e1[d] = verts[3 * (size_t)ib + d] - verts[3 * (size_t)ia + d]; e2[d] = verts[3 * (size_t)ic + d] - verts[3 * (size_t)ia + d]; }
-        cross3(e1, e2, n);
-        acc[0] += n[0]; acc[1] += n[1]; acc[2] += n[2];
+        for (int u = 0; u < 8; u++) {
+            const int fc = csr_idx[min(k0 + u, ke - 1)], f = fc / 3, c = fc % 3;
+            // corner c: cross(v[c+1] - v[c], v[c+2] - v[c]) -- the three per-corner expressions of the reference framework
+            iv[u][0] = faces[3 * f + c]; iv[u][1] = faces[3 * f + (c + 1) % 3]; iv[u][2] = faces[3 * f + (c + 2) % 3];
+        }
+        float p[8][3][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) p[u][w][d] = verts[3 * (size_t)iv[u][w] + d];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            float e1[3], e2[3], n[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { e1[d] = p[u][1][d] - p[u][0][d]; e2[d] = p[u][2][d] - p[u][0][d]; }
+            cross3(e1, e2, n);
+            if (k0 + u < ke) { acc[0] += n[0]; acc[1] += n[1]; acc[2] += n[2]; }
+        }
     }
     const float len = fmaxf(sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]), 1e-6f);
 #pragma unroll
@@ -465,9 +496,17 @@ __global__ void __launch_bounds__(256) k_corner_gather(int N, const int32_t *__r
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int k = csr_off[v]; k < csr_off[v + 1]; k++) {
-        const float *r = d_corner + 3 * (size_t)csr_idx[k];
-        a0 += r[0]; a1 += r[1]; a2 += r[2];
+    const int kb = csr_off[v], ke = csr_off[v + 1];
+    for (int k0 = kb; k0 < ke; k0 += 8) {   // 8 corners in flight per trip, summed in list order
+        float r[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float *q = d_corner + 3 * (size_t)csr_idx[min(k0 + u, ke - 1)];
+            r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + u < ke) { a0 += r[u][0]; a1 += r[u][1]; a2 += r[u][2]; }
     }
     d_verts[3 * (size_t)v] = a0; d_verts[3 * (size_t)v + 1] = a1; d_verts[3 * (size_t)v + 2] = a2;
 }
