@@ -15,6 +15,8 @@ from gomavatar_amd.train_util import unpack
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--img", type=int, default=512); ap.add_argument("--level", type=int, default=1); ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--graph", action="store_true", help="capture the frame once in a HIP graph (device-resident camera, fixed-capacity shadow list) and replay it")
+ap.add_argument("--overlap", action="store_true", help="mesh branch and splat rasterizer on two streams (Model.overlap_branches)")
 ap.add_argument("--subdivide", action="store_true", help="one mesh subdivision first (the reference subdivides during training: 4x the faces)")
 a = ap.parse_args()
 cfg = NS(img_size=(a.img, a.img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
@@ -29,10 +31,20 @@ if a.subdivide:
 model.eval()
 frames = [{k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(i, a.img).items()} for i in range(16)]
 
-def render(fr):
+def render_eager(fr):
     with torch.no_grad():
         rgbs, masks, _ = model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
         return unpack(rgbs, masks, fr["bgcolor"])
+
+model.overlap_branches = a.overlap
+if a.graph:
+    from gomavatar_amd.train_util import GraphedRender
+    # the graph evaluates the shadow MLP on a fixed number of pixel slots: 1.3 x the largest mesh footprint of the sequence
+    with torch.no_grad():
+        model.shadow_capacity = int(1.3 * max(int((model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])[1] > 0).sum()) for fr in frames))
+    render = GraphedRender(model)
+else:
+    render = render_eager
 
 for i in range(30):
     out = render(frames[i % 16])
@@ -49,4 +61,5 @@ for i in range(50):                       # latency of one frame, nothing else i
     lat.append(time.perf_counter() - t)
 lat.sort()
 print(json.dumps({"frames_per_s": round(a.frames / dt, 1), "latency_ms_median": round(lat[len(lat) // 2] * 1e3, 3), "img": a.img,
-                  "faces": int(model.faces.shape[0]), "coverage": round(float((out.sum(-1) > 0).float().mean()), 3)}))
+                  "faces": int(model.faces.shape[0]), "graph": bool(a.graph),
+                  "max_abs_diff_vs_eager": round(float((render(frames[3]) - render_eager(frames[3])).abs().max()), 6)}))

@@ -257,3 +257,28 @@ def test_shadow_mlp_fused_kernels_vs_torch_cpu(multires, width, depth, skips, n)
     assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
     for p, q in zip(sm.parameters(), ref.parameters()):
         assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1e-6, float(q.grad.abs().max())), tuple(p.shape)
+
+
+def test_graphed_render_and_two_stream_rendering_equal_the_eager_frame():
+    """train_util.GraphedRender (one HIP graph per frame, replayed with new poses / cameras) and Model.overlap_branches (mesh
+    branch on a side stream) against the plain eval-mode forward."""
+    from gomavatar_amd.train_util import GraphedRender, unpack
+    m = _small_model(96)
+    frames = [{k: v.cuda() for k, v in _frame(i, 96).items() if torch.is_tensor(v)} for i in range(3)]
+    m.eval()
+    def eager(fr):
+        with torch.no_grad():
+            rgbs, masks, _ = m(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            return unpack(rgbs, masks, fr["bgcolor"]).clone()
+    ref = [eager(fr) for fr in frames[:3]]
+    m.overlap_branches = True
+    for fr, r in zip(frames[:3], ref):
+        assert torch.equal(eager(fr), r)
+    for overlap in (False, True):
+        m.overlap_branches = overlap
+        render = GraphedRender(m)
+        for fr, r in zip(frames[:3], ref):           # first call captures, the others only rewrite the static inputs
+            d = (render(fr) - r).abs()               # (device-side camera products: last-bit differences, see the capture_safe test)
+            assert float(d.mean()) < 1e-6 and float(d.max()) < 1e-3, (overlap, float(d.mean()), float(d.max()))
+        m.capture_safe = False
+    m.overlap_branches = False
