@@ -250,13 +250,26 @@ def test_shadow_mlp_fused_kernels_vs_torch_cpu(multires, width, depth, skips, n)
                 m.bias.normal_(0, 0.1)
     ref = copy.deepcopy(sm).cpu()
     x, w = torch.randn(n, 3), torch.randn(n, 1)
+    # A pre-activation within rounding of 0 lands on either side of the ReLU kink depending on the summation order (against fp64
+    # it is as often the CPU as the kernel that is "wrong"; about one row in a few thousand).  Such rows get loss weight 0, so
+    # the comparison of the gradients is exact about everything else -- a dropped or doubled row would still show.
+    with torch.no_grad():
+        refd, pre = copy.deepcopy(ref).double(), []
+        hooks = [m.register_forward_hook(lambda _m, _i, o: pre.append(o.abs().min(-1).values.reshape(-1))) for m in list(refd.block_mlps)[:-1]
+                 if isinstance(m, torch.nn.Linear)]
+        refd(x.double())
+        for h in hooks:
+            h.remove()
+        w[torch.stack(pre).min(0).values < 1e-5] = 0.0
     xr = x.clone().requires_grad_(); yr = ref(xr); (yr * w).sum().backward()
     xg = x.cuda().requires_grad_(); yg = sm(xg); (yg * w.cuda()).sum().backward()
     assert yg.shape == yr.shape
     assert float((yg.detach().cpu() - yr.detach()).abs().max()) <= 2e-6
     assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    # every parameter gradient is a sum over the n rows: fp32 accumulation error scales with sum |w_r| even where the terms cancel
+    floor = 1e-3 * float(w.abs().sum())
     for p, q in zip(sm.parameters(), ref.parameters()):
-        assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1e-6, float(q.grad.abs().max())), tuple(p.shape)
+        assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(floor, float(q.grad.abs().max())), tuple(p.shape)
 
 
 def test_graphed_render_and_two_stream_rendering_equal_the_eager_frame():
