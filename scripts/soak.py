@@ -10,7 +10,7 @@ import sys, os, time, traceback
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 os.chdir("/root/repo")
 import numpy as np, torch
-import test_gpu_raster as TR, test_gpu_batch as TB, test_gpu_vgg_bf16 as TV, test_gpu_model as TM
+import test_gpu_raster as TR, test_gpu_batch as TB, test_gpu_vgg_bf16 as TV, test_gpu_model as TM, test_gpu_mesh as TMe, test_gpu_metrics as TMt
 t0 = time.time(); n_ok = n_bad = 0
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -43,5 +43,15 @@ while time.time() - t0 < budget:
             TM.test_shadow_mlp_fused_kernels_vs_torch_cpu(*cfgm); n_ok += 1
         except Exception as e:
             n_bad += 1; print("MLP FAIL", cfgm, repr(e)[:300], flush=True)
+    if seed % 15 == 0:
+        cfgs = (int(rng.integers(40, 120)), float(rng.uniform(0.8, 4.0)))
+        try:
+            TMe.test_forward_and_backward_match_oracle(*cfgs); n_ok += 1
+        except Exception as e:
+            n_bad += 1; print("MESH FAIL", cfgs, repr(e)[:300], flush=True)
+        try:
+            TMt.test_ssim_both_definitions_and_psnr(seed); n_ok += 1
+        except Exception as e:
+            n_bad += 1; print("SSIM FAIL", seed, repr(e)[:300], flush=True)
     seed += 1
 print("soak: ok", n_ok, "bad", n_bad, "last seed", seed, "in", round(time.time() - t0), "s")
