@@ -64,6 +64,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_linear_wgrad_slices": (c_int, []),
     "gom_linear_wgrad": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_l1_terms_forward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 3),
+    "gom_l1_terms_backward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
     "gom_mlp3_forward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 14),
     "gom_mlp3_backward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 15),
     "gom_posenc_forward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -80,3 +80,98 @@ extern "C" int gom_l1_loss(int H, int W, const float *pred, const float *shade, 
     return gom_l1_loss_batch(1, H, W, pred, shade, gt_rgb, gt_mask, bg, c_rgb, c_mask, grad_scale, dL_dpred, dL_dshade, loss_partials,
                              stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The three "mean |a - b|" terms of the reference's compute_loss (train.py:101-111 rgb and mask, train.py:141-149 normal mask
+// against the k x k dilation of the target mask) on ALREADY UNPACKED images, as `Model` + `train_util.compute_loss` see them:
+// one launch for the three sums (+ a one-block fold), one for the three gradient images.  Through torch the same arithmetic is
+// 10 launches forward and ~14 backward, each 3-5 us of kernel and ~10 us of host time.
+namespace {
+
+struct L1Terms {
+    const float *a[3];   // predictions: rgb (HW*3), mask (HW), normal mask (HW) -- a null `a` switches the term off
+    const float *b[3];   // targets: rgb (HW*3), mask (HW), mask again (dilated on the fly for term 2)
+    float *da[3];        // backward only
+};
+
+// max over the k x k window of the target mask clipped to the image (F.max_pool2d, stride 1, padding k/2: pads with -inf)
+__device__ __forceinline__ float dilated(const float *__restrict__ m, int H, int W, int p, int k) {
+    const int y = p / W, x = p - y * W, r = k / 2;
+    float v = -INFINITY;
+    for (int yy = max(0, y - r); yy <= min(H - 1, y + r); yy++)
+        for (int xx = max(0, x - r); xx <= min(W - 1, x + r); xx++) v = fmaxf(v, m[yy * W + xx]);
+    return v;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_l1_terms(L1Terms t, int H, int W, int dil_k, const float *__restrict__ g, float *__restrict__ partials) {
+    __shared__ float s_red[3][4];
+    const int HW = H * W;
+    float sum[3] = {0.f, 0.f, 0.f};
+    float gs[3] = {0.f, 0.f, 0.f};
+    if (BWD) { gs[0] = g[0] / (3.f * (float)HW); gs[1] = g[1] / (float)HW; gs[2] = g[2] / (float)HW; }
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        if (t.a[0]) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float d = t.a[0][3 * (size_t)p + c] - t.b[0][3 * (size_t)p + c];
+                if (BWD) t.da[0][3 * (size_t)p + c] = sgn(d) * gs[0]; else sum[0] += fabsf(d);
+            }
+        }
+        if (t.a[1]) {
+            const float d = t.a[1][p] - t.b[1][p];
+            if (BWD) t.da[1][p] = sgn(d) * gs[1]; else sum[1] += fabsf(d);
+        }
+        if (t.a[2]) {
+            const float d = t.a[2][p] - (dil_k > 1 ? dilated(t.b[2], H, W, p, dil_k) : t.b[2][p]);
+            if (BWD) t.da[2][p] = sgn(d) * gs[2]; else sum[2] += fabsf(d);
+        }
+    }
+    if (BWD) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum[q] += __shfl_xor(sum[q], d, 64);
+        if (lane == 0) s_red[q][wave] = sum[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partials[3 * blockIdx.x + threadIdx.x] = (s_red[threadIdx.x][0] + s_red[threadIdx.x][1]) + (s_red[threadIdx.x][2] + s_red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(64) k_l1_terms_fold(int HW, int nblocks, const float *__restrict__ partials, float *__restrict__ out) {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblocks; b += 64) { s[0] += partials[3 * b]; s[1] += partials[3 * b + 1]; s[2] += partials[3 * b + 2]; }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[q] += __shfl_xor(s[q], d, 64);
+    if (threadIdx.x == 0) { out[0] = s[0] / (3.f * (float)HW); out[1] = s[1] / (float)HW; out[2] = s[2] / (float)HW; }
+}
+
+}  // namespace
+
+extern "C" int gom_l1_terms_forward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
+                                    const float *normal_mask, int dil_k, float *out3, float *partials, void *stream) {
+    if (H <= 0 || W <= 0 || dil_k < 0 || (dil_k > 1 && !(dil_k & 1))) { gom_set_error("gom_l1_terms_forward: bad image size or even dilation window"); return -1; }
+    if (!out3 || !partials || (rgb && !rgb_gt) || ((mask || normal_mask) && !mask_gt)) { gom_set_error("gom_l1_terms_forward: null pointer"); return -1; }
+    L1Terms t = {{rgb, mask, normal_mask}, {rgb_gt, mask_gt, mask_gt}, {nullptr, nullptr, nullptr}};
+    hipLaunchKernelGGL(k_l1_terms<false>, dim3(GOM_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, t, H, W, dil_k, (const float *)nullptr, partials);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_l1_terms_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, H * W, GOM_LOSS_BLOCKS, partials, out3);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_l1_terms_backward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
+                                     const float *normal_mask, int dil_k, const float *g3, float *d_rgb, float *d_mask, float *d_normal_mask,
+                                     void *stream) {
+    if (H <= 0 || W <= 0 || dil_k < 0 || (dil_k > 1 && !(dil_k & 1))) { gom_set_error("gom_l1_terms_backward: bad image size or even dilation window"); return -1; }
+    if (!g3 || (rgb && (!rgb_gt || !d_rgb)) || (mask && (!mask_gt || !d_mask)) || (normal_mask && (!mask_gt || !d_normal_mask))) {
+        gom_set_error("gom_l1_terms_backward: null pointer"); return -1;
+    }
+    L1Terms t = {{rgb, mask, normal_mask}, {rgb_gt, mask_gt, mask_gt}, {d_rgb, d_mask, d_normal_mask}};
+    hipLaunchKernelGGL(k_l1_terms<true>, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, H, W, dil_k, g3, (float *)nullptr);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

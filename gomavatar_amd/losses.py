@@ -61,3 +61,41 @@ def compute_loss_l1(pred_chw, gt_rgb, gt_mask, bgcolor, loss_cfg=None, shade=Non
     total, l_rgb, l_mask = l1_photometric(pred_chw, gt_rgb, gt_mask, bgcolor, shade, c_rgb, c_mask)
     losses = {"rgb": {"unscaled": l_rgb, "scaled": l_rgb * c_rgb}, "mask": {"unscaled": l_mask, "scaled": l_mask * c_mask}}
     return total, losses
+
+
+class _L1Terms(torch.autograd.Function):
+    """The three mean-|a - b| terms of compute_loss (rgb, mask, normal mask vs the dilated target mask) on unpacked images:
+    csrc/loss.hip gom_l1_terms_forward / _backward.  Returns a (3,) tensor; a term whose prediction is None is 0."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_gt, mask, mask_gt, normal_mask, dil_k):
+        lib = _lib.load()
+        H, W = mask_gt.shape[-2:]
+        keep = [None if x is None else x.float().contiguous() for x in (rgb, rgb_gt, mask, mask_gt, normal_mask)]
+        r, rg, m, mg, nm = keep
+        out = torch.empty(3, dtype=torch.float32, device=mg.device)
+        partials = torch.empty(_lib.GOM_LOSS_BLOCKS * 3, dtype=torch.float32, device=mg.device)
+        _lib.check(lib.gom_l1_terms_forward(H, W, _lib.ptr(r), _lib.ptr(rg), _lib.ptr(m), _lib.ptr(mg), _lib.ptr(nm), int(dil_k), _lib.ptr(out),
+                                            _lib.ptr(partials), _lib.stream_ptr()))
+        ctx.keep, ctx.dil_k, ctx.hw = keep, int(dil_k), (H, W)
+        ctx.shapes = [None if x is None else (x.shape, x.dtype) for x in (rgb, mask, normal_mask)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r, rg, m, mg, nm = ctx.keep
+        g = g.float().contiguous()
+        d = [None if x is None else torch.empty_like(x) for x in (r, m, nm)]
+        _lib.check(lib.gom_l1_terms_backward(ctx.hw[0], ctx.hw[1], _lib.ptr(r), _lib.ptr(rg), _lib.ptr(m), _lib.ptr(mg), _lib.ptr(nm), ctx.dil_k,
+                                             _lib.ptr(g), _lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[2]), _lib.stream_ptr()))
+        d = [None if x is None else x.reshape(s[0]).to(s[1]) for x, s in zip(d, ctx.shapes)]
+        return d[0], None, d[1], None, d[2], None
+
+
+def l1_terms(rgb_pred, rgb_gt, mask_pred, mask_gt, normal_mask=None, dilate: int = 0) -> torch.Tensor:
+    """(3,) = mean|rgb_pred - rgb_gt|, mean|mask_pred - mask_gt|, mean|normal_mask - maxpool_dilate(mask_gt)| for ONE image
+    ((1,H,W,3) / (1,H,W) tensors on the HIP device); value and gradients as torch's abs().mean() (sign(0) = 0)."""
+    if not mask_gt.is_cuda:
+        raise RuntimeError("gomavatar_amd.losses: tensors must be on the HIP device (no CPU fallback)")
+    return _L1Terms.apply(rgb_pred, rgb_gt, mask_pred, mask_gt, normal_mask, dilate)

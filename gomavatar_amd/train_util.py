@@ -47,16 +47,35 @@ def mesh_color_consistency(colors, face_connectivity, loss_topo=None) -> torch.T
     return (colors[face_connectivity[:, 0]] - colors[face_connectivity[:, 1]]).abs().mean()
 
 
+_COEFF_CACHE = {}
+_REF_ORDER = ("rgb", "mask", "lpips", "laplacian_canoincal", "laplacian_observation", "normal_mask", "normal_consist", "color_consist")
+
+
 def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=None, i_iter=0, tb=None, lpips_func=None, **kwargs):
     """train.py:98-163.  `lpips_func(pred_nchw_pm1, gt_nchw_pm1)` as in the reference, or an object with `.loss(pred_nhwc01,
     gt_nhwc01)` (gomavatar_amd.lpips.LPIPSMatrixCore)."""
-    losses = {}
+    names, values, coeffs = [], [], []
 
     def put(name, value, coeff):
-        losses[name] = {"unscaled": value, "scaled": value * coeff}
+        names.append(name); values.append(value); coeffs.append(float(coeff))
 
-    put("rgb", torch.mean(torch.abs(rgb_pred - rgb_gt)), _get(loss_cfg, "rgb.coeff", 1.0))
-    put("mask", torch.mean(torch.abs(mask_pred - mask_gt)), _get(loss_cfg, "mask.coeff", 5.0))
+    want_nm = _get(loss_cfg, "normal.coeff_mask", 0.0) > 0 and outputs.get("normal_mask") is not None
+    k = int(_get(loss_cfg, "normal.kernel_size", 5))
+    fused = rgb_pred.is_cuda and rgb_pred.shape[0] == 1 and rgb_pred.dtype == torch.float32 and (k % 2 == 1 or not want_nm)
+    if fused:      # the three mean-|a - b| terms in one kernel each way (csrc/loss.hip), the dilation of the target mask included
+        from .losses import l1_terms
+        l1 = l1_terms(rgb_pred, rgb_gt, mask_pred, mask_gt, outputs["normal_mask"] if want_nm else None, k if want_nm else 0)
+        put("rgb", None, _get(loss_cfg, "rgb.coeff", 1.0))
+        put("mask", None, _get(loss_cfg, "mask.coeff", 5.0))
+    else:
+        put("rgb", torch.mean(torch.abs(rgb_pred - rgb_gt)), _get(loss_cfg, "rgb.coeff", 1.0))
+        put("mask", torch.mean(torch.abs(mask_pred - mask_gt)), _get(loss_cfg, "mask.coeff", 5.0))
+    if want_nm:    # (the reference's dict order is rgb, mask, lpips, ..., normal_mask: only the summation order of `total` differs)
+        if fused:
+            put("normal_mask", None, loss_cfg.normal.coeff_mask)
+        else:
+            dil = F.max_pool2d(mask_gt.unsqueeze(1), kernel_size=k, stride=1, padding=k // 2).squeeze(1)
+            put("normal_mask", torch.mean(torch.abs(outputs["normal_mask"] - dil)), loss_cfg.normal.coeff_mask)
     if lpips_func is not None and _get(loss_cfg, "lpips.coeff", 1.0) > 0:
         if hasattr(lpips_func, "loss"):
             lp = lpips_func.loss(rgb_pred, rgb_gt)
@@ -67,17 +86,29 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
         put("laplacian_canoincal", mesh_laplacian_smoothing(outputs["mesh_canonical"]), loss_cfg.laplacian.coeff_canonical)
     if _get(loss_cfg, "laplacian.coeff_observation", 0.0) > 0:
         put("laplacian_observation", mesh_laplacian_smoothing(outputs["mesh"]), loss_cfg.laplacian.coeff_observation)
-    if _get(loss_cfg, "normal.coeff_mask", 0.0) > 0 and outputs.get("normal_mask") is not None:
-        k = int(_get(loss_cfg, "normal.kernel_size", 5))
-        dil = F.max_pool2d(mask_gt.unsqueeze(1), kernel_size=k, stride=1, padding=k // 2).squeeze(1)
-        put("normal_mask", torch.mean(torch.abs(outputs["normal_mask"] - dil)), loss_cfg.normal.coeff_mask)
     if _get(loss_cfg, "normal.coeff_consist", 0.0) > 0:
         put("normal_consist", mesh_normal_consistency(outputs["mesh"], outputs["face_connectivity"]), loss_cfg.normal.coeff_consist)
     if _get(loss_cfg, "color_consist.coeff", 0.0) > 0:
         put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"], getattr(outputs.get("mesh"), "loss_topo", None)),
             loss_cfg.color_consist.coeff)
-    total = sum(item["scaled"] for item in losses.values())
-    return total, losses
+    if not fused:
+        order = sorted(range(len(names)), key=lambda i: _REF_ORDER.index(names[i]))
+        losses = {names[i]: {"unscaled": values[i], "scaled": values[i] * coeffs[i]} for i in order}
+        return sum(item["scaled"] for item in losses.values()), losses
+    # One vector of all terms: total = (vector * coefficients).sum() is three launches instead of a multiply and an add per term
+    # (and as many again backward); the dict entries are views into it, still differentiable.
+    rest = [v.reshape(1) for v in values if v is not None]
+    vec = torch.cat([l1[:3 if want_nm else 2]] + rest) if rest else l1[:3 if want_nm else 2]
+    key = (tuple(coeffs), vec.device)
+    cvec = _COEFF_CACHE.get(key)
+    if cvec is None:
+        if len(_COEFF_CACHE) > 64:
+            _COEFF_CACHE.clear()
+        cvec = _COEFF_CACHE[key] = torch.tensor(coeffs, dtype=vec.dtype, device=vec.device)
+    scaled = vec * cvec
+    order = sorted(range(len(names)), key=lambda i: _REF_ORDER.index(names[i]))      # the reference's dict order
+    losses = {names[i]: {"unscaled": vec[i], "scaled": scaled[i]} for i in order}
+    return scaled.sum(), losses
 
 
 class GraphedTrainStep:

@@ -166,6 +166,15 @@ int gom_posenc_backward(int64_t n, int L, const float *x, const float *g_out, fl
 int gom_linear_wgrad_slices(void);
 int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float *X, const float *dY, float *dW, float *db, float *workspace, void *stream);
 
+/* ---- the three "mean |a - b|" terms of compute_loss on unpacked images (train.py:101-111: rgb (H,W,3) and mask (H,W) against
+ * their targets; train.py:141-149: normal mask (H,W) against the dil_k x dil_k max-pool dilation of the target mask, dil_k odd or
+ * <= 1 for none).  A null prediction switches its term off (its output is 0).  forward: out3 = the three means, partials
+ * [GOM_LOSS_BLOCKS][3] scratch.  backward: g3 = dL/d out3 (device), d_* = g * sign(a - b) / count, like torch's abs / mean. */
+int gom_l1_terms_forward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
+                         const float *normal_mask, int dil_k, float *out3, float *partials, void *stream);
+int gom_l1_terms_backward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
+                          const float *normal_mask, int dil_k, const float *g3, float *d_rgb, float *d_mask, float *d_normal_mask, void *stream);
+
 /* ---- the shadow MLP at its default shape (shadow_module.py:66-117 with mlp_depth 3: D0 -> H -> H -> H -> 1, ReLU x 3, sigmoid),
  * D0, H <= 128, nn.Linear weight layout [out][in].  forward: x [n][D0] -> h1, h2, h3 [n][H] (post-ReLU, kept for the backward) and
  * out [n].  backward: g [n] = dL/d out -> dz4 [n], dz3, dz2, dz1 [n][H] (the dY of every layer: feed them to gom_linear_wgrad with

@@ -32,3 +32,43 @@ def test_l1_photometric_matches_reference_formula(with_shade):
     np.testing.assert_allclose(hp.grad.cpu().numpy() / 2.0, p.grad.numpy(), atol=1e-9, rtol=1e-5)
     if with_shade:
         np.testing.assert_allclose(hs.grad.cpu().numpy() / 2.0, s.grad.numpy(), atol=1e-9, rtol=1e-5)
+
+
+@pytest.mark.parametrize("H,W,k,with_nm", [(64, 64, 7, True), (37, 91, 5, True), (48, 40, 7, False), (33, 35, 1, True)])
+def test_l1_terms_match_torch_formulas(H, W, k, with_nm):
+    """csrc/loss.hip gom_l1_terms_*: mean|rgb - gt|, mean|mask - gt|, mean|normal_mask - maxpool_k(gt mask)| (train.py:101-111,
+    141-149) against torch, values and gradients; then compute_loss's total / dict against the term-by-term composition."""
+    import torch.nn.functional as F
+    from types import SimpleNamespace as NS
+    from gomavatar_amd.losses import l1_terms
+    from gomavatar_amd.train_util import compute_loss
+    g = torch.Generator().manual_seed(H * 100 + W)
+    rgb, rgb_gt = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    mask, mask_gt = torch.rand(1, H, W, generator=g), (torch.rand(1, H, W, generator=g) > 0.7).float()
+    nm = torch.rand(1, H, W, 1, generator=g)
+    rgb[0, :3, :3] = rgb_gt[0, :3, :3]                      # exact zeros: sign(0) = 0 like torch's abs backward
+    coeff = torch.tensor([1.3, 0.7, 2.1])
+    def ref(r, m, n):
+        dil = F.max_pool2d(mask_gt.unsqueeze(1), kernel_size=k, stride=1, padding=k // 2).squeeze(1) if k > 1 else mask_gt
+        out = [torch.mean(torch.abs(r - rgb_gt)), torch.mean(torch.abs(m - mask_gt))]
+        out.append(torch.mean(torch.abs(n[..., 0] - dil)) if with_nm else torch.zeros(()))
+        return torch.stack(out)
+    leaves_c = [x.clone().requires_grad_() for x in (rgb, mask, nm)]
+    vr = ref(*leaves_c); (vr * coeff).sum().backward()
+    leaves_g = [x.cuda().requires_grad_() for x in (rgb, mask, nm)]
+    vg = l1_terms(leaves_g[0], rgb_gt.cuda(), leaves_g[1], mask_gt.cuda(), leaves_g[2][..., 0] if with_nm else None, k if with_nm else 0)
+    (vg * coeff.cuda()).sum().backward()
+    assert torch.allclose(vg.cpu(), vr, rtol=2e-6, atol=1e-7), (vg.cpu(), vr)
+    for a, b in zip(leaves_g[:3 if with_nm else 2], leaves_c):
+        assert torch.allclose(a.grad.cpu(), b.grad, rtol=1e-6, atol=1e-12)
+    # compute_loss on device tensors: same dict keys / order as the reference, total = sum of the scaled entries
+    cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=0.0),
+             normal=NS(coeff_mask=1.5 if with_nm else 0.0, kernel_size=max(k, 1), coeff_consist=0.0), color_consist=NS(coeff=0.0))
+    lg = [x.detach().clone().requires_grad_() for x in leaves_g]
+    total, losses = compute_loss(lg[0], lg[1], {"normal_mask": lg[2][..., 0]}, rgb_gt.cuda(), mask_gt.cuda(), cfg)
+    total.backward()
+    assert list(losses) == (["rgb", "mask", "normal_mask"] if with_nm else ["rgb", "mask"])
+    exp = vr[0] * 1.0 + vr[1] * 5.0 + (vr[2] * 1.5 if with_nm else 0.0)
+    assert abs(float(total.detach()) - float(exp.detach())) <= 2e-6 * abs(float(exp.detach()))
+    assert abs(float(losses["mask"]["scaled"]) - 5.0 * float(vr[1])) <= 1e-5 and abs(float(losses["rgb"]["unscaled"]) - float(vr[0])) <= 1e-6
+    assert torch.allclose(lg[1].grad.cpu(), leaves_c[1].grad * (5.0 / 0.7), rtol=1e-5, atol=1e-12)
