@@ -93,6 +93,8 @@ SIGNATURES = {
     "gom_mesh_raster_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gom_mesh_raster_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
     "gom_mesh_pix_to_face": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gom_ndc_from_world_forward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5),
+    "gom_ndc_from_world_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 6),
     "gom_vertex_normals_forward": (c_int, [c_int, c_int] + [c_void_p] * 7),
     "gom_vertex_normals_backward": (c_int, [c_int, c_int] + [c_void_p] * 9),
     "gom_mesh_laplacian": (c_int, [c_int] + [c_void_p] * 6),

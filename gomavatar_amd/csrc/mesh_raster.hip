@@ -600,3 +600,67 @@ extern "C" int gom_vertex_normals_backward(int N, int F, const float *verts, con
     GOM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- world -> the mesh rasterizer's NDC (utils/pc_util.py:30-46 ndc_T_world): c = E [v; 1], cam = c.xyz / c.w, p = K cam,
+// xy = p.xy / p.z, then x, y -> -(2 xy / S - a) with S the shorter image side; output (x_ndc, y_ndc, cam.z) per vertex.
+// Through torch this is 14 launches forward and ~25 backward on a 27 000-vertex array; here one each (the camera matrices are read
+// from device memory: nothing for a graph capture to freeze).
+namespace {
+
+struct NdcCam { float E[16], K[9]; };
+
+__device__ __forceinline__ void ndc_forward_point(const float *__restrict__ E, const float *__restrict__ K, float x, float y, float z, float (&c)[4], float (&p)[3]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = E[4 * r] * x + E[4 * r + 1] * y + E[4 * r + 2] * z + E[4 * r + 3];
+    const float cam[3] = {c[0] / c[3], c[1] / c[3], c[2] / c[3]};
+#pragma unroll
+    for (int r = 0; r < 3; r++) p[r] = K[3 * r] * cam[0] + K[3 * r + 1] * cam[1] + K[3 * r + 2] * cam[2];
+}
+
+__global__ void __launch_bounds__(256) k_ndc_fwd(int N, float S, float ax, float ay, const float *__restrict__ verts, const float *__restrict__ K,
+                                                 const float *__restrict__ E, float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float c[4], p[3];
+    ndc_forward_point(E, K, verts[n], verts[(size_t)N + n], verts[2 * (size_t)N + n], c, p);
+    out[3 * (size_t)n] = -((p[0] / p[2] / S) * 2.f - ax);
+    out[3 * (size_t)n + 1] = -((p[1] / p[2] / S) * 2.f - ay);
+    out[3 * (size_t)n + 2] = c[2] / c[3];
+}
+
+__global__ void __launch_bounds__(256) k_ndc_bwd(int N, float S, const float *__restrict__ verts, const float *__restrict__ K, const float *__restrict__ E,
+                                                 const float *__restrict__ d_out, float *__restrict__ d_verts) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float c[4], p[3];
+    ndc_forward_point(E, K, verts[n], verts[(size_t)N + n], verts[2 * (size_t)N + n], c, p);
+    const float dxy0 = -2.f / S * d_out[3 * (size_t)n], dxy1 = -2.f / S * d_out[3 * (size_t)n + 1];
+    const float ip2 = 1.f / p[2];
+    const float dp[3] = {dxy0 * ip2, dxy1 * ip2, -(dxy0 * p[0] + dxy1 * p[1]) * ip2 * ip2};
+    float dcam[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) dcam[j] = K[j] * dp[0] + K[3 + j] * dp[1] + K[6 + j] * dp[2];
+    dcam[2] += d_out[3 * (size_t)n + 2];
+    const float ic3 = 1.f / c[3];
+    const float dc[4] = {dcam[0] * ic3, dcam[1] * ic3, dcam[2] * ic3, -(dcam[0] * c[0] + dcam[1] * c[1] + dcam[2] * c[2]) * ic3 * ic3};
+#pragma unroll
+    for (int j = 0; j < 3; j++) d_verts[(size_t)j * N + n] = E[j] * dc[0] + E[4 + j] * dc[1] + E[8 + j] * dc[2] + E[12 + j] * dc[3];
+}
+
+}  // namespace
+
+extern "C" int gom_ndc_from_world_forward(int N, int H, int W, const float *verts, const float *K, const float *E, float *out, void *stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !verts || !K || !E || !out) { gom_set_error("gom_ndc_from_world_forward: bad arguments"); return -1; }
+    const float S = (float)(H < W ? H : W), ax = H < W ? (float)W / (float)H : 1.f, ay = H < W ? 1.f : (float)H / (float)W;
+    hipLaunchKernelGGL(k_ndc_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, S, ax, ay, verts, K, E, out);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_ndc_from_world_backward(int N, int H, int W, const float *verts, const float *K, const float *E, const float *d_out, float *d_verts,
+                                        void *stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !verts || !K || !E || !d_out || !d_verts) { gom_set_error("gom_ndc_from_world_backward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_ndc_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, (float)(H < W ? H : W), verts, K, E, d_out, d_verts);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -22,6 +22,8 @@ from .rasterizer import RasterState
 
 def ndc_T_world(xyzs_world: torch.Tensor, K: torch.Tensor, E: torch.Tensor, H: int, W: int) -> torch.Tensor:
     """utils/pc_util.py:30-46.  (B,3,N) world points -> (B,N,3): negated NDC x, y (shorter side in [-1,1]), camera z."""
+    if xyzs_world.is_cuda and xyzs_world.shape[0] == 1 and xyzs_world.dtype == torch.float32 and not (K.requires_grad or E.requires_grad):
+        return _NdcTWorld.apply(xyzs_world, K, E, H, W)       # one kernel each way (csrc/mesh_raster.hip)
     ones = torch.ones_like(xyzs_world[:, :1])
     cam_ = torch.bmm(E, torch.cat([xyzs_world, ones], 1))
     cam = cam_[:, :3] / cam_[:, 3:]
@@ -34,6 +36,29 @@ def ndc_T_world(xyzs_world: torch.Tensor, K: torch.Tensor, E: torch.Tensor, H: i
         xs = -((xy[:, 0] / W) * 2.0 - 1.0)
         ys = -((xy[:, 1] / W) * 2.0 - (H / W))
     return torch.stack([xs, ys, cam[:, 2]], -1)
+
+
+class _NdcTWorld(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, K, E, H, W):
+        lib = _lib.load()
+        v = xyz[0].contiguous()
+        k, e = K[0].float().contiguous(), E[0].float().contiguous()
+        N = v.shape[1]
+        out = torch.empty(1, N, 3, dtype=torch.float32, device=v.device)
+        _lib.check(lib.gom_ndc_from_world_forward(N, int(H), int(W), _lib.ptr(v), _lib.ptr(k), _lib.ptr(e), _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(v, k, e)
+        ctx.hw = (int(H), int(W))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, k, e = ctx.saved_tensors
+        lib = _lib.load()
+        g = g.float().contiguous()
+        d = torch.empty(1, 3, v.shape[1], dtype=torch.float32, device=v.device)
+        _lib.check(lib.gom_ndc_from_world_backward(v.shape[1], ctx.hw[0], ctx.hw[1], _lib.ptr(v), _lib.ptr(k), _lib.ptr(e), _lib.ptr(g), _lib.ptr(d), _lib.stream_ptr()))
+        return d, None, None, None, None
 
 
 class _VertexNormals(torch.autograd.Function):

@@ -346,7 +346,8 @@ class Model(nn.Module):
                 s_all = torch.where(pos[-1] >= cap, torch.full_like(s_all, float("nan")), s_all)
             else:
                 idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
-                s_sel = self.shadow_module(torch.cat([flat[idx], flat.new_zeros(1, 3)], 0)[None]).reshape(-1, 1)
+                # (index_select: its backward is one index_add; `flat[idx]` goes through a sort-based accumulate, ~12 launches)
+                s_sel = self.shadow_module(torch.cat([flat.index_select(0, idx), flat.new_zeros(1, 3)], 0)[None]).reshape(-1, 1)
                 s_all = s_sel[-1:].expand(flat.shape[0], 1).clone().index_put((idx,), s_sel[:-1])
             return normal, normal_mask, s_all.reshape(Bn, H, W, 1) * 2
         return normal, normal_mask, None

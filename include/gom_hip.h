@@ -292,6 +292,12 @@ int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, const float
 int gom_mesh_raster_backward(GomState *s, int N, int F, int H, int W, const int32_t *csr_off, const int32_t *csr_idx, const float *d_normal_map,
                              const float *d_alpha, float *d_verts_ndc, float *d_vnormals, void *stream);
 int gom_mesh_pix_to_face(GomState *s, int32_t *dst /*[H][W], -1 = background*/, void *stream);
+/* world -> the mesh rasterizer's NDC (utils/pc_util.py:30-46 ndc_T_world) for one frame: verts [3][N] world points, K [9] and
+ * E [16] row-major in DEVICE memory -> out [N][3] = (negated NDC x, negated NDC y with the shorter image side in [-1, 1], camera z).
+ * backward: d_out [N][3] -> d_verts [3][N] (no gradient for K, E: data in the reference). */
+int gom_ndc_from_world_forward(int N, int H, int W, const float *verts, const float *K, const float *E, float *out, void *stream);
+int gom_ndc_from_world_backward(int N, int H, int W, const float *verts, const float *K, const float *E, const float *d_out, float *d_verts, void *stream);
+
 /* vertex normals of a mesh (PyTorch3D Meshes.verts_normals_padded, models/model.py:271): verts [N][3], faces [F][3];
  * sums [N][3] = un-normalised sums (kept for the backward), normals [N][3] = sums / max(|sums|, 1e-6).
  * backward: d_normals [N][3] -> d_verts [N][3]; d_corner_scratch [F][9]. */

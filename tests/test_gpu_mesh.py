@@ -126,3 +126,22 @@ def test_degenerate_and_offscreen_faces_are_harmless():
     assert set(p2f.unique().tolist()) <= {-1, 0}                       # only the first face is ever on top
     assert float((alpha.detach().cpu().double() - a_o).abs().max()) < 2e-5
     assert float(v.grad[3:].abs().max()) == 0.0                        # nothing reaches the other three faces' vertices
+
+
+@pytest.mark.parametrize("H,W", [(96, 96), (64, 112), (120, 72)])
+def test_ndc_from_world_kernel_matches_the_torch_formula(H, W):
+    """gom_ndc_from_world_forward / _backward (utils/pc_util.py:30-46) against the same formula in torch on the CPU, square and both
+    non-square orientations, values and vertex gradient."""
+    from gomavatar_amd.mesh_renderer import ndc_T_world
+    v, faces, K, E = _scene(96)
+    g = torch.Generator().manual_seed(H + W)
+    wgt = torch.randn(1, v.shape[2], 3, generator=g)
+    vc = v.clone().requires_grad_()
+    ref = ndc_T_world(vc, K, E, H, W)                     # host tensors: the torch formula
+    (ref * wgt).sum().backward()
+    vg = v.cuda().requires_grad_()
+    out = ndc_T_world(vg, K.cuda(), E.cuda(), H, W)       # device tensors: the kernel
+    (out * wgt.cuda()).sum().backward()
+    assert out.shape == ref.shape
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert float((vg.grad.cpu() - vc.grad).abs().max()) <= 1e-5 * float(vc.grad.abs().max())
