@@ -64,6 +64,10 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "gom_linear_wgrad_slices": (c_int, []),
     "gom_linear_wgrad": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_compose_forward": (c_int, [c_int, c_int] + [c_void_p] * 6),
+    "gom_compose_backward": (c_int, [c_int, c_int] + [c_void_p] * 8),
+    "gom_unpack_forward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5),
+    "gom_unpack_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 7),
     "gom_l1_terms_forward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 3),
     "gom_l1_terms_backward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
     "gom_mlp3_forward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 14),

@@ -175,3 +175,94 @@ extern "C" int gom_l1_terms_backward(int H, int W, const float *rgb, const float
     GOM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Image composition around the rasterizer's (4,H,W) output, one launch each way instead of the slice / permute / multiply chains:
+//   compose (models/model.py:262-287):  albedo = img[:3] as (H,W,3), mask = img[3], rgb = albedo * shade
+//   unpack  (train.py:53-55):            out = rgb * mask + bg * (1 - mask)
+namespace {
+
+__global__ void __launch_bounds__(256) k_compose_fwd(int HW, const float *__restrict__ img, const float *__restrict__ shade, float *__restrict__ albedo,
+                                                     float *__restrict__ mask, float *__restrict__ rgb) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float s = shade ? shade[p] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = img[(size_t)c * HW + p];
+        albedo[3 * (size_t)p + c] = a;
+        if (rgb) rgb[3 * (size_t)p + c] = a * s;
+    }
+    mask[p] = img[3 * (size_t)HW + p];
+}
+
+__global__ void __launch_bounds__(256) k_compose_bwd(int HW, const float *__restrict__ img, const float *__restrict__ shade, const float *__restrict__ d_albedo,
+                                                     const float *__restrict__ d_mask, const float *__restrict__ d_rgb, float *__restrict__ d_img,
+                                                     float *__restrict__ d_shade) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float s = shade ? shade[p] : 1.f;
+    float ds = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float gr = d_rgb ? d_rgb[3 * (size_t)p + c] : 0.f;
+        d_img[(size_t)c * HW + p] = (d_albedo ? d_albedo[3 * (size_t)p + c] : 0.f) + gr * s;
+        ds += gr * img[(size_t)c * HW + p];
+    }
+    d_img[3 * (size_t)HW + p] = d_mask ? d_mask[p] : 0.f;
+    if (d_shade) d_shade[p] = ds;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_unpack(int HW, const float *__restrict__ rgb, const float *__restrict__ mask, const float *__restrict__ bg,
+                                                const float *__restrict__ g, float *__restrict__ out, float *__restrict__ d_rgb, float *__restrict__ d_mask) {
+    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;   // b: image of the batch
+    if (p >= HW) return;
+    const size_t q = (size_t)b * HW + p;
+    const float m = mask[q];
+    float dm = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float r = rgb[3 * q + c], k = bg[3 * b + c];
+        if (!BWD) out[3 * q + c] = r * m + k * (1.f - m);
+        else {
+            const float gc = g[3 * q + c];
+            d_rgb[3 * q + c] = gc * m;
+            dm += gc * (r - k);
+        }
+    }
+    if (BWD) d_mask[q] = dm;
+}
+
+}  // namespace
+
+extern "C" int gom_compose_forward(int H, int W, const float *img, const float *shade, float *albedo, float *mask, float *rgb, void *stream) {
+    if (H <= 0 || W <= 0 || !img || !albedo || !mask) { gom_set_error("gom_compose_forward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_compose_fwd, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H * W, img, shade, albedo, mask, rgb);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_compose_backward(int H, int W, const float *img, const float *shade, const float *d_albedo, const float *d_mask, const float *d_rgb,
+                                    float *d_img, float *d_shade, void *stream) {
+    if (H <= 0 || W <= 0 || !img || !d_img) { gom_set_error("gom_compose_backward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_compose_bwd, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H * W, img, shade, d_albedo, d_mask, d_rgb, d_img, d_shade);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_unpack_forward(int B, int H, int W, const float *rgb, const float *mask, const float *bg, float *out, void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || !rgb || !mask || !bg || !out) { gom_set_error("gom_unpack_forward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_unpack<false>, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, H * W, rgb, mask, bg, (const float *)nullptr, out,
+                       (float *)nullptr, (float *)nullptr);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_unpack_backward(int B, int H, int W, const float *rgb, const float *mask, const float *bg, const float *g, float *d_rgb, float *d_mask,
+                                   void *stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || !rgb || !mask || !bg || !g || !d_rgb || !d_mask) { gom_set_error("gom_unpack_backward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_unpack<true>, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, H * W, rgb, mask, bg, g, (float *)nullptr, d_rgb, d_mask);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -99,3 +99,71 @@ def l1_terms(rgb_pred, rgb_gt, mask_pred, mask_gt, normal_mask=None, dilate: int
     if not mask_gt.is_cuda:
         raise RuntimeError("gomavatar_amd.losses: tensors must be on the HIP device (no CPU fallback)")
     return _L1Terms.apply(rgb_pred, rgb_gt, mask_pred, mask_gt, normal_mask, dilate)
+
+
+class _Compose(torch.autograd.Function):
+    """(4,H,W) rasterizer output (+ shading (1,H,W,1)) -> albedo (1,H,W,3), mask (1,H,W), rgb = albedo * shading (1,H,W,3)."""
+
+    @staticmethod
+    def forward(ctx, img, shade):
+        lib = _lib.load()
+        _, H, W = img.shape
+        im = img.float().contiguous()
+        sh = shade.float().contiguous() if shade is not None else None
+        albedo = torch.empty(1, H, W, 3, dtype=torch.float32, device=im.device)
+        mask = torch.empty(1, H, W, dtype=torch.float32, device=im.device)
+        rgb = torch.empty_like(albedo) if sh is not None else None
+        _lib.check(lib.gom_compose_forward(H, W, _lib.ptr(im), _lib.ptr(sh), _lib.ptr(albedo), _lib.ptr(mask), _lib.ptr(rgb), _lib.stream_ptr()))
+        ctx.save_for_backward(im, sh)
+        ctx.shade_shape = None if shade is None else shade.shape
+        if rgb is None:
+            return albedo, mask
+        return albedo, mask, rgb
+
+    @staticmethod
+    def backward(ctx, d_albedo, d_mask, d_rgb=None):
+        im, sh = ctx.saved_tensors
+        lib = _lib.load()
+        _, H, W = im.shape
+        keep = [None if g is None else g.float().contiguous() for g in (d_albedo, d_mask, d_rgb)]
+        d_img = torch.empty_like(im)
+        d_shade = torch.empty_like(sh) if sh is not None and ctx.needs_input_grad[1] else None
+        _lib.check(lib.gom_compose_backward(H, W, _lib.ptr(im), _lib.ptr(sh), _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(keep[2]), _lib.ptr(d_img),
+                                            _lib.ptr(d_shade), _lib.stream_ptr()))
+        return d_img, (d_shade.reshape(ctx.shade_shape) if d_shade is not None else None)
+
+
+def compose(img_chw: torch.Tensor, shade: Optional[torch.Tensor] = None):
+    """model.py:262-287 around the splat image: (albedos (1,H,W,3), masks (1,H,W), rgbs (1,H,W,3) = albedos * shade); without a
+    shading the rgbs ARE the albedos."""
+    if not img_chw.is_cuda:
+        raise RuntimeError("gomavatar_amd.losses: tensors must be on the HIP device (no CPU fallback)")
+    out = _Compose.apply(img_chw, shade)
+    return out if len(out) == 3 else (out[0], out[1], out[0])
+
+
+class _Unpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgbs, masks, bg):
+        lib = _lib.load()
+        B, H, W, _ = rgbs.shape
+        r, m, k = rgbs.float().contiguous(), masks.float().contiguous(), bg.float().contiguous()
+        out = torch.empty_like(r)
+        _lib.check(lib.gom_unpack_forward(B, H, W, _lib.ptr(r), _lib.ptr(m), _lib.ptr(k), _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(r, m, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r, m, k = ctx.saved_tensors
+        lib = _lib.load()
+        B, H, W, _ = r.shape
+        g = g.float().contiguous()
+        d_r, d_m = torch.empty_like(r), torch.empty_like(m)
+        _lib.check(lib.gom_unpack_backward(B, H, W, _lib.ptr(r), _lib.ptr(m), _lib.ptr(k), _lib.ptr(g), _lib.ptr(d_r), _lib.ptr(d_m), _lib.stream_ptr()))
+        return d_r, d_m, None
+
+
+def unpack_fused(rgbs, masks, bgcolors):
+    """train.py:53-55 as one kernel each way: rgbs (B,H,W,3), masks (B,H,W), bgcolors (B,3)."""
+    return _Unpack.apply(rgbs, masks, bgcolors)

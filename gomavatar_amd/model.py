@@ -24,6 +24,7 @@ from . import _lib
 from .geometry import MeshTopology, apply_lbs, face_gaussians, get_global_RTs, posed_face_gaussians
 from .mesh_renderer import MeshNormalRenderer, vertex_normals
 from .rasterizer import DeviceCamera, rasterize
+from .losses import compose
 from . import synthetic as _syn
 
 
@@ -348,7 +349,8 @@ class Model(nn.Module):
                 idx = (flat != 0).any(-1).nonzero(as_tuple=True)[0]
                 # (index_select: its backward is one index_add; `flat[idx]` goes through a sort-based accumulate, ~12 launches)
                 s_sel = self.shadow_module(torch.cat([flat.index_select(0, idx), flat.new_zeros(1, 3)], 0)[None]).reshape(-1, 1)
-                s_all = s_sel[-1:].expand(flat.shape[0], 1).clone().index_put((idx,), s_sel[:-1])
+                body, bg_val = torch.split(s_sel, [s_sel.shape[0] - 1, 1])        # (one cat in the backward instead of two padded slices)
+                s_all = bg_val.expand(flat.shape[0], 1).clone().index_put((idx,), body)
             return normal, normal_mask, s_all.reshape(Bn, H, W, 1) * 2
         return normal, normal_mask, None
 
@@ -400,7 +402,6 @@ class Model(nn.Module):
             with torch.cuda.stream(self._side_stream):
                 normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E)
         img, _ = rasterize(xyz, cov6, feat, opacity, cam)
-        albedos, masks = img[:3].permute(1, 2, 0)[None], img[3][None]
         if overlap:
             cur.wait_stream(self._side_stream)
             for t_ in (normal, normal_mask, shadings):
@@ -408,7 +409,8 @@ class Model(nn.Module):
                     t_.record_stream(cur)
         else:
             normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E)
-        rgbs = albedos * shadings if shadings is not None else albedos
+        # albedos = img[:3] as (1,H,W,3), masks = img[3], rgbs = albedos * shadings: one kernel each way (csrc/loss.hip)
+        albedos, masks, rgbs = compose(img, shadings)
         outputs = {}
         if self.training:
             vo, vc = vertices_observation.T, vertices_canonical.T

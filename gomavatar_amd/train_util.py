@@ -11,6 +11,9 @@ from .model import _get
 
 def unpack(rgbs, masks, bgcolors):
     """train.py:53-55."""
+    if rgbs.is_cuda and rgbs.dtype == torch.float32 and rgbs.dim() == 4 and rgbs.shape[-1] == 3 and bgcolors.dim() == 2 and not bgcolors.requires_grad:
+        from .losses import unpack_fused
+        return unpack_fused(rgbs, masks, bgcolors)            # one kernel each way (csrc/loss.hip)
     return rgbs * masks.unsqueeze(-1) + bgcolors[:, None, None, :] * (1 - masks).unsqueeze(-1)
 
 

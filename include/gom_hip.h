@@ -166,6 +166,19 @@ int gom_posenc_backward(int64_t n, int L, const float *x, const float *g_out, fl
 int gom_linear_wgrad_slices(void);
 int gom_linear_wgrad(int64_t n, int in_dim, int out_dim, const float *X, const float *dY, float *dW, float *db, float *workspace, void *stream);
 
+/* ---- image composition around the rasterizer's output, one launch each way ------------------------------------------------
+ * compose (models/model.py:262-287): img (4,H,W) = albedo rgb + alpha, shade (H,W) or NULL -> albedo (H,W,3), mask (H,W),
+ *   rgb (H,W,3) = albedo * shade (rgb may be NULL).  backward: any of d_albedo / d_mask / d_rgb may be NULL (= zero);
+ *   d_img (4,H,W), d_shade (H,W) or NULL.
+ * unpack (train.py:53-55): out = rgb * mask + bg * (1 - mask) for B images, rgb (B,H,W,3), mask (B,H,W), bg (B,3).
+ *   backward: g (B,H,W,3) -> d_rgb, d_mask (no gradient for the background colour: data). */
+int gom_compose_forward(int H, int W, const float *img, const float *shade, float *albedo, float *mask, float *rgb, void *stream);
+int gom_compose_backward(int H, int W, const float *img, const float *shade, const float *d_albedo, const float *d_mask, const float *d_rgb,
+                         float *d_img, float *d_shade, void *stream);
+int gom_unpack_forward(int B, int H, int W, const float *rgb, const float *mask, const float *bg, float *out, void *stream);
+int gom_unpack_backward(int B, int H, int W, const float *rgb, const float *mask, const float *bg, const float *g, float *d_rgb, float *d_mask,
+                        void *stream);
+
 /* ---- the three "mean |a - b|" terms of compute_loss on unpacked images (train.py:101-111: rgb (H,W,3) and mask (H,W) against
  * their targets; train.py:141-149: normal mask (H,W) against the dil_k x dil_k max-pool dilation of the target mask, dil_k odd or
  * <= 1 for none).  A null prediction switches its term off (its output is 0).  forward: out3 = the three means, partials

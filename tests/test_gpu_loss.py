@@ -72,3 +72,31 @@ def test_l1_terms_match_torch_formulas(H, W, k, with_nm):
     assert abs(float(total.detach()) - float(exp.detach())) <= 2e-6 * abs(float(exp.detach()))
     assert abs(float(losses["mask"]["scaled"]) - 5.0 * float(vr[1])) <= 1e-5 and abs(float(losses["rgb"]["unscaled"]) - float(vr[0])) <= 1e-6
     assert torch.allclose(lg[1].grad.cpu(), leaves_c[1].grad * (5.0 / 0.7), rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("H,W,with_shade", [(40, 56, True), (33, 31, False)])
+def test_compose_and_unpack_kernels_match_the_torch_chains(H, W, with_shade):
+    """csrc/loss.hip gom_compose_* (model.py:262-287: albedo / mask views of the splat image, rgb = albedo * shading) and gom_unpack_*
+    (train.py:53-55) against the slice / permute / multiply chains they replace, values and gradients."""
+    from gomavatar_amd.losses import compose
+    from gomavatar_amd.train_util import unpack
+    g = torch.Generator().manual_seed(H + W)
+    img, shade, bg = torch.rand(4, H, W, generator=g), torch.rand(1, H, W, 1, generator=g) * 2, torch.rand(1, 3, generator=g)
+    w = [torch.randn(1, H, W, 3, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, 3, generator=g)]
+    def chain(im, sh, dev):
+        albedos, masks = im[:3].permute(1, 2, 0)[None], im[3][None]
+        rgbs = albedos * sh if sh is not None else albedos
+        out = rgbs * masks.unsqueeze(-1) + bg.to(dev)[:, None, None, :] * (1 - masks).unsqueeze(-1)     # unpack, the torch formula
+        return albedos, masks, rgbs, out
+    ic, sc = img.clone().requires_grad_(), (shade.clone().requires_grad_() if with_shade else None)
+    a, m, r, o = chain(ic, sc, "cpu")
+    ((a * w[0]).sum() + (m * w[1]).sum() + (o * w[2]).sum()).backward()
+    ig, sg = img.cuda().requires_grad_(), (shade.cuda().requires_grad_() if with_shade else None)
+    a2, m2, r2 = compose(ig, sg)
+    o2 = unpack(r2, m2, bg.cuda())
+    ((a2 * w[0].cuda()).sum() + (m2 * w[1].cuda()).sum() + (o2 * w[2].cuda()).sum()).backward()
+    for x, y in ((a2, a), (m2, m), (r2, r), (o2, o)):
+        assert x.shape == y.shape and torch.allclose(x.detach().cpu(), y.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(ig.grad.cpu(), ic.grad, rtol=1e-5, atol=1e-6)
+    if with_shade:
+        assert torch.allclose(sg.grad.cpu(), sc.grad, rtol=1e-5, atol=1e-6)
