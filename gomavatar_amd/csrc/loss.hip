@@ -156,9 +156,11 @@ extern "C" int gom_l1_terms_forward(int H, int W, const float *rgb, const float 
     if (H <= 0 || W <= 0 || dil_k < 0 || (dil_k > 1 && !(dil_k & 1))) { gom_set_error("gom_l1_terms_forward: bad image size or even dilation window"); return -1; }
     if (!out3 || !partials || (rgb && !rgb_gt) || ((mask || normal_mask) && !mask_gt)) { gom_set_error("gom_l1_terms_forward: null pointer"); return -1; }
     L1Terms t = {{rgb, mask, normal_mask}, {rgb_gt, mask_gt, mask_gt}, {nullptr, nullptr, nullptr}};
-    hipLaunchKernelGGL(k_l1_terms<false>, dim3(GOM_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, t, H, W, dil_k, (const float *)nullptr, partials);
+    // one pixel per thread up to 4 x GOM_LOSS_BLOCKS workgroups (the dilation is a 49-load loop per pixel: latency, not bandwidth)
+    const int nblocks = min((H * W + 255) / 256, 4 * GOM_LOSS_BLOCKS);
+    hipLaunchKernelGGL(k_l1_terms<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, t, H, W, dil_k, (const float *)nullptr, partials);
     GOM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_l1_terms_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, H * W, GOM_LOSS_BLOCKS, partials, out3);
+    hipLaunchKernelGGL(k_l1_terms_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, H * W, nblocks, partials, out3);
     GOM_LAUNCH_CHECK();
     return 0;
 }

@@ -74,7 +74,7 @@ class _L1Terms(torch.autograd.Function):
         keep = [None if x is None else x.float().contiguous() for x in (rgb, rgb_gt, mask, mask_gt, normal_mask)]
         r, rg, m, mg, nm = keep
         out = torch.empty(3, dtype=torch.float32, device=mg.device)
-        partials = torch.empty(_lib.GOM_LOSS_BLOCKS * 3, dtype=torch.float32, device=mg.device)
+        partials = torch.empty(4 * _lib.GOM_LOSS_BLOCKS * 3, dtype=torch.float32, device=mg.device)
         _lib.check(lib.gom_l1_terms_forward(H, W, _lib.ptr(r), _lib.ptr(rg), _lib.ptr(m), _lib.ptr(mg), _lib.ptr(nm), int(dil_k), _lib.ptr(out),
                                             _lib.ptr(partials), _lib.stream_ptr()))
         ctx.keep, ctx.dil_k, ctx.hw = keep, int(dil_k), (H, W)

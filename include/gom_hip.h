@@ -182,7 +182,7 @@ int gom_unpack_backward(int B, int H, int W, const float *rgb, const float *mask
 /* ---- the three "mean |a - b|" terms of compute_loss on unpacked images (train.py:101-111: rgb (H,W,3) and mask (H,W) against
  * their targets; train.py:141-149: normal mask (H,W) against the dil_k x dil_k max-pool dilation of the target mask, dil_k odd or
  * <= 1 for none).  A null prediction switches its term off (its output is 0).  forward: out3 = the three means, partials
- * [GOM_LOSS_BLOCKS][3] scratch.  backward: g3 = dL/d out3 (device), d_* = g * sign(a - b) / count, like torch's abs / mean. */
+ * [4 * GOM_LOSS_BLOCKS][3] scratch.  backward: g3 = dL/d out3 (device), d_* = g * sign(a - b) / count, like torch's abs / mean. */
 int gom_l1_terms_forward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
                          const float *normal_mask, int dil_k, float *out3, float *partials, void *stream);
 int gom_l1_terms_backward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
