@@ -30,8 +30,12 @@ struct MeshGrid {
     float rngx, offx, rngy, offy;  // pix_to_non_square_ndc
 };
 
-__device__ __forceinline__ float pix_x(const MeshGrid &g, int xi) { return -g.offx + (g.rngx * (float)(g.W - 1 - xi) + g.offx) / (float)g.W; }
-__device__ __forceinline__ float pix_y(const MeshGrid &g, int yi) { return -g.offy + (g.rngy * (float)(g.H - 1 - yi) + g.offy) / (float)g.H; }
+// a / b as a * v_rcp_f32(b) (1 ulp): an IEEE division is a ~10-instruction sequence on gfx950 and the per-(face, pixel) evaluation
+// below had twelve of them; the forward, the backward and pix_to_face all go through the same functions, so they stay consistent
+// with each other, and against the fp64 oracle 1 ulp is far inside the tolerances (tests/test_gpu_mesh.py)
+__device__ __forceinline__ float qdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float pix_x(const MeshGrid &g, int xi) { return -g.offx + qdiv(g.rngx * (float)(g.W - 1 - xi) + g.offx, (float)g.W); }
+__device__ __forceinline__ float pix_y(const MeshGrid &g, int yi) { return -g.offy + qdiv(g.rngy * (float)(g.H - 1 - yi) + g.offy, (float)g.H); }
 // continuous pixel coordinate of an NDC value (inverse of the above)
 __device__ __forceinline__ float ndc_to_px(const MeshGrid &g, float x) { return (float)(g.W - 1) - ((x + g.offx) * (float)g.W - g.offx) / g.rngx; }
 __device__ __forceinline__ float ndc_to_py(const MeshGrid &g, float y) { return (float)(g.H - 1) - ((y + g.offy) * (float)g.H - g.offy) / g.rngy; }
@@ -45,7 +49,7 @@ __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float a
     const float l2 = dx * dx + dy * dy;
     degenerate = !(l2 > kEpsArea);
     if (degenerate) { t_out = 1.f; return (px - bx) * (px - bx) + (py - by) * (py - by); }
-    float t = ((px - ax) * dx + (py - ay) * dy) / l2;
+    float t = qdiv((px - ax) * dx + (py - ay) * dy, l2);
     t = fminf(fmaxf(t, 0.f), 1.f);
     t_out = t;
     const float qx = ax + t * dx, qy = ay + t * dy;
@@ -68,8 +72,8 @@ __device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py
     const float xmin = fminf(fminf(x0, x1), x2), xmax = fmaxf(fmaxf(x0, x1), x2);
     const float ymin = fminf(fminf(y0, y1), y2), ymax = fmaxf(fmaxf(y0, y1), y2);
     if (px > xmax + blur || px < xmin - blur || py > ymax + blur || py < ymin - blur) return r;
-    const float den = area + kEpsArea;
-    const float w0 = edge_fn(px, py, x1, y1, x2, y2) / den, w1 = edge_fn(px, py, x2, y2, x0, y0) / den, w2 = edge_fn(px, py, x0, y0, x1, y1) / den;
+    const float iden = __builtin_amdgcn_rcpf(area + kEpsArea);
+    const float w0 = edge_fn(px, py, x1, y1, x2, y2) * iden, w1 = edge_fn(px, py, x2, y2, x0, y0) * iden, w2 = edge_fn(px, py, x0, y0, x1, y1) * iden;
     r.inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
     if (r.inside) {
         const float pz = w0 * z0 + w1 * z1 + w2 * z2;
@@ -78,8 +82,8 @@ __device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py
     }
     // soft pass: clipped barycentrics for the depth test
     const float c0 = fminf(fmaxf(w0, 0.f), 1.f), c1 = fminf(fmaxf(w1, 0.f), 1.f), c2 = fminf(fmaxf(w2, 0.f), 1.f);
-    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-    const float pzs = (c0 / s) * z0 + (c1 / s) * z1 + (c2 / s) * z2;
+    const float is = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
+    const float pzs = (c0 * is) * z0 + (c1 * is) * z1 + (c2 * is) * z2;
     if (!(pzs >= 0.f)) return r;
     float t0, t1, t2;
     bool g0, g1, g2;
@@ -90,7 +94,7 @@ __device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py
     if (!r.inside && !(d < blur_radius)) return r;
     r.soft = true;
     const float sd = r.inside ? -d : d;
-    r.prob = 1.f / (1.f + __expf(sd * inv_sigma));   // sigmoid(-sd / sigma)
+    r.prob = __builtin_amdgcn_rcpf(1.f + __expf(sd * inv_sigma));   // sigmoid(-sd / sigma)
     return r;
 }
 
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                     const FaceEval r = eval_face(fg, px, py, blur, blur_radius, inv_sigma);
                     if (!r.soft) continue;
                     // alpha = 1 - prod(1 - p_j), p = sigmoid(-sd/sigma):  d alpha / d sd_k = -(Q / (1 - p_k)) p_k (1 - p_k) / sigma
-                    const float others = s_Q[lp] / fmaxf(1.f - r.prob, 1e-30f);
+                    const float others = qdiv(s_Q[lp], fmaxf(1.f - r.prob, 1e-30f));
                     float gd = -s_da[lp] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
                     if (r.inside) gd = -gd;                                                    // sd = -dist inside
                     const int ia = r.edge, ib = (r.edge + 1) % 3;
