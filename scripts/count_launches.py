@@ -1,3 +1,9 @@
+#!/usr/bin/env python
+"""Kernel launches per phase of the whole-`Model` training iteration (forward / loss / backward / optimizer step), by the aten op or
+autograd function that issued them, and by autograd node for the backward: the tool behind the launch diet in DESIGN.md §6.
+Runs scripts/train_synthetic.py's setup (level 1, 512x512), then profiles ten iterations with torch.profiler.
+
+    python scripts/count_launches.py"""
 import sys, collections, torch
 sys.path.insert(0, "/root/repo")
 sys.argv = ["x", "--iters", "30", "--img", "512", "--level", "1"]
