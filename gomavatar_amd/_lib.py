@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 3
+GOM_ABI_VERSION = 4
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
@@ -99,8 +99,8 @@ SIGNATURES = {
     "gom_mesh_pix_to_face": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gom_ndc_from_world_forward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 5),
     "gom_ndc_from_world_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 6),
-    "gom_vertex_normals_forward": (c_int, [c_int, c_int] + [c_void_p] * 7),
-    "gom_vertex_normals_backward": (c_int, [c_int, c_int] + [c_void_p] * 9),
+    "gom_vertex_normals_forward": (c_int, [c_int, c_int] + [c_void_p] * 8),
+    "gom_vertex_normals_backward": (c_int, [c_int, c_int] + [c_void_p] * 10),
     "gom_mesh_laplacian": (c_int, [c_int] + [c_void_p] * 6),
     "gom_mesh_laplacian_backward": (c_int, [c_int] + [c_void_p] * 6),
     "gom_mesh_normal_consistency": (c_int, [c_int] + [c_void_p] * 6),

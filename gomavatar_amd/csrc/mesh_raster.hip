@@ -427,7 +427,7 @@ __device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
 }
 __global__ void __launch_bounds__(256) k_vnormal_fwd(int N, const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                      const int32_t *__restrict__ csr_off, const int32_t *__restrict__ csr_idx,
-                                                     float *__restrict__ sums, float *__restrict__ normals) {
+                                                     const float *__restrict__ R, float *__restrict__ sums, float *__restrict__ normals) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -458,20 +458,29 @@ __global__ void __launch_bounds__(256) k_vnormal_fwd(int N, const float *__restr
     }
     const float len = fmaxf(sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]), 1e-6f);
 #pragma unroll
-    for (int d = 0; d < 3; d++) { sums[3 * (size_t)v + d] = acc[d]; normals[3 * (size_t)v + d] = acc[d] / len; }
+    for (int d = 0; d < 3; d++) sums[3 * (size_t)v + d] = acc[d];
+    const float n[3] = {acc[0] / len, acc[1] / len, acc[2] / len};
+#pragma unroll
+    for (int d = 0; d < 3; d++)   // optional rotation of the unit normal (into the camera frame: models/model.py:272)
+        normals[3 * (size_t)v + d] = R ? (R[3 * d] * n[0] + R[3 * d + 1] * n[1]) + R[3 * d + 2] * n[2] : n[d];
 }
 // per face: g = sum over its corners of d L / d sums[corner vertex]; n = (v1 - v0) x (v2 - v0):
 // dL/dv1 = (v2 - v0) x g, dL/dv2 = g x (v1 - v0), dL/dv0 = -(dL/dv1 + dL/dv2)   -> d_corner [F][3][3]
 __global__ void __launch_bounds__(256) k_vnormal_bwd_face(int F, const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                           const float *__restrict__ sums, const float *__restrict__ d_normals,
-                                                          float *__restrict__ d_corner) {
+                                                          const float *__restrict__ R, float *__restrict__ d_corner) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
     int idx[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     float g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float *sv = sums + 3 * (size_t)idx[c], *dn = d_normals + 3 * (size_t)idx[c];
+        const float *sv = sums + 3 * (size_t)idx[c], *dr = d_normals + 3 * (size_t)idx[c];
+        float dn[3] = {dr[0], dr[1], dr[2]};
+        if (R) {   // the forward rotated the unit normal: dL/dn = R^T dL/d(R n)
+#pragma unroll
+            for (int d = 0; d < 3; d++) dn[d] = (R[d] * dr[0] + R[3 + d] * dr[1]) + R[6 + d] * dr[2];
+        }
         const float l = sqrtf(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
         if (l > 1e-6f) {   // y = s / |s|: dL/ds = (dn - y (y . dn)) / |s|
             const float y[3] = {sv[0] / l, sv[1] / l, sv[2] / l};
@@ -584,21 +593,22 @@ extern "C" int gom_mesh_pix_to_face(GomState *s, int32_t *dst, void *stream) {
 }
 
 extern "C" int gom_vertex_normals_forward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
-                                          float *sums, float *normals, void *stream) {
+                                          const float *R, float *sums, float *normals, void *stream) {
     (void)F;
     if (N <= 0 || !verts || !faces || !csr_off || !csr_idx || !sums || !normals) { gom_set_error("gom_vertex_normals_forward: bad arguments"); return -1; }
-    hipLaunchKernelGGL(k_vnormal_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, verts, faces, csr_off, csr_idx, sums, normals);
+    hipLaunchKernelGGL(k_vnormal_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, verts, faces, csr_off, csr_idx, R, sums, normals);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gom_vertex_normals_backward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
-                                           const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts, void *stream) {
+                                           const float *R, const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts,
+                                           void *stream) {
     if (N <= 0 || F <= 0 || !verts || !faces || !csr_off || !csr_idx || !sums || !d_normals || !d_corner_scratch || !d_verts) {
         gom_set_error("gom_vertex_normals_backward: bad arguments");
         return -1;
     }
-    hipLaunchKernelGGL(k_vnormal_bwd_face, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, F, verts, faces, sums, d_normals, d_corner_scratch);
+    hipLaunchKernelGGL(k_vnormal_bwd_face, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, F, verts, faces, sums, d_normals, R, d_corner_scratch);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_corner_gather, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, csr_off, csr_idx, d_corner_scratch, d_verts);
     GOM_LAUNCH_CHECK();

@@ -63,33 +63,35 @@ class _NdcTWorld(torch.autograd.Function):
 
 class _VertexNormals(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, topo: MeshTopology):
+    def forward(ctx, verts, topo: MeshTopology, rotation):
         lib = _lib.load()
         v = verts.float().contiguous()
+        r = rotation.detach().float().contiguous() if rotation is not None else None
         N = v.shape[0]
         sums, normals = torch.empty_like(v), torch.empty_like(v)
         _lib.check(lib.gom_vertex_normals_forward(N, topo.n_faces, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(topo.csr_off), _lib.ptr(topo.csr_idx),
-                                                  _lib.ptr(sums), _lib.ptr(normals), _lib.stream_ptr()))
-        ctx.save_for_backward(v, sums)
+                                                  _lib.ptr(r), _lib.ptr(sums), _lib.ptr(normals), _lib.stream_ptr()))
+        ctx.save_for_backward(v, sums, r)
         ctx.topo = topo
         return normals
 
     @staticmethod
     def backward(ctx, d_normals):
-        v, sums = ctx.saved_tensors
+        v, sums, r = ctx.saved_tensors
         topo, lib = ctx.topo, _lib.load()
         dn = d_normals.float().contiguous()
         scratch = torch.empty((topo.n_faces, 9), dtype=torch.float32, device=v.device)
         d_verts = torch.empty_like(v)
         _lib.check(lib.gom_vertex_normals_backward(v.shape[0], topo.n_faces, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(topo.csr_off), _lib.ptr(topo.csr_idx),
-                                                   _lib.ptr(sums), _lib.ptr(dn), _lib.ptr(scratch), _lib.ptr(d_verts), _lib.stream_ptr()))
-        return d_verts, None
+                                                   _lib.ptr(r), _lib.ptr(sums), _lib.ptr(dn), _lib.ptr(scratch), _lib.ptr(d_verts), _lib.stream_ptr()))
+        return d_verts, None, None
 
 
-def vertex_normals(verts: torch.Tensor, topo: MeshTopology) -> torch.Tensor:
+def vertex_normals(verts: torch.Tensor, topo: MeshTopology, rotation: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PyTorch3D `Meshes.verts_normals_packed` (models/model.py:271): area-weighted face normals summed on the corners,
-    normalize(eps=1e-6).  verts (N,3) -> (N,3).  CSR gather (deterministic), not index_add."""
-    return _VertexNormals.apply(verts, topo)
+    normalize(eps=1e-6).  verts (N,3) -> (N,3).  CSR gather (deterministic), not index_add.  `rotation` (3,3, no gradient) is
+    applied to the unit normals in the same kernel (model.py:272 takes them into the camera frame with E[:3,:3])."""
+    return _VertexNormals.apply(verts, topo, rotation)
 
 
 class _MeshRaster(torch.autograd.Function):

@@ -320,8 +320,7 @@ class Model(nn.Module):
     def _mesh_branch(self, vertices_observation, K, E):
         """model.py:270-282: camera-space vertex normals, normal map + soft silhouette, shading = 2 * shadow_module(normal)."""
         # normals, normal map, silhouette (model.py:270-273)
-        vn = vertex_normals(vertices_observation.T, self.topo)
-        vn = (E[0, :3, :3] @ vn.T).T
+        vn = vertex_normals(vertices_observation.T, self.topo, rotation=E[0, :3, :3])      # (E[:3,:3] @ vn.T).T inside the kernel
         normal, normal_mask = self.normal_renderer(vertices_observation.unsqueeze(0), vn[None], K, E, faces=self.faces)
         if self.shadow_module is not None:
             Bn, H, W, _ = normal.shape

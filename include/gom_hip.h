@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 3
+#define GOM_ABI_VERSION 4
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -312,12 +312,14 @@ int gom_ndc_from_world_forward(int N, int H, int W, const float *verts, const fl
 int gom_ndc_from_world_backward(int N, int H, int W, const float *verts, const float *K, const float *E, const float *d_out, float *d_verts, void *stream);
 
 /* vertex normals of a mesh (PyTorch3D Meshes.verts_normals_padded, models/model.py:271): verts [N][3], faces [F][3];
- * sums [N][3] = un-normalised sums (kept for the backward), normals [N][3] = sums / max(|sums|, 1e-6).
- * backward: d_normals [N][3] -> d_verts [N][3]; d_corner_scratch [F][9]. */
+ * sums [N][3] = un-normalised sums (kept for the backward), normals [N][3] = R (sums / max(|sums|, 1e-6)) with R [9] a row-major
+ * 3x3 in DEVICE memory or NULL for none (models/model.py:272 rotates the normals into the camera frame with E[:3,:3]).
+ * backward: d_normals [N][3] -> d_verts [N][3]; d_corner_scratch [F][9]; same R as the forward. */
 int gom_vertex_normals_forward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
-                               float *sums, float *normals, void *stream);
+                               const float *R, float *sums, float *normals, void *stream);
 int gom_vertex_normals_backward(int N, int F, const float *verts, const int32_t *faces, const int32_t *csr_off, const int32_t *csr_idx,
-                                const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts, void *stream);
+                                const float *R, const float *sums, const float *d_normals, float *d_corner_scratch, float *d_verts,
+                                void *stream);
 
 /* ---- mesh regularisers (train.py:123-160) ------------------------------------------------------------------------------
  * verts [N][3]; nbr_off [N+1] / nbr_idx [2E]: vertex -> neighbouring vertices; pairs [P][2]: faces sharing an edge

@@ -145,3 +145,22 @@ def test_ndc_from_world_kernel_matches_the_torch_formula(H, W):
     assert out.shape == ref.shape
     assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     assert float((vg.grad.cpu() - vc.grad).abs().max()) <= 1e-5 * float(vc.grad.abs().max())
+
+
+def test_vertex_normals_rotation_option_equals_the_matrix_product():
+    """vertex_normals(..., rotation=R) = (R @ vertex_normals(...).T).T (models/model.py:271-272), values and vertex gradient."""
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, vertex_normals
+    v, faces, K, E = _scene(64)
+    r = MeshNormalRenderer(img_size=(64, 64)).cuda()
+    fc = faces.cuda()
+    topo = r.topology(fc, v.shape[2])
+    R = E[0, :3, :3].cuda()
+    w = torch.randn(v.shape[2], 3, generator=torch.Generator().manual_seed(1)).cuda()
+    a = v[0].T.contiguous().cuda().requires_grad_()
+    n_a = (R @ vertex_normals(a, topo).T).T
+    (n_a * w).sum().backward()
+    b = v[0].T.contiguous().cuda().requires_grad_()
+    n_b = vertex_normals(b, topo, rotation=R)
+    (n_b * w).sum().backward()
+    assert torch.allclose(n_a.detach(), n_b.detach(), rtol=1e-5, atol=1e-6)
+    assert float((a.grad - b.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max())
