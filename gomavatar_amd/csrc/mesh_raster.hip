@@ -32,10 +32,12 @@ struct MeshGrid {
 
 // a / b as a * v_rcp_f32(b) (1 ulp): an IEEE division is a ~10-instruction sequence on gfx950 and the per-(face, pixel) evaluation
 // below had twelve of them; the forward, the backward and pix_to_face all go through the same functions, so they stay consistent
-// with each other, and against the fp64 oracle 1 ulp is far inside the tolerances (tests/test_gpu_mesh.py)
+// with each other, and against the fp64 oracle 1 ulp is far inside the tolerances (tests/test_gpu_mesh.py).  The pixel centres
+// keep their IEEE divisions: they decide on which side of an edge a pixel lies, and with approximate centres the silhouette of
+// 2 of 14 random scenes of the soak differed from the oracle's by 4e-3 at single pixels.
 __device__ __forceinline__ float qdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float pix_x(const MeshGrid &g, int xi) { return -g.offx + qdiv(g.rngx * (float)(g.W - 1 - xi) + g.offx, (float)g.W); }
-__device__ __forceinline__ float pix_y(const MeshGrid &g, int yi) { return -g.offy + qdiv(g.rngy * (float)(g.H - 1 - yi) + g.offy, (float)g.H); }
+__device__ __forceinline__ float pix_x(const MeshGrid &g, int xi) { return -g.offx + (g.rngx * (float)(g.W - 1 - xi) + g.offx) / (float)g.W; }
+__device__ __forceinline__ float pix_y(const MeshGrid &g, int yi) { return -g.offy + (g.rngy * (float)(g.H - 1 - yi) + g.offy) / (float)g.H; }
 // continuous pixel coordinate of an NDC value (inverse of the above)
 __device__ __forceinline__ float ndc_to_px(const MeshGrid &g, float x) { return (float)(g.W - 1) - ((x + g.offx) * (float)g.W - g.offx) / g.rngx; }
 __device__ __forceinline__ float ndc_to_py(const MeshGrid &g, float y) { return (float)(g.H - 1) - ((y + g.offy) * (float)g.H - g.offy) / g.rngy; }

@@ -10,7 +10,7 @@ import sys, os, time, traceback
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 os.chdir("/root/repo")
 import numpy as np, torch
-import test_gpu_raster as TR, test_gpu_batch as TB, test_gpu_vgg_bf16 as TV, test_gpu_model as TM, test_gpu_mesh as TMe, test_gpu_metrics as TMt
+import test_gpu_raster as TR, test_gpu_batch as TB, test_gpu_vgg_bf16 as TV, test_gpu_model as TM, test_gpu_mesh as TMe, test_gpu_metrics as TMt, test_gpu_loss as TL
 t0 = time.time(); n_ok = n_bad = 0
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -43,6 +43,15 @@ while time.time() - t0 < budget:
             TM.test_shadow_mlp_fused_kernels_vs_torch_cpu(*cfgm); n_ok += 1
         except Exception as e:
             n_bad += 1; print("MLP FAIL", cfgm, repr(e)[:300], flush=True)
+    if seed % 5 == 0:
+        H, W = int(rng.integers(9, 200)), int(rng.integers(9, 200))
+        for name, fn, cfgl in (("L1TERMS", TL.test_l1_terms_match_torch_formulas, (H, W, int(rng.choice([1, 3, 5, 7, 9])), bool(rng.integers(0, 2)))),
+                               ("COMPOSE", TL.test_compose_and_unpack_kernels_match_the_torch_chains, (H, W, bool(rng.integers(0, 2)))),
+                               ("NDC", TMe.test_ndc_from_world_kernel_matches_the_torch_formula, (H, W))):
+            try:
+                fn(*cfgl); n_ok += 1
+            except Exception as e:
+                n_bad += 1; print(name, "FAIL", cfgl, repr(e)[:300], flush=True)
     if seed % 15 == 0:
         cfgs = (int(rng.integers(40, 120)), float(rng.uniform(0.8, 4.0)))
         try:

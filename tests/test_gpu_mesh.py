@@ -143,7 +143,8 @@ def test_ndc_from_world_kernel_matches_the_torch_formula(H, W):
     out = ndc_T_world(vg, K.cuda(), E.cuda(), H, W)       # device tensors: the kernel
     (out * wgt.cuda()).sum().backward()
     assert out.shape == ref.shape
-    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    # (a few ulp of the largest coordinate: with a very narrow image the NDC range of the long side reaches +-10 and more)
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=max(1e-6, 4e-7 * float(ref.abs().max())))
     assert float((vg.grad.cpu() - vc.grad).abs().max()) <= 1e-5 * float(vc.grad.abs().max())
 
 
