@@ -70,7 +70,8 @@ def test_l1_terms_match_torch_formulas(H, W, k, with_nm):
     assert list(losses) == (["rgb", "mask", "normal_mask"] if with_nm else ["rgb", "mask"])
     exp = vr[0] * 1.0 + vr[1] * 5.0 + (vr[2] * 1.5 if with_nm else 0.0)
     assert abs(float(total.detach()) - float(exp.detach())) <= 2e-6 * abs(float(exp.detach()))
-    assert abs(float(losses["mask"]["scaled"]) - 5.0 * float(vr[1])) <= 1e-5 and abs(float(losses["rgb"]["unscaled"]) - float(vr[0])) <= 1e-6
+    assert abs(float(losses["mask"]["scaled"].detach()) - 5.0 * float(vr[1].detach())) <= 1e-5
+    assert abs(float(losses["rgb"]["unscaled"].detach()) - float(vr[0].detach())) <= 1e-6
     assert torch.allclose(lg[1].grad.cpu(), leaves_c[1].grad * (5.0 / 0.7), rtol=1e-5, atol=1e-12)
 
 
