@@ -71,6 +71,7 @@ SIGNATURES = {
     "gom_l1_terms_forward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 3),
     "gom_l1_terms_backward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
     "gom_mlp3_forward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 14),
+    "gom_mlp3_wgrad": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 18),
     "gom_mlp3_backward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 15),
     "gom_posenc_forward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "gom_posenc_backward": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -11,12 +11,11 @@ namespace {
 
 constexpr int kRows = 32;   // rows staged per trip
 
-// grid = (row slices, out blocks of 64, in blocks of 64); block = 256 threads = 16 x 16 sub-blocks of 4 x 4
-__global__ void __launch_bounds__(256) k_linear_wgrad_partial(int64_t n, int in_dim, int out_dim, const float *__restrict__ X, const float *__restrict__ dY,
-                                                              float *__restrict__ partial /* [slices][129][128]: row 128 = bias */) {
+// one workgroup: row slice blockIdx.x of gridDim.x, the 64 x 64 block (o0, i0) of out x in; 256 threads = 16 x 16 sub-blocks of 4 x 4
+__device__ __forceinline__ void wgrad_partial_block(int64_t n, int in_dim, int out_dim, const float *__restrict__ X, const float *__restrict__ dY,
+                                                    float *__restrict__ partial /* [slices][129][128]: row 128 = bias */, int o0, int i0) {
     __shared__ __attribute__((aligned(16))) float s_x[kRows][64], s_y[kRows][64];
     const int tid = threadIdx.x, to = tid >> 4, ti = tid & 15;
-    const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r_lo = (int64_t)blockIdx.x * per, r_hi = r_lo + per < n ? r_lo + per : n;
     float acc[4][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -64,12 +63,31 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_partial(int64_t n, int in_
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         *reinterpret_cast<float4 *>(dst + (size_t)(o0 + 4 * to + a) * 128 + i0 + 4 * ti) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
-        if (ti == 0 && blockIdx.z == 0) dst[128 * 128 + o0 + 4 * to + a] = accb[a];
+        if (ti == 0 && i0 == 0) dst[128 * 128 + o0 + 4 * to + a] = accb[a];
     }
 }
 
-__global__ void __launch_bounds__(256) k_linear_wgrad_reduce(int slices, int in_dim, int out_dim, const float *__restrict__ partial, float *__restrict__ dW,
-                                                             float *__restrict__ db) {
+// grid = (row slices, out blocks of 64, in blocks of 64)
+__global__ void __launch_bounds__(256) k_linear_wgrad_partial(int64_t n, int in_dim, int out_dim, const float *__restrict__ X, const float *__restrict__ dY,
+                                                              float *__restrict__ partial) {
+    wgrad_partial_block(n, in_dim, out_dim, X, dY, partial, blockIdx.y * 64, blockIdx.z * 64);
+}
+
+// The four layers of the shadow MLP in one launch: grid = (row slices, 2 out blocks, 4 layers x 2 in blocks); blocks beyond a
+// layer's width return at once.  Four launches of 512 workgroups each left the chip half empty four times over.
+struct WgradLayers {
+    const float *X[4], *dY[4];
+    float *dW[4], *db[4];
+    int in_dim[4], out_dim[4];
+};
+__global__ void __launch_bounds__(256) k_mlp3_wgrad_partial(int64_t n, WgradLayers L, float *__restrict__ partial, int slices) {
+    const int layer = blockIdx.z >> 1, o0 = blockIdx.y * 64, i0 = (blockIdx.z & 1) * 64;
+    if (o0 >= L.out_dim[layer] || i0 >= L.in_dim[layer]) return;
+    wgrad_partial_block(n, L.in_dim[layer], L.out_dim[layer], L.X[layer], L.dY[layer], partial + (size_t)layer * slices * 129 * 128, o0, i0);
+}
+
+__device__ __forceinline__ void wgrad_reduce_block(int slices, int in_dim, int out_dim, const float *__restrict__ partial, float *__restrict__ dW,
+                                                   float *__restrict__ db) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // over 129 x 128
     if (idx >= 129 * 128) return;
     const int o = idx >> 7, i = idx & 127;
@@ -85,6 +103,14 @@ __global__ void __launch_bounds__(256) k_linear_wgrad_reduce(int slices, int in_
     }
     if (is_bias) db[i] = s;
     else dW[(size_t)o * in_dim + i] = s;
+}
+__global__ void __launch_bounds__(256) k_linear_wgrad_reduce(int slices, int in_dim, int out_dim, const float *__restrict__ partial, float *__restrict__ dW,
+                                                             float *__restrict__ db) {
+    wgrad_reduce_block(slices, in_dim, out_dim, partial, dW, db);
+}
+__global__ void __launch_bounds__(256) k_mlp3_wgrad_reduce(int slices, WgradLayers L, const float *__restrict__ partial) {
+    const int layer = blockIdx.y;
+    wgrad_reduce_block(slices, L.in_dim[layer], L.out_dim[layer], partial + (size_t)layer * slices * 129 * 128, L.dW[layer], L.db[layer]);
 }
 
 }  // namespace
@@ -327,6 +353,22 @@ extern "C" int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const
     if (!g || !out || !h1 || !h2 || !h3 || !W1 || !W2 || !W3 || !w4 || !dz4 || !dz3 || !dz2 || !dz1 || !dx) { gom_set_error("gom_mlp3_backward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_mlp3_bwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4,
                        dz3, dz2, dz1, dx);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_mlp3_wgrad(int64_t n, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3, const float *dz1, const float *dz2,
+                              const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3, float *dW4,
+                              float *db4, float *workspace, void *stream) {
+    if (n <= 0 || D0 < 1 || D0 > 128 || H < 1 || H > 128) { gom_set_error("gom_mlp3_wgrad: widths must be in 1..128"); return -1; }
+    if (!x || !h1 || !h2 || !h3 || !dz1 || !dz2 || !dz3 || !dz4 || !dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || !dW4 || !db4 || !workspace) {
+        gom_set_error("gom_mlp3_wgrad: null pointer"); return -1;
+    }
+    WgradLayers L = {{x, h1, h2, h3}, {dz1, dz2, dz3, dz4}, {dW1, dW2, dW3, dW4}, {db1, db2, db3, db4}, {D0, H, H, H}, {H, H, H, 1}};
+    const int slices = gom_linear_wgrad_slices();
+    hipLaunchKernelGGL(k_mlp3_wgrad_partial, dim3(slices, 2, 8), dim3(256), 0, (hipStream_t)stream, n, L, workspace, slices);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mlp3_wgrad_reduce, dim3((129 * 128 + 255) / 256, 4), dim3(256), 0, (hipStream_t)stream, slices, L, workspace);
     GOM_LAUNCH_CHECK();
     return 0;
 }

@@ -114,7 +114,8 @@ class _LinearLongBatch(torch.autograd.Function):
 
 class _ShadowMLP3(torch.autograd.Function):
     """Linear-ReLU x 3 -> Linear -> sigmoid as one HIP kernel forward and one backward (csrc/mlp.hip: gom_mlp3_forward / _backward),
-    weight gradients through gom_linear_wgrad.  Same values as the nn.Sequential up to fp32 summation order."""
+    weight gradients of the four layers through gom_mlp3_wgrad (two launches).  Same values as the nn.Sequential up to fp32
+    summation order."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4):
@@ -146,14 +147,10 @@ class _ShadowMLP3(torch.autograd.Function):
         _lib.check(lib.gom_mlp3_backward(n, D0, H, _lib.ptr(g2), _lib.ptr(out), _lib.ptr(hs[0]), _lib.ptr(hs[1]), _lib.ptr(hs[2]), _lib.ptr(W1),
                                          _lib.ptr(W2), _lib.ptr(W3), _lib.ptr(W4), _lib.ptr(dz4), _lib.ptr(dz[2]), _lib.ptr(dz[1]), _lib.ptr(dz[0]),
                                          _lib.ptr(dx), st))
-        ws = torch.empty(lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=dev)
-        grads = []
-        for X, dY, W in ((x2, dz[0], W1), (hs[0], dz[1], W2), (hs[1], dz[2], W3), (hs[2], dz4, W4)):
-            out_dim, in_dim = W.shape
-            dW = torch.empty(out_dim, in_dim, dtype=torch.float32, device=dev)
-            db = torch.empty(out_dim, dtype=torch.float32, device=dev)
-            _lib.check(lib.gom_linear_wgrad(n, in_dim, out_dim, _lib.ptr(X), _lib.ptr(dY), _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ws), st))
-            grads += [dW, db]
+        ws = torch.empty(4 * lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(p) for p in (W1, b1, W2, b2, W3, b3, W4, b4)]
+        _lib.check(lib.gom_mlp3_wgrad(n, D0, H, _lib.ptr(x2), _lib.ptr(hs[0]), _lib.ptr(hs[1]), _lib.ptr(hs[2]), _lib.ptr(dz[0]), _lib.ptr(dz[1]), _lib.ptr(dz[2]),
+                                      _lib.ptr(dz4), *[_lib.ptr(g_) for g_ in grads], _lib.ptr(ws), st))
         return (dx.reshape(ctx.shape).to(ctx.dtype) if ctx.needs_input_grad[0] else None, *grads)
 
 

@@ -197,6 +197,11 @@ int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const float *W1, 
 int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
                       const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
                       float *dx, void *stream);
+/* the weight / bias gradients of all four layers from what gom_mlp3_forward / _backward left behind (x, h1..h3, dz1..dz4), two
+ * launches instead of four gom_linear_wgrad calls; workspace: 4 * gom_linear_wgrad_slices() * 129 * 128 floats. */
+int gom_mlp3_wgrad(int64_t n, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3, const float *dz1, const float *dz2,
+                   const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3, float *dW4, float *db4,
+                   float *workspace, void *stream);
 
 /* ---- skeleton + skinning ----------------------------------------------------
  * cnl_gtfms [24][4][4], dst_Rs [24][3][3], dst_Ts [24][3] -> RT [24][12]
