@@ -77,14 +77,15 @@ class _L1Terms(torch.autograd.Function):
         partials = torch.empty(4 * _lib.GOM_LOSS_BLOCKS * 3, dtype=torch.float32, device=mg.device)
         _lib.check(lib.gom_l1_terms_forward(H, W, _lib.ptr(r), _lib.ptr(rg), _lib.ptr(m), _lib.ptr(mg), _lib.ptr(nm), int(dil_k), _lib.ptr(out),
                                             _lib.ptr(partials), _lib.stream_ptr()))
-        ctx.keep, ctx.dil_k, ctx.hw = keep, int(dil_k), (H, W)
+        ctx.save_for_backward(*keep)
+        ctx.dil_k, ctx.hw = int(dil_k), (H, W)
         ctx.shapes = [None if x is None else (x.shape, x.dtype) for x in (rgb, mask, normal_mask)]
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        r, rg, m, mg, nm = ctx.keep
+        r, rg, m, mg, nm = ctx.saved_tensors
         g = g.float().contiguous()
         d = [None if x is None else torch.empty_like(x) for x in (r, m, nm)]
         _lib.check(lib.gom_l1_terms_backward(ctx.hw[0], ctx.hw[1], _lib.ptr(r), _lib.ptr(rg), _lib.ptr(m), _lib.ptr(mg), _lib.ptr(nm), ctx.dil_k,
