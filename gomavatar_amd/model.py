@@ -325,7 +325,7 @@ class Model(nn.Module):
             # the MLP output is one constant: evaluate it once there and per pixel only under the mesh (~15 % of the image).
             flat = normal.reshape(-1, 3)
             # The all-zero background normal rides along as one extra row of the same MLP call (a second call for that single
-            # row would double the ~25 GEMM launches of the module's forward + backward: the iteration is launch-bound).
+            # row would double the module's launches, forward and backward).
             if self.capture_safe:
                 # same result with static shapes: the pixels under the mesh are compacted into a list of fixed capacity
                 # (prefix sum, no nonzero()); every unused slot points at its own dummy row (duplicate indices would send

@@ -116,9 +116,9 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
 
 class GraphedTrainStep:
     """The reference's training iteration (train.py:309-349: zero_grad -> forward -> unpack -> compute_loss -> backward ->
-    optimizer step) captured ONCE in a HIP graph and replayed per frame.  An iteration is ~350 kernel launches of a few
-    microseconds each; launched one by one from Python the host, not the GPU, sets the pace (~10 ms per iteration against
-    ~5 ms of kernels).  Everything per-frame lives in static device buffers that `step(frame)` overwrites before the replay.
+    optimizer step) captured ONCE in a HIP graph and replayed per frame.  An iteration is ~210 kernel launches of a few
+    microseconds each (2.7 ms of kernels on MI355X); on a slower host than the GPU the launches, not the kernels, set the pace.
+    Everything per-frame lives in static device buffers that `step(frame)` overwrites before the replay.
 
         step = GraphedTrainStep(model, optimizer, loss_cfg, lpips_func)    # optimizer: capturable=True
         for frame in loader:
