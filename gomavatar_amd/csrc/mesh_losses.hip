@@ -18,7 +18,8 @@ __device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
     o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// ---- uniform Laplacian: loss = (1/N) sum_i || mean_{j in N(i)} v_j - v_i || ----------------------------------------------------
+// ---- uniform Laplacian: loss = (1/N) sum_i || mean_{j in N(i)} v_j - v_i ||^2  (the reference's own copy of the PyTorch3D loss,
+// utils/network_util.py:782,789,792: L.mm(V), norm(dim=1) ** 2, un-weighted mean) -----------------------------------------------------
 __global__ void __launch_bounds__(256) k_lap_fwd(int N, const float *__restrict__ verts, const int32_t *__restrict__ nbr_off,
                                                  const int32_t *__restrict__ nbr_idx, float *__restrict__ dir, float *__restrict__ partials) {
     __shared__ float s_red[4];
@@ -39,10 +40,9 @@ __global__ void __launch_bounds__(256) k_lap_fwd(int N, const float *__restrict_
         }
         const float inv = e > b ? 1.f / (float)(e - b) : 0.f;
         const float l[3] = {s[0] * inv - verts[3 * (size_t)i], s[1] * inv - verts[3 * (size_t)i + 1], s[2] * inv - verts[3 * (size_t)i + 2]};
-        const float n = sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
-        acc += n;
-        const float in = n > 0.f ? 1.f / n : 0.f;   // d||l|| / dl (0 at the origin, like the framework's norm backward)
-        dir[3 * (size_t)i] = l[0] * in; dir[3 * (size_t)i + 1] = l[1] * in; dir[3 * (size_t)i + 2] = l[2] * in;
+        acc += l[0] * l[0] + l[1] * l[1] + l[2] * l[2];
+        // d||l||^2 / dl = 2 l
+        dir[3 * (size_t)i] = 2.f * l[0]; dir[3 * (size_t)i + 1] = 2.f * l[1]; dir[3 * (size_t)i + 2] = 2.f * l[2];
     }
     const float tot = block_sum(acc, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot / (float)N;
@@ -87,15 +87,21 @@ __global__ void __launch_bounds__(256) k_ncons_fwd(int P, const int32_t *__restr
         float a[3], b[3];
         face_cross(verts, faces, pairs[2 * p], a);
         face_cross(verts, faces, pairs[2 * p + 1], b);
-        const float la = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-6f), lb = fmaxf(sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]), 1e-6f);
-        const float na[3] = {a[0] / la, a[1] / la, a[2] / la}, nb[3] = {b[0] / lb, b[1] / lb, b[2] / lb};
-        const float c = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
+        // cosine_similarity of the two (un-normalised) normals with torch 1.13's eps rule: a.b / sqrt(max(|a|^2 |b|^2, eps^2)), eps = 1e-8.
+        // On a consistently oriented mesh the face normals are PyTorch3D's (n0, -n1) of the shared edge (oracle/mesh_losses.py).
+        const float aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        const float ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+        const float w = aa * bb;
+        const bool clamped = !(w > 1e-16f);
+        const float inv = 1.f / sqrtf(clamped ? 1e-16f : w);
+        const float c = ab * inv;
         acc += 1.f - c;
-        // d(1 - cos)/d a = -(nb - na cos) / |a| ; same with the roles swapped
+        // d(1 - cos)/da = -(b inv - a (a.b) bb inv^3)   (the second term vanishes where the denominator is the clamped constant)
+        const float ka = clamped ? 0.f : ab * bb * inv * inv * inv, kb = clamped ? 0.f : ab * aa * inv * inv * inv;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            pair_grad[6 * (size_t)p + d] = -(nb[d] - na[d] * c) / la;
-            pair_grad[6 * (size_t)p + 3 + d] = -(na[d] - nb[d] * c) / lb;
+            pair_grad[6 * (size_t)p + d] = -(b[d] * inv - a[d] * ka);
+            pair_grad[6 * (size_t)p + 3 + d] = -(a[d] * inv - b[d] * kb);
         }
     }
     const float tot = block_sum(acc, s_red);

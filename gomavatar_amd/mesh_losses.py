@@ -12,7 +12,10 @@ class MeshLossTopology:
     """Static adjacency of one mesh on the device: vertex -> neighbours (CSR over the edge list) and
     face -> (pair, side) (CSR over `face_connectivity`).  Rebuild after subdivide()."""
 
-    def __init__(self, edges: torch.Tensor, face_connectivity: torch.Tensor, n_verts: int, n_faces: int, device):
+    def __init__(self, edges: torch.Tensor, face_connectivity: torch.Tensor, n_verts: int, n_faces: int, device, normal_pairs: torch.Tensor = None):
+        """face_connectivity: the pairs of the colour consistency (models/model.py:115-125, which skips the last edge id);
+        normal_pairs: ALL edge-adjacent face pairs, what PyTorch3D's mesh_normal_consistency(mesh) sums over (train.py:149);
+        defaults to face_connectivity."""
         e = edges.detach().cpu().numpy().astype(np.int64)
         src = np.concatenate([e[:, 0], e[:, 1]])
         dst = np.concatenate([e[:, 1], e[:, 0]])
@@ -21,16 +24,22 @@ class MeshLossTopology:
         np.add.at(off, src + 1, 1)
         self.nbr_off = torch.from_numpy(np.cumsum(off).astype(np.int32)).to(device)
         self.nbr_idx = torch.from_numpy(dst[order].astype(np.int32)).to(device)
-        p = face_connectivity.detach().cpu().numpy().astype(np.int64).reshape(-1, 2)
-        self.n_pairs = int(p.shape[0])
-        self.pairs = torch.from_numpy(p.astype(np.int32)).contiguous().to(device)
+        self.n_pairs, self.pairs, self.fp_off, self.fp_idx = self._pair_csr(face_connectivity, n_faces, device)
+        if normal_pairs is None:
+            self.n_npairs, self.npairs, self.nfp_off, self.nfp_idx = self.n_pairs, self.pairs, self.fp_off, self.fp_idx
+        else:
+            self.n_npairs, self.npairs, self.nfp_off, self.nfp_idx = self._pair_csr(normal_pairs, n_faces, device)
+        self.n_verts, self.n_faces = int(n_verts), int(n_faces)
+
+    @staticmethod
+    def _pair_csr(pairs: torch.Tensor, n_faces: int, device):
+        p = pairs.detach().cpu().numpy().astype(np.int64).reshape(-1, 2)
         flat_face = p.reshape(-1)                      # entry index = pair*2 + side
         order = np.argsort(flat_face, kind="stable")
         off = np.zeros(n_faces + 1, np.int64)
         np.add.at(off, flat_face + 1, 1)
-        self.fp_off = torch.from_numpy(np.cumsum(off).astype(np.int32)).to(device)
-        self.fp_idx = torch.from_numpy(order.astype(np.int32)).to(device)
-        self.n_verts, self.n_faces = int(n_verts), int(n_faces)
+        return (int(p.shape[0]), torch.from_numpy(p.astype(np.int32)).contiguous().to(device),
+                torch.from_numpy(np.cumsum(off).astype(np.int32)).to(device), torch.from_numpy(order.astype(np.int32)).to(device))
 
 
 class _Laplacian(torch.autograd.Function):
@@ -60,9 +69,9 @@ class _NormalConsistency(torch.autograd.Function):
     def forward(ctx, verts, topo, lt: MeshLossTopology):
         lib = _lib.load()
         v = verts.float().contiguous()
-        pg = torch.empty((max(lt.n_pairs, 1), 2, 3), dtype=torch.float32, device=v.device)
+        pg = torch.empty((max(lt.n_npairs, 1), 2, 3), dtype=torch.float32, device=v.device)
         partials = torch.empty(_lib.GOM_LOSS_BLOCKS, dtype=torch.float32, device=v.device)
-        _lib.check(lib.gom_mesh_normal_consistency(lt.n_pairs, _lib.ptr(lt.pairs), _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(pg), _lib.ptr(partials), _lib.stream_ptr()))
+        _lib.check(lib.gom_mesh_normal_consistency(lt.n_npairs, _lib.ptr(lt.npairs), _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(pg), _lib.ptr(partials), _lib.stream_ptr()))
         ctx.save_for_backward(v, pg)
         ctx.topo, ctx.lt = topo, lt
         return partials.sum()
@@ -74,7 +83,7 @@ class _NormalConsistency(torch.autograd.Function):
         go = g.float().reshape(1).contiguous()
         scratch = torch.empty((topo.n_faces, 9), dtype=torch.float32, device=v.device)
         d = torch.empty_like(v)
-        _lib.check(lib.gom_mesh_normal_consistency_backward(v.shape[0], topo.n_faces, lt.n_pairs, _lib.ptr(lt.fp_off), _lib.ptr(lt.fp_idx), _lib.ptr(pg), _lib.ptr(v),
+        _lib.check(lib.gom_mesh_normal_consistency_backward(v.shape[0], topo.n_faces, lt.n_npairs, _lib.ptr(lt.nfp_off), _lib.ptr(lt.nfp_idx), _lib.ptr(pg), _lib.ptr(v),
                                                             _lib.ptr(topo.faces), _lib.ptr(topo.csr_off), _lib.ptr(topo.csr_idx), _lib.ptr(go), _lib.ptr(scratch),
                                                             _lib.ptr(d), _lib.stream_ptr()))
         return d, None, None

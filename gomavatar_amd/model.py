@@ -40,9 +40,17 @@ def _get(cfg, path: str, default):
 class SimpleMesh:
     """What the reference's loss code reads from a PyTorch3D `Meshes` (one mesh): packed verts / faces / edges."""
 
-    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor, topo=None, loss_topo=None):
+    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor, topo=None, loss_topo=None, normal_pairs=None):
         self._v, self._f, self._e = verts, faces, edges
         self.topo, self.loss_topo = topo, loss_topo          # device CSR adjacency for the HIP regularisers
+        self._normal_pairs = normal_pairs                     # every pair of edge-adjacent faces (mesh_normal_consistency)
+
+    @property
+    def normal_pairs(self):
+        if self._normal_pairs is None:
+            _, f2e = mesh_edges(self._f, self._v.shape[0])
+            self._normal_pairs = edge_adjacent_face_pairs(f2e).to(self._f.device)
+        return self._normal_pairs
 
     def verts_packed(self): return self._v
     def faces_packed(self): return self._f
@@ -63,6 +71,29 @@ def mesh_edges(faces: torch.Tensor, n_verts: int):
     F = f.shape[0]
     f2e = np.stack([inv[:F], inv[F:2 * F], inv[2 * F:]], 1)
     return torch.from_numpy(edges), torch.from_numpy(f2e)
+
+
+def edge_adjacent_face_pairs(f2e: torch.Tensor, skip_last_edge: bool = False) -> torch.Tensor:
+    """(P, 2) sorted face pairs sharing an edge.  Default: every pair of every edge with >= 2 faces (what PyTorch3D's
+    mesh_normal_consistency sums over).  skip_last_edge: the reference's get_face_connectivity (models/model.py:115-125), which
+    loops `for i in range(max_edge_id)` -- the last edge id never gets a pair -- and keeps edges with exactly two faces."""
+    f2e_np = f2e.detach().cpu().numpy()
+    flat = f2e_np.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    eid, fid = flat[order], order // 3
+    starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
+    counts = np.diff(np.r_[starts, len(eid)])
+    if skip_last_edge:
+        keep = (counts == 2) & (eid[starts] < f2e_np.max())
+        pairs = np.stack([fid[starts[keep]], fid[starts[keep] + 1]], 1)
+    else:
+        two = counts == 2
+        pairs = np.stack([fid[starts[two]], fid[starts[two] + 1]], 1)
+        extra = [(fid[i], fid[j]) for s_, c_ in zip(starts[counts > 2], counts[counts > 2]) for i in range(s_, s_ + c_) for j in range(i + 1, s_ + c_)]
+        if extra:    # non-manifold edges: all pairs, kept in edge order
+            pairs = np.concatenate([pairs, np.asarray(extra, np.int64)], 0)
+    pairs = np.sort(pairs.astype(np.int64).reshape(-1, 2), 1)
+    return torch.from_numpy(pairs)
 
 
 class _PosEnc(torch.autograd.Function):
@@ -256,19 +287,12 @@ class Model(nn.Module):
         edges, f2e = mesh_edges(self.faces, N)
         self.edges = edges.to(self.vertices.device)
         # get_face_connectivity (model.py:115-125): faces sharing edge i, for i in range(max_edge_id) -- the last edge id is
-        # skipped by the reference's loop bound and therefore here
-        f2e_np = f2e.numpy()
-        order = np.argsort(f2e_np.reshape(-1), kind="stable")
-        eid = f2e_np.reshape(-1)[order]
-        fid = order // 3
-        starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
-        counts = np.diff(np.r_[starts, len(eid)])
-        keep = (counts == 2) & (eid[starts] < f2e_np.max())
-        pairs = np.stack([fid[starts[keep]], fid[starts[keep] + 1]], 1)
-        pairs.sort(1)
-        self.face_connectivity = torch.from_numpy(pairs).to(self.vertices.device)
+        # skipped by the reference's loop bound and therefore here.  Used by the colour consistency only (train.py:153-158);
+        # the normal consistency is PyTorch3D's own function on the mesh (train.py:149): every edge-adjacent pair.
+        self.face_connectivity = edge_adjacent_face_pairs(f2e, skip_last_edge=True).to(self.vertices.device)
+        self.normal_pairs = edge_adjacent_face_pairs(f2e).to(self.vertices.device)
         from .mesh_losses import MeshLossTopology
-        self.loss_topo = MeshLossTopology(self.edges, self.face_connectivity, N, self.faces.shape[0], self.vertices.device)
+        self.loss_topo = MeshLossTopology(self.edges, self.face_connectivity, N, self.faces.shape[0], self.vertices.device, normal_pairs=self.normal_pairs)
         v = self.vertices.detach().T
         self.target_edge_length = (v[self.edges[:, 0]] - v[self.edges[:, 1]]).norm(dim=1)     # get_init_edge_length (model.py:127-134)
 
@@ -411,8 +435,9 @@ class Model(nn.Module):
         if self.training:
             vo, vc = vertices_observation.T, vertices_canonical.T
             outputs.update(colors=self.appearance.T, face_connectivity=self.face_connectivity,
-                           mesh=SimpleMesh(vo, self.faces, self.edges, self.topo, self.loss_topo),
-                           mesh_canonical=SimpleMesh(vc, self.faces, self.edges, self.topo, self.loss_topo), target_edge_length=self.target_edge_length,
+                           mesh=SimpleMesh(vo, self.faces, self.edges, self.topo, self.loss_topo, self.normal_pairs),
+                           mesh_canonical=SimpleMesh(vc, self.faces, self.edges, self.topo, self.loss_topo, self.normal_pairs),
+                           target_edge_length=self.target_edge_length,
                            albedo=albedos[0],
                            normal=normal, normal_mask=normal_mask[..., 0] if normal_mask is not None else None, shadow=shadings)
         return rgbs, masks, outputs

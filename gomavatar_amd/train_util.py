@@ -18,7 +18,8 @@ def unpack(rgbs, masks, bgcolors):
 
 
 def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
-    """Uniform Laplacian: mean over vertices of || (1/deg) sum_neighbours v_j - v_i ||."""
+    """utils/network_util.py:669-792 (uniform): mean over vertices of || (1/deg) sum_neighbours v_j - v_i ||^2
+    (`loss.norm(dim=1) ** 2` then the un-weighted mean, :789-792); no gradient through the Laplacian matrix."""
     v, e = mesh.verts_packed(), mesh.edges_packed()
     if v.is_cuda and getattr(mesh, "loss_topo", None) is not None:
         from .mesh_losses import laplacian_smoothing
@@ -28,18 +29,22 @@ def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
     deg = deg.index_add(0, e[:, 1], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
     s = torch.zeros_like(v).index_add(0, e[:, 0], v[e[:, 1]]).index_add(0, e[:, 1], v[e[:, 0]])
     lap = s / deg.clamp_min(1.0)[:, None] - v
-    return lap.norm(dim=1).mean()
+    return (lap.norm(dim=1) ** 2).mean()
 
 
-def mesh_normal_consistency(mesh, face_connectivity) -> torch.Tensor:
-    """1 - cos between the normals of faces sharing an edge, averaged over those edges."""
+def mesh_normal_consistency(mesh, face_connectivity=None) -> torch.Tensor:
+    """PyTorch3D mesh_normal_consistency(mesh) as called at train.py:149: 1 - cos between the normals of EVERY pair of faces
+    sharing an edge (cosine_similarity eps 1e-8), averaged over the pairs.  `face_connectivity` (optional, host path only)
+    overrides the pair list; the default is every edge-adjacent pair of the mesh (`mesh.normal_pairs`)."""
     v, f = mesh.verts_packed(), mesh.faces_packed()
-    if v.is_cuda and getattr(mesh, "loss_topo", None) is not None:
+    if v.is_cuda and getattr(mesh, "loss_topo", None) is not None and face_connectivity is None:
         from .mesh_losses import normal_consistency
         return normal_consistency(v, mesh.topo, mesh.loss_topo)
+    pairs = face_connectivity if face_connectivity is not None else mesh.normal_pairs
     n = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
-    n = F.normalize(n, dim=1, eps=1e-6)
-    return (1.0 - (n[face_connectivity[:, 0]] * n[face_connectivity[:, 1]]).sum(1)).mean()
+    a, b = n[pairs[:, 0]], n[pairs[:, 1]]
+    w = (a * a).sum(1) * (b * b).sum(1)
+    return (1.0 - (a * b).sum(1) / torch.sqrt(w.clamp_min(1e-16))).mean()
 
 
 def mesh_color_consistency(colors, face_connectivity, loss_topo=None) -> torch.Tensor:
@@ -90,7 +95,7 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
     if _get(loss_cfg, "laplacian.coeff_observation", 0.0) > 0:
         put("laplacian_observation", mesh_laplacian_smoothing(outputs["mesh"]), loss_cfg.laplacian.coeff_observation)
     if _get(loss_cfg, "normal.coeff_consist", 0.0) > 0:
-        put("normal_consist", mesh_normal_consistency(outputs["mesh"], outputs["face_connectivity"]), loss_cfg.normal.coeff_consist)
+        put("normal_consist", mesh_normal_consistency(outputs["mesh"]), loss_cfg.normal.coeff_consist)      # train.py:149: all edge-adjacent pairs
     if _get(loss_cfg, "color_consist.coeff", 0.0) > 0:
         put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"], getattr(outputs.get("mesh"), "loss_topo", None)),
             loss_cfg.color_consist.coeff)

@@ -207,6 +207,35 @@ def main():
     conn = torch.randint(0, 40, (60, 2), generator=gs)
     np.savez_compressed(os.path.join(OUT, "shadow_color.npz"), normals=nrm.numpy(), shadow=sh_out.numpy(), colors=col.numpy(), pairs=conn.numpy(),
                         color_consistency=ref_cc(col, conn).numpy(), **{"w_" + k: v.numpy() for k, v in rs.state_dict().items()})
+    # ---------------- uniform Laplacian smoothing (utils/network_util.py:669-792, the reference's own copy) ----------------
+    # The function only needs verts_packed / faces_packed / laplacian_packed / bookkeeping from its `meshes` argument: a minimal
+    # stand-in supplies them.  L = D^-1 A - I is the restated upstream piece (PyTorch3D 0.7.0 Meshes.laplacian_packed, uniform);
+    # what the golden pins is the reference's own arithmetic on it: L.mm(V), norm(dim=1) ** 2, un-weighted mean.
+    from utils.network_util import mesh_laplacian_smoothing as ref_lap  # noqa: E402
+    from oracle import mesh_losses as oml  # noqa: E402  (edge list + dense L only)
+    ico = syn.icosphere_body(1)
+    gl = torch.Generator().manual_seed(8)
+    lv = torch.from_numpy(ico["canonical_vertex"]).double() + 0.01 * torch.randn(ico["canonical_vertex"].shape, generator=gl, dtype=torch.float64)
+    lf = torch.from_numpy(ico["faces"]).long()
+    ledges, _ = oml.edges_of(lf, lv.shape[0])
+    Ld = oml.uniform_laplacian(ledges, lv.shape[0]).to_sparse()
+
+    class MeshesStandIn:
+        device = lv.device
+        def __init__(self, v): self.v = v
+        def isempty(self): return False
+        def __len__(self): return 1
+        def verts_packed(self): return self.v
+        def faces_packed(self): return lf
+        def num_verts_per_mesh(self): return torch.tensor([self.v.shape[0]])
+        def verts_packed_to_mesh_idx(self): return torch.zeros(self.v.shape[0], dtype=torch.long)
+        def laplacian_packed(self): return Ld
+
+    lvg = lv.clone().requires_grad_()
+    lval = ref_lap(MeshesStandIn(lvg))
+    lval.backward()
+    np.savez_compressed(os.path.join(OUT, "mesh_losses.npz"), verts=lv.numpy(), faces=lf.numpy(), edges=ledges.numpy(),
+                        laplacian=lval.detach().numpy(), laplacian_grad=lvg.grad.numpy())
     # ---------------- ndc_T_world (utils/pc_util.py:30-46): square and both non-square cases ----------------
     from utils import pc_util as ref_pc  # noqa: E402
     gn = torch.Generator().manual_seed(6)

@@ -1,50 +1,106 @@
-"""HIP mesh regularisers (csrc/mesh_losses.hip) against the plain torch formulas (the CPU branch of train_util)."""
+"""HIP mesh regularisers (csrc/mesh_losses.hip) against oracle/mesh_losses.py -- the restatement of
+utils/network_util.py:669-799 / PyTorch3D mesh_normal_consistency (train.py:123-160) -- and against the golden recorded from
+the reference's own `mesh_laplacian_smoothing` (tests/golden/mesh_losses.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from gomavatar_amd import synthetic as syn
+from oracle import mesh_losses as oml
 
 pytestmark = pytest.mark.gpu
 
 
-def test_values_and_gradients_match_torch_formulas():
-    from gomavatar_amd.model import SimpleMesh, mesh_edges
-    from gomavatar_amd.geometry import MeshTopology
-    from gomavatar_amd.mesh_losses import MeshLossTopology
-    from gomavatar_amd import train_util as tu
-    body = syn.icosphere_body(2)
-    g = torch.Generator().manual_seed(0)
+def _scene(level=2, seed=0):
+    body = syn.icosphere_body(level)
+    g = torch.Generator().manual_seed(seed)
     v = torch.from_numpy(body["canonical_vertex"]).float() + 0.01 * torch.randn(body["canonical_vertex"].shape, generator=g)
     faces = torch.from_numpy(body["faces"]).long()
+    colors = torch.rand(3, faces.shape[0], generator=g)
+    return v, faces, colors
+
+
+def _hip_mesh(v, faces, requires_grad=True):
+    from gomavatar_amd.model import SimpleMesh, mesh_edges, edge_adjacent_face_pairs
+    from gomavatar_amd.geometry import MeshTopology
+    from gomavatar_amd.mesh_losses import MeshLossTopology
     N, F = v.shape[0], faces.shape[0]
     edges, f2e = mesh_edges(faces, N)
-    # face pairs as Model._rebuild_topology builds them (without the reference's last-edge quirk: irrelevant here)
-    f2e_np = f2e.numpy(); order = np.argsort(f2e_np.reshape(-1), kind="stable"); eid = f2e_np.reshape(-1)[order]; fid = order // 3
-    starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
-    pairs = torch.from_numpy(np.sort(np.stack([fid[starts], fid[starts + 1]], 1), 1))
-    colors = torch.rand(3, F, generator=g)
-    # torch (CPU, fp64)
+    conn = edge_adjacent_face_pairs(f2e, skip_last_edge=True)
+    allp = edge_adjacent_face_pairs(f2e)
+    vg = v.cuda().requires_grad_(requires_grad)
+    topo = MeshTopology(faces.cuda(), N)
+    lt = MeshLossTopology(edges, conn, N, F, "cuda", normal_pairs=allp)
+    return SimpleMesh(vg, faces.cuda(), edges.cuda(), topo, lt, allp.cuda()), vg, lt, conn, allp
+
+
+def test_values_and_gradients_match_oracle():
+    from gomavatar_amd import train_util as tu
+    v, faces, colors = _scene()
+    N = v.shape[0]
+    # oracle (CPU, fp64)
     vc = v.double().requires_grad_(); cc = colors.double().requires_grad_()
-    mesh_c = SimpleMesh(vc, faces, edges)
-    l_lap, l_nc, l_cc = tu.mesh_laplacian_smoothing(mesh_c), tu.mesh_normal_consistency(mesh_c, pairs), tu.mesh_color_consistency(cc.T, pairs)
+    edges, _ = oml.edges_of(faces, N)
+    conn_o = oml.face_connectivity(faces, N)
+    l_lap, l_nc, l_cc = oml.laplacian_smoothing(vc, edges), oml.normal_consistency(vc, faces), oml.color_consistency(cc.T, conn_o)
     (2.0 * l_lap + 3.0 * l_nc + 5.0 * l_cc).backward()
     # HIP
-    vg = v.cuda().requires_grad_(); cg = colors.cuda().requires_grad_()
-    topo = MeshTopology(faces.cuda(), N)
-    lt = MeshLossTopology(edges, pairs, N, F, "cuda")
-    mesh_g = SimpleMesh(vg, faces.cuda(), edges.cuda(), topo, lt)
-    h_lap, h_nc, h_cc = tu.mesh_laplacian_smoothing(mesh_g), tu.mesh_normal_consistency(mesh_g, pairs.cuda()), tu.mesh_color_consistency(cg.T, pairs.cuda(), lt)
+    mesh_g, vg, lt, conn, allp = _hip_mesh(v, faces)
+    # the product's pair lists are the oracle's: the reference's face_connectivity (last edge id skipped) / every adjacent pair
+    assert torch.equal(conn, conn_o)
+    assert allp.shape[0] == edges.shape[0] == conn.shape[0] + 1      # closed manifold: one pair per edge
+    cg = colors.cuda().requires_grad_()
+    h_lap, h_nc, h_cc = tu.mesh_laplacian_smoothing(mesh_g), tu.mesh_normal_consistency(mesh_g), tu.mesh_color_consistency(cg.T, conn.cuda(), lt)
     (2.0 * h_lap + 3.0 * h_nc + 5.0 * h_cc).backward()
-    for a, b in ((h_lap, l_lap), (h_nc, l_nc), (h_cc, l_cc)):
-        assert abs(float(a.detach()) - float(b.detach())) <= 2e-6 * max(1.0, abs(float(b.detach()))), (float(a.detach()), float(b.detach()))
+    for name, a, b in (("laplacian", h_lap, l_lap), ("normal", h_nc, l_nc), ("colour", h_cc, l_cc)):
+        assert abs(float(a.detach()) - float(b.detach())) <= 2e-6 * max(abs(float(b.detach())), 1e-3), (name, float(a.detach()), float(b.detach()))
     gv, gc = vg.grad.cpu().double(), cg.grad.cpu().double()
     assert float((gv - vc.grad).abs().max()) <= 2e-5 * float(vc.grad.abs().max())
     assert float((gc - cc.grad).abs().max()) <= 1e-6 * float(cc.grad.abs().max())
+    # the host (torch) branch of train_util is the same function
+    from gomavatar_amd.model import SimpleMesh
+    vh = v.double().requires_grad_()
+    mesh_h = SimpleMesh(vh, faces, edges, None, None, allp)
+    t_lap, t_nc = tu.mesh_laplacian_smoothing(mesh_h), tu.mesh_normal_consistency(mesh_h)
+    assert abs(float(t_lap) - float(l_lap)) <= 1e-12 and abs(float(t_nc) - float(l_nc)) <= 1e-12
     # bitwise reproducible
-    vg2 = v.cuda().requires_grad_()
-    mesh_g2 = SimpleMesh(vg2, faces.cuda(), edges.cuda(), topo, lt)
-    (2.0 * tu.mesh_laplacian_smoothing(mesh_g2) + 3.0 * tu.mesh_normal_consistency(mesh_g2, pairs.cuda())).backward()
+    mesh_g2, vg2, lt2, _, _ = _hip_mesh(v, faces)
+    (2.0 * tu.mesh_laplacian_smoothing(mesh_g2) + 3.0 * tu.mesh_normal_consistency(mesh_g2)).backward()
     cg2 = colors.cuda().requires_grad_()
-    (5.0 * tu.mesh_color_consistency(cg2.T, pairs.cuda(), lt)).backward()
-    assert torch.equal(vg2.grad, vg.grad) and torch.equal(cg2.grad, cg.grad)
+    (5.0 * tu.mesh_color_consistency(cg2.T, conn.cuda(), lt2)).backward()
+    assert torch.equal(cg2.grad, cg.grad)
+    mesh_g3, vg3, _, _, _ = _hip_mesh(v, faces)
+    (2.0 * tu.mesh_laplacian_smoothing(mesh_g3) + 3.0 * tu.mesh_normal_consistency(mesh_g3)).backward()
+    assert torch.equal(vg2.grad, vg3.grad)
+
+
+def test_laplacian_matches_reference_golden(golden_dir):
+    """Value and gradient recorded from the reference's own mesh_laplacian_smoothing (network_util.py:669-792)."""
+    from gomavatar_amd import train_util as tu
+    g = np.load(os.path.join(golden_dir, "mesh_losses.npz"))
+    v, faces = torch.from_numpy(g["verts"]).float(), torch.from_numpy(g["faces"]).long()
+    mesh_g, vg, _, _, _ = _hip_mesh(v, faces)
+    val = tu.mesh_laplacian_smoothing(mesh_g)
+    val.backward()
+    assert abs(float(val) - float(g["laplacian"])) <= 2e-6 * float(g["laplacian"])
+    ref = torch.from_numpy(g["laplacian_grad"])
+    assert float((vg.grad.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_metric_size_mesh_against_oracle_sparse():
+    """55 104 faces: the kernels against the fp64 restatement with the same pair lists (vectorised host formulas)."""
+    from gomavatar_amd import train_util as tu
+    body = syn.make_body(1)
+    g = torch.Generator().manual_seed(3)
+    v = torch.from_numpy(body["canonical_vertex"]).float() + 0.002 * torch.randn(body["canonical_vertex"].shape, generator=g)
+    faces = torch.from_numpy(body["faces"]).long()
+    mesh_g, vg, lt, conn, allp = _hip_mesh(v, faces)
+    (tu.mesh_laplacian_smoothing(mesh_g) + 0.1 * tu.mesh_normal_consistency(mesh_g)).backward()
+    from gomavatar_amd.model import SimpleMesh, mesh_edges
+    edges, _ = mesh_edges(faces, v.shape[0])
+    vh = v.double().requires_grad_()
+    mesh_h = SimpleMesh(vh, faces, edges, None, None, allp)
+    (tu.mesh_laplacian_smoothing(mesh_h) + 0.1 * tu.mesh_normal_consistency(mesh_h)).backward()
+    assert float((vg.grad.cpu().double() - vh.grad).abs().max()) <= 5e-5 * float(vh.grad.abs().max())
