@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
                                                     const float *__restrict__ RT, const int32_t *__restrict__ csr_off,
                                                     const int32_t *__restrict__ csr_idx, const float *__restrict__ d_corner,
                                                     const float *__restrict__ d_extra, float *__restrict__ d_obs,
-                                                    float *__restrict__ d_xyz, float *__restrict__ dRT, int F) {
+                                                    float *__restrict__ d_xyz, int F) {
     extern __shared__ float s_rt[];
     {  // blockIdx.y = frame of a batched launch (F = faces, the stride of d_corner)
         const size_t fr = blockIdx.y;
@@ -401,7 +401,6 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
         if (d_corner) d_corner += fr * 9 * F;
         if (d_extra) d_extra += fr * 3 * N;
         if (d_obs) d_obs += fr * 3 * N;
-        if (dRT) dRT += fr * J * 12;
     }
     for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
     __syncthreads();
@@ -442,7 +441,6 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
     float x = 0.f, y = 0.f, z = 0.f;
     if (ok) { x = xyz[n]; y = xyz[(size_t)N + n]; z = xyz[2 * (size_t)N + n]; }
     float ox = 0.f, oy = 0.f, oz = 0.f;
-    const int lane = threadIdx.x & 63;
     for (int j = 0; j < J; j++) {
         const float wj = ok ? w[(size_t)j * N + n] : 0.f;
         if (wj != 0.f) {
@@ -451,23 +449,62 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
             oy += (m[1] * g[0] + m[4] * g[1] + m[7] * g[2]) * wj;
             oz += (m[2] * g[0] + m[5] * g[1] + m[8] * g[2]) * wj;
         }
-        if (dRT) {
-            if (__ballot(wj != 0.f) != 0ull) {
-                const float v[12] = {wj * g[0] * x, wj * g[0] * y, wj * g[0] * z, wj * g[1] * x, wj * g[1] * y, wj * g[1] * z,
-                                     wj * g[2] * x, wj * g[2] * y, wj * g[2] * z, wj * g[0], wj * g[1], wj * g[2]};
-#pragma unroll
-                for (int q = 0; q < 12; q++) {
-                    const float s = wave_sum(v[q]);
-                    if (lane == 0) atomicAdd(&dRT[12 * j + q], s);
-                }
-            }
-        }
     }
     if (ok) {
         d_xyz[n] = ox;
         d_xyz[(size_t)N + n] = oy;
         d_xyz[2 * (size_t)N + n] = oz;
     }
+}
+
+// Pose gradient dRT [J][12] = sum_n w_jn (g_n x_n^T | g_n), g_n = gathered gradient of the posed vertex.  One workgroup per
+// (joint, frame): thread t owns the vertices t, t + 256, ... (fixed), the 256 partial sums are folded by a shuffle butterfly and
+// the four waves in wave order.  No float atomics: bitwise reproducible like the rest of the backward (the first version
+// added per-wave sums with atomicAdd in arrival order).  Most joints weigh a few hundred vertices (top-4 skinning weights):
+// the row of w is streamed, only its non-zeros gather.
+__global__ void __launch_bounds__(256) k_pose_grad(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
+                                                   const int32_t *__restrict__ csr_off, const int32_t *__restrict__ csr_idx,
+                                                   const float *__restrict__ d_corner, const float *__restrict__ d_extra,
+                                                   float *__restrict__ dRT, int F) {
+    __shared__ float s_part[4][12];
+    const int j = blockIdx.x;
+    {
+        const size_t fr = blockIdx.y;
+        if (d_corner) d_corner += fr * 9 * F;
+        if (d_extra) d_extra += fr * 3 * N;
+        dRT += fr * J * 12;
+    }
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) acc[q] = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float wj = w[(size_t)j * N + n];
+        if (wj == 0.f) continue;
+        float g[3] = {0.f, 0.f, 0.f};
+        if (csr_off) {   // same corner order as k_vertex_bwd
+            const int b = csr_off[n], e = csr_off[n + 1];
+            for (int k = b; k < e; k++) {
+                const int ci = csr_idx[k];
+                g[0] += d_corner[3 * (size_t)ci]; g[1] += d_corner[3 * (size_t)ci + 1]; g[2] += d_corner[3 * (size_t)ci + 2];
+            }
+        }
+        if (d_extra) { g[0] += d_extra[n]; g[1] += d_extra[(size_t)N + n]; g[2] += d_extra[2 * (size_t)N + n]; }
+        const float x = xyz[n], y = xyz[(size_t)N + n], z = xyz[2 * (size_t)N + n];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float wg = wj * g[r];
+            acc[3 * r] += wg * x; acc[3 * r + 1] += wg * y; acc[3 * r + 2] += wg * z;
+            acc[9 + r] += wg;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) acc[q] = wave_sum(acc[q]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) s_part[threadIdx.x >> 6][q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) dRT[12 * j + threadIdx.x] = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
 }
 
 // dst_k[i] = sum_b src_k[b * n_k + i] for up to four tensors in one launch, frames in a fixed order
@@ -580,8 +617,13 @@ int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, cons
     if (!xyz || !weights || !RT || !d_xyz) { gom_set_error("gom_vertex_backward: null pointer"); return -1; }
     if ((csr_off == nullptr) != (csr_idx == nullptr) || (csr_off && !d_corner)) { gom_set_error("gom_vertex_backward: inconsistent CSR arguments"); return -1; }
     hipLaunchKernelGGL(k_vertex_bwd, dim3((N + 255) / 256, B), dim3(256), J * 12 * sizeof(float), (hipStream_t)stream, N, J, xyz, weights,
-                       RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, dRT, F);
+                       RT, csr_off, csr_idx, d_corner, d_verts_extra, d_verts_obs, d_xyz, F);
     GOM_LAUNCH_CHECK();
+    if (dRT) {   // pose gradient (pose refinement / test-time pose optimisation only): deterministic per-joint reduction
+        hipLaunchKernelGGL(k_pose_grad, dim3(J, B), dim3(256), 0, (hipStream_t)stream, N, J, xyz, weights, csr_off, csr_idx, d_corner,
+                           d_verts_extra, dRT, F);
+        GOM_LAUNCH_CHECK();
+    }
     return 0;
 }
 

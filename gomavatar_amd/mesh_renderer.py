@@ -17,7 +17,12 @@ import torch
 
 from . import _lib
 from .geometry import MeshTopology
-from .rasterizer import RasterState
+from .rasterizer import RasterState, _StatePool, _StateLease
+
+# Scratch of the mesh rasterizer, leased per forward like the splat rasterizer's: the backward reads what ITS forward left in the
+# state (face setup, per-pixel products), so two forwards in flight (gradient accumulation over frames, a no_grad preview between
+# a forward and its backward) must not share one.
+_MESH_POOL = _StatePool()
 
 
 def ndc_T_world(xyzs_world: torch.Tensor, K: torch.Tensor, E: torch.Tensor, H: int, W: int) -> torch.Tensor:
@@ -96,15 +101,16 @@ def vertex_normals(verts: torch.Tensor, topo: MeshTopology, rotation: Optional[t
 
 class _MeshRaster(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts_ndc, vnormals, topo: MeshTopology, state: RasterState, H, W, blur_radius, sigma, want_alpha):
+    def forward(ctx, verts_ndc, vnormals, topo: MeshTopology, lease, H, W, blur_radius, sigma, want_alpha):
         lib = _lib.load()
+        state = lease.st
         v, n = verts_ndc.float().contiguous(), vnormals.float().contiguous()
         N, F = v.shape[0], topo.n_faces
         normal = torch.empty((H, W, 3), dtype=torch.float32, device=v.device)
         alpha = torch.empty((H, W), dtype=torch.float32, device=v.device) if want_alpha else None
         _lib.check(lib.gom_mesh_raster_forward(state.handle, N, F, H, W, _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(n), float(blur_radius), float(sigma),
                                                _lib.ptr(normal), _lib.ptr(alpha), _lib.stream_ptr()))
-        ctx.topo, ctx.state, ctx.dims, ctx.want_alpha = topo, state, (N, F, H, W), want_alpha
+        ctx.topo, ctx.lease, ctx.dims, ctx.want_alpha = topo, lease, (N, F, H, W), want_alpha
         if want_alpha:
             return normal, alpha
         return normal, torch.zeros((), device=v.device)
@@ -117,8 +123,11 @@ class _MeshRaster(torch.autograd.Function):
         da = d_alpha.float().contiguous() if ctx.want_alpha else None
         d_verts = torch.empty((N, 3), dtype=torch.float32, device=dn.device)
         d_vn = torch.empty((N, 3), dtype=torch.float32, device=dn.device)
-        _lib.check(lib.gom_mesh_raster_backward(ctx.state.handle, N, F, H, W, _lib.ptr(ctx.topo.csr_off), _lib.ptr(ctx.topo.csr_idx), _lib.ptr(dn),
+        if ctx.lease.done:
+            raise RuntimeError("mesh rasterizer: backward called twice on the same forward (its scratch has been released)")
+        _lib.check(lib.gom_mesh_raster_backward(ctx.lease.st.handle, N, F, H, W, _lib.ptr(ctx.topo.csr_off), _lib.ptr(ctx.topo.csr_idx), _lib.ptr(dn),
                                                 _lib.ptr(da), _lib.ptr(d_verts), _lib.ptr(d_vn), _lib.stream_ptr()))
+        ctx.lease.finish()
         return d_verts, d_vn, None, None, None, None, None, None, None
 
 
@@ -134,15 +143,9 @@ class MeshNormalRenderer(torch.nn.Module):
         self.sigma = 1e-4 if sigma is None else float(sigma)
         self.soft_mask = soft_mask
         self.blur_radius = math.log(1.0 / 1e-4 - 1.0) * self.sigma
-        self._state = None      # created on first use: constructing a Model for checkpoint IO needs no HIP device
         self._topo = None
         self._topo_key = None
-
-    @property
-    def state(self) -> RasterState:
-        if self._state is None:
-            self._state = RasterState()
-        return self._state
+        self.state = None
 
     def topology(self, faces: torch.Tensor, n_verts: int) -> MeshTopology:
         key = (faces.data_ptr(), int(faces.shape[0]), n_verts)
@@ -155,7 +158,11 @@ class MeshNormalRenderer(torch.nn.Module):
         xyzs_ndc = ndc_T_world(xyzs_observation, K, E, H, W)      # (1,N,3)
         assert xyzs_ndc.shape[0] == 1, "the reference renders one frame per call (B = 1)"
         topo = self.topology(faces, xyzs_ndc.shape[1])
-        normal, alpha = _MeshRaster.apply(xyzs_ndc[0], vertex_normals_[0], topo, self.state, H, W, self.blur_radius, self.BLEND_SIGMA, self.training)
+        lease = _StateLease(_MESH_POOL.acquire(xyzs_ndc.device), pool=_MESH_POOL)      # goes back when the backward has run (or the graph is dropped)
+        self.state = lease.st      # scratch of the MOST RECENT forward (pix_to_face export in the tests); may be re-leased once released
+        normal, alpha = _MeshRaster.apply(xyzs_ndc[0], vertex_normals_[0], topo, lease, H, W, self.blur_radius, self.BLEND_SIGMA, self.training)
+        if not normal.requires_grad:   # no autograd graph was recorded: nothing will call backward
+            lease.finish()
         if not self.training:
             return normal[None], None
         return normal[None], alpha[None, ..., None]

@@ -327,16 +327,10 @@ class Model(nn.Module):
 
     # -- the per-frame forward (model.py:184-303) -------------------------------------------------------------------------
     def _camera(self, K, E, bg4):
+        from .camera import camera_block
         W, H = self.img_size
-        Kc, Ec = K[0].detach().cpu().numpy(), E[0].detach().cpu().numpy()
-        fx, fy, px, py = float(Kc[0, 0]), float(Kc[1, 1]), float(Kc[0, 2]), float(Kc[1, 2])
-        tanfovx, tanfovy = math.tan(math.atan(W / (2 * fx))), math.tan(math.atan(H / (2 * fy)))
-        znear, zfar = 0.001, 100
-        K_ndc = np.array([[2 * fx / W, 0, (2 * px - W) / W, 0], [0, 2 * fy / H, (2 * py - H) / H, 0],
-                          [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]], dtype=np.float32)
-        view = np.ascontiguousarray(Ec.T.astype(np.float32))
-        proj = (Ec.T.astype(np.float32) @ K_ndc.T).astype(np.float32)
-        return _lib.make_camera(H, W, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
+        tanfov, view, proj = camera_block(K[0].detach().cpu(), E[0].detach().cpu(), H, W)      # host camera: the reference's own .item() reads
+        return _lib.make_camera(H, W, float(tanfov[0]), float(tanfov[1]), view.reshape(-1).numpy(), proj.reshape(-1).numpy(), list(bg4))
 
     def _mesh_branch(self, vertices_observation, K, E):
         """model.py:270-282: camera-space vertex normals, normal map + soft silhouette, shading = 2 * shadow_module(normal)."""

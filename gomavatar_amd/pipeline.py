@@ -97,20 +97,11 @@ class RenderStep:
         self.cam = self._make_camera(K, E, bg4)
 
     def _make_camera(self, K, E, bg4):
-        import math
-        import numpy as np
-        K = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32).reshape(3, 3)
-        E = np.asarray(E.detach().cpu() if torch.is_tensor(E) else E, dtype=np.float32).reshape(4, 4)
-        w, h = self.W, self.H
-        fx, fy, px, py = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
-        tanfovx = math.tan(2 * math.atan(w / (2 * fx)) * 0.5)
-        tanfovy = math.tan(2 * math.atan(h / (2 * fy)) * 0.5)
-        znear, zfar = 0.001, 100
-        K_ndc = np.array([[2 * fx / w, 0, (2 * px - w) / w, 0], [0, 2 * fy / h, (2 * py - h) / h, 0],
-                          [0, 0, zfar / (zfar - znear), -zfar * znear / (zfar - znear)], [0, 0, 1, 0]], dtype=np.float32)
-        view = np.ascontiguousarray(E.T)
-        proj = (E.T @ K_ndc.T).astype(np.float32)
-        return _lib.make_camera(h, w, tanfovx, tanfovy, view.reshape(-1), proj.reshape(-1), list(bg4))
+        from .camera import camera_block
+        K = torch.as_tensor(K).detach().cpu().reshape(3, 3)
+        E = torch.as_tensor(E).detach().cpu().reshape(4, 4)
+        tanfov, view, proj = camera_block(K, E, self.H, self.W)
+        return _lib.make_camera(self.H, self.W, float(tanfov[0]), float(tanfov[1]), view.reshape(-1).numpy(), proj.reshape(-1).numpy(), list(bg4))
 
     # -- one frame --------------------------------------------------------------
     def _frame_struct(self) -> "_lib.GomFrame":

@@ -123,14 +123,15 @@ _POOL = _StatePool()
 class _StateLease:
     """Lets go of the state when finished or when the autograd graph drops it."""
 
-    def __init__(self, st: RasterState):
+    def __init__(self, st: RasterState, pool: "_StatePool" = None):
         self.st = st
         self.done = False
+        self.pool = pool if pool is not None else _POOL
 
     def finish(self):
         if not self.done:
             self.done = True
-            _POOL.release(self.st)
+            self.pool.release(self.st)
 
     def __del__(self):
         try:
@@ -163,18 +164,8 @@ class DeviceCamera:
 
     def update(self, K: torch.Tensor, E: torch.Tensor, bg=(0.0, 0.0, 0.0, 0.0), znear: float = 0.001, zfar: float = 100.0) -> "DeviceCamera":
         """K (3,3), E (4,4) device tensors -> tanfov, viewmatrix = E^T, projmatrix = E^T K_ndc^T (gaussian.py:28-51)."""
-        H, W = self.H, self.W
-        K, E = K.detach().float(), E.detach().float()
-        fx, fy, px, py = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
-        zero, one = torch.zeros((), device=K.device), torch.ones((), device=K.device)
-        K_ndc = torch.stack([torch.stack([2 * fx / W, zero, (2 * px - W) / W, zero]),
-                             torch.stack([zero, 2 * fy / H, (2 * py - H) / H, zero]),
-                             torch.stack([zero, zero, one * (zfar / (zfar - znear)), one * (-zfar * znear / (zfar - znear))]),
-                             torch.stack([zero, zero, one, zero])])
-        view = E.T.contiguous()
-        proj = view @ K_ndc.T
-        # tan(atan(x)) written out like the host path (Model._camera) so both agree to the last bit
-        tanfov = torch.stack([torch.tan(torch.atan(W / (2 * fx))), torch.tan(torch.atan(H / (2 * fy)))])
+        from .camera import camera_block
+        tanfov, view, proj = camera_block(K, E, self.H, self.W, znear, zfar)      # the one camera function of the package, on the device
         self.data[2:4] = tanfov
         self.data[4:20] = view.reshape(-1)
         self.data[20:36] = proj.reshape(-1)

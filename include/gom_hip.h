@@ -226,8 +226,8 @@ int gom_face_backward(int N, int F, const float *verts, const int32_t *faces, co
 /* Gathers per-corner gradients onto vertices through the CSR vertex->corner
  * adjacency (csr_off [N+1], csr_idx [3F] = face*3+corner; no atomics), adds
  * d_verts_extra [3][N] (may be NULL), and applies the LBS backward:
- * d_xyz [3][N] = sum_j w_j R_j^T g.  If dRT != NULL also accumulates
- * dRT [J][12] += sum_n w_jn (g_n x_n^T | g_n) (dRT must be zeroed by the caller). */
+ * d_xyz [3][N] = sum_j w_j R_j^T g.  If dRT != NULL also writes
+ * dRT [J][12] = sum_n w_jn (g_n x_n^T | g_n) (overwritten; fixed summation order, no atomics). */
 int gom_vertex_backward(int N, int J, const float *xyz, const float *weights, const float *RT,
                         const int32_t *csr_off, const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra,
                         float *d_verts_obs, float *d_xyz, float *dRT, void *stream);

@@ -170,3 +170,45 @@ def test_vertex_normals_rotation_option_equals_the_matrix_product():
     (n_b * w).sum().backward()
     assert torch.allclose(n_a.detach(), n_b.detach(), rtol=1e-5, atol=1e-6)
     assert float((a.grad - b.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max())
+
+
+def test_two_forwards_in_flight_keep_their_own_scratch():
+    """Two Model-style forwards before either backward (gradient accumulation over frames) and a no_grad preview render in
+    between: every backward must see ITS forward's scratch (the first version kept one state per renderer)."""
+    from gomavatar_amd import synthetic as syn
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, vertex_normals
+    body = syn.icosphere_body(3)
+    img = 96
+    faces = torch.from_numpy(body["faces"]).long().cuda()
+    r = MeshNormalRenderer(img_size=(img, img), sigma=1e-5).cuda().train()
+    g = torch.Generator().manual_seed(0)
+    wn, wa = torch.randn(img, img, 3, generator=g).cuda(), torch.randn(img, img, generator=g).cuda()
+
+    def frame(i):
+        fr = syn.make_frame(i, img)
+        K, E = torch.from_numpy(fr["K"]).cuda(), torch.from_numpy(fr["E"]).cuda()
+        K = K.clone(); K[:, 0, 0] *= 4; K[:, 1, 1] *= 4
+        v = (torch.from_numpy(body["canonical_vertex"]).T[None] * 0.5 + torch.tensor([0.0, 1.2, 0.0]).view(1, 3, 1)).cuda().requires_grad_()
+        vn = vertex_normals(v[0].T, r.topology(faces, v.shape[2]))
+        return v, vn, K, E
+
+    def loss(n, a):
+        return (n[0] * wn).sum() + (a[0, ..., 0] * wa).sum()
+
+    # reference gradients: one forward/backward at a time
+    refs = []
+    for i in (0, 3):
+        v, vn, K, E = frame(i)
+        loss(*r(v, vn[None], K, E, faces)).backward()
+        refs.append(v.grad.clone())
+    # interleaved: forward 0, forward 3, a no_grad preview, then the two backwards in the "wrong" order
+    v0, vn0, K0, E0 = frame(0)
+    out0 = r(v0, vn0[None], K0, E0, faces)
+    v3, vn3, K3, E3 = frame(3)
+    out3 = r(v3, vn3[None], K3, E3, faces)
+    with torch.no_grad():
+        vp, vnp, Kp, Ep = frame(5)
+        r(vp.detach(), vnp[None], Kp, Ep, faces)
+    loss(*out0).backward()
+    loss(*out3).backward()
+    assert torch.equal(v0.grad, refs[0]) and torch.equal(v3.grad, refs[1])
