@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) k_ncons_fwd(int P, const int32_t *__restr
         face_cross(verts, faces, pairs[2 * p], a);
         face_cross(verts, faces, pairs[2 * p + 1], b);
         // cosine_similarity of the two (un-normalised) normals with torch 1.13's eps rule: a.b / sqrt(max(|a|^2 |b|^2, eps^2)), eps = 1e-8.
-        // On a consistently oriented mesh the face normals are PyTorch3D's (n0, -n1) of the shared edge (oracle/mesh_losses.py).
+        // On a consistently oriented mesh the face normals are PyTorch3D's (n0, -n1) of the shared edge.
         const float aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
         const float ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
         const float w = aa * bb;

@@ -38,8 +38,15 @@ def to_reference_state_dict(model) -> Dict[str, torch.Tensor]:
 def load_reference_state_dict(model, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
     """Load a reference `network` state dict; subdivides the model first when the checkpoint's mesh is a subdivision of it."""
     n_faces = int(sd["faces"].shape[0]) if "faces" in sd else int(sd["so3"].shape[1])
-    while model.faces.shape[0] < n_faces:
-        model.subdivide()
+    if "faces" in sd and "vertices" in sd and not (model.faces.shape == sd["faces"].shape and torch.equal(model.faces.cpu(), sd["faces"].cpu().to(model.faces.dtype))):
+        # The checkpoint carries its own (possibly subdivided) topology: adopt it instead of re-deriving it.  The reference numbers
+        # the midpoints of a subdivision in trimesh's `grouping.unique_rows` order (utils/pc_util.py:95-121), which this package's
+        # `synthetic.subdivide` (np.unique, lexicographic) need not reproduce -- the same surface with another vertex / face
+        # numbering -- so a re-subdivided model would only match by luck.  Everything per-vertex / per-face is in the state dict.
+        _adopt_topology(model, sd)
+    else:
+        while model.faces.shape[0] < n_faces:
+            model.subdivide()
     if model.faces.shape[0] != n_faces:
         raise ValueError(f"checkpoint has {n_faces} faces, the model {model.faces.shape[0]} (not a midpoint subdivision of each other)")
     own = dict(model.named_parameters())
@@ -69,6 +76,27 @@ def load_reference_state_dict(model, sd: Dict[str, torch.Tensor], strict: bool =
     model._rebuild_topology()
     if "target_edge_length" in sd:   # a buffer of the reference model: the edge lengths at (the last) subdivision, not today's
         model.target_edge_length = sd["target_edge_length"].to(model.vertices.device, torch.float32)
+
+
+def _adopt_topology(model, sd: Dict[str, torch.Tensor]) -> None:
+    """Resize the model to the mesh of a checkpoint: faces from the checkpoint, per-vertex / per-face parameters re-created with
+    the checkpoint's shapes (their values are copied by the caller), adjacency rebuilt."""
+    import torch.nn as nn
+    dev = model.vertices.device
+    faces = sd["faces"].to(dev, model.faces.dtype).contiguous()
+    N, F = int(sd["vertices"].shape[1]), int(faces.shape[0])
+    if int(faces.max()) >= N or int(faces.min()) < 0:
+        raise ValueError("checkpoint faces index vertices the checkpoint does not have")
+    model.faces = faces
+    model.vertices = nn.Parameter(torch.zeros(3, N, device=dev))
+    for name in ("so3", "scale", "appearance"):
+        old = getattr(model, name)
+        setattr(model, name, nn.Parameter(torch.zeros(3, F, device=dev), requires_grad=old.requires_grad))
+    if "lbs_weights" in sd:
+        model.lbs_weights = sd["lbs_weights"].to(dev, torch.float32).contiguous()
+    elif model.lbs_weights.shape[1] != N:
+        raise KeyError("checkpoint with its own topology but without lbs_weights")
+    model._rebuild_topology()
 
 
 def save_checkpoint(path: str, n_iter: int, model, optimizer) -> None:

@@ -313,7 +313,11 @@ class Model(nn.Module):
     def get_param_groups(self, cfg):
         """model.py:305-327 (lr names of configs/default.yaml)."""
         lr = cfg.lr
-        groups = [{"name": "appearance", "params": [self.appearance], "lr": lr.appearance},
+        # The reference's FIRST group is the skinning-weight tensor -- a buffer unless lbs_weights.refine (model.py:306-309,64-69):
+        # it receives no gradient and Adam skips it, but it occupies param_groups[0] / state index 0 of every optimizer state the
+        # reference saves, so it is kept for `optimizer.load_state_dict` of a reference checkpoint (formats.load_checkpoint).
+        groups = [{"name": "lbs_weights", "params": [self.lbs_weights], "lr": _get(lr, "lbs_weights", 0.0)},
+                  {"name": "appearance", "params": [self.appearance], "lr": lr.appearance},
                   {"name": "canonical_geometry_xyz", "params": [self.vertices], "lr": lr.canonical_geometry_xyz},
                   {"name": "canonical_geometry", "params": [self.scale], "lr": lr.canonical_geometry},
                   {"name": "canonical_geometry", "params": [self.so3], "lr": lr.canonical_geometry}]

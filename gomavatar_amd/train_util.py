@@ -189,9 +189,10 @@ class GraphedRender:
         image = render(frame)          # frame: K, E, cnl_gtfms, dst_Rs, dst_Ts, bgcolor;  returns a static (1, H, W, 3) buffer"""
 
     FRAME_KEYS = ("K", "E", "cnl_gtfms", "dst_Rs", "dst_Ts", "bgcolor")
+    OPTIONAL_KEYS = ("dst_posevec",)      # read by the pose-refinement / non-rigid modules (eval.py:341-343 passes data['dst_posevec'])
 
-    def __init__(self, model, warmup: int = 3):
-        self.model, self.warmup, self.graph, self.static, self.out = model, warmup, None, None, None
+    def __init__(self, model, warmup: int = 3, i_iter: float = 1e7):
+        self.model, self.warmup, self.graph, self.static, self.out, self.i_iter = model, warmup, None, None, None, i_iter
 
     def invalidate(self):
         self.graph = None
@@ -199,13 +200,16 @@ class GraphedRender:
     def _frame(self):
         fr = self.static
         with torch.no_grad():
-            rgbs, masks, _ = self.model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            rgbs, masks, _ = self.model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], dst_posevec=fr.get("dst_posevec"), i_iter=self.i_iter)
             return unpack(rgbs, masks, fr["bgcolor"])
 
     def __call__(self, frame):
         if self.graph is None:
             self.model.capture_safe = True
             self.static = {k: frame[k].clone() for k in self.FRAME_KEYS}
+            self.static.update({k: frame[k].clone() for k in self.OPTIONAL_KEYS if frame.get(k) is not None})
+            if (self.model.pose_refinement_module is not None or self.model.non_rigid_module is not None) and "dst_posevec" not in self.static:
+                raise KeyError("GraphedRender: the model has pose-conditioned modules, the frame needs 'dst_posevec'")
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -216,7 +220,7 @@ class GraphedRender:
             with torch.cuda.graph(self.graph):
                 self.out = self._frame()
         else:
-            for k in self.FRAME_KEYS:
+            for k in self.static:
                 self.static[k].copy_(frame[k], non_blocking=True)
         self.graph.replay()
         return self.out

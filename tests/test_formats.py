@@ -21,7 +21,7 @@ def test_checkpoint_round_trip_with_subdivision(tmp_path):
     m.subdivide()
     with torch.no_grad():
         m.appearance.uniform_(0, 1); m.so3.normal_(0, 0.1); m.vertices.add_(0.01)
-    opt = torch.optim.Adam(m.get_param_groups(NS(lr=NS(appearance=1e-3, canonical_geometry=1e-3, canonical_geometry_xyz=1e-4, shadow=1e-3))))
+    opt = torch.optim.Adam(m.get_param_groups(NS(lr=NS(lbs_weights=1e-4, appearance=1e-3, canonical_geometry=1e-3, canonical_geometry_xyz=1e-4, shadow=1e-3))))
     path = os.path.join(tmp_path, "checkpoints", "iter_1000.pt")
     formats.save_checkpoint(path, 1000, m, opt)
     sd = torch.load(path, map_location="cpu")["network"]
@@ -38,6 +38,45 @@ def test_checkpoint_round_trip_with_subdivision(tmp_path):
     auto = Model(_cfg(), body, device="cpu")                       # without the iteration list: subdivide until the face counts match
     formats.load_reference_state_dict(auto, sd)
     assert torch.equal(auto.appearance, m.appearance)
+
+
+def test_reference_layout_optimizer_state_and_foreign_vertex_numbering_load(tmp_path):
+    """A checkpoint as the reference writes it: (i) its Adam state has the `lbs_weights` group first (models/model.py:306-309),
+    (ii) its subdivided mesh numbers the midpoints differently from this package's subdivide (trimesh's unique_rows order)."""
+    body = syn.icosphere_body(1)
+    lr = NS(lr=NS(lbs_weights=1e-4, appearance=1e-3, canonical_geometry=1e-3, canonical_geometry_xyz=1e-4, shadow=1e-3))
+    m = Model(_cfg(), body, device="cpu")
+    m.subdivide()
+    # renumber the vertices (a permutation that keeps the original vertices first, like a different midpoint order)
+    N0 = body["canonical_vertex"].shape[0]
+    N = m.vertices.shape[1]
+    g = torch.Generator().manual_seed(0)
+    perm = torch.cat([torch.arange(N0), N0 + torch.randperm(N - N0, generator=g)])      # new index -> old index
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(N)
+    sd = formats.to_reference_state_dict(m)
+    sd["vertices"] = sd["vertices"][:, perm].contiguous()
+    sd["lbs_weights"] = sd["lbs_weights"][:, perm].contiguous()
+    sd["faces"] = inv[sd["faces"]]
+    groups = m.get_param_groups(lr)
+    assert [g_["name"] for g_ in groups][:5] == ["lbs_weights", "appearance", "canonical_geometry_xyz", "canonical_geometry", "canonical_geometry"]
+    opt = torch.optim.Adam(groups)
+    for p_ in m.parameters():
+        p_.grad = torch.ones_like(p_)
+    opt.step()                                                        # creates Adam state; the lbs_weights buffer gets none (no grad)
+    osd = opt.state_dict()
+    assert len(osd["param_groups"]) == 6 and osd["param_groups"][0]["name"] == "lbs_weights" and 0 not in osd["state"]
+    path = os.path.join(tmp_path, "iter_60000.pt")
+    torch.save({"iter": 60000, "network": sd, "optimizer": osd}, path)
+    fresh = Model(_cfg(), body, device="cpu")
+    opt2 = torch.optim.Adam(fresh.get_param_groups(lr))
+    # (the reference rebuilds its optimizer after each subdivision, train.py:341-346; do the same around the load)
+    ckpt = torch.load(path, map_location="cpu")
+    formats.load_reference_state_dict(fresh, ckpt["network"])
+    assert torch.equal(fresh.faces, sd["faces"]) and torch.equal(fresh.vertices, sd["vertices"]) and torch.equal(fresh.lbs_weights, sd["lbs_weights"])
+    assert fresh.so3.shape == m.so3.shape and torch.equal(fresh.appearance, sd["appearance_module.appearance"])
+    opt2 = torch.optim.Adam(fresh.get_param_groups(lr))
+    opt2.load_state_dict(ckpt["optimizer"])                           # same number of groups / parameters per group as the reference's
+    assert opt2.state_dict()["param_groups"][1]["lr"] == 1e-3
 
 
 def test_dataset_directory_round_trip(tmp_path):
