@@ -1,24 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- rendered frames/sec (fwd+bwd) of the GoMAvatar hot path on MI355X.
 
-One "step" = one batch of B frames (--batch, default 8) per GPU through the
-whole hot path, forward AND backward, in ONE sequence of 17 kernel launches:
-FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused
-unpack+L1(rgb)+L1(mask) loss fwd/bwd -> splat backward -> face backward ->
-vertex gather + LBS backward -> sum of the per-frame gradients, producing the
-batch gradient for vertices / so3 / scale / appearance.  Workload (BASELINE.json
-metric): 512x512, 55 104 Gaussians (SMPL-topology body, one midpoint
-subdivision), synthetic poses/cameras/targets already resident in HBM when the
-timed region starts.  `value` counts FRAMES per second (B per step per GPU).
+One "step" = one batch of B frames (--batch, default 8) per GPU through the whole hot path, forward AND backward, in ONE
+sequence of kernel launches: FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused unpack + L1(rgb) +
+L1(mask) loss fwd/bwd -> splat backward -> face backward -> vertex gather + LBS backward -> sum of the per-frame gradients,
+producing the batch gradient for vertices / so3 / scale / appearance.  Workload (BASELINE.json metric; built by
+gomavatar_amd.workload, the same object the -m gpu parity tests check): 512x512, 55 104 Gaussians (SMPL-topology body, one
+midpoint subdivision), synthetic poses / cameras / targets already resident in HBM when the timed region starts.
+`value` counts FRAMES per second, with ONE step in flight per GPU by default (what an optimizer loop can do: step k + 1
+needs step k's update).  The other operating points are measured in the same run and reported under `modes`.
 
-N > 1 (launched by torch.distributed.run): frame-parallel data parallelism, B
-frames per GPU per step, plus ONE RCCL all-reduce of the flat fp32 gradient
-buffer (951 023 floats = the reference model's full parameter count) per step
-inside the timed region.  Weak scaling: per-GPU work is fixed.
+`python bench.py --gpus N` launches itself: with WORLD_SIZE unset and N > 1 it re-executes under torch.distributed.run
+(one rank per GPU, RCCL); with fewer devices than ranks (the 1-GPU development lease) the ranks share device 0 over gloo --
+a functional proof of the N > 1 path, labelled as such.  N > 1: frame-parallel data parallelism, B frames per GPU per
+step, plus ONE all-reduce of the flat fp32 gradient buffer (951 023 floats = the reference model's parameter count)
+per step inside the timed region.  Weak scaling: per-GPU work is fixed.
 
-Prints one JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (dominant kernel, HIP-event timed on its own stream) and, at N=1,
-`cpu_baseline` (the CPU oracle timed on this box's host cores).
+Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.  When such a
+region is shorter than 0.25 s (the driver's K = 20 is 17 ms) it is REPEATED -- each repetition again exactly K steps between
+the same brackets -- and `ms_per_step` / `value` are taken over all repetitions (`timed_regions` says how many).
+
+Prints one JSON line on rank 0 carrying `roofline` (dominant kernel, HIP-event timed on its own stream), `modes`, and at N=1
+`cpu_baseline` (the CPU oracle on this box's host cores, 1 thread and all physical cores, S and M sizes).
 """
 from __future__ import annotations
 
@@ -26,13 +29,12 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (needed by RCCL across processes)
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -40,6 +42,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
+MIN_TIMED_S = 0.25
+PROFILE_TAG = "r02"
 
 
 def parse():
@@ -51,19 +55,52 @@ def parse():
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
     ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames cycled through")
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU, rendered by one batched launch sequence")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=1,
                     help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
-                         "1 = strictly one step after the other")
+                         "1 (default) = strictly one step after the other, as an optimizer loop runs")
     ap.add_argument("--seg-shift", type=int, default=0, help="log2 of the tile-list segment size (0 = library default)")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue the 17 kernels of a frame one by one instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step one by one instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-modes", action="store_true", help="skip the other operating points (modes) and the raster-only / full-step figures")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames per CPU-baseline row at all cores (1 at one thread)")
     ap.add_argument("--task-grid-pct", type=int, default=0, help="GOM_OPT_TASK_GRID_PCT, 10..100 (0 = library default, 100)")
+    ap.add_argument("--backend", default="auto", help="auto: nccl (= RCCL) with one device per rank, gloo when ranks share a device")
     return ap.parse_args()
 
 
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def physical_cores() -> int:
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def algorithmic_bytes(P, D, HW, C):
-    """SURVEY.md section 8(d) byte model, per kernel, per frame."""
+    """SURVEY.md section 8(d) byte model, per kernel, per launch (P Gaussians, D pairs, HW pixels of the whole launch)."""
     return {
         "preprocess": P * (12 + 24 + 4 * C + 4) + P * (8 + 4 + 16 + 4 + 4),
         "scan_tiles": 0,
@@ -77,19 +114,262 @@ def algorithmic_bytes(P, D, HW, C):
     }
 
 
+class Runner:
+    """S steps in flight of B frames each on one GPU: slot k owns a stream, a RenderStep (scratch + intermediates) and a flat
+    gradient buffer (the all-reduce payload; the hot path's gradients are views into it)."""
+
+    def __init__(self, wl, B, S, graph, world, args):
+        import torch
+        from gomavatar_amd import _lib
+        from gomavatar_amd.parallel import FrameParallel, shapes_for_model
+        self.torch, self.wl, self.B, self.S, self.graph, self.world = torch, wl, B, S, graph, world
+        n_own = 3 * wl.N + 9 * wl.F
+        pad = MODEL_PARAMS_M if wl.subdiv == 1 else n_own   # padded to the reference model's full parameter count: the collective moves what a real step moves
+        self.slots = []
+        for k in range(S):
+            st = wl.step(B)
+            fp = FrameParallel(shapes_for_model(wl.N, wl.F), wl.device, pad_to=pad)
+            for name in ("vertices", "so3", "scale", "appearance"):
+                st.grads[name] = fp.grads[name]
+            if args.seg_shift:
+                st.state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
+            if args.task_grid_pct:
+                st.state.set_option(_lib.OPT_TASK_GRID_PCT, args.task_grid_pct)
+            self.slots.append(dict(step=st, fp=fp, stream=torch.cuda.Stream(device=wl.device)))   # (the legacy NULL stream cannot be graph-captured)
+        self.batches = wl.batches(self.slots[0]["step"])
+        assert self.batches, "not enough frames for one batch"
+        self.payload = int(self.slots[0]["fp"].grads.flat.numel())
+
+    def run_step(self, i):
+        torch = self.torch
+        bt = self.batches[i % len(self.batches)]
+        sl = self.slots[i % self.S]
+        with torch.cuda.stream(sl["stream"]):
+            sl["step"].cam = bt["cam"]
+            if self.B > 1:
+                sl["step"].cams_dev.copy_(bt["cams_dev"], non_blocking=True)   # this step's cameras (device array read by the kernels)
+            sl["step"].forward_backward(self.wl.params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
+            sl["fp"].all_reduce_grads()  # no-op at world size 1
+
+    def region(self, steps, warmup, first=0):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        torch = self.torch
+        for i in range(warmup):
+            self.run_step(first + i)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.run_step(first + warmup + i)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=self.wl.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def measure(self, steps, warmup):
+        """-> (total seconds, total steps, regions).  Regions shorter than MIN_TIMED_S are repeated (same brackets, no new warm-up)."""
+        el = self.region(steps, warmup)
+        total, n = el, 1
+        if el < MIN_TIMED_S:
+            reps = min(200, int(math.ceil(MIN_TIMED_S * 1.2 / max(el, 1e-6))) - 1)   # el is the MAX over ranks: every rank repeats equally often
+            for r in range(reps):
+                total += self.region(steps, 0, first=(r + 1) * steps)
+                n += 1
+        return total, steps * n, n
+
+    def check(self):
+        n_pairs, overflow = self.slots[0]["step"].state.poll()
+        assert not overflow, "pair buffer overflow during the benchmark"
+        assert all(self.torch.isfinite(g).all() for g in self.slots[0]["step"].grads.values()), "non-finite gradients"
+        return n_pairs
+
+    def kernel_profile(self, rounds):
+        """Per-kernel HIP-event durations (ms) with this runner's steps in flight: the library brackets every launch with events
+        on the launch stream (the step is then enqueued kernel by kernel instead of replayed from its graph)."""
+        from gomavatar_amd import _lib
+        torch = self.torch
+        for sl in self.slots:
+            sl["step"].state.set_option(_lib.OPT_PROFILE, 1)
+        acc, n, D = {}, 0, 0
+        for r in range(rounds):
+            if self.S == 1:
+                torch.cuda.synchronize()
+            for k in range(self.S):
+                self.run_step(r * self.S + k)
+            torch.cuda.synchronize()
+            for sl in self.slots:
+                for kname, v in sl["step"].state.kernel_times_ms().items():
+                    acc[kname] = acc.get(kname, 0.0) + v
+                D += sl["step"].state.poll()[0]
+                n += 1
+        for sl in self.slots:
+            sl["step"].state.set_option(_lib.OPT_PROFILE, 0)
+        torch.cuda.synchronize()
+        return {k: acc[k] / n for k in _lib.KERNEL_NAMES}, D / n
+
+
+def timeit(torch, fn, min_s=MIN_TIMED_S, warm=5, chunk=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            fn()
+        torch.cuda.synchronize()
+        n += chunk
+        el = time.perf_counter() - t0
+        if el >= min_s:
+            return n / el
+
+
+def extra_figures(torch, wl):
+    """(i) raster only fwd+bwd, fused 4-channel and the reference's two 3-channel calls; (iii) full step =
+    render path + LPIPS-VGG in the reference's precision (fp32 trunk through the library convolutions) + Adam.  One frame
+    at a time (the reference's semantics), launched from Python through autograd."""
+    from gomavatar_amd import rasterizer as R
+    from gomavatar_amd.geometry import MeshTopology, posed_face_gaussians
+    from gomavatar_amd.losses import compute_loss_l1
+    from gomavatar_amd.lpips import LPIPS, lpips_loss
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev, img, F, N = wl.device, wl.img, wl.F, wl.N
+    out = {}
+    d = wl.frames[0]
+    step = wl.step(1)
+    step.set_camera(d["K"], d["E"])
+    step.forward_backward(wl.params, d, d["gt_rgb"], d["gt_mask"], d["bg"])
+    torch.cuda.synchronize()
+    xyz, cov6, feat, op, cam = step.xyz.clone(), step.cov6.clone(), step.feat.clone(), step.opacity.clone(), step.cam
+    wimg = torch.randn(4, img, img, device=dev)
+
+    def raster4():
+        a = [t.detach().requires_grad_() for t in (xyz, cov6, feat)]
+        o, _ = R.rasterize(a[0], a[1], a[2], op, cam)
+        (o * wimg).sum().backward()
+    out["raster_only_fused4_b1_fps"] = round(timeit(torch, raster4), 1)
+    rs = GaussianRasterizationSettings(image_height=img, image_width=img, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(4, device=dev),
+                                       scale_modifier=1.0, viewmatrix=torch.tensor(list(cam.view), device=dev).view(4, 4),
+                                       projmatrix=torch.tensor(list(cam.proj), device=dev).view(4, 4), sh_degree=0,
+                                       campos=torch.zeros(3, device=dev), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(None)
+    rast.raster_settings = rs
+    feat6 = torch.cat([feat, feat[:, :2]], -1)
+
+    def raster2x3():   # gaussian.py:77-94
+        a = [t.detach().requires_grad_() for t in (xyz, cov6, feat6)]
+        m2d = torch.zeros_like(a[0], requires_grad=True)
+        outs = [rast(means3D=a[0], means2D=m2d, colors_precomp=a[2][:, i:i + 3], shs=None, opacities=op[:, None], scales=None, rotations=None,
+                     cov3D_precomp=a[1])[0] for i in (0, 3)]
+        (torch.cat(outs, 0)[:4] * wimg).sum().backward()
+    out["raster_only_reference_2x3_b1_fps"] = round(timeit(torch, raster2x3), 1)
+
+    topo = MeshTopology(wl.faces, N, device=dev)
+    w25 = wl.w25.to(dev)
+    lp = LPIPS(trunk_seed=0, trunk_dtype=torch.float32, device=dev)
+    P = {k: v.clone().requires_grad_() for k, v in wl.params.items()}
+    opt = torch.optim.Adam(list(P.values()), lr=1e-4)
+
+    def full():   # train.py:313-339 without the mesh / shadow branch
+        opt.zero_grad(set_to_none=True)
+        x, c6, _ = posed_face_gaussians(P["vertices"], P["so3"], P["scale"], d["dst_Rs"], d["dst_Ts"], d["cnl_gtfms"], w25, topo, 1e-3)
+        f4 = torch.cat([P["appearance"].T, torch.ones(F, 1, device=dev)], 1)
+        o, _ = R.rasterize(x, c6, f4, op, cam)
+        total, _ = compute_loss_l1(o, d["gt_rgb"], d["gt_mask"], d["bg"])
+        rgb, mask = o[:3].permute(1, 2, 0), o[3]
+        unpacked = rgb * mask[..., None] + d["bg"] * (1 - mask[..., None])
+        (total + lpips_loss(lp, unpacked[None], d["gt_rgb"][None])).backward()
+        opt.step()
+    try:
+        out["full_step_lpips_fp32_adam_b1_fps"] = round(timeit(torch, full, warm=3, chunk=5), 1)
+    except Exception as e:  # report, do not hide
+        out["full_step_lpips_fp32_adam_b1_fps"] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+def cpu_baseline(torch, args, wl_M, batched_step, batched_batch):
+    """The oracle (`kind: port`) on this box's host cores: fwd+bwd of the render path (geometry + raster + L1 losses), 1 thread
+    and all physical cores, at S (BASELINE configs[0]: 13 776 Gaussians) and M (the metric workload).  Bounded sample."""
+    from oracle import geometry as og, raster as orast
+    from gomavatar_amd.workload import MetricWorkload
+    phys, logical = physical_cores(), os.cpu_count() or 1
+    rows, keep = {}, {}
+    wl_S = MetricWorkload(wl_M.device, subdiv=0, img=wl_M.img, n_frames=max(2, args.cpu_frames + 1))
+    for tag, wl in (("S", wl_S), ("M", wl_M)):
+        for k in (1, phys):
+            torch.set_num_threads(k)
+            orast.set_threads(k)
+            n = 1 if k == 1 else args.cpu_frames
+            times = []
+            for i in range(n + (0 if k == 1 else 1)):
+                fr = wl.oracle_frame(i)
+                po = {kk: v.clone().requires_grad_() for kk, v in wl.params_cpu.items()}
+                gt = wl.frames[i]
+                gt_rgb, gt_mask = gt["gt_rgb"].cpu()[None], gt["gt_mask"].cpu()[None]
+                t1 = time.perf_counter()
+                o_rgb, o_mask, _ = og.render_path(po, fr, wl.faces, wl.w25, wl.img)
+                l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt_rgb, gt_mask)
+                (l1 + 5.0 * l2).backward()
+                times.append(time.perf_counter() - t1)
+                if tag == "M" and k == phys:
+                    keep[i] = (o_rgb[0].detach(), o_mask[0].detach())
+            if k != 1:
+                times = times[1:]   # the first multi-threaded frame warms the thread pool / page-faults
+            rows[f"{tag}_threads{k}"] = {"frames_per_s": round(len(times) / sum(times), 3), "frames": len(times), "threads": k,
+                                         "gaussians": wl.F}
+    # "PSNR vs ref": the BATCHED step's own image (what the timed loop renders) against the oracle's render of the same frames
+    mse, n = 0.0, 0
+    img = batched_step.image.reshape(batched_step.B, 4, wl_M.img, wl_M.img)
+    for pos, fi in enumerate(batched_batch["frames"]):
+        if fi in keep:
+            o_rgb, o_mask = keep[fi]
+            h = img[pos].permute(1, 2, 0).cpu()
+            dd = torch.cat([h[..., :3] - o_rgb, (h[..., 3] - o_mask)[..., None]], -1).double()
+            mse += float((dd ** 2).mean()); n += 1
+    head = rows[f"M_threads{phys}"]
+    cb = {"value": head["frames_per_s"], "unit": "frames/s", "cores": phys, "kind": "port",
+          "sample": f"{head['frames']} frames of the metric workload (fwd+bwd: geometry + raster + L1 losses) through the CPU oracle, {phys} threads "
+                    f"(torch + OpenMP) = all physical cores; host has {logical} logical CPUs.  `rows`: the same at 1 thread and at S = BASELINE configs[0]",
+          "rows": rows, "physical_cores": phys, "logical_cpus": logical}
+    return cb, (round(-10.0 * math.log10(max(mse / n, 1e-30)), 2) if n else None)
+
+
+def read_profile_json(name):
+    p = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
+    self_launch(args)
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1, "no HIP device"
+    shared = world > n_dev                      # fewer devices than ranks: functional proof of the N > 1 path on a small lease
+    dev_idx = local_rank % n_dev
+    torch.cuda.set_device(dev_idx)
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    dev = torch.device("cuda", torch.cuda.current_device())
+        backend = args.backend if args.backend != "auto" else ("gloo" if shared else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_idx))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_idx)
 
     from __graft_entry__ import build
     from gomavatar_amd import build as hip_build
@@ -97,223 +377,114 @@ def main():
         build()
     if world > 1:
         dist.barrier()
-    from gomavatar_amd import _lib, synthetic as syn
-    from gomavatar_amd.pipeline import RenderStep
+    from gomavatar_amd import _lib
+    from gomavatar_amd.workload import MetricWorkload
 
-    # ---------------- workload (synthetic, seeded; resident in HBM) ----------------
-    img = args.img
-    body = syn.make_body(args.subdiv)
-    N, F = body["canonical_vertex"].shape[0], body["faces"].shape[0]
-    w = torch.from_numpy(body["canonical_lbs_weights"]).T
-    w25 = torch.cat([w, torch.zeros(1, N)], 0).contiguous()
-    faces = torch.from_numpy(body["faces"])
-    B = max(1, args.batch)
-    gen = RenderStep(faces, N, (img, img), w25, device=dev)   # single-frame instance: renders the targets
-    step = RenderStep(faces, N, (img, img), w25, device=dev, batch=B)
+    img, B, S = args.img, max(1, args.batch), max(1, args.inflight)
+    wl = MetricWorkload(dev, subdiv=args.subdiv, img=img, n_frames=max(args.frames, B), rank=rank)
+    F, N = wl.F, wl.N
+    main_run = Runner(wl, B, S, not args.no_graph, world, args)
 
-    def dev_params(seed):
-        gp = syn.make_gaussian_params(F, seed)
-        return dict(vertices=torch.from_numpy(body["canonical_vertex"]).T.contiguous().to(dev), so3=torch.from_numpy(gp["so3"]).to(dev),
-                    scale=torch.from_numpy(gp["scale"]).to(dev), appearance=torch.from_numpy(gp["appearance"]).to(dev))
+    # ---------------- the timed region(s) ----------------
+    elapsed, n_steps, regions = main_run.measure(args.steps, args.warmup)
+    main_run.check()
+    value = world * B * n_steps / elapsed
 
-    # flat fp32 gradient buffer = the all-reduce payload; the hot path's gradients are views into it.
-    # Padded to the reference model's full parameter count so the collective moves what a real step moves.
-    from gomavatar_amd.parallel import FrameParallel, shapes_for_model
-    n_own = 3 * N + 9 * F
-    fp = FrameParallel(shapes_for_model(N, F), dev, pad_to=MODEL_PARAMS_M if args.subdiv == 1 else n_own)
-    flat = fp.grads.flat
-    for k in ("vertices", "so3", "scale", "appearance"):
-        step.grads[k] = fp.grads[k]
-    params = dev_params(1)
-    target_params = dev_params(2)
-    frames = []
-    for i in range(max(args.frames, B)):
-        fr = syn.make_frame(rank * 1000 + i, img)  # each rank renders different frames
-        d = {k: torch.from_numpy(fr[k][0]).contiguous().to(dev) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
-        d["K"], d["E"], d["bg"] = fr["K"][0], fr["E"][0], torch.from_numpy(fr["bgcolor"][0]).to(dev)
-        # target = render of a different parameter set (so gradients are non-zero), produced by the HIP path itself
-        gen.set_camera(d["K"], d["E"])
-        dummy_rgb = torch.zeros((img, img, 3), device=dev)
-        dummy_m = torch.zeros((img, img), device=dev)
-        gen.forward_backward(target_params, d, dummy_rgb, dummy_m, d["bg"], backward=False)
-        rgb, mask = gen.rgb_mask()
-        d["gt_rgb"] = (rgb[0] * mask[0, ..., None] + d["bg"] * (1 - mask[0, ..., None])).contiguous().clone()
-        d["gt_mask"] = mask[0].contiguous().clone()
-        frames.append(d)
-    torch.cuda.synchronize()
-    del gen
-    # batches of B consecutive frames: stacked per-frame inputs + one device camera array each
-    batches = []
-    for j in range(len(frames) // B):
-        grp = frames[j * B:(j + 1) * B]
-        bt = {k: torch.stack([g[k] for g in grp]).contiguous() for k in ("cnl_gtfms", "dst_Rs", "dst_Ts", "gt_rgb", "gt_mask", "bg")}
-        if B == 1:
-            bt = {k: v[0] for k, v in bt.items()}
-        step.set_cameras([g["K"] for g in grp], [g["E"] for g in grp]) if B > 1 else step.set_camera(grp[0]["K"], grp[0]["E"])
-        torch.cuda.synchronize()
-        bt["cams_dev"], bt["cam"] = step.cams_dev.clone(), step.cam
-        batches.append(bt)
-
-    # steps in flight: slot k owns a stream, a RenderStep (scratch + intermediates) and a gradient buffer
-    S = max(1, args.inflight)
-    slots = [dict(step=step, fp=fp, stream=torch.cuda.Stream(device=dev))]  # (the legacy NULL stream cannot be graph-captured)
-    for k in range(1, S):
-        st_k = RenderStep(faces, N, (img, img), w25, device=dev, batch=B)
-        fp_k = FrameParallel(shapes_for_model(N, F), dev, pad_to=flat.numel())
-        for name in ("vertices", "so3", "scale", "appearance"):
-            st_k.grads[name] = fp_k.grads[name]
-        slots.append(dict(step=st_k, fp=fp_k, stream=torch.cuda.Stream(device=dev)))
-
-    if args.seg_shift:
-        for sl in slots:
-            sl["step"].state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
-    # GOM_OPT_TASK_GRID_PCT: with several steps in flight, giving every step's persistent task-queue grids HALF of the workgroup
-    # slots lets kernels of different steps run side by side (+4 % frames/s: 13.1-13.2 k) at the price of every kernel running longer
-    # (k_seg_bwd 360 us instead of 230) -- the default keeps full grids so that the per-kernel durations behind `roofline` stay those
-    # of the kernels themselves.
-    if args.task_grid_pct:
-        for sl in slots:
-            sl["step"].state.set_option(_lib.OPT_TASK_GRID_PCT, args.task_grid_pct)
-
-    def run_step(i):
-        bt = batches[i % len(batches)]
-        sl = slots[i % S]
-        with torch.cuda.stream(sl["stream"]):
-            sl["step"].cam = bt["cam"]
-            if B > 1:
-                sl["step"].cams_dev.copy_(bt["cams_dev"], non_blocking=True)   # this step's cameras (device array read by the kernels)
-            sl["step"].forward_backward(params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=not args.no_graph)
-            sl["fp"].all_reduce_grads()  # no-op at world size 1
-
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        run_step(i)
-    torch.cuda.synchronize()
+    # ---------------- the collective alone (N > 1) ----------------
+    allreduce_us = None
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_pairs, overflow = step.state.poll()
-    assert not overflow, "pair buffer overflow during the benchmark"
-    assert all(torch.isfinite(g).all() for g in step.grads.values()), "non-finite gradients"
+        fp = main_run.slots[0]["fp"]
+        for _ in range(5):
+            fp.all_reduce_grads()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            fp.all_reduce_grads()
+        torch.cuda.synchronize()
+        allreduce_us = round((time.perf_counter() - t0) / 50 * 1e6, 1)
 
-    # ---------------- per-kernel times: HIP events recorded by the library on each launch stream ----------------
-    # Same loop, same frames in flight as the timed region (profiling brackets every launch with events, so the
-    # frame is enqueued kernel by kernel instead of replayed from its graph).  The rocprofv3 --kernel-trace --stats
-    # summary of this very command (profiles/) must agree with these averages.
-    for sl in slots:
-        sl["step"].state.set_option(_lib.OPT_PROFILE, 1)
-    acc, n_prof = {}, 0
-    rounds = max(4, 48 // S)
-    for r in range(rounds):
-        for k in range(S):
-            run_step(r * S + k)
-        for sl in slots:
-            for kname, v in sl["step"].state.kernel_times_ms().items():
-                acc[kname] = acc.get(kname, 0.0) + v
-            nd, _ = sl["step"].state.poll()
-            acc["D"] = acc.get("D", 0) + nd
-            n_prof += 1
-    # the same kernels with ONE step in flight (nothing else on the GPU): what a launch costs when it owns the chip
-    iso, n_iso = {}, 8
-    for r in range(n_iso):
-        torch.cuda.synchronize()
-        run_step(r * S)          # slot 0
-        torch.cuda.synchronize()
-        for kname, v in slots[0]["step"].state.kernel_times_ms().items():
-            iso[kname] = iso.get(kname, 0.0) + v / n_iso
-    for sl in slots:
-        sl["step"].state.set_option(_lib.OPT_PROFILE, 0)
-    torch.cuda.synchronize()
-    kt = {k: acc[k] / n_prof for k in _lib.KERNEL_NAMES}
-    D_avg = acc["D"] / n_prof
+    # ---------------- per-kernel times, one step in flight (the kernels own the chip) ----------------
+    alone_run = main_run if S == 1 else Runner(wl, B, 1, not args.no_graph, world, args)
+    iso, D_avg = alone_run.kernel_profile(12)
     abytes = algorithmic_bytes(F * B, D_avg, img * img * B, 4)   # per launch: B frames (D_avg already counts all B)
-    # Dominant kernel = the one that costs most when it owns the chip.  (With several steps in flight a kernel's duration also
-    # counts the time it spends sharing CUs with the other steps' kernels -- a property of the mix, not of the kernel; the
-    # few long tile lists of k_sort, two launches under one event pair, stretch most that way.)  Both durations are reported.
-    dom = max(iso, key=iso.get)
-    achieved = abytes[dom] / (kt[dom] * 1e-3) / 1e9
-    # HBM traffic of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, FETCH doubled per
-    # MI355X_MICROARCH.md), recorded by scripts/collect_profiles.sh into profiles/<round>_traffic.json
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tj) and args.subdiv == 1 and img == 512:
-        try:
-            tjd = json.load(open(tj))
-            traffic = (int(tjd.get("k_" + dom, {}).get("hbm_bytes")) or None) if tjd.get("batch", 1) == B else None
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_us": round(kt[dom] * 1e3, 2),
-                "algorithmic_bytes": int(abytes[dom]),
-                "all_kernels_us": {k: round(v * 1e3, 2) for k, v in kt.items()}, "pairs_D": int(D_avg),
-                # same launch with the GPU to itself (one step in flight): duration and the fraction it would reach
-                "alone": {"avg_us": round(iso[dom] * 1e3, 2), "frac": round(abytes[dom] / (iso[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                          "all_kernels_us": {k: round(iso[k] * 1e3, 2) for k in _lib.KERNEL_NAMES}}}
+    dom = max(iso, key=iso.get)                                   # dominant kernel = the one that costs most when it owns the chip
+    traffic_j = read_profile_json("traffic") if (args.subdiv == 1 and img == 512) else None
+    valu_j = read_profile_json("valu") if (args.subdiv == 1 and img == 512) else None
+
+    def kernel_row(name, us):
+        gbs = abytes[name] / (us * 1e-6) / 1e9 if us > 0 and abytes[name] else 0.0
+        tr = None
+        if traffic_j and traffic_j.get("batch") == B and ("k_" + name) in traffic_j:
+            tr = int(traffic_j["k_" + name].get("hbm_bytes") or 0) or None
+        return {"kernel": "k_" + name, "avg_us": round(us, 2), "algorithmic_bytes": int(abytes[name]), "achieved": round(gbs, 2),
+                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": tr}
+    dr = kernel_row(dom, iso[dom] * 1e3)
+    roofline = {"kernel": dr["kernel"], "bound": "hbm", "achieved": dr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dr["frac"],
+                "traffic": dr["traffic"], "avg_us": dr["avg_us"], "algorithmic_bytes": dr["algorithmic_bytes"], "pairs_D": int(D_avg),
+                "steps_in_flight": 1, "all_kernels_us": {k: round(v * 1e3, 2) for k, v in iso.items()},
+                "raster_backward": kernel_row("seg_bwd", iso["seg_bwd"] * 1e3) | {"with_preprocess_bwd_frac": round(
+                    (abytes["seg_bwd"] + abytes["preprocess_bwd"]) / ((iso["seg_bwd"] + iso["preprocess_bwd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                # These kernels are VALU-issue bound, not bandwidth bound: the second axis, from the SQ counters
+                # of the PMC pass (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES and useful lanes), when profiles/ holds it
+                "valu": (valu_j or {}).get("k_" + dom)}
 
     out = {
         "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians; PSNR vs ref",
-        "value": round(world * B * args.steps / elapsed, 2),
+        "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "ms_per_step": round(1e3 * elapsed / n_steps, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "timed_regions": regions,
         "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, {B} frames per GPU per step "
-                               "(one batched launch sequence)" + (", + RCCL all-reduce of the flat grad buffer" if world > 1 else ""),
+                               f"(one batched launch sequence), {S} step(s) in flight per GPU"
+                               + (", + all-reduce of the flat grad buffer" if world > 1 else ""),
                    "gaussians": F, "image": [img, img], "frames_per_step": world * B, "frames_per_gpu_per_step": B,
                    "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S,
-                   "allreduce_floats": int(flat.numel()) if world > 1 else 0},
+                   "allreduce_floats": main_run.payload if world > 1 else 0, "allreduce_us": allreduce_us,
+                   "backend": (("rccl" if backend == "nccl" else backend) + (f" ({world} ranks share {n_dev} device(s): functional proof, not a scaling number)" if shared else ""))
+                   if world > 1 else None},
         "roofline": roofline,
     }
 
+    # ---------------- the other operating points (N = 1) ----------------
+    if world == 1 and not args.no_modes:
+        modes = {f"b{B}_inflight{S}": round(value, 1)}
+        for (b_, s_) in ((1, 1), (8, 1), (8, 3)):
+            key = f"b{b_}_inflight{s_}"
+            if key in modes:
+                continue
+            r_ = Runner(wl, b_, s_, not args.no_graph, 1, args)
+            el, ns, _ = r_.measure(100 if b_ > 1 else 400, 20)
+            r_.check()
+            modes[key] = round(b_ * ns / el, 1)
+            if (b_, s_) == (8, 3):   # the kernel that dominates when three steps share the chip (k_sort's long lists stretch most)
+                mix, _ = r_.kernel_profile(max(4, 24 // s_))
+                dm = max(mix, key=mix.get)
+                roofline["dominant_in_mix"] = kernel_row(dm, mix[dm] * 1e3) | {"steps_in_flight": 3, "all_kernels_us": {k: round(v * 1e3, 2) for k, v in mix.items()}}
+            del r_
+        out["modes"] = {"unit": "frames/s", "what": "render path fwd+bwd (b = frames per launch sequence, inflight = independent steps on separate streams)", **modes}
+        out["modes"].update(extra_figures(torch, wl))
+
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only) ----------------
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import geometry as og, raster as orast
-        cores = os.cpu_count() or 1
-        threads = max(1, min(cores, 64))
-        torch.set_num_threads(threads)
-        orast.set_threads(threads)
-        pc = {k: v.detach().cpu() for k, v in params.items()}
-        times = []
-        check = RenderStep(faces, N, (img, img), w25, device=dev)   # single-frame HIP render of the same frames: PSNR vs the oracle
-        mse_sum, mse_n = 0.0, 0
-        for i in range(args.cpu_frames + 1):
-            fr = {k: torch.from_numpy(v) for k, v in syn.make_frame(i, img).items()}
-            po = {k: v.clone().requires_grad_() for k, v in pc.items()}
-            t1 = time.perf_counter()
-            o_rgb, o_mask, _ = og.render_path(po, fr, faces, w25, img)
-            gt = frames[i % len(frames)]
-            l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt["gt_rgb"].cpu()[None], gt["gt_mask"].cpu()[None])
-            (l1 + 5.0 * l2).backward()
-            times.append(time.perf_counter() - t1)
-            fd = frames[i % len(frames)]
-            if i < len(frames):   # frames[i] was generated from make_frame(i) on rank 0: identical inputs on both sides
-                check.set_camera(fd["K"], fd["E"])
-                check.forward_backward(params, fd, fd["gt_rgb"], fd["gt_mask"], fd["bg"], backward=False)
-                h_rgb, h_mask = check.rgb_mask()
-                d = torch.cat([h_rgb[0].cpu() - o_rgb[0].detach(), (h_mask[0].cpu() - o_mask[0].detach())[..., None]], -1).double()
-                mse_sum += float((d ** 2).mean()); mse_n += 1
-        times = times[1:]  # first frame warms caches / page-faults
-        if mse_n:
-            out["psnr_vs_oracle_db"] = round(-10.0 * math.log10(max(mse_sum / mse_n, 1e-30)), 2)   # "PSNR vs ref" of BASELINE.json's metric
-        out["cpu_baseline"] = {"value": round(len(times) / sum(times), 3), "unit": "frames/s", "cores": threads, "kind": "port",
-                               "sample": f"{len(times)} frames of the same workload (fwd+bwd) through the CPU oracle, "
-                                         f"{threads} threads (torch + OpenMP), host has {cores} logical cores"}
+        st0 = main_run.slots[0]["step"]
+        bt0 = main_run.batches[0]
+        with torch.cuda.stream(main_run.slots[0]["stream"]):
+            st0.cam = bt0["cam"]
+            if B > 1:
+                st0.cams_dev.copy_(bt0["cams_dev"])
+            st0.forward_backward(wl.params, bt0, bt0["gt_rgb"], bt0["gt_mask"], bt0["bg"], graph=not args.no_graph)
+        torch.cuda.synchronize()
+        out["cpu_baseline"], psnr = cpu_baseline(torch, args, wl, st0, bt0)
+        if psnr is not None:
+            out["psnr_vs_oracle_db"] = psnr   # "PSNR vs ref" of BASELINE.json's metric, on the batched step's own image
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

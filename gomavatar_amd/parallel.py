@@ -55,6 +55,7 @@ class FrameParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.average = average
+        self._native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.params = FlatBuffer(shapes, device)
         self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
 
@@ -67,10 +68,15 @@ class FrameParallel:
             dist.broadcast(self.params.flat, src=src, group=self.group)
 
     def all_reduce_grads(self) -> None:
+        """ONE collective on the flat buffer (enqueued on the current stream).  RCCL averages inside the collective
+        (ReduceOp.AVG: no separate scaling launch); gloo (CPU tests, ranks sharing a device) sums and scales."""
         if self.world > 1:
-            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                self.grads.flat.mul_(1.0 / self.world)
+            if self.average and self._native_avg:
+                dist.all_reduce(self.grads.flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    self.grads.flat.mul_(1.0 / self.world)
 
     def make_adam(self, lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8) -> torch.optim.Adam:
         """Adam with one param group per tensor (the reference uses per-group

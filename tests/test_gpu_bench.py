@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU box: the contract of the JSON line, and `--gpus 2` launching itself (WORLD_SIZE unset ->
+re-exec under torch.distributed.run; on a 1-GPU box the two ranks share device 0 over gloo: a functional proof that process-group
+init, the collective inside `torch.cuda.stream(...)` and the MAX-reduced timing work before an 8-GPU node runs them over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_single_gpu():
+    d = _run("--steps", "20", "--warmup", "5", "--no-modes", "--cpu-frames", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "frames/s" and d["vs_baseline"] is None
+    assert d["config"]["gaussians"] == 55104 and d["config"]["image"] == [512, 512] and d["config"]["steps_in_flight_per_gpu"] == 1
+    # 20 steps are a few milliseconds: the region is repeated until 0.25 s are covered, every repetition exactly 20 steps
+    assert d["timed_regions"] > 1 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and set(c["rows"]) >= {"S_threads1", "M_threads1"}
+    assert d["psnr_vs_oracle_db"] > 80.0
+
+
+def test_bench_launches_itself_for_two_ranks():
+    d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 16 and d["config"]["allreduce_floats"] == 951023
+    assert d["config"]["allreduce_us"] > 0 and d["config"]["parallelism"] == "frame-dp2" and d["value"] > 0
+    assert "cpu_baseline" not in d     # rank 0 at N = 1 only
