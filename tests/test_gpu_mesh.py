@@ -113,7 +113,7 @@ def test_degenerate_and_offscreen_faces_are_harmless():
     and gradients stay finite."""
     from gomavatar_amd.mesh_renderer import _MeshRaster, vertex_normals
     from gomavatar_amd.geometry import MeshTopology
-    from gomavatar_amd.rasterizer import RasterState
+    from gomavatar_amd.rasterizer import RasterState, _StateLease
     H = W = 48
     verts = torch.tensor([[0.3, 0.3, 5.0], [-0.3, 0.3, 5.0], [0.0, -0.3, 5.0],      # a visible triangle
                           [0.1, 0.1, 4.0], [0.1, 0.1, 4.0], [0.1, 0.1, 4.0],        # three coincident points: zero area
@@ -124,7 +124,7 @@ def test_degenerate_and_offscreen_faces_are_harmless():
     v = verts.cuda().requires_grad_()
     topo = MeshTopology(faces.cuda(), 12)
     vn = vertex_normals(v, topo)
-    normal, alpha = _MeshRaster.apply(v, vn, topo, RasterState(), H, W, 9.21e-5, 1e-4, True)
+    normal, alpha = _MeshRaster.apply(v, vn, topo, _StateLease(RasterState()), H, W, 9.21e-5, 1e-4, True)      # a pinned (un-pooled) state
     (normal.sum() + alpha.sum()).backward()
     assert torch.isfinite(normal).all() and torch.isfinite(alpha).all() and torch.isfinite(v.grad).all()
     n_o, a_o, p2f = om.render(verts.double(), faces, om.vertex_normals(verts.double(), faces), H, W, sigma_cfg=1e-5)

@@ -82,10 +82,11 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
     e = _export_batch(step, B, P, img, img)
 
     # ---- (a) a batch is bitwise the frames one by one (same segment size), gradients their frame-ordered sum
+    frame_grads = None
     if B > 1:
         single = wl.step(1)
         single.state.set_option(_lib.OPT_SEG_SHIFT, 8)
-        acc = None
+        acc, frame_grads = None, []
         for b in range(B):
             d = wl.frames[b]
             single.set_camera(d["K"], d["E"])
@@ -93,6 +94,7 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
             torch.cuda.synchronize()
             assert torch.equal(single.image, image[b]), b
             assert torch.equal(single.radii, step.radii[b]) and torch.equal(single.loss_partials, step.loss_partials[b])
+            frame_grads.append({k: v.clone() for k, v in single.grads.items()})
             acc = {k: v.clone() for k, v in single.grads.items()} if acc is None else {k: acc[k] + single.grads[k] for k in acc}
         for k in acc:
             assert torch.equal(grads[k], acc[k]), k
@@ -131,8 +133,16 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
         print(f"\n[metric workload, B={B}] pairs D={e['D']}  threshold-flip pixels (|d|>1e-4): {flips_total} of {B * img * img}"
               f"  n_contrib mismatches: {ncontrib_mismatch}  max |d|={worst:.2e}")
 
-    # ---- (c) losses and gradients of the whole step against the fp64 oracle (sum over the frames, like the batch)
+    # ---- (c) losses and gradients of the whole step against the fp64 oracle: every frame on its own (the batch is bitwise their
+    # ordered sum, (a)) and the sum over the frames
+    def grad_stats(got, ref):
+        scale = float(ref.abs().max())
+        err = (got - ref).abs().flatten()
+        sub = err[torch.randperm(err.numel(), generator=torch.Generator().manual_seed(0))[:1_000_000]] if err.numel() > 1_000_000 else err
+        return float(err.median()) / scale, float(torch.quantile(sub, 0.99)) / scale, float(torch.quantile(sub, 0.999)) / scale, float(err.max()) / scale
+
     ref = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in wl.params_cpu.items()}
+    worst = {k: (0.0, 0.0, 0.0, 0.0) for k in ref}
     for b in range(B):
         po = {k: v.double().requires_grad_() for k, v in wl.params_cpu.items()}
         fr = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in wl.oracle_frame(b).items()}
@@ -140,14 +150,19 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
         d = wl.frames[b]
         l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, d["gt_rgb"].cpu().double()[None], d["gt_mask"].cpu().double()[None])
         (l1 + 5.0 * l2).backward()
-        assert abs(float(l1) - float(lr[b])) <= 1e-5 and abs(float(l2) - float(lm[b])) <= 1e-5, (b, float(l1), float(lr[b]), float(l2), float(lm[b]))
+        assert abs(float(l1.detach()) - float(lr[b])) <= 1e-5 and abs(float(l2.detach()) - float(lm[b])) <= 1e-5, (b, float(l1.detach()), float(lr[b]), float(l2.detach()), float(lm[b]))
         for k in ref:
             ref[k] += po[k].grad
+            if frame_grads is not None:
+                st = grad_stats(frame_grads[b][k].cpu().double(), po[k].grad)
+                worst[k] = tuple(max(a, c) for a, c in zip(worst[k], st))
+    with capsys.disabled():
+        for k in ref:
+            st = grad_stats(grads[k].cpu().double(), ref[k])
+            print(f"[metric workload, B={B}] d{k}: |err|/max|g|  median {st[0]:.1e}  q99 {st[1]:.1e}  q99.9 {st[2]:.1e}  max {st[3]:.1e}"
+                  + (f"   worst single frame: median {worst[k][0]:.1e} q99 {worst[k][1]:.1e} q99.9 {worst[k][2]:.1e} max {worst[k][3]:.1e}" if frame_grads is not None else ""))
     for k in ref:
-        got = grads[k].cpu().double()
-        scale = float(ref[k].abs().max())
-        err = (got - ref[k]).abs().flatten()
-        # L1's sign() and the raster's thresholds make isolated elements jump (a flipped pixel moves its Gaussians' gradients); the
-        # bulk agrees to fp32 round-off
-        q = float(torch.quantile(err[torch.randperm(err.numel())[:1_000_000]] if err.numel() > 1_000_000 else err, 0.999))
-        assert float(err.median()) <= 1e-5 * scale and q <= 2e-3 * scale and float(err.max()) <= 0.1 * scale, (k, float(err.median()), q, float(err.max()), scale)
+        # L1's sign() and the raster's thresholds make isolated elements jump (a flipped pixel moves the gradients of its Gaussians and,
+        # through the faces, of their vertices); the bulk agrees to fp32 round-off
+        for st in (grad_stats(grads[k].cpu().double(), ref[k]),) + ((worst[k],) if frame_grads is not None else ()):
+            assert st[0] <= 1e-5 and st[1] <= 2e-3 and st[2] <= 5e-2 and st[3] <= 0.25, (k, st)      # (measured: 2e-8 / 4e-5 / 2e-2 / 8e-2 on the worst frame, 4 flipped pixels in 8 frames)
