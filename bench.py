@@ -111,6 +111,10 @@ def algorithmic_bytes(P, D, HW, C):
         "combine": HW * (4 * C + 4 + 4),                      # B_ren_fwd, per-pixel part
         "seg_bwd": HW * (4 * C + 4 + 4) + D * (4 + 8 + 16 + 4 * C) + P * (8 + 12 + 4 + 4 * C),   # B_ren_bwd
         "preprocess_bwd": P * (12 + 24 + 4 + 12 + 8) + P * (12 + 24),
+        # depth ranking (not in the reference's pipeline, whose global radix sort it replaces): depth + visibility read twice,
+        # 8-byte keys written + read, 48-byte records gathered and written in rank order
+        "depth_hist": P * 8,
+        "depth_rank": P * (8 + 8 + 8) + P * (36 + 52),
     }
 
 

@@ -20,6 +20,7 @@ SOURCES = [
     ("gom_api.hip", []),
     ("raster_pre.hip", ["-ffp-contract=off"]),
     ("raster_render.hip", []),
+    ("raster_rank.hip", []),
     ("geom.hip", []),
     ("loss.hip", []),
     ("lpips.hip", []),

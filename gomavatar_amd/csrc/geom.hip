@@ -438,8 +438,6 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
             d_obs[2 * (size_t)N + n] = g[2];
         }
     }
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (ok) { x = xyz[n]; y = xyz[(size_t)N + n]; z = xyz[2 * (size_t)N + n]; }
     float ox = 0.f, oy = 0.f, oz = 0.f;
     for (int j = 0; j < J; j++) {
         const float wj = ok ? w[(size_t)j * N + n] : 0.f;

@@ -48,8 +48,9 @@ extern "C" GomState *gom_state_create(void) {
 extern "C" void gom_state_destroy(GomState *s) {
     if (!s) return;
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
-                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
-                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face};
+                    s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
+                    s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->srt_rec, s->rank_of, s->keys32, s->tile_qlim, s->work_small, s->work_big};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -80,6 +81,10 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value < 10 || value > 100) { gom_set_error("task grid share must be in [10, 100] percent"); return -1; }
             s->taskGridPct = (int)value;
             return 0;
+        case GOM_OPT_SORT_MODE:
+            if (value < 0 || value > 2) { gom_set_error("sort mode must be 0 (auto), 1 (per-tile merge sort) or 2 (depth ranking)"); return -1; }
+            s->sortMode = (int)value;
+            return 0;
         case GOM_OPT_PROFILE:
             if (value && !s->ev[0]) {
                 for (int i = 0; i < 2 * GOM_NUM_KERNELS; i++) GOM_HIP_CHECK(hipEventCreate(&s->ev[i]));
@@ -109,13 +114,32 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     if (P > s->capP) {
         const int cap = P + P / 8 + 256;
         if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
-            grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap))
+            grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap) || grow(&s->bkeys, cap) || grow(&s->bkeys_scratch, cap) ||
+            grow(&s->srt_rec, (size_t)cap * 3) || grow(&s->rank_of, cap))
             return -2;
         s->capP = cap;
     }
+    // depth ranking: NB = 2^nbShift buckets per frame, ~200 Gaussians each (one 256-thread sort workgroup per bucket)
+    {
+        int sh = 6;
+        while (sh < 11 && (P_frame >> sh) > 256) sh++;
+        s->nbShift = sh;
+        const int64_t nbuck = (int64_t)B << sh;
+        if (nbuck > s->capBuckets) {
+            if (grow(&s->bucket_count, (size_t)nbuck) || grow(&s->bucket_base, (size_t)nbuck + 1) || grow(&s->bucket_cursor, (size_t)nbuck)) return -2;
+            GOM_HIP_CHECK(hipMemset(s->bucket_count, 0, (size_t)nbuck * sizeof(uint32_t)));
+            s->capBuckets = nbuck;
+        }
+        const int64_t nmm = (int64_t)B * ((P_frame + 255) / 256);      // one (min, max) pair per preprocess block
+        if (nmm > s->capFrames) {
+            if (grow(&s->depth_minmax, (size_t)nmm * 2)) return -2;
+            s->capFrames = (int)nmm;
+        }
+    }
     if (tiles > s->capTiles) {
         if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||
-            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1))
+            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1) || grow(&s->tile_qlim, tiles) || grow(&s->work_small, tiles) ||
+            grow(&s->work_big, tiles))
             return -2;
         GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
         s->capTiles = tiles;
@@ -131,7 +155,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     if (s->wantPairs <= 0 && want < (4 << 20)) want = 4 << 20;
     if (want > 0xffffffffLL) want = 0xffffffffLL;
     if (want != s->capPairs && (want > s->capPairs || s->wantPairs > 0)) {
-        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) || grow(&s->pair_pos, (size_t)want) ||
+        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) || grow(&s->pair_pos, (size_t)want) || grow(&s->ent_slot, (size_t)want) || grow(&s->keys32, (size_t)want) ||
             grow(&s->ent_geo, (size_t)want * 3) || grow(&s->ent_col, (size_t)want * 4) ||
             grow(&s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
             return -2;
@@ -181,9 +205,19 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
     } else {
         if (int rc = ensure_capacity(s, P, cam->H, cam->W, B)) return rc;
         s->P = P; s->H = cam->H; s->W = cam->W; s->cams = cams;
+        // Tile-list order: rank the frame's Gaussians by depth once + a linear bitmap pass per tile (raster_rank.hip), unless
+        // the frame's bitmap would not fit in LDS (P > 2^19) or the caller asked for the per-tile merge sort.
+        s->rankSort = s->sortMode == 2 || (s->sortMode == 0 && P <= (1 << 18));
+        if (s->rankSort && P > 393216) { gom_set_error("GOM_OPT_SORT_MODE 2 needs P <= 393216 per frame (the frame's rank bitmap lives in 64 KiB of LDS)"); return -1; }
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
-        if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
-        if (int rc = gom_launch_sort(s, st)) return rc;
+        if (s->rankSort) {
+            if (int rc = gom_launch_depth_hist(s, P, st)) return rc;
+            if (int rc = gom_launch_scan_emit(s, P, st, true)) return rc;
+            if (int rc = gom_launch_tile_rank(s, st)) return rc;
+        } else {
+            if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
+            if (int rc = gom_launch_sort(s, st)) return rc;
+        }
     }
     s->C = C;
     if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, reuse, st)) return rc;
@@ -288,7 +322,9 @@ extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_byte
         case GOM_BUF_TILES_TOUCHED: src = s->tiles_touched; bytes = P * 4; break;
         case GOM_BUF_RECT: src = s->rect; bytes = P * 8; break;
         case GOM_BUF_TILE_BASE: src = s->tile_base; bytes = (tiles + 1) * 4; break;
-        case GOM_BUF_KEYS: src = s->keys; bytes = dst_bytes < s->capPairs * 8 ? dst_bytes : s->capPairs * 8; break;
+        case GOM_BUF_KEYS:
+            if (s->rankSort) { if (int rc = gom_launch_rebuild_keys(s, (hipStream_t)stream)) return rc; }   // (the ranking path never materialises them)
+            src = s->keys; bytes = dst_bytes < s->capPairs * 8 ? dst_bytes : s->capPairs * 8; break;
         case GOM_BUF_POINT_LIST: src = s->point_list; bytes = dst_bytes < s->capPairs * 4 ? dst_bytes : s->capPairs * 4; break;
         case GOM_BUF_FINAL_T: src = s->final_T; bytes = pix * 4; break;
         case GOM_BUF_N_CONTRIB: src = s->n_contrib; bytes = pix * 4; break;

@@ -32,7 +32,8 @@ struct GomDevStatus {
     // The splat preprocess allocates from 8 cursors, one per eighth of pair_pos, 128 bytes apart: a single device-scope word takes
     // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
     uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
-    uint32_t pad_[27];
+    uint32_t n_work_small, n_work_big;   // lengths of the work lists of k_tile_rank
+    uint32_t pad_[25];
     uint32_t shard_cursor[8][32];   // [shard][0] used
 };
 
@@ -81,6 +82,8 @@ struct GomState {
     uint32_t *tile_base = nullptr;    // [tiles+1]
     uint32_t *tile_cursor = nullptr;
     uint32_t *tile_nmax = nullptr;    // max n_contrib over the tile's pixels (entries beyond it are dead for backward)
+    uint32_t *tile_qlim = nullptr;    // 1 + packed depth rank of the tile's last contributing entry (0: none): liveness test of the per-Gaussian backward
+    uint32_t *work_small = nullptr, *work_big = nullptr;   // [tiles] non-empty tiles with short / long lists (scan kernel -> k_tile_rank)
     uint32_t *seg_base = nullptr;     // [tiles+1] exclusive scan of ceil(count/GOM_SEG)
     // per gaussian: start of its private range in pair_pos
     uint32_t *pair_off = nullptr;
@@ -88,7 +91,9 @@ struct GomState {
     uint64_t *keys = nullptr;
     uint32_t *point_list = nullptr;
     uint32_t *pair_pos = nullptr;     // [capPairs] sorted position of (gaussian, k-th tile of its rect)
-    float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE]
+    float *partial = nullptr;         // [capPairs][GOM_PARTIAL_STRIDE] gradient records.  Splat path: GAUSSIAN-major (record of the k-th tile of
+                                      // Gaussian g at pair_off[g] + k: the per-Gaussian backward streams them); mesh path: list order
+    uint32_t *ent_slot = nullptr;     // [capPairs] list order: record slot of the entry (= pair_off[g] + k)
     // per segment (x 256 pixels of the tile, quadrant-major)
     int64_t capSegs = 0;
     uint4 *seg_qmax = nullptr;        // [capSegs] max n_contrib over each 8x8 quadrant of the segment's tile (combine pass, for the backward)
@@ -105,6 +110,18 @@ struct GomState {
     float *sub_C = nullptr;           // [capSegs][4][4][256]  colour the sub-range really added to the pixel
     float *sub_Tend = nullptr;        // [capSegs][4][256]     transmittance behind the sub-range
     // per pixel
+    // depth ranking of the splat path (raster_rank.hip)
+    bool rankSort = false;            // this binning used it (decided per forward: GOM_OPT_SORT_MODE, P small enough for the LDS bitmap)
+    int sortMode = 0;                 // GOM_OPT_SORT_MODE: 0 auto, 1 per-tile merge sort, 2 depth ranking
+    int nbShift = 8;                  // log2 of the depth buckets per frame
+    int capFrames = 0;
+    int64_t capBuckets = 0;
+    uint32_t *depth_minmax = nullptr; // [capFrames = frames x preprocess blocks][2] bit patterns of the min / max visible depth of a block
+    uint32_t *bucket_count = nullptr, *bucket_base = nullptr, *bucket_cursor = nullptr;   // [capBuckets (+1)]
+    uint64_t *bkeys = nullptr, *bkeys_scratch = nullptr;   // [capP] (depth_bits << 32 | index in frame), bucket-major
+    float4 *srt_rec = nullptr;        // [capP][3] 48-byte record of a Gaussian (geometry, id, depth bits, rect, record slots) in packed rank order
+    uint32_t *rank_of = nullptr;      // [capP] packed rank of a (visible) Gaussian
+    uint32_t *keys32 = nullptr;       // [capPairs] emitted ranks, tile-major
     float *final_T = nullptr;
     uint32_t *n_contrib = nullptr;
     float *scratch_img = nullptr;     // [4][capPix] image sink when the backward has to re-create its checkpoints
@@ -154,7 +171,13 @@ int gom_ensure_capacity(GomState *s, int P_frame, int H, int W, int B);
 // ---- launchers (one per kernel family; defined in the .hip files) ----------
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
                           const float *opacity, int32_t *radii_out, hipStream_t st);
-int gom_launch_scan_emit(GomState *s, int P, hipStream_t st);
+int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false);
+int gom_launch_depth_hist(GomState *s, int P, hipStream_t st);
+int gom_launch_depth_rank(GomState *s, int P, hipStream_t st);
+int gom_launch_tile_rank(GomState *s, hipStream_t st);
+int gom_launch_rebuild_keys(GomState *s, hipStream_t st);
+// lists of up to this many entries go to the 4-wave instantiations of the per-tile kernels (0: one instantiation takes all)
+static inline uint32_t gom_sort_small_max(const GomState *s) { return s->B > 1 ? GOM_SORT_SMALL : 0u; }
 int gom_launch_sort(GomState *s, hipStream_t st);
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st);

@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
-                                                    int gx, int gy, uint32_t cap_pairs) {
+                                                    int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_dmin[4], s_dmax[4];
     __shared__ uint32_t s_blockbase;
     const int n_tiles = gx * gy;  // per frame
     const int fr = blockIdx.y;
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
     }
     const int ty_off = fr * gy;  // tile rows of this frame in the stacked grid
     uint32_t my_tiles = 0;
+    float my_depth = 0.f;
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
         __syncthreads();
@@ -189,12 +191,25 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
         my_tiles = o_tiles;
+        my_depth = o_depth;
         rect[i] = make_ushort4((unsigned short)x0, (unsigned short)(y0 + ty_off), (unsigned short)x1, (unsigned short)(y1 + ty_off));
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
                 if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
                 else atomicAdd(&tile_count[y * gx + x], 1u);
             }
+    }
+    // Depth range of the block's visible Gaussians (bit patterns: depths are > 0.2, unsigned order = float order) for the
+    // bucket map of the depth ranking (raster_rank.hip): wave reduction, one (min, max) pair per block.
+    if (depth_minmax) {
+        const bool vis = my_tiles != 0u;
+        uint32_t lo = vis ? __float_as_uint(my_depth) : 0xffffffffu, hi = vis ? lo : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { s_dmin[threadIdx.x >> 6] = lo; s_dmax[threadIdx.x >> 6] = hi; }
     }
     // Private range of this gaussian in pair_pos: block-level exclusive scan + ONE atomic per block
     // (the order of the ranges is irrelevant, they only index a scratch table).
@@ -217,6 +232,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                 if (base + tot > shard_cap) { atomicOr(&status->shard_overflow, 1u); base = 0; }   // poisoned frame: stay in bounds
             }
             s_blockbase = shard * shard_cap + base;
+            if (depth_minmax) {   // per-block partial (no atomics: 1 728 blocks on 16 words cost the kernel 30 us); the rank kernels fold them
+                uint2 *mm = reinterpret_cast<uint2 *>(depth_minmax) + (size_t)fr * gridDim.x + blockIdx.x;
+                *mm = make_uint2(min(min(s_dmin[0], s_dmin[1]), min(s_dmin[2], s_dmin[3])), max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])));
+            }
         }
         __syncthreads();
         uint32_t woff = 0;
@@ -259,10 +278,13 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
 __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
                                                      uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ seg_base,
                                                      uint32_t *__restrict__ tile_nmax, int n_tiles,
-                                                     GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift) {
+                                                     GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift,
+                                                     uint32_t *__restrict__ bucket_count, uint32_t *__restrict__ bucket_base,
+                                                     uint32_t *__restrict__ bucket_cursor, int n_buckets,
+                                                     uint32_t *__restrict__ work_small, uint32_t *__restrict__ work_big, uint32_t small_max) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
-    uint32_t carry = 0, seg_carry = 0;
+    uint32_t carry = 0, seg_carry = 0, ws_carry = 0, wb_carry = 0;
     // 8 consecutive tiles per thread and trip: a batched launch (8 192 tiles at 8 x 512x512) is ONE trip = one load latency and
     // two block scans, where one tile per thread took eight dependent trips (20 us of a single workgroup's latency chain).
     constexpr int kPer = 8;
@@ -318,6 +340,40 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
         carry += tot;
         seg_carry += stot;
+        if (work_small) {   // non-empty tiles by list length -> the two work lists of k_tile_rank (tile order kept)
+            uint32_t cs = 0, cb = 0;
+#pragma unroll
+            for (int k = 0; k < kPer; k++) { cs += (v[k] != 0u && v[k] <= small_max) ? 1u : 0u; cb += v[k] > small_max ? 1u : 0u; }
+            uint32_t ts, tb;
+            uint32_t ps = ws_carry + block_excl_scan_1024(cs, s_wave, ts);
+            uint32_t pb = wb_carry + block_excl_scan_1024(cb, s_wave, tb);
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                if (v[k] != 0u && v[k] <= small_max) work_small[ps++] = (uint32_t)(i0 + k);
+                else if (v[k] > small_max) work_big[pb++] = (uint32_t)(i0 + k);
+            }
+            ws_carry += ts;
+            wb_carry += tb;
+        }
+    }
+    // depth ranking (raster_rank.hip): exclusive scan of the (frame, bucket) counts = packed ranks at which the buckets start
+    if (bucket_count) {
+        uint32_t bcarry = 0;
+        for (int base = 0; base < n_buckets; base += 1024 * kPer) {
+            const int i0 = base + tid * kPer;
+            uint32_t v[kPer], tsum = 0;
+#pragma unroll
+            for (int k = 0; k < kPer; k++) { v[k] = i0 + k < n_buckets ? bucket_count[i0 + k] : 0u; tsum += v[k]; }
+            uint32_t tot;
+            uint32_t excl = bcarry + block_excl_scan_1024(tsum, s_wave, tot);
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                if (i0 + k < n_buckets) { bucket_base[i0 + k] = excl; bucket_cursor[i0 + k] = excl; bucket_count[i0 + k] = 0u; }
+                excl += v[k];
+            }
+            bcarry += tot;
+        }
+        if (tid == 0) bucket_base[n_buckets] = bcarry;
     }
     if (tid == 0) {
         tile_base[n_tiles] = carry;
@@ -328,6 +384,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         status->num_segs = over ? 0u : seg_carry;
         status->pair_cursor = 0;
         status->shard_overflow = 0;
+        status->n_work_small = over ? 0u : ws_carry;
+        status->n_work_big = over ? 0u : wb_carry;
         for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
@@ -336,11 +394,13 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
 // Emit (depth_bits << 32 | gaussian) into the tile's exact range.  The order
 // inside a range is arbitrary here; the per-tile sort on the unique 64-bit key
 // makes the final list identical to a stable sort on (tile, depth bits).
-template <bool LDS_AGG>
+// RANK: the depth ranking has run (raster_rank.hip): the entry is the Gaussian's 32-bit packed rank, not a 64-bit key.
+template <bool LDS_AGG, bool RANK>
 __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ depth, const int32_t *__restrict__ radii,
                                               const ushort4 *__restrict__ rect, uint32_t *__restrict__ tile_cursor,
                                               uint64_t *__restrict__ keys, int gx, int gy,
-                                              const GomDevStatus *__restrict__ status) {
+                                              const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ rank_of,
+                                              uint32_t *__restrict__ keys32) {
     extern __shared__ uint32_t s_mem[];
     if (status->overflow) return;
     const int n_tiles = gx * gy;  // per frame
@@ -354,7 +414,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
     uint64_t key = 0;
     if (vis) {
         r = rect[i];
-        key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+        key = RANK ? (uint64_t)rank_of[i] : ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
     }
     tile_cursor += (size_t)fr * n_tiles;  // rect rows are stacked: bring them back to this frame's tile block
     r.y -= (unsigned short)(vis ? fr * gy : 0);
@@ -377,13 +437,13 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
             for (int x = r.x; x < r.z; x++) {
                 const int t = y * gx + x;
                 const uint32_t slot = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-                keys[slot] = key;
+                if (RANK) keys32[slot] = (uint32_t)key; else keys[slot] = key;
             }
     } else {
         for (int y = r.y; y < r.w; y++)
             for (int x = r.x; x < r.z; x++) {
                 const uint32_t slot = atomicAdd(&tile_cursor[y * gx + x], 1u);
-                keys[slot] = key;
+                if (RANK) keys32[slot] = (uint32_t)key; else keys[slot] = key;
             }
     }
 }
@@ -393,13 +453,15 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 // render backward left in `partial` (position found by binary search on the
 // unique sort key), then conic -> cov2D -> (cov3D, mean3D) and the projection
 // term of the screen-space mean gradient.
-template <int C>
+template <int C, bool RANK>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
                                                         const float *__restrict__ cov6, const int32_t *__restrict__ radii,
                                                         const uint32_t *__restrict__ tiles_touched,
                                                         const float4 *__restrict__ conic_opacity,
                                                         const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_pos,
-                                                        const float *__restrict__ partial,
+                                                        const ushort4 *__restrict__ rect, const uint32_t *__restrict__ tile_base,
+                                                        const uint32_t *__restrict__ tile_nmax, const uint32_t *__restrict__ rank_of,
+                                                        const uint32_t *__restrict__ tile_qlim, int gx, const float *__restrict__ partial,
                                                         const GomDevStatus *__restrict__ status,
                                                         float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
                                                         float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
@@ -410,7 +472,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
     const GomCamera cam = pick_camera(cam1, cams, fr);
     {
         const size_t go = (size_t)fr * P;
-        means += 3 * go; cov6 += 6 * go; radii += go; tiles_touched += go; conic_opacity += go; pair_off += go;
+        means += 3 * go; cov6 += 6 * go; radii += go; tiles_touched += go; conic_opacity += go; pair_off += go; rect += go;
         dL_dmeans += 3 * go; dL_dcov6 += 6 * go; dL_dcolors += C * go; dL_dopacity += go;
         if (dL_dmeans2D) dL_dmeans2D += 3 * go;
     }
@@ -421,22 +483,36 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
     const bool bad = status->overflow != 0;
     if (!bad && radii[i] > 0) {
-        // k-th tile of this gaussian's rect -> sorted position of that (tile, gaussian) pair -> its record.
-        // Independent gathers, 8 records in flight per trip (a gaussian over 72 tiles costs 9 dependent round
-        // trips instead of 72); fixed k order keeps the sum reproducible.
+        // The records of this Gaussian (one per tile of its rect, written by the render backward) are ONE contiguous run at
+        // pair_off[i]: 48 nt bytes streamed, where the list-ordered layout of round 1 cost a 128-byte line per record (4.7x
+        // the algorithmic traffic).  The k-th tile's entry is dead -- never written, not read -- when its list index is at or
+        // beyond the tile's last contributor: about half of all pairs on a body (back-facing surface).  With the depth ranking that
+        // is a comparison of the Gaussian's rank with the rank of the tile's last contributor (tile_qlim, from the forward's combine
+        // pass); with the per-tile merge sort, of its list index (pair_pos) with tile_nmax.
+        // 8 records in flight per trip; fixed k order keeps the sum reproducible.
         const uint32_t nt = tiles_touched[i];
-        const uint32_t *pp = pair_pos + pair_off[i];
+        const uint32_t po = pair_off[i];
+        const ushort4 rc = rect[i];
+        const uint32_t rw = (uint32_t)(rc.z - rc.x);
+        const uint32_t myq = RANK ? rank_of[(size_t)fr * P + i] : 0u;
         for (uint32_t k0 = 0; k0 < nt; k0 += 8) {
-            float4 q0[8], q1[8], q2[8];
+            bool live[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t k = k0 + u < nt ? k0 + u : k0;
-                const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)pp[k] * GOM_PARTIAL_STRIDE);
+                const uint32_t tile = ((uint32_t)rc.y + k / rw) * (uint32_t)gx + (uint32_t)rc.x + k % rw;   // (stacked tile rows: rect carries the frame offset)
+                live[u] = k0 + u < nt && (RANK ? myq < tile_qlim[tile] : pair_pos[po + k] - tile_base[tile] < tile_nmax[tile]);
+            }
+            float4 q0[8], q1[8], q2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                // (a dead entry re-reads the Gaussian's first slot -- same cache line, no branch around the loads -- and is masked below)
+                const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)(po + (live[u] ? k0 + u : 0u)) * GOM_PARTIAL_STRIDE);
                 q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                if (k0 + u < nt) {
+                if (live[u]) {
                     acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
                     acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;
                     acc[8] += q2[u].x; acc[9] += q2[u].y;
@@ -544,34 +620,42 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
         hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), n_tiles * sizeof(uint32_t), st, cam, s->cams, P, means3D, cov6,
                            opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
-                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap);
+                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr);
     else
         hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, opacity, s->depth,
                            s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
-                           s->status, s->gx, s->gy, cap);
+                           s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
-int gom_launch_scan_emit(GomState *s, int P, hipStream_t st) {
+// rank: the splat path with depth ranking (the caller has run gom_launch_depth_hist): the scan kernel also turns the bucket counts
+// into ranges, the Gaussians are ranked (gom_launch_depth_rank) and the emission writes 32-bit ranks.
+int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank) {
     const int n_tiles = s->gx * s->gy;
     const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
-                           s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift);
+                           s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
+                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_small : nullptr, s->work_big, gom_sort_small_max(s));
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
+    if (rank) {
+        if (int rc = gom_launch_depth_rank(s, P, st)) return rc;
+    }
     GomKernelTimer timer(s, GOM_K_EMIT, st);
     const dim3 grid(blocks, s->B);
-    if (n_tiles <= GOM_LDS_TILE_LIMIT)
-        hipLaunchKernelGGL(k_emit<true>, grid, dim3(256), 2 * n_tiles * sizeof(uint32_t), st, P, s->depth, s->radii,
-                           s->rect, s->tile_cursor, s->keys, s->gx, s->gy, s->status);
-    else
-        hipLaunchKernelGGL(k_emit<false>, grid, dim3(256), 0, st, P, s->depth, s->radii, s->rect, s->tile_cursor,
-                           s->keys, s->gx, s->gy, s->status);
+#define GOM_EMIT(AGG, RK, LDS) hipLaunchKernelGGL((k_emit<AGG, RK>), grid, dim3(256), LDS, st, P, s->depth, s->radii, s->rect, s->tile_cursor, s->keys, s->gx, s->gy, \
+                                                  s->status, s->rank_of, s->keys32)
+    if (n_tiles <= GOM_LDS_TILE_LIMIT) {
+        if (rank) GOM_EMIT(true, true, 2 * n_tiles * sizeof(uint32_t)); else GOM_EMIT(true, false, 2 * n_tiles * sizeof(uint32_t));
+    } else {
+        if (rank) GOM_EMIT(false, true, 0); else GOM_EMIT(false, false, 0);
+    }
+#undef GOM_EMIT
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -583,14 +667,12 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
     const dim3 grid(blocks, s->B);
-    if (C == 3)
-        hipLaunchKernelGGL(k_preprocess_bwd<3>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii,
-                           s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
-                           dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
-    else
-        hipLaunchKernelGGL(k_preprocess_bwd<4>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii,
-                           s->tiles_touched, s->conic_opacity, s->pair_off, s->pair_pos, s->partial, s->status,
-                           dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D);
+#define GOM_PB(CC, RK) hipLaunchKernelGGL((k_preprocess_bwd<CC, RK>), grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii, s->tiles_touched,         \
+                                          s->conic_opacity, s->pair_off, s->pair_pos, s->rect, s->tile_base, s->tile_nmax, s->rank_of, s->tile_qlim, s->gx, s->partial, \
+                                          s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D)
+    if (C == 3) { if (s->rankSort) GOM_PB(3, true); else GOM_PB(3, false); }
+    else { if (s->rankSort) GOM_PB(4, true); else GOM_PB(4, false); }
+#undef GOM_PB
     GOM_LAUNCH_CHECK();
     return 0;
 }

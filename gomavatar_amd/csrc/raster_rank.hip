@@ -1,0 +1,331 @@
+// Depth ranking of the Gaussians + bitmap ranking of the tile lists: the splat path's replacement for "sort every tile
+// list" (cub::DeviceRadixSort::SortPairs of the CUDA extension the reference calls at
+// models/modules/renderer/gaussian.py:83-91; algorithm: SURVEY.md App. A.2).
+//
+// The reference orders every tile list by (depth bits, Gaussian index).  That order does not depend on the tile: it is the
+// restriction of ONE order of the frame's Gaussians.  So instead of sorting D ~ 150 k (tile, Gaussian) pairs per frame in
+// ~170 lists (round 1: a merge sort per tile, 168 us per 8-frame launch, a 6 000-entry list being one workgroup's 50 us
+// chain), the P = 55 104 Gaussians of a frame are ranked ONCE and a tile list is sorted by a pass that is linear in its
+// length:
+//
+//   k_depth_hist      per Gaussian: depth -> one of NB equal-width buckets between the frame's min / max depth (a monotone
+//   k_bucket_scatter  map: every key of bucket b precedes every key of bucket b + 1); counts, then (after the scan kernel)
+//                     (depth_bits << 32 | index) keys scattered into the bucket's range.
+//   k_bucket_sort     per bucket (~200 keys): merge sort in registers + LDS -> rank q of every visible Gaussian in the
+//                     packed (frame, depth, index) order, and its record (geometry, rect, record slots) stored AT q.
+//   k_emit<RANK>      (raster_pre.hip) writes q instead of a 64-bit key into the tile's range, in arbitrary order.
+//   k_tile_rank       per tile: the ranks of its entries set bits of a P-bit bitmap in LDS; a popcount scan turns the bitmap
+//                     into the sorted list; the entries' records are gathered at ascending q and written in LIST order
+//                     (point_list, keys, ent_geo, ent_slot, pair_pos, segment descriptors).  No comparison, no log factor,
+//                     no limit on the list length.
+//
+// The result is bit-identical to the per-tile sort (tests/test_gpu_raster.py runs both and compares every integer output with
+// the oracle).  Buckets longer than one sort chunk (degenerate depth distributions: a plane facing the camera) take the
+// chunk + global-merge path of sort_util.hpp: slower, same result.
+#include "gom_internal.h"
+#include "sort_util.hpp"
+
+namespace {
+
+using namespace gom_sort;
+
+struct BucketMap {
+    float dmin, scale;
+    uint32_t nb;
+    __device__ __forceinline__ uint32_t operator()(float d) const {
+        const float v = (d - dmin) * scale;              // monotone in d (IEEE subtraction / multiplication by a constant >= 0)
+        const uint32_t b = v > 0.f ? (uint32_t)v : 0u;   // (truncation is monotone; NaN cannot occur: scale is finite)
+        return b < nb ? b : nb - 1u;
+    }
+};
+
+// The frame's depth range from the per-block (min, max) pairs k_preprocess left (float BIT PATTERNS: depths are > 0.2, unsigned
+// order = float order; a block without a visible Gaussian wrote min > max): every workgroup folds the ~200 pairs itself --
+// 1.7 KB from L2 -- instead of a reduction kernel or contended atomics.  Ends with a __syncthreads().
+__device__ __forceinline__ BucketMap bucket_map(const uint32_t *__restrict__ minmax, int fr, int nblk, uint32_t nb, uint32_t *s_red /* [8] */) {
+    const uint2 *mm = reinterpret_cast<const uint2 *>(minmax) + (size_t)fr * nblk;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
+        const uint2 v = mm[k];
+        lo = min(lo, v.x);
+        hi = max(hi, v.y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = lo; s_red[4 + (threadIdx.x >> 6)] = hi; }
+    __syncthreads();
+    lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    BucketMap m;
+    m.nb = nb;
+    m.dmin = __uint_as_float(lo);
+    const float span = lo < hi ? __uint_as_float(hi) - __uint_as_float(lo) : 0.f;
+    float sc = span > 0.f ? (float)nb / span : 0.f;
+    if (!(sc < 1.0e30f)) sc = 0.f;   // a span of a few ulps: one bucket (still correct, the bucket sort orders it)
+    m.scale = sc;
+    return m;
+}
+
+// ---- counts per (frame, bucket) ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_depth_hist(int P, uint32_t nb, const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                                    const uint32_t *__restrict__ minmax, uint32_t *__restrict__ bucket_count,
+                                                    const GomDevStatus *__restrict__ status) {
+    extern __shared__ uint32_t s_cnt[];
+    __shared__ uint32_t s_red[8];
+    const int fr = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
+    const BucketMap bm = bucket_map(minmax, fr, gridDim.x, nb, s_red);
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)fr * P + il;
+    if (il < P && radii[i] > 0) atomicAdd(&s_cnt[bm(depth[i])], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t c = s_cnt[b];
+        if (c) atomicAdd(&bucket_count[(size_t)fr * nb + b], c);
+    }
+}
+
+// ---- keys into the bucket ranges (order inside a bucket arbitrary: the bucket sort fixes it) -------------------------------
+__global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, const float *__restrict__ depth, const int32_t *__restrict__ radii,
+                                                        const uint32_t *__restrict__ minmax, uint32_t *__restrict__ bucket_cursor,
+                                                        uint64_t *__restrict__ bkeys) {
+    extern __shared__ uint32_t s_mem[];
+    uint32_t *s_cnt = s_mem, *s_base = s_mem + nb;
+    __shared__ uint32_t s_red[8];
+    const int fr = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
+    const BucketMap bm = bucket_map(minmax, fr, gridDim.x, nb, s_red);
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)fr * P + il;
+    const bool vis = il < P && radii[i] > 0;
+    uint32_t b = 0, dbits = 0;
+    if (vis) {
+        const float d = depth[i];
+        dbits = __float_as_uint(d);
+        b = bm(d);
+        atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nb; k += 256) {
+        const uint32_t c = s_cnt[k];
+        if (c) {
+            s_base[k] = atomicAdd(&bucket_cursor[(size_t)fr * nb + k], c);
+            s_cnt[k] = 0;
+        }
+    }
+    __syncthreads();
+    if (vis) bkeys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = ((uint64_t)dbits << 32) | (uint32_t)il;   // index INSIDE the frame: ties keep Gaussian order
+}
+
+// ---- per bucket: sort, then the records in rank order ---------------------------------------------------------------
+// srt_rec [q][3] float4 : (x, y, conic a, conic b) (conic c, opacity, bits of the global Gaussian id, depth bits)
+//                         (bits of: rect xmin | ymin << 16, rect xmax | ymax << 16, start of the record slots, 0)
+// -- ONE contiguous 48-byte record per rank: the tile pass gathers it with three 16-byte loads from one or two cache lines
+// (three separate arrays were three lines per entry).  Tile rows of the rect are stacked over the frames.
+__global__ void __launch_bounds__(256) k_bucket_sort(int P, uint32_t nb, const uint32_t *__restrict__ bucket_base, uint64_t *__restrict__ bkeys,
+                                                     uint64_t *__restrict__ scratch, const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
+                                                     const ushort4 *__restrict__ rect, const uint32_t *__restrict__ pair_off,
+                                                     float4 *__restrict__ srt_rec, uint32_t *__restrict__ rank_of, uint32_t log_chunk,
+                                                     const GomDevStatus *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * 256];
+    const int fr = blockIdx.y;
+    if (status->overflow) return;
+    const uint32_t base = bucket_base[(size_t)fr * nb + blockIdx.x];
+    const uint32_t n = bucket_base[(size_t)fr * nb + blockIdx.x + 1] - base;
+    if (n == 0) return;
+    uint64_t x[8];
+    bool in_regs;
+    const uint64_t *sorted = block_sort_any<256>(bkeys + base, scratch + base, n, s_x, log_chunk, x, in_regs);
+    if (in_regs) {   // blocked registers -> LDS, so that the loop below is striped (coalesced writes)
+#pragma unroll
+        for (int r = 0; r < 8; r += 2)
+            if (8 * threadIdx.x + r < ((n + 7u) & ~7u)) *reinterpret_cast<ulonglong2 *>(s_x + 8 * threadIdx.x + r) = make_ulonglong2(x[r], x[r + 1]);
+        __syncthreads();
+        sorted = s_x;
+    }
+    const size_t go = (size_t)fr * P;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t key = sorted[i];
+        const uint32_t il = (uint32_t)key;
+        const size_t g = go + il;
+        const uint32_t q = base + i;
+        const float2 c = xy[g];
+        const float4 co = conic_opacity[g];
+        const ushort4 rc = rect[g];
+        const uint32_t po = pair_off[g];
+        float4 *d = srt_rec + 3 * (size_t)q;
+        d[0] = make_float4(c.x, c.y, co.x, co.y);
+        d[1] = make_float4(co.z, co.w, __uint_as_float((uint32_t)g), __uint_as_float((uint32_t)(key >> 32)));
+        d[2] = make_float4(__uint_as_float((uint32_t)rc.x | ((uint32_t)rc.y << 16)), __uint_as_float((uint32_t)rc.z | ((uint32_t)rc.w << 16)), __uint_as_float(po), 0.f);
+        rank_of[g] = q;
+    }
+}
+
+// ---- per tile: bitmap of ranks -> sorted list -> records in list order -------------------------------------------------
+// The scan kernel left the non-empty tiles in two work lists: lists of up to `small_max` entries (NT = 256 workgroups) and longer
+// ones (NT = 1024: a list of 5 000 entries is 2 trips of the 4-deep loops below instead of 20 dependent ones).  Each launch is
+// a resident grid striding over its list -- four fifths of a body frame's tiles are empty, and a workgroup per tile that only
+// finds that out cost more than the work itself.
+#define GOM_RANK_STAGE 4096   // sorted ranks staged in LDS per window (lists longer than this take several windows)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
+                                                  const uint32_t *__restrict__ work, const uint32_t *__restrict__ n_work_p,
+                                                  const uint32_t *__restrict__ keys32, const uint32_t *__restrict__ bucket_base,
+                                                  const float4 *__restrict__ srt_rec, uint32_t *__restrict__ point_list, uint4 *__restrict__ seg_desc,
+                                                  uint32_t *__restrict__ ent_slot, float2 *__restrict__ ent_geo,
+                                                  const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words) {
+    extern __shared__ uint32_t s_mem[];
+    __shared__ uint32_t s_wsum[NT / 64];
+    uint32_t *s_bm = s_mem, *s_stage = s_mem + bm_words;
+    if (status->overflow) return;
+    const uint32_t n_work = *n_work_p;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wid = t >> 6;
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int tile = (int)work[wi];
+        const uint32_t base = tile_base[tile];
+        const uint32_t n = tile_base[tile + 1] - base;
+        const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
+        for (uint32_t i = t; i < nseg; i += NT)
+            seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
+        const int fr = tile / (gx * gy);
+        const int tx = tile % gx, ty = tile / gx;                 // ty: row in the STACKED grid (rects carry the same offset)
+        const uint32_t fs = bucket_base[(size_t)fr * nb];         // first packed rank of this frame
+        const uint32_t nvis = bucket_base[(size_t)(fr + 1) * nb] - fs;
+        const uint32_t W = (nvis + 31u) >> 5;                     // (<= bm_words: at most P visible Gaussians per frame)
+        for (uint32_t w = t; w < W; w += NT) s_bm[w] = 0u;
+        __syncthreads();
+        for (uint32_t i0 = t; i0 < n; i0 += 4 * NT) {            // 4 independent loads in flight per thread
+            uint32_t r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = i0 + u * NT < n ? keys32[base + i0 + u * NT] - fs : 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (r[u] != 0xffffffffu) atomicOr(&s_bm[r[u] >> 5], 1u << (r[u] & 31u));   // ranks of one frame are unique, a Gaussian is in a tile list once
+        }
+        __syncthreads();
+        // thread t owns the words [w0, w1): how many set bits precede them
+        const uint32_t wpt = (W + NT - 1u) / NT;
+        const uint32_t w0 = min(W, t * wpt), w1 = min(W, w0 + wpt);
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; w++) mine += __popc(s_bm[w]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += y;
+        }
+        if (lane == 63) s_wsum[wid] = incl;
+        __syncthreads();
+        uint32_t first = incl - mine;
+        for (uint32_t w = 0; w < wid; w++) first += s_wsum[w];
+        for (uint32_t c0 = 0; c0 < n; c0 += GOM_RANK_STAGE) {
+            const uint32_t c1 = min(n, c0 + GOM_RANK_STAGE);
+            if (first < c1 && first + mine > c0) {   // some of my bits fall into this window
+                uint32_t pos = first;
+                for (uint32_t w = w0; w < w1 && pos < c1; w++) {
+                    uint32_t bits = s_bm[w];
+                    while (bits) {
+                        const uint32_t bit = __ffs(bits) - 1u;
+                        bits &= bits - 1u;
+                        if (pos >= c0 && pos < c1) s_stage[pos - c0] = (w << 5) | bit;
+                        pos++;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t cnt = c1 - c0;
+            for (uint32_t i0 = t; i0 < cnt; i0 += 4 * NT) {       // 4 entries per trip: their record gathers are issued before the first store
+                float4 r0[4], r1[4], r2[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + u * NT;
+                    const float4 *rec = srt_rec + 3 * (size_t)(fs + s_stage[i < cnt ? i : i0]);
+                    r0[u] = rec[0]; r1[u] = rec[1]; r2[u] = rec[2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + u * NT;
+                    if (i < cnt) {
+                        const uint32_t li = base + c0 + i;
+                        const uint32_t rlo = __float_as_uint(r2[u].x), rhi = __float_as_uint(r2[u].y), po = __float_as_uint(r2[u].z);
+                        const uint32_t rx0 = rlo & 0xffffu, ry0 = rlo >> 16, rx1 = rhi & 0xffffu;
+                        const uint32_t k = ((uint32_t)ty - ry0) * (rx1 - rx0) + ((uint32_t)tx - rx0);
+                        point_list[li] = __float_as_uint(r1[u].z);
+                        ent_slot[li] = po + k;
+                        float2 *dst = ent_geo + 3 * (size_t)li;
+                        dst[0] = make_float2(r0[u].x, r0[u].y); dst[1] = make_float2(r0[u].z, r0[u].w); dst[2] = make_float2(r1[u].x, r1[u].y);
+                    }
+                }
+            }
+            __syncthreads();   // stage and bitmap are re-used by the next window / tile
+        }
+    }
+}
+
+// keys (depth_bits << 32 | gaussian) of the sorted lists, for gom_state_export: the ranking path never materialises them
+__global__ void __launch_bounds__(256) k_rebuild_keys(const uint32_t *__restrict__ point_list, const float *__restrict__ depth, uint64_t *__restrict__ keys,
+                                                      const GomDevStatus *__restrict__ status) {
+    if (status->overflow) return;
+    const uint32_t D = status->num_pairs;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D; i += gridDim.x * 256) {
+        const uint32_t g = point_list[i];
+        keys[i] = ((uint64_t)__float_as_uint(depth[g]) << 32) | g;
+    }
+}
+
+}  // namespace
+
+int gom_launch_depth_rank(GomState *s, int P, hipStream_t st) {
+    // (called between the scan kernel -- which turned bucket_count into bucket_base / bucket_cursor -- and the emission)
+    const int blocks = (P + 255) / 256;
+    if (blocks == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_DEPTH_RANK, st);
+    const uint32_t nb = 1u << s->nbShift;
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->depth_minmax,
+                       s->bucket_cursor, s->bkeys);
+    GOM_LAUNCH_CHECK();
+    const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < 2048 ? s->sortCap : 2048)));
+    hipLaunchKernelGGL(k_bucket_sort, dim3(nb, s->B), dim3(256), 0, st, P, nb, s->bucket_base, s->bkeys, s->bkeys_scratch, s->xy, s->conic_opacity, s->rect,
+                       s->pair_off, s->srt_rec, s->rank_of, lc, s->status);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_launch_depth_hist(GomState *s, int P, hipStream_t st) {
+    const int blocks = (P + 255) / 256;
+    if (blocks == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_DEPTH_HIST, st);
+    const uint32_t nb = 1u << s->nbShift;
+    hipLaunchKernelGGL(k_depth_hist, dim3(blocks, s->B), dim3(256), nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->depth_minmax, s->bucket_count,
+                       s->status);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_launch_tile_rank(GomState *s, hipStream_t st) {
+    const int n_tiles = s->gx * s->gy * s->B;
+    if (n_tiles == 0) return 0;
+    GomKernelTimer timer(s, GOM_K_SORT, st);
+    const uint32_t nb = 1u << s->nbShift;
+    const uint32_t bm_words = ((uint32_t)s->P + 31u) >> 5;
+    const size_t lds = (bm_words + GOM_RANK_STAGE) * sizeof(uint32_t);
+    // resident grids striding over the work lists of the scan kernel (gom_sort_small_max: which list a tile is on)
+    const int g_small = n_tiles < 2048 ? n_tiles : 2048, g_big = n_tiles < 512 ? n_tiles : 512;
+#define GOM_TR(NT, GRID, WORK, NWORK) hipLaunchKernelGGL((k_tile_rank<NT>), dim3(GRID), dim3(NT), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, WORK, NWORK, \
+                                                         s->keys32, s->bucket_base, s->srt_rec, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status,       \
+                                                         (uint32_t)s->segShift, bm_words)
+    if (gom_sort_small_max(s)) { GOM_TR(256, g_small, s->work_small, &s->status->n_work_small); GOM_LAUNCH_CHECK(); }
+    GOM_TR(1024, g_big, s->work_big, &s->status->n_work_big);
+#undef GOM_TR
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_launch_rebuild_keys(GomState *s, hipStream_t st) {
+    hipLaunchKernelGGL(k_rebuild_keys, dim3(1024), dim3(256), 0, st, s->point_list, s->depth, s->keys, s->status);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

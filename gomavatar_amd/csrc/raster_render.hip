@@ -48,6 +48,7 @@
 // loop is branch-free and keeps its state in VGPRs (float masks) so that the
 // serial T chain never round-trips through SALU/VCC logic.
 #include "gom_internal.h"
+#include "sort_util.hpp"
 #include <cstdlib>
 
 #ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py ... -DGOM_PHASE_PROF): cycles per phase of k_seg_bwd
@@ -165,103 +166,8 @@ __device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float
 }
 
 // ---------------------------------------------------------------- sort ------
-// Per-tile merge sort of the unique 64-bit keys (depth_bits << 32 | gaussian): identical to the reference's stable
-// radix order on (tile, depth bits) because ties in depth fall back to the Gaussian index.
-//
-// Every thread owns 8 consecutive list positions.  It sorts its 8 keys in registers (19 compare-exchanges), then
-// log2(n/8) merge levels follow: the sorted runs of length L sit in LDS, each thread finds by binary search
-// ("merge path") where its 8 outputs start in the two runs being merged and merges 8 elements sequentially.
-// O(n log n) work instead of the O(n log^2 n) of a bitonic network -- 4-5x fewer instructions at n = 2048..8192,
-// which matters because a batched launch is VALU-bound here (scripts/ubench/dpp_bench.hip: ~2.6 cycles per wave
-// instruction per SIMD at best).
-__device__ __forceinline__ void cmpswap(uint64_t &lo, uint64_t &hi) {
-    const uint64_t a = lo, b = hi;
-    const bool sw = a > b;
-    lo = sw ? b : a;
-    hi = sw ? a : b;
-}
-
-template <int MASK>
-__device__ __forceinline__ void sort_step_regs(uint64_t (&x)[8]) {
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        if ((r ^ MASK) > r) cmpswap(x[r], x[r ^ MASK]);
-}
-
-// normalised bitonic network on 8 registers (every comparator ascending)
-__device__ __forceinline__ void sort8_regs(uint64_t (&x)[8]) {
-    sort_step_regs<1>(x);
-    sort_step_regs<3>(x); sort_step_regs<1>(x);
-    sort_step_regs<7>(x); sort_step_regs<2>(x); sort_step_regs<1>(x);
-}
-
-// Outputs [o, o+8) of the merge of the sorted runs A = src[0, la) and B = src[L, L + lb)  (la, lb = real lengths;
-// positions past la + lb yield +inf).  PTR: LDS or global pointer to uint64_t.
-template <typename PTR>
-__device__ __forceinline__ void merge8(PTR src, uint32_t L, uint32_t la, uint32_t lb, uint32_t o, uint64_t (&out)[8]) {
-    const uint64_t INF = ~0ull;
-    if (o >= la + lb) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) out[k] = INF;
-        return;
-    }
-    // merge path: i = how many of the first o outputs come from A
-    uint32_t lo = o > lb ? o - lb : 0u, hi = o < la ? o : la;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint64_t a = src[mid], b = src[L + (o - 1 - mid)];
-        if (a < b) lo = mid + 1; else hi = mid;
-    }
-    uint32_t i = lo, j = o - lo;
-    uint64_t a = i < la ? src[i] : INF;
-    uint64_t b = j < lb ? src[L + j] : INF;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const bool take = a <= b;   // unique keys; +inf only ever ties with +inf
-        out[k] = take ? a : b;
-        i += take ? 1u : 0u;
-        j += take ? 0u : 1u;
-        if (k < 7) {
-            const bool ok = take ? (i < la) : (j < lb);
-            const uint64_t v = ok ? src[take ? i : L + j] : INF;
-            a = take ? v : a;
-            b = take ? b : v;
-        }
-    }
-}
-
-// Sorts keys[0, n) (n <= 8 * NT) in place in registers + LDS; on return thread t holds positions 8t .. 8t+7 in x.
-template <int NT>
-__device__ __forceinline__ void block_merge_sort(const uint64_t *__restrict__ keys, uint32_t n, uint64_t *s_x, uint64_t (&x)[8]) {
-    const uint32_t t = threadIdx.x;
-    uint32_t n_pad = 8;
-    while (n_pad < n) n_pad <<= 1;
-    const bool active = 8 * t < n_pad;
-    // coalesced (striped) global loads, then blocked ownership (8 consecutive positions per thread) through LDS
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t i = (uint32_t)r * NT + t;
-        if ((uint32_t)r * NT < n_pad) s_x[i] = i < n ? keys[i] : ~0ull;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; r++) x[r] = active ? s_x[8 * t + r] : ~0ull;
-    if (active) sort8_regs(x);
-    for (uint32_t L = 8; L < n_pad; L <<= 1) {
-        __syncthreads();  // readers of the previous level are done
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) *reinterpret_cast<ulonglong2 *>(s_x + 8 * t + r) = make_ulonglong2(x[r], x[r + 1]);
-        }
-        __syncthreads();
-        if (active) {
-            const uint32_t pbase = (8 * t) & ~(2 * L - 1), o = 8 * t - pbase;
-            const uint32_t la = n > pbase ? min(L, n - pbase) : 0u;
-            const uint32_t lb = n > pbase + L ? min(L, n - pbase - L) : 0u;
-            merge8(s_x + pbase, L, la, lb, o, x);
-        }
-    }
-}
+// (merge-sort building blocks: sort_util.hpp)
+using namespace gom_sort;
 
 // One workgroup per tile.  Lists of up to 2^log_chunk (= 8 * NT) keys are sorted in registers + LDS.  Longer lists
 // (a handful of tiles at the 220k-Gaussian configuration) are cut into chunks of that size, each sorted as above,
@@ -273,7 +179,7 @@ template <int NT>
 __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                uint4 *__restrict__ seg_desc, const ushort4 *__restrict__ rect,
-                                               const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos,
+                                               const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos, uint32_t *__restrict__ ent_slot,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
                                                float2 *__restrict__ ent_geo, uint64_t *__restrict__ scratch,
                                                const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max, uint32_t seg_shift) {
@@ -328,6 +234,7 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
                     point_list[base + i] = g;
                     const uint32_t k = (uint32_t)(ty - (int)rc[u].y) * (uint32_t)(rc[u].z - rc[u].x) + (uint32_t)(tx - (int)rc[u].x);
                     pair_pos[po[u] + k] = base + i;
+                    ent_slot[base + i] = po[u] + k;
                     // geometry of the entry in LIST order: the compositing kernels read it contiguously
                     float2 *dst = ent_geo + 3 * (size_t)(base + i);
                     dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
@@ -369,7 +276,9 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
         point_list[base + i] = g;
         const ushort4 rc = rect[g];
         const uint32_t k = (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
-        pair_pos[pair_off[g] + k] = base + i;
+        const uint32_t slot = pair_off[g] + k;
+        pair_pos[slot] = base + i;
+        ent_slot[base + i] = slot;
         const float2 c = xy[g];
         const float4 co = conic_opacity[g];
         float2 *d2 = ent_geo + 3 * (size_t)(base + i);
@@ -769,7 +678,9 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      float *__restrict__ seg_Sbehind, float *__restrict__ out_color,
                                                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                      uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
-                                                     const GomDevStatus *__restrict__ status) {
+                                                     const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
+                                                     const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
+                                                     uint32_t *__restrict__ tile_qlim) {
     __shared__ uint32_t s_nmax[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
@@ -795,7 +706,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
             final_T[pix] = nanv;
             n_contrib[pix] = 0;
         }
-        if (threadIdx.x == 0) tile_nmax[tile] = 0;
+        if (threadIdx.x == 0) { tile_nmax[tile] = 0; if (rank_of) tile_qlim[tile] = 0; }
         return;
     }
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
@@ -875,7 +786,13 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
     const uint32_t wmax = wave_max_u32(inside ? last : 0u);
     if (lane == 0) s_nmax[wave] = wmax;
     __syncthreads();
-    if (threadIdx.x == 0) tile_nmax[tile] = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
+    if (threadIdx.x == 0) {
+        const uint32_t nm = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
+        tile_nmax[tile] = nm;
+        // depth ranking: 1 + rank of the tile's last contributing entry -- the per-Gaussian backward compares a Gaussian's own rank
+        // with it instead of looking up its list position
+        if (rank_of) tile_qlim[tile] = nm ? rank_of[point_list[tile_base[tile] + nm - 1u]] + 1u : 0u;
+    }
     // the four quadrant maxima once per SEGMENT of the tile: the backward finds them with the segment index alone
     for (uint32_t i = threadIdx.x; i < nseg; i += 256) seg_qmax[sb + i] = make_uint4(s_nmax[0], s_nmax[1], s_nmax[2], s_nmax[3]);
 }
@@ -895,7 +812,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
-                                                  float *__restrict__ partial, const GomDevStatus *__restrict__ status,
+                                                  const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
                                                   uint32_t *__restrict__ task_ctr) {
     constexpr int NV = 6 + C;  // values reduced per entry
     // [task parity][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote.
@@ -934,19 +851,18 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
         const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;  // list index of the first entry of the sub-range
         const bool empty = (uint32_t)sub * sub_sz >= cnt;
         const uint32_t scnt = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
-        float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)(start + (uint32_t)sub * sub_sz + threadIdx.x) * GOM_PARTIAL_STRIDE);
         const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
-        if (empty || s0 >= tmax) {  // no entries, or every pixel of the tile stopped before this sub-range: all-zero records
-            if (threadIdx.x < scnt) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                rec[0] = z; rec[1] = z; rec[2] = z;
-            }
+        if (empty || s0 >= tmax) {
+            // No entries, or every pixel of the tile stopped before this sub-range.  Nothing is written: the per-Gaussian backward
+            // skips entries at or beyond the tile's last contributor (tile_nmax) without reading their record.
             tq.request();
             tq.publish(s_task);
             __syncthreads();
             continue;
         }
         const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));  // max n_contrib over this wave's 8x8 pixels
+        // record slot of "my" entry (Gaussian-major: the per-Gaussian backward reads a Gaussian's records as one contiguous run)
+        const uint32_t my_slot = threadIdx.x < scnt ? ent_slot[start + (uint32_t)sub * sub_sz + threadIdx.x] : 0u;
         unsigned long long done = 0ull;
         bool requested = false;
         if (wmax > s0) {
@@ -1091,6 +1007,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 #pragma unroll
                 for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][threadIdx.x][qq] : 0.f;
             }
+            float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)my_slot * GOM_PARTIAL_STRIDE);
             rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
             rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
             rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
@@ -1118,12 +1035,12 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     const uint32_t small_max = s->B > 1 ? GOM_SORT_SMALL : 0u;
     if (small_max) {
         hipLaunchKernelGGL(k_sort<256>, dim3(n_tiles), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                           s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial),
+                           s->rect, s->pair_off, s->pair_pos, s->ent_slot, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial),
                            s->status, lc < 11u ? lc : 11u, small_max, (uint32_t)s->segShift);
         GOM_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_sort<1024>, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
-                       s->rect, s->pair_off, s->pair_pos, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial), s->status,
+                       s->rect, s->pair_off, s->pair_pos, s->ent_slot, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial), s->status,
                        lc, small_max, (uint32_t)s->segShift);
     GOM_LAUNCH_CHECK();
     return 0;
@@ -1179,7 +1096,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 #define GOM_CF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
-                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status)
+                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim)
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }
@@ -1196,7 +1113,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 #define GOM_SB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_RESIDENT(k_seg_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->partial, s->status, GOM_TASK_CTR)
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB
     GOM_LAUNCH_CHECK();

@@ -90,18 +90,23 @@ enum {
     GOM_OPT_PROFILE = 2,       /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
     GOM_OPT_SEG_SHIFT = 3,     /* log2 of the tile-list segment size: 7 (128 entries), 8 (256) or 0 = auto (7 for one frame,
                                   8 for a batched launch).  Results for different sizes agree to fp32 round-off, not bitwise. */
-    GOM_OPT_TASK_GRID_PCT = 4  /* 10..100 (default 100): share of the chip the persistent task-queue grids of a batched launch
+    GOM_OPT_TASK_GRID_PCT = 4, /* 10..100 (default 100): share of the chip the persistent task-queue grids of a batched launch
                                   occupy.  100 is fastest when the step has the GPU to itself; with several steps in flight on
                                   separate streams ~50 lets their kernels run side by side (a full grid holds every workgroup
                                   slot until it ends).  Results do not depend on it. */
+    GOM_OPT_SORT_MODE = 5      /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
+                                  frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
+                                  bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */
 };
 
 /* kernel ids for gom_state_kernel_times */
 enum {
     GOM_K_PREPROCESS = 0, GOM_K_SCAN = 1, GOM_K_EMIT = 2, GOM_K_SORT = 3, GOM_K_SEG_T = 4, GOM_K_SEG_FWD = 5,
-    GOM_K_COMBINE = 6, GOM_K_SEG_BWD = 7, GOM_K_PREPROCESS_BWD = 8
+    GOM_K_COMBINE = 6, GOM_K_SEG_BWD = 7, GOM_K_PREPROCESS_BWD = 8,
+    GOM_K_DEPTH_HIST = 9,  /* depth ranking: bucket histogram                                   */
+    GOM_K_DEPTH_RANK = 10  /* depth ranking: bucket scatter + per-bucket sort (two launches)    */
 };
-#define GOM_NUM_KERNELS 9
+#define GOM_NUM_KERNELS 11
 
 const char *gom_last_error(void);
 int gom_abi_version(void);

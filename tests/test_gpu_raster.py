@@ -36,15 +36,25 @@ def assert_image_parity(img, ref):
 
 
 def _compare_forward(cam, means, cov6, colors, op, sort_cap=None):
+    """Both ways of ordering the tile lists -- merge sort per tile, depth ranking + bitmap pass (csrc/raster_rank.hip) -- against the
+    oracle and against each other (bitwise)."""
     from gpu_util import hip_forward, export_state, assert_binning_bit_exact
     from gomavatar_amd import _lib, rasterizer as R
-    st = R.RasterState()
-    if sort_cap is not None:
-        st.set_option(_lib.OPT_SORT_CAP, sort_cap)
-    out, radii, st, _ = hip_forward(cam, means, cov6, colors, op, state=st)
     f = orast.forward(cam, means, cov6, colors, op)
-    e = export_state(st, means.shape[0], cam["H"], cam["W"])
-    assert_binning_bit_exact(e, f)
+    prev = None
+    for mode in (_lib.SORT_TILE_MERGE, _lib.SORT_DEPTH_RANK):
+        st = R.RasterState()
+        st.set_option(_lib.OPT_SORT_MODE, mode)
+        if sort_cap is not None:
+            st.set_option(_lib.OPT_SORT_CAP, sort_cap)
+        out, radii, st, _ = hip_forward(cam, means, cov6, colors, op, state=st)
+        e = export_state(st, means.shape[0], cam["H"], cam["W"])
+        assert_binning_bit_exact(e, f)
+        if prev is not None:
+            assert torch.equal(out, prev[0]) and torch.equal(radii, prev[1])
+            for k in ("keys", "point_list", "n_contrib", "final_T"):
+                np.testing.assert_array_equal(e[k], prev[2][k])
+        prev = (out, radii, e)
     np.testing.assert_array_equal(radii.cpu().numpy(), f["radii"])
     img = out.cpu().numpy()
     assert_image_parity(img, f["color"])
@@ -87,6 +97,24 @@ def test_forward_equal_depth_ties_keep_gaussian_order():
     assert np.count_nonzero((k[1:] >> np.uint64(32)) == (k[:-1] >> np.uint64(32))) > 50
 
 
+def test_forward_all_depths_equal_one_bucket_takes_the_chunked_sort():
+    """Every Gaussian at the same depth: the depth ranking's bucket map puts all of them into ONE bucket, far longer than a sort
+    chunk (-> chunk sorts + global merge passes), and the order inside every tile list is the Gaussian index alone."""
+    cam, means, cov6, colors, op = small_scene(seed=25, P=5000, H=64, W=64, opacity=0.5, scale=0.02)
+    K = np.array([[60.0, 0, 32], [0, 60.0, 32], [0, 0, 1]], np.float32)
+    E = np.eye(4, dtype=np.float32); E[2, 3] = 3.0
+    cam = og.camera_from_KE(K, E, 64, 64)
+    means[:, 2] = 0.25
+    _, f, e = _compare_forward(cam, means, cov6, colors, op)
+    assert np.unique(e["keys"] >> np.uint64(32)).size == 1
+    tb = e["tile_base"].astype(np.int64)
+    for t in np.nonzero(np.diff(tb) > 1)[0][:50]:
+        assert np.all(np.diff(e["point_list"][tb[t]:tb[t + 1]].astype(np.int64)) > 0)
+    # two depth values, the nearer one on the higher indices
+    means[2500:, 2] = 0.2
+    _compare_forward(cam, means, cov6, colors, op)
+
+
 def test_forward_empty_and_culled():
     from gpu_util import hip_forward
     cam, means, cov6, colors, op = small_scene(seed=23, P=64, H=32, W=32)
@@ -114,14 +142,18 @@ def test_pair_buffer_overflow_is_loud():
     assert torch.isnan(out).all()
 
 
+@pytest.mark.parametrize("sort_mode", [1, 2])
 @pytest.mark.parametrize("C", [3, 4])
-def test_backward_matches_oracle(C):
+def test_backward_matches_oracle(C, sort_mode):
     from gpu_util import hip_forward
+    from gomavatar_amd import _lib, rasterizer as R
     cam, means, cov6, colors, op = small_scene(seed=31, P=1200, H=64, W=64, opacity=(0.3, 1.0), scale=0.05, C=C)
     cam["bg"] = np.array([0.2, 0.5, 0.1, 0.4], np.float32)
     rng = np.random.default_rng(1)
     wimg = rng.normal(size=(C, 64, 64)).astype(np.float32)
-    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True)
+    st0 = R.RasterState()
+    st0.set_option(_lib.OPT_SORT_MODE, sort_mode)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True, state=st0)
     (out * torch.from_numpy(wimg).cuda()).sum().backward()
     f = orast.forward(cam, means, cov6, colors, op, dtype=np.float64)
     g = orast.backward(f, wimg.astype(np.float64))
