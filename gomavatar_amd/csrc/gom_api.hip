@@ -50,7 +50,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->srt_rec, s->rank_of, s->keys32, s->tile_qlim, s->work_small, s->work_big};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -115,7 +115,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const int cap = P + P / 8 + 256;
         if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
             grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap) || grow(&s->bkeys, cap) || grow(&s->bkeys_scratch, cap) ||
-            grow(&s->srt_rec, (size_t)cap * 3) || grow(&s->rank_of, cap))
+            grow(&s->rec_g, (size_t)cap * 3) || grow(&s->order, cap) || grow(&s->rank_of, cap))
             return -2;
         s->capP = cap;
     }
@@ -138,8 +138,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     }
     if (tiles > s->capTiles) {
         if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||
-            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1) || grow(&s->tile_qlim, tiles) || grow(&s->work_small, tiles) ||
-            grow(&s->work_big, tiles))
+            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1) || grow(&s->tile_qlim, tiles))
             return -2;
         GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
         s->capTiles = tiles;
@@ -161,6 +160,13 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
             return -2;
         s->capPairs = want;
         s->capSegs = 0;
+    }
+    {
+        const int64_t wantItems = s->capTiles + s->capPairs / GOM_RANK_WIN + 1;
+        if (wantItems > s->capItems) {
+            if (grow(&s->work_items, (size_t)wantItems)) return -2;
+            s->capItems = wantItems;
+        }
     }
     // every tile has at most count/GOM_SEG + 1 segments
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
@@ -207,7 +213,8 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         s->P = P; s->H = cam->H; s->W = cam->W; s->cams = cams;
         // Tile-list order: rank the frame's Gaussians by depth once + a linear bitmap pass per tile (raster_rank.hip), unless
         // the frame's bitmap would not fit in LDS (P > 2^19) or the caller asked for the per-tile merge sort.
-        s->rankSort = s->sortMode == 2 || (s->sortMode == 0 && P <= (1 << 18));
+        const bool rank_fits = (int64_t)s->gx * s->gy * B < (1 << 24);   // (k_tile_rank's work items carry the tile in 24 bits)
+        s->rankSort = rank_fits && (s->sortMode == 2 || (s->sortMode == 0 && P <= (1 << 18)));
         if (s->rankSort && P > 393216) { gom_set_error("GOM_OPT_SORT_MODE 2 needs P <= 393216 per frame (the frame's rank bitmap lives in 64 KiB of LDS)"); return -1; }
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
         if (s->rankSort) {

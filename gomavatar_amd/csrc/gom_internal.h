@@ -9,6 +9,7 @@
 
 #define GOM_TILE 16
 #define GOM_SORT_CAP_MAX 8192       // tile-list entries sortable in LDS (64 KiB of 64-bit keys)
+#define GOM_RANK_WIN 2048           // list positions per work item of k_tile_rank (raster_rank.hip)
 #define GOM_SORT_SMALL 2048         // lists up to this length are sorted by the 256-thread instantiation of k_sort
 #define GOM_PARTIAL_STRIDE 12       // floats per (tile, gaussian) partial-gradient record (10 used)
 #ifndef GOM_SEG
@@ -32,8 +33,8 @@ struct GomDevStatus {
     // The splat preprocess allocates from 8 cursors, one per eighth of pair_pos, 128 bytes apart: a single device-scope word takes
     // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
     uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
-    uint32_t n_work_small, n_work_big;   // lengths of the work lists of k_tile_rank
-    uint32_t pad_[25];
+    uint32_t n_work_items;     // length of the work list of k_tile_rank
+    uint32_t pad_[26];
     uint32_t shard_cursor[8][32];   // [shard][0] used
 };
 
@@ -83,7 +84,8 @@ struct GomState {
     uint32_t *tile_cursor = nullptr;
     uint32_t *tile_nmax = nullptr;    // max n_contrib over the tile's pixels (entries beyond it are dead for backward)
     uint32_t *tile_qlim = nullptr;    // 1 + packed depth rank of the tile's last contributing entry (0: none): liveness test of the per-Gaussian backward
-    uint32_t *work_small = nullptr, *work_big = nullptr;   // [tiles] non-empty tiles with short / long lists (scan kernel -> k_tile_rank)
+    uint32_t *work_items = nullptr;   // [tiles + capPairs / GOM_RANK_WIN] (tile | window << 24) items of k_tile_rank, listed by the scan kernel
+    int64_t capItems = 0;
     uint32_t *seg_base = nullptr;     // [tiles+1] exclusive scan of ceil(count/GOM_SEG)
     // per gaussian: start of its private range in pair_pos
     uint32_t *pair_off = nullptr;
@@ -119,7 +121,8 @@ struct GomState {
     uint32_t *depth_minmax = nullptr; // [capFrames = frames x preprocess blocks][2] bit patterns of the min / max visible depth of a block
     uint32_t *bucket_count = nullptr, *bucket_base = nullptr, *bucket_cursor = nullptr;   // [capBuckets (+1)]
     uint64_t *bkeys = nullptr, *bkeys_scratch = nullptr;   // [capP] (depth_bits << 32 | index in frame), bucket-major
-    float4 *srt_rec = nullptr;        // [capP][3] 48-byte record of a Gaussian (geometry, id, depth bits, rect, record slots) in packed rank order
+    float4 *rec_g = nullptr;          // [capP][3] 48-byte record of a Gaussian: (x, y, conic a, b) (conic c, opacity, -, depth bits) (rect lo, rect hi, pair_off, -)
+    uint32_t *order = nullptr;        // [capP] Gaussian at packed depth rank q
     uint32_t *rank_of = nullptr;      // [capP] packed rank of a (visible) Gaussian
     uint32_t *keys32 = nullptr;       // [capPairs] emitted ranks, tile-major
     float *final_T = nullptr;

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
-                                                    int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax) {
+                                                    int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax,
+                                                    float4 *__restrict__ rec_g) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_dmin[4], s_dmax[4];
@@ -124,11 +125,14 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         means += 3 * go; cov6 += 6 * go; opacity += go; depth += go; xy += go; conic_opacity += go; tiles_touched += go;
         rect += go; radii += go; pair_off += go;
         if (radii_user) radii_user += go;
+        if (rec_g) rec_g += 3 * go;
         tile_count += (size_t)fr * n_tiles;
     }
     const int ty_off = fr * gy;  // tile rows of this frame in the stacked grid
-    uint32_t my_tiles = 0;
+    uint32_t my_tiles = 0, my_rlo = 0, my_rhi = 0;
     float my_depth = 0.f;
+    float4 my_r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 my_r1 = make_float2(0.f, 0.f);
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
         __syncthreads();
@@ -193,6 +197,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         my_tiles = o_tiles;
         my_depth = o_depth;
         rect[i] = make_ushort4((unsigned short)x0, (unsigned short)(y0 + ty_off), (unsigned short)x1, (unsigned short)(y1 + ty_off));
+        my_r0 = make_float4(o_x, o_y, o_cx, o_cy);
+        my_r1 = make_float2(o_cz, o_op);
+        my_rlo = (uint32_t)x0 | ((uint32_t)(y0 + ty_off) << 16);
+        my_rhi = (uint32_t)x1 | ((uint32_t)(y1 + ty_off) << 16);
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
                 if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
@@ -240,7 +248,16 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         __syncthreads();
         uint32_t woff = 0;
         for (int w = 0; w < wid; w++) woff += s_wsum[w];
-        if (i < P) pair_off[i] = s_blockbase + woff + (x - my_tiles);
+        if (i < P) {
+            const uint32_t po = s_blockbase + woff + (x - my_tiles);
+            pair_off[i] = po;
+            if (rec_g) {   // everything the tile pass of the depth ranking needs of this Gaussian, in one 48-byte record
+                float4 *d = rec_g + 3 * (size_t)i;
+                d[0] = my_r0;
+                d[1] = make_float4(my_r1.x, my_r1.y, 0.f, my_depth);
+                d[2] = make_float4(__uint_as_float(my_rlo), __uint_as_float(my_rhi), __uint_as_float(po), 0.f);
+            }
+        }
     }
     if (LDS_HIST) {
         for (int t = threadIdx.x; t < n_tiles; t += 256) {
@@ -281,10 +298,10 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
                                                      GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift,
                                                      uint32_t *__restrict__ bucket_count, uint32_t *__restrict__ bucket_base,
                                                      uint32_t *__restrict__ bucket_cursor, int n_buckets,
-                                                     uint32_t *__restrict__ work_small, uint32_t *__restrict__ work_big, uint32_t small_max) {
+                                                     uint32_t *__restrict__ work_items) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
-    uint32_t carry = 0, seg_carry = 0, ws_carry = 0, wb_carry = 0;
+    uint32_t carry = 0, seg_carry = 0, wi_carry = 0;
     // 8 consecutive tiles per thread and trip: a batched launch (8 192 tiles at 8 x 512x512) is ONE trip = one load latency and
     // two block scans, where one tile per thread took eight dependent trips (20 us of a single workgroup's latency chain).
     constexpr int kPer = 8;
@@ -340,20 +357,16 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
         carry += tot;
         seg_carry += stot;
-        if (work_small) {   // non-empty tiles by list length -> the two work lists of k_tile_rank (tile order kept)
-            uint32_t cs = 0, cb = 0;
+        if (work_items) {   // work items of k_tile_rank: (tile | window << 24) for every window of GOM_RANK_WIN list positions of a non-empty tile
+            uint32_t ci = 0;
 #pragma unroll
-            for (int k = 0; k < kPer; k++) { cs += (v[k] != 0u && v[k] <= small_max) ? 1u : 0u; cb += v[k] > small_max ? 1u : 0u; }
-            uint32_t ts, tb;
-            uint32_t ps = ws_carry + block_excl_scan_1024(cs, s_wave, ts);
-            uint32_t pb = wb_carry + block_excl_scan_1024(cb, s_wave, tb);
+            for (int k = 0; k < kPer; k++) ci += (v[k] + GOM_RANK_WIN - 1u) / GOM_RANK_WIN;
+            uint32_t ti;
+            uint32_t pi = wi_carry + block_excl_scan_1024(ci, s_wave, ti);
 #pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                if (v[k] != 0u && v[k] <= small_max) work_small[ps++] = (uint32_t)(i0 + k);
-                else if (v[k] > small_max) work_big[pb++] = (uint32_t)(i0 + k);
-            }
-            ws_carry += ts;
-            wb_carry += tb;
+            for (int k = 0; k < kPer; k++)
+                for (uint32_t w = 0; w * GOM_RANK_WIN < v[k]; w++) work_items[pi++] = (uint32_t)(i0 + k) | (w << 24);
+            wi_carry += ti;
         }
     }
     // depth ranking (raster_rank.hip): exclusive scan of the (frame, bucket) counts = packed ranks at which the buckets start
@@ -384,8 +397,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         status->num_segs = over ? 0u : seg_carry;
         status->pair_cursor = 0;
         status->shard_overflow = 0;
-        status->n_work_small = over ? 0u : ws_carry;
-        status->n_work_big = over ? 0u : wb_carry;
+        status->n_work_items = over ? 0u : wi_carry;
         for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
@@ -620,11 +632,11 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     if (n_tiles <= GOM_LDS_TILE_LIMIT)
         hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), n_tiles * sizeof(uint32_t), st, cam, s->cams, P, means3D, cov6,
                            opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
-                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr);
+                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr);
     else
         hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, opacity, s->depth,
                            s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
-                           s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr);
+                           s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -638,7 +650,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank) {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
                            s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
-                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_small : nullptr, s->work_big, gom_sort_small_max(s));
+                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;

@@ -12,12 +12,12 @@
 //   k_bucket_scatter  map: every key of bucket b precedes every key of bucket b + 1); counts, then (after the scan kernel)
 //                     (depth_bits << 32 | index) keys scattered into the bucket's range.
 //   k_bucket_sort     per bucket (~200 keys): merge sort in registers + LDS -> rank q of every visible Gaussian in the
-//                     packed (frame, depth, index) order, and its record (geometry, rect, record slots) stored AT q.
+//                     packed (frame, depth, index) order: order[q] = Gaussian, rank_of[Gaussian] = q.
 //   k_emit<RANK>      (raster_pre.hip) writes q instead of a 64-bit key into the tile's range, in arbitrary order.
 //   k_tile_rank       per tile: the ranks of its entries set bits of a P-bit bitmap in LDS; a popcount scan turns the bitmap
-//                     into the sorted list; the entries' records are gathered at ascending q and written in LIST order
-//                     (point_list, keys, ent_geo, ent_slot, pair_pos, segment descriptors).  No comparison, no log factor,
-//                     no limit on the list length.
+//                     into the sorted list; the entries' 48-byte records (rec_g, left by k_preprocess) are gathered through
+//                     order[] and written in LIST order (point_list, ent_geo, ent_slot, segment descriptors).  No comparison,
+//                     no log factor, no limit on the list length.
 //
 // The result is bit-identical to the per-tile sort (tests/test_gpu_raster.py runs both and compares every integer output with
 // the oracle).  Buckets longer than one sort chunk (degenerate depth distributions: a plane facing the camera) take the
@@ -120,61 +120,55 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, cons
     if (vis) bkeys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = ((uint64_t)dbits << 32) | (uint32_t)il;   // index INSIDE the frame: ties keep Gaussian order
 }
 
-// ---- per bucket: sort, then the records in rank order ---------------------------------------------------------------
-// srt_rec [q][3] float4 : (x, y, conic a, conic b) (conic c, opacity, bits of the global Gaussian id, depth bits)
-//                         (bits of: rect xmin | ymin << 16, rect xmax | ymax << 16, start of the record slots, 0)
-// -- ONE contiguous 48-byte record per rank: the tile pass gathers it with three 16-byte loads from one or two cache lines
-// (three separate arrays were three lines per entry).  Tile rows of the rect are stacked over the frames.
-__global__ void __launch_bounds__(256) k_bucket_sort(int P, uint32_t nb, const uint32_t *__restrict__ bucket_base, uint64_t *__restrict__ bkeys,
-                                                     uint64_t *__restrict__ scratch, const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
-                                                     const ushort4 *__restrict__ rect, const uint32_t *__restrict__ pair_off,
-                                                     float4 *__restrict__ srt_rec, uint32_t *__restrict__ rank_of, uint32_t log_chunk,
-                                                     const GomDevStatus *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * 256];
+// ---- per bucket: sort -> rank of every visible Gaussian ---------------------------------------------------------------
+// order[q] = global Gaussian id at packed rank q, rank_of[g] = q.  Nothing else moves here: the tile pass fetches a Gaussian's
+// 48-byte record (rec_g, written by k_preprocess in Gaussian order) through order[] -- the entries of one tile are neighbours on
+// the mesh, so their records are neighbours in memory, where a copy in rank order (first version: 113 MB of sector traffic to
+// build it, 30 us) scattered them by depth.  A bucket is ~200 keys: 2-wave workgroups, 8 keys per thread.
+#define GOM_BSORT_NT 128
+__global__ void __launch_bounds__(GOM_BSORT_NT) k_bucket_sort(int P, uint32_t nb, const uint32_t *__restrict__ bucket_base, uint64_t *__restrict__ bkeys,
+                                                              uint64_t *__restrict__ scratch, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
+                                                              uint32_t log_chunk, const GomDevStatus *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * GOM_BSORT_NT];
     const int fr = blockIdx.y;
     if (status->overflow) return;
     const uint32_t base = bucket_base[(size_t)fr * nb + blockIdx.x];
     const uint32_t n = bucket_base[(size_t)fr * nb + blockIdx.x + 1] - base;
     if (n == 0) return;
+    const uint32_t go = (uint32_t)fr * (uint32_t)P;
     uint64_t x[8];
     bool in_regs;
-    const uint64_t *sorted = block_sort_any<256>(bkeys + base, scratch + base, n, s_x, log_chunk, x, in_regs);
-    if (in_regs) {   // blocked registers -> LDS, so that the loop below is striped (coalesced writes)
+    const uint64_t *sorted = block_sort_any<GOM_BSORT_NT>(bkeys + base, scratch + base, n, s_x, log_chunk, x, in_regs);
+    if (in_regs) {   // blocked registers: thread t holds positions 8t .. 8t+7
 #pragma unroll
-        for (int r = 0; r < 8; r += 2)
-            if (8 * threadIdx.x + r < ((n + 7u) & ~7u)) *reinterpret_cast<ulonglong2 *>(s_x + 8 * threadIdx.x + r) = make_ulonglong2(x[r], x[r + 1]);
-        __syncthreads();
-        sorted = s_x;
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = 8 * threadIdx.x + r;
+            if (i < n) {
+                const uint32_t g = go + (uint32_t)x[r];
+                order[base + i] = g;
+                rank_of[g] = base + i;
+            }
+        }
+        return;
     }
-    const size_t go = (size_t)fr * P;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint64_t key = sorted[i];
-        const uint32_t il = (uint32_t)key;
-        const size_t g = go + il;
-        const uint32_t q = base + i;
-        const float2 c = xy[g];
-        const float4 co = conic_opacity[g];
-        const ushort4 rc = rect[g];
-        const uint32_t po = pair_off[g];
-        float4 *d = srt_rec + 3 * (size_t)q;
-        d[0] = make_float4(c.x, c.y, co.x, co.y);
-        d[1] = make_float4(co.z, co.w, __uint_as_float((uint32_t)g), __uint_as_float((uint32_t)(key >> 32)));
-        d[2] = make_float4(__uint_as_float((uint32_t)rc.x | ((uint32_t)rc.y << 16)), __uint_as_float((uint32_t)rc.z | ((uint32_t)rc.w << 16)), __uint_as_float(po), 0.f);
-        rank_of[g] = q;
+    for (uint32_t i = threadIdx.x; i < n; i += GOM_BSORT_NT) {
+        const uint32_t g = go + (uint32_t)sorted[i];
+        order[base + i] = g;
+        rank_of[g] = base + i;
     }
 }
 
 // ---- per tile: bitmap of ranks -> sorted list -> records in list order -------------------------------------------------
-// The scan kernel left the non-empty tiles in two work lists: lists of up to `small_max` entries (NT = 256 workgroups) and longer
-// ones (NT = 1024: a list of 5 000 entries is 2 trips of the 4-deep loops below instead of 20 dependent ones).  Each launch is
-// a resident grid striding over its list -- four fifths of a body frame's tiles are empty, and a workgroup per tile that only
-// finds that out cost more than the work itself.
-#define GOM_RANK_STAGE 4096   // sorted ranks staged in LDS per window (lists longer than this take several windows)
+// Work item = (non-empty tile, window of GOM_RANK_WIN consecutive list positions), listed by the scan kernel: four fifths of a
+// body frame's tiles are empty (a workgroup per tile that only finds that out cost more than the work), and a 5 000-entry list
+// becomes three items of the same size as everybody else's instead of one long chain.  Every item of a tile rebuilds the tile's
+// whole bitmap (4 bytes per entry from L2) and writes only its own window.  One resident grid strides over the items.
 template <int NT>
 __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ seg_base,
                                                   const uint32_t *__restrict__ work, const uint32_t *__restrict__ n_work_p,
                                                   const uint32_t *__restrict__ keys32, const uint32_t *__restrict__ bucket_base,
-                                                  const float4 *__restrict__ srt_rec, uint32_t *__restrict__ point_list, uint4 *__restrict__ seg_desc,
+                                                  const uint32_t *__restrict__ order, const float4 *__restrict__ rec_g,
+                                                  uint32_t *__restrict__ point_list, uint4 *__restrict__ seg_desc,
                                                   uint32_t *__restrict__ ent_slot, float2 *__restrict__ ent_geo,
                                                   const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words) {
     extern __shared__ uint32_t s_mem[];
@@ -184,12 +178,17 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
     const uint32_t n_work = *n_work_p;
     const uint32_t t = threadIdx.x, lane = t & 63u, wid = t >> 6;
     for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-        const int tile = (int)work[wi];
+        const uint32_t item = work[wi];
+        const int tile = (int)(item & 0xffffffu);
+        const uint32_t c0 = (item >> 24) * GOM_RANK_WIN;
         const uint32_t base = tile_base[tile];
         const uint32_t n = tile_base[tile + 1] - base;
-        const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
-        for (uint32_t i = t; i < nseg; i += NT)
-            seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
+        const uint32_t c1 = min(n, c0 + GOM_RANK_WIN);
+        if (c0 == 0) {
+            const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
+            for (uint32_t i = t; i < nseg; i += NT)
+                seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
+        }
         const int fr = tile / (gx * gy);
         const int tx = tile % gx, ty = tile / gx;                 // ty: row in the STACKED grid (rects carry the same offset)
         const uint32_t fs = bucket_base[(size_t)fr * nb];         // first packed rank of this frame
@@ -197,12 +196,12 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
         const uint32_t W = (nvis + 31u) >> 5;                     // (<= bm_words: at most P visible Gaussians per frame)
         for (uint32_t w = t; w < W; w += NT) s_bm[w] = 0u;
         __syncthreads();
-        for (uint32_t i0 = t; i0 < n; i0 += 4 * NT) {            // 4 independent loads in flight per thread
-            uint32_t r[4];
+        for (uint32_t i0 = t; i0 < n; i0 += 8 * NT) {            // 8 independent loads in flight per thread
+            uint32_t r[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) r[u] = i0 + u * NT < n ? keys32[base + i0 + u * NT] - fs : 0xffffffffu;
+            for (int u = 0; u < 8; u++) r[u] = i0 + u * NT < n ? keys32[base + i0 + u * NT] - fs : 0xffffffffu;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < 8; u++)
                 if (r[u] != 0xffffffffu) atomicOr(&s_bm[r[u] >> 5], 1u << (r[u] & 31u));   // ranks of one frame are unique, a Gaussian is in a tile list once
         }
         __syncthreads();
@@ -221,47 +220,49 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
         __syncthreads();
         uint32_t first = incl - mine;
         for (uint32_t w = 0; w < wid; w++) first += s_wsum[w];
-        for (uint32_t c0 = 0; c0 < n; c0 += GOM_RANK_STAGE) {
-            const uint32_t c1 = min(n, c0 + GOM_RANK_STAGE);
-            if (first < c1 && first + mine > c0) {   // some of my bits fall into this window
-                uint32_t pos = first;
-                for (uint32_t w = w0; w < w1 && pos < c1; w++) {
-                    uint32_t bits = s_bm[w];
-                    while (bits) {
-                        const uint32_t bit = __ffs(bits) - 1u;
-                        bits &= bits - 1u;
-                        if (pos >= c0 && pos < c1) s_stage[pos - c0] = (w << 5) | bit;
-                        pos++;
-                    }
+        if (first < c1 && first + mine > c0) {   // some of my bits fall into this item's window
+            uint32_t pos = first;
+            for (uint32_t w = w0; w < w1 && pos < c1; w++) {
+                uint32_t bits = s_bm[w];
+                while (bits) {
+                    const uint32_t bit = __ffs(bits) - 1u;
+                    bits &= bits - 1u;
+                    if (pos >= c0 && pos < c1) s_stage[pos - c0] = (w << 5) | bit;
+                    pos++;
                 }
             }
-            __syncthreads();
-            const uint32_t cnt = c1 - c0;
-            for (uint32_t i0 = t; i0 < cnt; i0 += 4 * NT) {       // 4 entries per trip: their record gathers are issued before the first store
-                float4 r0[4], r1[4], r2[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + u * NT;
-                    const float4 *rec = srt_rec + 3 * (size_t)(fs + s_stage[i < cnt ? i : i0]);
-                    r0[u] = rec[0]; r1[u] = rec[1]; r2[u] = rec[2];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + u * NT;
-                    if (i < cnt) {
-                        const uint32_t li = base + c0 + i;
-                        const uint32_t rlo = __float_as_uint(r2[u].x), rhi = __float_as_uint(r2[u].y), po = __float_as_uint(r2[u].z);
-                        const uint32_t rx0 = rlo & 0xffffu, ry0 = rlo >> 16, rx1 = rhi & 0xffffu;
-                        const uint32_t k = ((uint32_t)ty - ry0) * (rx1 - rx0) + ((uint32_t)tx - rx0);
-                        point_list[li] = __float_as_uint(r1[u].z);
-                        ent_slot[li] = po + k;
-                        float2 *dst = ent_geo + 3 * (size_t)li;
-                        dst[0] = make_float2(r0[u].x, r0[u].y); dst[1] = make_float2(r0[u].z, r0[u].w); dst[2] = make_float2(r1[u].x, r1[u].y);
-                    }
-                }
-            }
-            __syncthreads();   // stage and bitmap are re-used by the next window / tile
         }
+        __syncthreads();
+        const uint32_t cnt = c1 - c0;
+        for (uint32_t i0 = t; i0 < cnt; i0 += 4 * NT) {       // 4 entries per trip: their record gathers are issued before the first store
+            float4 r0[4], r1[4], r2[4];
+            uint32_t g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * NT;
+                g4[u] = order[fs + s_stage[i < cnt ? i : i0]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4 *rec = rec_g + 3 * (size_t)g4[u];
+                r0[u] = rec[0]; r1[u] = rec[1]; r2[u] = rec[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * NT;
+                if (i < cnt) {
+                    const uint32_t li = base + c0 + i;
+                    const uint32_t rlo = __float_as_uint(r2[u].x), rhi = __float_as_uint(r2[u].y), po = __float_as_uint(r2[u].z);
+                    const uint32_t rx0 = rlo & 0xffffu, ry0 = rlo >> 16, rx1 = rhi & 0xffffu;
+                    const uint32_t k = ((uint32_t)ty - ry0) * (rx1 - rx0) + ((uint32_t)tx - rx0);
+                    point_list[li] = g4[u];
+                    ent_slot[li] = po + k;
+                    float2 *dst = ent_geo + 3 * (size_t)li;
+                    dst[0] = make_float2(r0[u].x, r0[u].y); dst[1] = make_float2(r0[u].z, r0[u].w); dst[2] = make_float2(r1[u].x, r1[u].y);
+                }
+            }
+        }
+        __syncthreads();   // stage and bitmap are re-used by the next item
     }
 }
 
@@ -287,9 +288,10 @@ int gom_launch_depth_rank(GomState *s, int P, hipStream_t st) {
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->depth_minmax,
                        s->bucket_cursor, s->bkeys);
     GOM_LAUNCH_CHECK();
-    const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < 2048 ? s->sortCap : 2048)));
-    hipLaunchKernelGGL(k_bucket_sort, dim3(nb, s->B), dim3(256), 0, st, P, nb, s->bucket_base, s->bkeys, s->bkeys_scratch, s->xy, s->conic_opacity, s->rect,
-                       s->pair_off, s->srt_rec, s->rank_of, lc, s->status);
+    const int cap = 8 * GOM_BSORT_NT;
+    const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < cap ? s->sortCap : cap)));
+    hipLaunchKernelGGL(k_bucket_sort, dim3(nb, s->B), dim3(GOM_BSORT_NT), 0, st, P, nb, s->bucket_base, s->bkeys, s->bkeys_scratch, s->order, s->rank_of, lc,
+                       s->status);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -311,15 +313,11 @@ int gom_launch_tile_rank(GomState *s, hipStream_t st) {
     GomKernelTimer timer(s, GOM_K_SORT, st);
     const uint32_t nb = 1u << s->nbShift;
     const uint32_t bm_words = ((uint32_t)s->P + 31u) >> 5;
-    const size_t lds = (bm_words + GOM_RANK_STAGE) * sizeof(uint32_t);
-    // resident grids striding over the work lists of the scan kernel (gom_sort_small_max: which list a tile is on)
-    const int g_small = n_tiles < 2048 ? n_tiles : 2048, g_big = n_tiles < 512 ? n_tiles : 512;
-#define GOM_TR(NT, GRID, WORK, NWORK) hipLaunchKernelGGL((k_tile_rank<NT>), dim3(GRID), dim3(NT), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, WORK, NWORK, \
-                                                         s->keys32, s->bucket_base, s->srt_rec, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status,       \
-                                                         (uint32_t)s->segShift, bm_words)
-    if (gom_sort_small_max(s)) { GOM_TR(256, g_small, s->work_small, &s->status->n_work_small); GOM_LAUNCH_CHECK(); }
-    GOM_TR(1024, g_big, s->work_big, &s->status->n_work_big);
-#undef GOM_TR
+    const size_t lds = (bm_words + GOM_RANK_WIN) * sizeof(uint32_t);
+    const int cap_items = n_tiles + (int)(s->capPairs / GOM_RANK_WIN < 0x7fffffff ? s->capPairs / GOM_RANK_WIN : 0x7fffffff);
+    const int grid = cap_items < 2048 ? cap_items : 2048;   // a resident grid striding over the work items of the scan kernel
+    hipLaunchKernelGGL((k_tile_rank<256>), dim3(grid), dim3(256), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, s->work_items, &s->status->n_work_items,
+                       s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words);
     GOM_LAUNCH_CHECK();
     return 0;
 }
