@@ -81,6 +81,10 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value < 10 || value > 100) { gom_set_error("task grid share must be in [10, 100] percent"); return -1; }
             s->taskGridPct = (int)value;
             return 0;
+        case GOM_OPT_BWD_MODE:
+            if (value < 0 || value > 1) { gom_set_error("backward mode must be 0 (per segment) or 1 (per sub-range)"); return -1; }
+            s->bwdMode = (int)value;
+            return 0;
         case GOM_OPT_SORT_MODE:
             if (value < 0 || value > 2) { gom_set_error("sort mode must be 0 (auto), 1 (per-tile merge sort) or 2 (depth ranking)"); return -1; }
             s->sortMode = (int)value;

@@ -465,6 +465,9 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 // render backward left in `partial` (position found by binary search on the
 // unique sort key), then conic -> cov2D -> (cov3D, mean3D) and the projection
 // term of the screen-space mean gradient.
+#ifndef GOM_PB_W
+#define GOM_PB_W 4
+#endif
 template <int C, bool RANK>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
                                                         const float *__restrict__ cov6, const int32_t *__restrict__ radii,
@@ -501,29 +504,30 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         // beyond the tile's last contributor: about half of all pairs on a body (back-facing surface).  With the depth ranking that
         // is a comparison of the Gaussian's rank with the rank of the tile's last contributor (tile_qlim, from the forward's combine
         // pass); with the per-tile merge sort, of its list index (pair_pos) with tile_nmax.
-        // 8 records in flight per trip; fixed k order keeps the sum reproducible.
+        // GOM_PB_W records in flight per trip (a Gaussian touches 2.7 tiles on average: 4 covers nine in ten in one trip, and 8 cost
+        // twice the load instructions and 126 VGPRs for nothing); fixed k order keeps the sum reproducible.
         const uint32_t nt = tiles_touched[i];
         const uint32_t po = pair_off[i];
         const ushort4 rc = rect[i];
         const uint32_t rw = (uint32_t)(rc.z - rc.x);
         const uint32_t myq = RANK ? rank_of[(size_t)fr * P + i] : 0u;
-        for (uint32_t k0 = 0; k0 < nt; k0 += 8) {
-            bool live[8];
+        for (uint32_t k0 = 0; k0 < nt; k0 += GOM_PB_W) {
+            bool live[GOM_PB_W];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GOM_PB_W; u++) {
                 const uint32_t k = k0 + u < nt ? k0 + u : k0;
                 const uint32_t tile = ((uint32_t)rc.y + k / rw) * (uint32_t)gx + (uint32_t)rc.x + k % rw;   // (stacked tile rows: rect carries the frame offset)
                 live[u] = k0 + u < nt && (RANK ? myq < tile_qlim[tile] : pair_pos[po + k] - tile_base[tile] < tile_nmax[tile]);
             }
-            float4 q0[8], q1[8], q2[8];
+            float4 q0[GOM_PB_W], q1[GOM_PB_W], q2[GOM_PB_W];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GOM_PB_W; u++) {
                 // (a dead entry re-reads the Gaussian's first slot -- same cache line, no branch around the loads -- and is masked below)
                 const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)(po + (live[u] ? k0 + u : 0u)) * GOM_PARTIAL_STRIDE);
                 q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GOM_PB_W; u++) {
                 if (live[u]) {
                     acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
                     acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;

@@ -384,11 +384,14 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 //   * The last workgroup to leave zeroes the heads for the next launch (graph replays included).
 // ctr layout: head of shard x at ctr[32 * x], workgroups that have left at ctr[32 * 8].
 #define GOM_TQ_WORDS (32 * GOM_TQ_SHARDS + 32)
-struct TaskQueue {
+template <int PER_SEG>
+struct TaskQueueT {
     uint32_t *ctr;
     uint32_t nsegs, per_shard_wgs, shard, tried, pend, it;
-    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? 4u * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
-    __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const { return (((j >> 2) * GOM_TQ_SHARDS + x) << 2) | (j & 3u); }
+    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? (uint32_t)PER_SEG * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
+    __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const {
+        return PER_SEG == 4 ? ((((j >> 2) * GOM_TQ_SHARDS + x) << 2) | (j & 3u)) : j * GOM_TQ_SHARDS + x;   // 4 pieces of a segment, or the segment itself
+    }
     // thread 0 only: local index j on the current shard -> task, moving to the next shards while the current one is empty
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {
         while (j >= shard_tasks(shard)) {
@@ -409,7 +412,7 @@ struct TaskQueue {
     __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
         if (!ctr) {
             const uint32_t t = blockIdx.x + it * gridDim.x;
-            return t < nsegs * 4u ? t : 0xffffffffu;
+            return t < nsegs * (uint32_t)PER_SEG ? t : 0xffffffffu;
         }
         return s_task[it & 1];
     }
@@ -426,6 +429,8 @@ struct TaskQueue {
         }
     }
 };
+
+using TaskQueue = TaskQueueT<4>;
 
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
@@ -894,7 +899,10 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             // checkpoint: state just behind this sub-range (T there; colour still to come = behind the segment
             // + the later pieces of this segment, smallest terms first)
             float T = sub_Tend[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi];
-            float accum_rec[C], last_color[C], last_alpha = 0.f;
+            // App. A.4 keeps accum_rec[ch] / last_color[ch] per channel, but they only ever meet the gradient through their dot product
+            // with this pixel's dL/dpix: the recurrence is linear, so it is carried as two scalars R = accum_rec . dpix and
+            // U_last = last_color . dpix (half the instructions of the serial chain, six registers fewer).
+            float R_acc, U_last = 0.f, last_alpha = 0.f;
             float S[C], cu[GOM_NSUB][C];
             ld4<C>(seg_Sbehind, seg, pxi, S);
 #pragma unroll
@@ -911,10 +919,11 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) S[ch] += cu[u][ch];
                 }
+            {
+                float sd = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                accum_rec[ch] = S[ch] * invT;
-                last_color[ch] = 0.f;
+                for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
+                R_acc = sd * invT;
             }
             unsigned long long mask = __ballot(r.keep);
             s_e0[q][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
@@ -958,15 +967,15 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);  // v_rcp_f32 (1 ulp), shared by both divisions
                     T = T * inv1ma;
                     const float w = a * T;
-                    float dL_dalpha = 0.f, v[NV];
+                    float v[NV], U = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) {
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = ecol[u][ch];
-                        dL_dalpha += (ecol[u][ch] - accum_rec[ch]) * dpix[ch];
+                        U += ecol[u][ch] * dpix[ch];
                         v[ch] = w * dpix[ch];
                     }
-                    dL_dalpha *= T;
+                    R_acc = last_alpha * U_last + (1.f - last_alpha) * R_acc;
+                    U_last = U;
+                    float dL_dalpha = (U - R_acc) * T;
                     last_alpha = a;
                     dL_dalpha += (-T_final * inv1ma) * bg_dot;
                     const float Q = G0[u] * dL_dalpha;
@@ -1021,6 +1030,210 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
         g_wg_t1[blockIdx.x] = wall_clock64();
     }
 #endif
+}
+
+// ------------------------------------------------ backward, one task per SEGMENT -
+// Same replay as k_seg_bwd, other task shape: a workgroup takes a whole segment (its 4 waves = the 4 quadrants) and every wave
+// walks the segment's sub-ranges back to front in ONE pass, carrying T and the accum_rec scalar in registers from piece to piece.
+// What that removes from k_seg_bwd (whose waves were parked at s_waitcnt / s_barrier for 64 % of their cycles, SQ_WAIT_ANY):
+//   * the per-pixel state (n_contrib, final_T, dL/dpix, background term) is loaded once per segment, not once per sub-range;
+//   * the checkpoint is the segment's (seg_Tend, seg_Sbehind); the per-sub-range ones (sub_Tend, up to three sub_C rows) are
+//     neither read here nor written by the forward any more;
+//   * the entries of the NEXT sub-range are loaded while the current one is replayed (the loads of a 64-entry piece used to be a
+//     dependent round trip at the start of every task);
+//   * a quarter of the queue round trips, descriptor loads and dead-task checks.
+// One barrier per live sub-range remains: the four quadrants' partial sums of an entry meet in LDS (s_acc, double-buffered by
+// piece parity as before) so that ONE record per (tile, entry) is written.
+#ifndef GOM_BWDS_WAVES
+#define GOM_BWDS_WAVES 5   // (6 waves per SIMD = an 80-register budget: 21 of them would spill)
+#endif
+template <int C>
+__global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+                                                  const GomCamera *__restrict__ cams,
+                                                  const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
+                                                  const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
+                                                  const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                  const float *__restrict__ dL_dpix, const float *__restrict__ seg_Tend,
+                                                  const float *__restrict__ seg_Sbehind,
+                                                  const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
+                                                  uint32_t *__restrict__ task_ctr) {
+    constexpr int NV = 6 + C;
+    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
+    __shared__ unsigned long long s_done[2][4];
+    __shared__ uint32_t s_task[2];
+    __shared__ float4 s_e0[4][64];
+    __shared__ float2 s_e1[4][64];
+    const uint32_t sub_sz = (1u << seg_shift) >> 2;
+    if (status->overflow) return;
+    const uint32_t nsegs = status->num_segs;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int pxi = q * 64 + lane;
+    const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);
+    const size_t HW = (size_t)H * W;
+    uint32_t piece = 0;   // parity of the s_acc buffer: counts live pieces over the whole life of the workgroup
+    TaskQueueT<1> tq;
+    for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
+        const uint32_t seg = tq.current(s_task);
+        if (seg == 0xffffffffu) break;
+        const uint4 d = seg_desc[seg];
+        const uint4 qm4 = seg_qmax[seg];
+        const uint32_t tile = d.x, start = d.y, cnt = d.z;
+        const uint32_t e0 = d.w << seg_shift;
+        const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
+        if (e0 >= tmax) {   // every pixel of the tile finished before this segment: nothing is written (the per-Gaussian backward skips these entries)
+            tq.request();
+            tq.publish(s_task);
+            __syncthreads();
+            continue;
+        }
+        const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));
+        const bool mine = wmax > e0;                        // my quadrant still has contributors in this segment (wave-uniform)
+        const uint32_t lim = mine ? min(cnt, wmax - e0) : 0u;   // entries at or beyond wmax are dead for this wave
+        const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;
+        const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
+        const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        const size_t fpix = (size_t)fr * HW + pix;
+        const float pfx = (float)px, pfy = (float)py;
+        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+        const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
+        uint32_t my_last = 0;
+        float T_final = 0.f, dpix[C], bg_dot = 0.f, T = 0.f, R_acc = 0.f, U_last = 0.f, last_alpha = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) dpix[ch] = 0.f;
+        const int nsub = (int)((cnt + sub_sz - 1) / sub_sz);
+        const int top = (int)((min(cnt, tmax - e0) + sub_sz - 1) / sub_sz) - 1;   // last sub-range that is live for the tile (>= 0 here)
+        EntryRegs<C> rn;                                   // entries of the piece about to be replayed (lane = entry)
+        rn.keep = false;
+        if (mine) {
+            my_last = inside ? n_contrib[fpix] : 0u;
+            T_final = final_T[inside ? fpix : 0];
+            float bg[4] = {bg0, bg1, bg2, bg3};
+            if (cams) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
+            }
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                dpix[ch] = inside ? dL_dpix[((size_t)fr * C + ch) * HW + pix] : 0.f;
+                bg_dot += bg[ch] * dpix[ch];
+            }
+            T = seg_Tend[(size_t)seg * GOM_TPX + pxi];     // state just behind the segment
+            float S[C];
+            ld4<C>(seg_Sbehind, seg, pxi, S);
+            rn = load_sub<C>(ent_geo, ent_col, start, lim, top, lane, qx0, qy0, qx1, qy1, sub_sz);
+            float sd = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
+            R_acc = T > 0.f ? sd / T : 0.f;
+        }
+        tq.request();  // (behind the loads of this task)
+        (void)nsub;
+        for (int sub = top; sub >= 0; sub--) {
+            const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;
+            const uint32_t scnt = min(sub_sz, cnt - (uint32_t)sub * sub_sz);
+            const int buf = (int)(piece & 1u);
+            piece++;
+            const uint32_t my_slot = threadIdx.x < scnt ? ent_slot[start + (uint32_t)sub * sub_sz + threadIdx.x] : 0u;
+            const EntryRegs<C> r = rn;
+            const bool work = mine && wmax > s0;
+            if (mine && sub > 0) rn = load_sub<C>(ent_geo, ent_col, start, lim, sub - 1, lane, qx0, qy0, qx1, qy1, sub_sz);   // in flight during the replay below
+            unsigned long long done = 0ull;
+            if (work) {
+                unsigned long long mask = __ballot(r.keep);
+                s_e0[q][lane] = make_float4(r.x, r.y, r.a, r.b);
+                s_e1[q][lane] = make_float2(r.c, r.o);
+                while (mask) {
+                    int kk[GOM_BWD_EPT];
+                    bool kv[GOM_BWD_EPT];
+                    float al[GOM_BWD_EPT], G0[GOM_BWD_EPT], dxs[GOM_BWD_EPT], dys[GOM_BWD_EPT], ecol[GOM_BWD_EPT][C];
+#pragma unroll
+                    for (int u = 0; u < GOM_BWD_EPT; u++) {
+                        kv[u] = mask != 0ull;
+                        const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
+                        mask &= ~(1ull << k);
+                        kk[u] = k;
+                        const float4 g0 = s_e0[q][k];
+                        const float2 g1 = s_e1[q][k];
+                        const float eo = kv[u] ? g1.y : 0.f;
+                        const float dx = g0.x - pfx, dy = g0.y - pfy;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
+                        const float power = gauss_power(g0.z, g0.w, g1.x, dx, dy);
+                        const float g = __expf(power);
+                        float a = fminf(kMaxAlpha, eo * g);
+                        a = (power <= 0.f) ? a : 0.f;
+                        a = (a >= kMinAlpha) ? a : 0.f;
+                        a = (s0 + (uint32_t)k < my_last) ? a : 0.f;
+                        al[u] = a;
+                        G0[u] = (a > 0.f) ? g : 0.f;
+                        dxs[u] = dx;
+                        dys[u] = dy;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GOM_BWD_EPT; u++) {
+                        if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;
+                        const float a = al[u];
+                        const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);
+                        T = T * inv1ma;
+                        const float w = a * T;
+                        float v[NV], U = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) {
+                            U += ecol[u][ch] * dpix[ch];
+                            v[ch] = w * dpix[ch];
+                        }
+                        R_acc = last_alpha * U_last + (1.f - last_alpha) * R_acc;
+                        U_last = U;
+                        float dL_dalpha = (U - R_acc) * T;
+                        last_alpha = a;
+                        dL_dalpha += (-T_final * inv1ma) * bg_dot;
+                        const float Q = G0[u] * dL_dalpha;
+                        const float dx = dxs[u], dy = dys[u];
+                        v[C + 0] = Q;
+                        v[C + 1] = Q * dx;
+                        v[C + 2] = Q * dy;
+                        v[C + 3] = Q * dx * dx;
+                        v[C + 4] = Q * dx * dy;
+                        v[C + 5] = Q * dy * dy;
+                        float w10[10], r0, r1, r2;
+#pragma unroll
+                        for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
+#pragma unroll
+                        for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
+                        wave_sum10_rows(w10, r0, r1, r2);
+                        done |= 1ull << kk[u];
+                        if ((lane & 15) == 15) {
+                            float *dst = &s_acc[buf][q][kk[u]][0];
+                            dst[row_slot] = r0;
+                            dst[4 + row_slot] = r1;
+                            if (lane & 16) dst[8 + (lane >> 5)] = r2;
+                        }
+                    }
+                }
+            }
+            if (lane == 0) s_done[buf][q] = done;
+            if (sub == 0) tq.publish(s_task);   // before the task's last barrier
+            __syncthreads();
+            if (threadIdx.x < scnt) {  // one 48-byte record per entry, quadrants summed in a fixed order
+                float rr[10];
+#pragma unroll
+                for (int qq = 0; qq < 10; qq++) rr[qq] = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; w4++) {
+                    const bool have = (s_done[buf][w4] >> threadIdx.x) & 1ull;
+#pragma unroll
+                    for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][threadIdx.x][qq] : 0.f;
+                }
+                float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)my_slot * GOM_PARTIAL_STRIDE);
+                rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
+                rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
+            }
+        }
+    }
+    tq.finish();
 }
 
 }  // namespace
@@ -1110,6 +1323,16 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
+    if (s->bwdMode != 1) {   // one task per segment (GOM_OPT_BWD_MODE 1: the per-sub-range kernel of round 1)
+#define GOM_SBS(CC)                                                                                                       \
+    hipLaunchKernelGGL((k_seg_bwd_seg<CC>), dim3(GOM_RESIDENT(k_seg_bwd_seg<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+                       s->seg_Tend, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
+        if (C == 3) GOM_SBS(3); else GOM_SBS(4);
+#undef GOM_SBS
+        GOM_LAUNCH_CHECK();
+        return 0;
+    }
 #define GOM_SB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_RESIDENT(k_seg_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \

@@ -353,3 +353,32 @@ def test_device_camera_entry_points_are_bitwise_the_host_camera_path():
     assert torch.equal(out, out2) and torch.equal(radii, radii2)
     for a, b in zip(t, t2):
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("seg_shift", [7, 8])
+def test_backward_task_shapes_agree(seg_shift):
+    """GOM_OPT_BWD_MODE: one backward task per segment (every wave walks the segment's sub-ranges in one pass) against one task per
+    sub-range (restart from the forward's per-sub-range checkpoints): same gradients up to fp32 round-off, both against the fp64 oracle."""
+    from gpu_util import hip_forward
+    from gomavatar_amd import _lib, rasterizer as R
+    cam, means, cov6, colors, op = small_scene(seed=41, P=4000, H=96, W=96, opacity=(0.3, 1.0), spread=0.25, scale=0.03, C=4)
+    cam["bg"] = np.array([0.2, 0.5, 0.1, 0.4], np.float32)
+    rng = np.random.default_rng(2)
+    wimg = rng.normal(size=(4, 96, 96)).astype(np.float32)
+    f = orast.forward(cam, means, cov6, colors, op, dtype=np.float64)
+    g = orast.backward(f, wimg.astype(np.float64))
+    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 600          # several segments per tile
+    got = []
+    for mode in (0, 1):
+        st = R.RasterState()
+        st.set_option(_lib.OPT_BWD_MODE, mode)
+        st.set_option(_lib.OPT_SEG_SHIFT, seg_shift)
+        out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True, state=st)
+        (out * torch.from_numpy(wimg).cuda()).sum().backward()
+        got.append([x.grad.cpu().numpy().astype(np.float64) for x in t])
+        for name, a, ref in zip(("means3D", "cov6", "colors", "opacity"), got[-1], (g["dL_dmeans3D"], g["dL_dcov6"], g["dL_dcolors"], g["dL_dopacity"])):
+            scale = np.abs(ref).max()
+            err = np.abs(a - ref)
+            assert np.quantile(err, 0.999) <= 2e-4 * scale and np.median(err) <= 1e-6 * scale, (mode, name, np.quantile(err, 0.999), np.median(err), scale)
+    for a, b in zip(*got):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
