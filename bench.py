@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-modes", action="store_true", help="skip the other operating points (modes) and the raster-only / full-step figures")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames per CPU-baseline row at all cores (1 at one thread)")
     ap.add_argument("--task-grid-pct", type=int, default=0, help="GOM_OPT_TASK_GRID_PCT, 10..100 (0 = library default, 100)")
+    ap.add_argument("--bwd-mode", type=int, default=-1, help="GOM_OPT_BWD_MODE (-1 = library default)")
+    ap.add_argument("--sort-mode", type=int, default=-1, help="GOM_OPT_SORT_MODE (-1 = library default)")
     ap.add_argument("--backend", default="auto", help="auto: nccl (= RCCL) with one device per rank, gloo when ranks share a device")
     return ap.parse_args()
 
@@ -139,6 +141,10 @@ class Runner:
                 st.state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
             if args.task_grid_pct:
                 st.state.set_option(_lib.OPT_TASK_GRID_PCT, args.task_grid_pct)
+            if args.bwd_mode >= 0:
+                st.state.set_option(_lib.OPT_BWD_MODE, args.bwd_mode)
+            if args.sort_mode >= 0:
+                st.state.set_option(_lib.OPT_SORT_MODE, args.sort_mode)
             self.slots.append(dict(step=st, fp=fp, stream=torch.cuda.Stream(device=wl.device)))   # (the legacy NULL stream cannot be graph-captured)
         self.batches = wl.batches(self.slots[0]["step"])
         assert self.batches, "not enough frames for one batch"

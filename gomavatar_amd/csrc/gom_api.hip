@@ -82,7 +82,7 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             s->taskGridPct = (int)value;
             return 0;
         case GOM_OPT_BWD_MODE:
-            if (value < 0 || value > 1) { gom_set_error("backward mode must be 0 (per segment) or 1 (per sub-range)"); return -1; }
+            if (value < -1 || value > 1) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges) or 1 (one sub-range per barrier)"); return -1; }
             s->bwdMode = (int)value;
             return 0;
         case GOM_OPT_SORT_MODE:

@@ -60,7 +60,8 @@ struct GomState {
     int B = 1;
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
-    int bwdMode = 0;                  // GOM_OPT_BWD_MODE: 0 = one backward task per segment, 1 = per sub-range (round 1)
+    int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 0 = two sub-ranges between barriers with opposite quadrants per wave, 1 = one sub-range per
+                                      // barrier (round 1); -1 = auto: 0 for a batched launch (+2 %), 1 for a single frame (+1 %)
     int segShift = 7;                 // log2 of the segment size of the current binning: 7 for one frame, 8 for a batch
     const GomCamera *cams = nullptr;  // device array of B cameras for a batched launch; nullptr: the by-value camera
     bool haveForward = false;

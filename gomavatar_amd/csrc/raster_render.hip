@@ -390,7 +390,8 @@ struct TaskQueueT {
     uint32_t nsegs, per_shard_wgs, shard, tried, pend, it;
     __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? (uint32_t)PER_SEG * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
     __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const {
-        return PER_SEG == 4 ? ((((j >> 2) * GOM_TQ_SHARDS + x) << 2) | (j & 3u)) : j * GOM_TQ_SHARDS + x;   // 4 pieces of a segment, or the segment itself
+        constexpr uint32_t SH = PER_SEG == 4 ? 2u : (PER_SEG == 2 ? 1u : 0u);   // PER_SEG queue items per segment: (segment << SH) | piece
+        return (((j >> SH) * GOM_TQ_SHARDS + x) << SH) | (j & ((1u << SH) - 1u));
     }
     // thread 0 only: local index j on the current shard -> task, moving to the next shards while the current one is empty
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {
@@ -644,6 +645,7 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
 #pragma unroll
             for (int ch = 0; ch < C; ch++) tot[ch] = 0.f;
             uint32_t lastc = 0;
+            float cadd[GOM_NSUB][C];
             bool going = true, stopped = false, any = false;
 #pragma unroll
             for (int u = 0; u < GOM_NSUB; u++) {
@@ -658,12 +660,22 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
                     Tc = fabsf(te);
                     if (te < 0.f) { going = false; stopped = true; }
                 }
-                // checkpoints for the backward: what this piece really added, and T behind it
+                // checkpoints for the backward: T behind this piece, and (below) the colour the LATER pieces of the segment really added
                 sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
-                float cu[C];
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) cu[ch] = counts ? s_c[u][ch][lane] : 0.f;
-                st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu);
+                for (int ch = 0; ch < C; ch++) cadd[u][ch] = counts ? s_c[u][ch][lane] : 0.f;
+            }
+            {   // sub_C[u] = sum of the pieces behind piece u, last piece first (small terms first): with seg_Sbehind the backward has
+                // the colour still to come behind ITS piece from two loads (it used to add up to three rows itself)
+                float run[C];
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) run[ch] = 0.f;
+#pragma unroll
+                for (int u = GOM_NSUB - 1; u >= 0; u--) {
+                    if (u < GOM_NSUB - 1) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) run[ch] += cadd[u][ch];
+                }
             }
             const size_t o = (size_t)seg * GOM_TPX + pxi;
             seg_Tend[o] = !any ? 0.f : (stopped ? -Tc : Tc);
@@ -903,22 +915,18 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             // with this pixel's dL/dpix: the recurrence is linear, so it is carried as two scalars R = accum_rec . dpix and
             // U_last = last_color . dpix (half the instructions of the serial chain, six registers fewer).
             float R_acc, U_last = 0.f, last_alpha = 0.f;
-            float S[C], cu[GOM_NSUB][C];
+            float S[C], cu[C];
             ld4<C>(seg_Sbehind, seg, pxi, S);
-#pragma unroll
-            for (int u = GOM_NSUB - 1; u > 0; u--)
-                if (u > sub) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, cu[u]);   // (wave-uniform condition)
+            if (sub < GOM_NSUB - 1) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + sub, pxi, cu);   // what the later pieces of the segment added (wave-uniform condition)
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
             const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             tq.request();  // (behind every load of this task)
             requested = true;
             const float invT = T > 0.f ? 1.f / T : 0.f;
+            if (sub < GOM_NSUB - 1) {
 #pragma unroll
-            for (int u = GOM_NSUB - 1; u > 0; u--)
-                if (u > sub) {
-#pragma unroll
-                    for (int ch = 0; ch < C; ch++) S[ch] += cu[u][ch];
-                }
+                for (int ch = 0; ch < C; ch++) S[ch] += cu[ch];
+            }
             {
                 float sd = 0.f;
 #pragma unroll
@@ -1032,32 +1040,28 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 #endif
 }
 
-// ------------------------------------------------ backward, one task per SEGMENT -
-// Same replay as k_seg_bwd, other task shape: a workgroup takes a whole segment (its 4 waves = the 4 quadrants) and every wave
-// walks the segment's sub-ranges back to front in ONE pass, carrying T and the accum_rec scalar in registers from piece to piece.
-// What that removes from k_seg_bwd (whose waves were parked at s_waitcnt / s_barrier for 64 % of their cycles, SQ_WAIT_ANY):
-//   * the per-pixel state (n_contrib, final_T, dL/dpix, background term) is loaded once per segment, not once per sub-range;
-//   * the checkpoint is the segment's (seg_Tend, seg_Sbehind); the per-sub-range ones (sub_Tend, up to three sub_C rows) are
-//     neither read here nor written by the forward any more;
-//   * the entries of the NEXT sub-range are loaded while the current one is replayed (the loads of a 64-entry piece used to be a
-//     dependent round trip at the start of every task);
-//   * a quarter of the queue round trips, descriptor loads and dead-task checks.
-// One barrier per live sub-range remains: the four quadrants' partial sums of an entry meet in LDS (s_acc, double-buffered by
-// piece parity as before) so that ONE record per (tile, entry) is written.
-#ifndef GOM_BWDS_WAVES
-#define GOM_BWDS_WAVES 5   // (6 waves per SIMD = an 80-register budget: 21 of them would spill)
-#endif
+// ------------------------------------------- backward, two sub-ranges between barriers -
+// Same replay and the same four-quadrant fold as k_seg_bwd, but a queue item is a PAIR of consecutive sub-ranges of a segment and
+// wave w takes quadrant w of the first and quadrant 3 - w -- the diagonally opposite one -- of the second before the workgroup
+// meets at the barrier.  Why: the four waves of k_seg_bwd wait for the busiest quadrant of every task, and on a body frame that
+// quadrant has twice the mean quadrant's survivors (oracle-side count over the live tasks: sum of max / sum of mean = 2.04;
+// SQ_WAIT_ANY: waves parked 64 % of their cycles).  Which quadrant is busy is a property of the TILE (where the silhouette crosses
+// it), so it is the same one in both sub-ranges: giving the wave that had it the opposite quadrant next evens the four waves out.
+//   (Measured and dropped on the way here: one task per SEGMENT with the next piece's entries prefetched -- 276 us instead of 205:
+//    a quarter of the tasks, and these kernels live on many short independent chains; one WAVE per task walking its four quadrants
+//    without any barrier -- 218-259 us: it needs ~100 VGPRs, and at five waves per SIMD with spills the gain is gone.)
 template <int C>
-__global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd_pair(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,
                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                                                  const float *__restrict__ dL_dpix, const float *__restrict__ seg_Tend,
-                                                  const float *__restrict__ seg_Sbehind,
+                                                  const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
+                                                  const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
                                                   uint32_t *__restrict__ task_ctr) {
     constexpr int NV = 6 + C;
+    // [half of the pair][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote
     __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
     __shared__ unsigned long long s_done[2][4];
     __shared__ uint32_t s_task[2];
@@ -1066,84 +1070,84 @@ __global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t se
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int pxi = q * 64 + lane;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);
     const size_t HW = (size_t)H * W;
-    uint32_t piece = 0;   // parity of the s_acc buffer: counts live pieces over the whole life of the workgroup
-    TaskQueueT<1> tq;
+    TaskQueueT<2> tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
-        const uint32_t seg = tq.current(s_task);
-        if (seg == 0xffffffffu) break;
+        const uint32_t task = tq.current(s_task);
+        if (task == 0xffffffffu) break;
+        const uint32_t seg = task >> 1;
+        const int sub_a = (int)(task & 1u) * 2;
         const uint4 d = seg_desc[seg];
         const uint4 qm4 = seg_qmax[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
         const uint32_t e0 = d.w << seg_shift;
         const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
-        if (e0 >= tmax) {   // every pixel of the tile finished before this segment: nothing is written (the per-Gaussian backward skips these entries)
+        const uint32_t s0a = e0 + (uint32_t)sub_a * sub_sz;
+        if ((uint32_t)sub_a * sub_sz >= cnt || s0a >= tmax) {   // no entries, or every pixel of the tile stopped before the pair: nothing is written
             tq.request();
             tq.publish(s_task);
             __syncthreads();
             continue;
         }
-        const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));
-        const bool mine = wmax > e0;                        // my quadrant still has contributors in this segment (wave-uniform)
-        const uint32_t lim = mine ? min(cnt, wmax - e0) : 0u;   // entries at or beyond wmax are dead for this wave
         const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;
-        const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
-        const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
-        const bool inside = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        const size_t fpix = (size_t)fr * HW + pix;
-        const float pfx = (float)px, pfy = (float)py;
-        const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
-        const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
-        uint32_t my_last = 0;
-        float T_final = 0.f, dpix[C], bg_dot = 0.f, T = 0.f, R_acc = 0.f, U_last = 0.f, last_alpha = 0.f;
+        float bg[4] = {bg0, bg1, bg2, bg3};
+        if (cams) {
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) dpix[ch] = 0.f;
-        const int nsub = (int)((cnt + sub_sz - 1) / sub_sz);
-        const int top = (int)((min(cnt, tmax - e0) + sub_sz - 1) / sub_sz) - 1;   // last sub-range that is live for the tile (>= 0 here)
-        EntryRegs<C> rn;                                   // entries of the piece about to be replayed (lane = entry)
-        rn.keep = false;
-        if (mine) {
-            my_last = inside ? n_contrib[fpix] : 0u;
-            T_final = final_T[inside ? fpix : 0];
-            float bg[4] = {bg0, bg1, bg2, bg3};
-            if (cams) {
-#pragma unroll
-                for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
-            }
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                dpix[ch] = inside ? dL_dpix[((size_t)fr * C + ch) * HW + pix] : 0.f;
-                bg_dot += bg[ch] * dpix[ch];
-            }
-            T = seg_Tend[(size_t)seg * GOM_TPX + pxi];     // state just behind the segment
-            float S[C];
-            ld4<C>(seg_Sbehind, seg, pxi, S);
-            rn = load_sub<C>(ent_geo, ent_col, start, lim, top, lane, qx0, qy0, qx1, qy1, sub_sz);
-            float sd = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
-            R_acc = T > 0.f ? sd / T : 0.f;
+            for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
         }
-        tq.request();  // (behind the loads of this task)
-        (void)nsub;
-        for (int sub = top; sub >= 0; sub--) {
+        bool live_h[2];
+        uint32_t scnt_h[2];
+        bool requested = false;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int sub = sub_a + half;
             const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;
-            const uint32_t scnt = min(sub_sz, cnt - (uint32_t)sub * sub_sz);
-            const int buf = (int)(piece & 1u);
-            piece++;
-            const uint32_t my_slot = threadIdx.x < scnt ? ent_slot[start + (uint32_t)sub * sub_sz + threadIdx.x] : 0u;
-            const EntryRegs<C> r = rn;
-            const bool work = mine && wmax > s0;
-            if (mine && sub > 0) rn = load_sub<C>(ent_geo, ent_col, start, lim, sub - 1, lane, qx0, qy0, qx1, qy1, sub_sz);   // in flight during the replay below
+            const bool empty = (uint32_t)sub * sub_sz >= cnt;
+            scnt_h[half] = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
+            live_h[half] = !empty && s0 < tmax;
+            const int q = half == 0 ? wv : 3 - wv;   // the diagonally opposite quadrant in the second sub-range
+            const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));
             unsigned long long done = 0ull;
-            if (work) {
+            if (live_h[half] && wmax > s0) {
+                const int pxi = q * 64 + lane;
+                const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
+                const int py = ty * 16 + (q >> 1) * 8 + (lane >> 3);
+                const bool inside = px < W && py < H;
+                const size_t pix = (size_t)py * W + px;
+                const size_t fpix = (size_t)fr * HW + pix;
+                const float pfx = (float)px, pfy = (float)py;
+                const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+                const uint32_t my_last = inside ? n_contrib[fpix] : 0u;
+                const float T_final = final_T[inside ? fpix : 0];
+                float dpix[C], bg_dot = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    dpix[ch] = inside ? dL_dpix[((size_t)fr * C + ch) * HW + pix] : 0.f;
+                    bg_dot += bg[ch] * dpix[ch];
+                }
+                float T = sub_Tend[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi];
+                float S[C], cu[C];
+                ld4<C>(seg_Sbehind, seg, pxi, S);
+                if (sub < GOM_NSUB - 1) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + sub, pxi, cu);
+                const uint32_t lim = min(cnt, wmax - e0);
+                const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx0 + 7.f, qy0 + 7.f, sub_sz);
+                if (!requested) { tq.request(); requested = true; }   // (behind the loads of this piece)
+                if (sub < GOM_NSUB - 1) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) S[ch] += cu[ch];
+                }
+                float R_acc, U_last = 0.f, last_alpha = 0.f;
+                {
+                    float sd = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
+                    R_acc = sd * (T > 0.f ? 1.f / T : 0.f);   // (same operations as k_seg_bwd: the two kernels agree bitwise)
+                }
                 unsigned long long mask = __ballot(r.keep);
-                s_e0[q][lane] = make_float4(r.x, r.y, r.a, r.b);
-                s_e1[q][lane] = make_float2(r.c, r.o);
+                s_e0[wv][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
+                s_e1[wv][lane] = make_float2(r.c, r.o);
                 while (mask) {
                     int kk[GOM_BWD_EPT];
                     bool kv[GOM_BWD_EPT];
@@ -1154,15 +1158,15 @@ __global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t se
                         const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
                         mask &= ~(1ull << k);
                         kk[u] = k;
-                        const float4 g0 = s_e0[q][k];
-                        const float2 g1 = s_e1[q][k];
-                        const float eo = kv[u] ? g1.y : 0.f;
+                        const float4 g0 = s_e0[wv][k];
+                        const float2 g1 = s_e1[wv][k];
+                        const float o_ = kv[u] ? g1.y : 0.f;
                         const float dx = g0.x - pfx, dy = g0.y - pfy;
 #pragma unroll
                         for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
                         const float power = gauss_power(g0.z, g0.w, g1.x, dx, dy);
                         const float g = __expf(power);
-                        float a = fminf(kMaxAlpha, eo * g);
+                        float a = fminf(kMaxAlpha, o_ * g);
                         a = (power <= 0.f) ? a : 0.f;
                         a = (a >= kMinAlpha) ? a : 0.f;
                         a = (s0 + (uint32_t)k < my_last) ? a : 0.f;
@@ -1205,7 +1209,7 @@ __global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t se
                         wave_sum10_rows(w10, r0, r1, r2);
                         done |= 1ull << kk[u];
                         if ((lane & 15) == 15) {
-                            float *dst = &s_acc[buf][q][kk[u]][0];
+                            float *dst = &s_acc[half][q][kk[u]][0];
                             dst[row_slot] = r0;
                             dst[4 + row_slot] = r1;
                             if (lane & 16) dst[8 + (lane >> 5)] = r2;
@@ -1213,25 +1217,32 @@ __global__ void __launch_bounds__(256, GOM_BWDS_WAVES) k_seg_bwd_seg(uint32_t se
                     }
                 }
             }
-            if (lane == 0) s_done[buf][q] = done;
-            if (sub == 0) tq.publish(s_task);   // before the task's last barrier
-            __syncthreads();
-            if (threadIdx.x < scnt) {  // one 48-byte record per entry, quadrants summed in a fixed order
+            if (lane == 0) s_done[half][q] = done;
+        }
+        if (!requested) tq.request();
+        tq.publish(s_task);
+        __syncthreads();
+        {   // one 48-byte record per entry of the two sub-ranges (threads 0..127), quadrants summed in a fixed order
+            const int half = threadIdx.x >> 6, e = threadIdx.x & 63;
+            if (half < 2 && live_h[half] && (uint32_t)e < scnt_h[half]) {
+                const uint32_t li = start + (uint32_t)(sub_a + half) * sub_sz + (uint32_t)e;
+                const uint32_t slot = ent_slot[li];
                 float rr[10];
 #pragma unroll
                 for (int qq = 0; qq < 10; qq++) rr[qq] = 0.f;
 #pragma unroll
                 for (int w4 = 0; w4 < 4; w4++) {
-                    const bool have = (s_done[buf][w4] >> threadIdx.x) & 1ull;
+                    const bool have = (s_done[half][w4] >> e) & 1ull;
 #pragma unroll
-                    for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][threadIdx.x][qq] : 0.f;
+                    for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[half][w4][e][qq] : 0.f;
                 }
-                float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)my_slot * GOM_PARTIAL_STRIDE);
+                float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)slot * GOM_PARTIAL_STRIDE);
                 rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
                 rec[1] = make_float4(rr[4], rr[5], rr[6], rr[7]);
                 rec[2] = make_float4(rr[8], rr[9], 0.f, 0.f);
             }
         }
+        __syncthreads();   // the next pair overwrites s_acc / s_done
     }
     tq.finish();
 }
@@ -1323,13 +1334,13 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
-    if (s->bwdMode != 1) {   // one task per segment (GOM_OPT_BWD_MODE 1: the per-sub-range kernel of round 1)
-#define GOM_SBS(CC)                                                                                                       \
-    hipLaunchKernelGGL((k_seg_bwd_seg<CC>), dim3(GOM_RESIDENT(k_seg_bwd_seg<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    if (s->bwdMode == 0 || (s->bwdMode < 0 && s->B > 1)) {   // two sub-ranges between barriers, opposite quadrants per wave (GOM_OPT_BWD_MODE 1: one sub-range per barrier, round 1)
+#define GOM_SBW(CC)                                                                                                       \
+    hipLaunchKernelGGL((k_seg_bwd_pair<CC>), dim3(GOM_RESIDENT(k_seg_bwd_pair<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->seg_Tend, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
-        if (C == 3) GOM_SBS(3); else GOM_SBS(4);
-#undef GOM_SBS
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
+        if (C == 3) GOM_SBW(3); else GOM_SBW(4);
+#undef GOM_SBW
         GOM_LAUNCH_CHECK();
         return 0;
     }

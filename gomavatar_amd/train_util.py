@@ -119,6 +119,43 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
     return scaled.sum(), losses
 
 
+def update_lr(optimizer, iter_step, train_cfg) -> None:
+    """train.py:166-175: lr = base * 0.1 ** (iter / lr_decay_steps), base = cfg.train.lr.<group name>."""
+    decay_value = 0.1 ** (iter_step / train_cfg.lr_decay_steps)
+    for param_group in optimizer.param_groups:
+        if not hasattr(train_cfg.lr, param_group["name"]):
+            raise AttributeError(f"no learning rate for parameter group {param_group['name']!r} (the reference's fallback reads an undefined cfg.train.train.lr)")
+        param_group["lr"] = getattr(train_cfg.lr, param_group["name"]) * decay_value
+
+
+def train_iteration(model, optimizer, data, train_cfg, n_iters, lpips_func=None, random_bgcolor: bool = True):
+    """One iteration of the reference's loop, train.py:313-348 (without logging / checkpoints / subdivision, which the caller owns):
+    zero_grad -> forward -> unpack -> compute_loss -> backward -> optimizer step -> update_lr.  Returns (loss, loss_items, rgb, mask)."""
+    optimizer.zero_grad()
+    rgb, mask, outputs = model(data["K"], data["E"], data["cnl_gtfms"], data["dst_Rs"], data["dst_Ts"], dst_posevec=data.get("dst_posevec"),
+                               canonical_joints=data.get("dst_tpose_joints"), i_iter=n_iters, bgcolor=data.get("bgcolor"))
+    if random_bgcolor:
+        rgb = unpack(rgb, mask, data["bgcolor"])
+    loss, loss_items = compute_loss(rgb, mask, outputs, data["target_rgbs"], data["target_masks"], train_cfg.losses, data, n_iters, lpips_func=lpips_func)
+    loss.backward()
+    optimizer.step()
+    update_lr(optimizer, n_iters, train_cfg)
+    return loss, loss_items, rgb, mask
+
+
+def eval_frame(model, data, bgcolor255=(255.0, 255.0, 255.0)):
+    """eval.py:339-357: no_grad forward, composition on cfg.bgcolor / 255, 8-bit quantisation -> (H,W,3) uint8 (+ the PSNR of
+    eval.py:101-104 against data['target_rgbs'] when present)."""
+    from .metrics import from_8b, psnr, to_8b
+    with torch.no_grad():
+        pred, mask, _ = model(data["K"], data["E"], data["cnl_gtfms"], data["dst_Rs"], data["dst_Ts"], data.get("dst_posevec"))
+        bg = torch.tensor(bgcolor255, dtype=torch.float32, device=pred.device)[None] / 255.0
+        pred = unpack(pred, mask, bg)
+    pred8 = to_8b(pred[0])
+    value = psnr(from_8b(pred8), from_8b(to_8b(data["target_rgbs"][0]))) if data.get("target_rgbs") is not None else None
+    return pred8, value
+
+
 class GraphedTrainStep:
     """The reference's training iteration (train.py:309-349: zero_grad -> forward -> unpack -> compute_loss -> backward ->
     optimizer step) captured ONCE in a HIP graph and replayed per frame.  An iteration is ~210 kernel launches of a few

@@ -94,9 +94,9 @@ enum {
                                   occupy.  100 is fastest when the step has the GPU to itself; with several steps in flight on
                                   separate streams ~50 lets their kernels run side by side (a full grid holds every workgroup
                                   slot until it ends).  Results do not depend on it. */
-    GOM_OPT_BWD_MODE = 6,      /* render backward task shape: 0 = one task per tile-list segment (each wave walks the segment's sub-ranges in one
-                                  pass), 1 = one task per sub-range, restarting from the forward's per-sub-range checkpoints.  Same
-                                  gradients up to fp32 round-off. */
+    GOM_OPT_BWD_MODE = 6,      /* render backward: 0 = a workgroup replays two consecutive sub-ranges between barriers, every wave taking
+                                  diagonally opposite 8x8 quadrants in the two (evens out the quadrant imbalance of a tile); 1 = one
+                                  sub-range per barrier (round 1); -1 (default) = 0 for a batched launch, 1 for a single frame.  Same gradients, bitwise. */
     GOM_OPT_SORT_MODE = 5      /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
                                   frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
                                   bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */

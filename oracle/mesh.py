@@ -63,12 +63,14 @@ def _seg_dist2(px, py, ax, ay, bx, by):
     return torch.where(l2 > K_EPS, d, (px - bx) ** 2 + (py - by) ** 2)
 
 
-def rasterize(verts_ndc, faces, H, W, blur_radius, chunk=2048):
-    """Per pixel and face: qualifies (bool), signed squared distance, interpolated depth.  Returns dense (HW, F)."""
+def rasterize(verts_ndc, faces, H, W, blur_radius, rows=None):
+    """Per pixel and face: qualifies (bool), signed squared distance, interpolated depth.  Returns dense (HW, F); `rows` = (r0, r1)
+    restricts the pixels to image rows r0 .. r1-1 (pixels are independent: large meshes are rendered in row bands)."""
     dt = verts_ndc.dtype
     xf, yf = pixel_centers(H, W, dt)
-    px = xf[None, :].expand(H, W).reshape(-1, 1)
-    py = yf[:, None].expand(H, W).reshape(-1, 1)
+    r0, r1 = rows if rows is not None else (0, H)
+    px = xf[None, :].expand(r1 - r0, W).reshape(-1, 1)
+    py = yf[r0:r1, None].expand(r1 - r0, W).reshape(-1, 1)
     v = verts_ndc[faces]                                  # (F,3,3)
     x0, y0, z0 = v[:, 0, 0][None], v[:, 0, 1][None], v[:, 0, 2][None]
     x1, y1, z1 = v[:, 1, 0][None], v[:, 1, 1][None], v[:, 1, 2][None]
@@ -94,9 +96,12 @@ def rasterize(verts_ndc, faces, H, W, blur_radius, chunk=2048):
     return qual, torch.where(inside, -d, d), pz
 
 
-def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50, training=True):
-    """mesh.py:114-128.  Returns (normal (H,W,3), mask (H,W) or None, pix_to_face (H,W))."""
-    qual, _, pz = rasterize(verts_ndc, faces, H, W, 0.0)
+def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50, training=True, rows=None):
+    """mesh.py:114-128.  Returns (normal (H,W,3), mask (H,W) or None, pix_to_face (H,W)) -- of the row band `rows` when given."""
+    Hfull = H
+    qual, _, pz = rasterize(verts_ndc, faces, H, W, 0.0, rows)
+    if rows is not None:
+        H = rows[1] - rows[0]
     zsel = torch.where(qual, pz, torch.full_like(pz, float("inf")))
     zmin, top = zsel.min(1)
     hit = torch.isfinite(zmin)
@@ -106,7 +111,7 @@ def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50,
     if not training:
         return normal.reshape(H, W, 3), None, pix_to_face.reshape(H, W)
     blur_radius = math.log(1.0 / 1e-4 - 1.0) * sigma_cfg
-    qual, sd, pz = rasterize(verts_ndc, faces, H, W, blur_radius)
+    qual, sd, pz = rasterize(verts_ndc, faces, Hfull, W, blur_radius, rows)
     zsel = torch.where(qual, pz, torch.full_like(pz, float("inf")))
     k = min(faces_per_pixel, zsel.shape[1])
     zk, idx = torch.topk(zsel, k, dim=1, largest=False)

@@ -7,7 +7,7 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o pmc -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-graph --no-cpu-baseline "$@" > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + "/*counter_collection.csv")
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 if not f:
     print(open(sys.argv[1] + "/log.txt").read()[-2000:]); sys.exit(0)
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)

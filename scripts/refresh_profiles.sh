@@ -1,20 +1,44 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round tag (run through gpurun; results land in gpurun_out/profiles_$TAG,
-# copy them into profiles/ afterwards):   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r01'
-TAG=${1:-r01}
+# copy them into profiles/ afterwards):   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
+# Runs TWICE the PMC-derived pieces feed bench.py: the bench line of the second pass carries roofline.traffic / roofline.valu read
+# from the json files the first pass produced (copy them to profiles/ in between, or simply run this script twice).
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
-bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1
-bash scripts/collect_profiles.sh ${TAG}_alone "--inflight 1" > gpurun_out/collect_${TAG}_alone.log 2>&1
-bash scripts/pmc_pass.sh ${TAG}_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" > gpurun_out/pmc_${TAG}_insts.log 2>&1
-bash scripts/pmc_pass.sh ${TAG}_busy "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" > gpurun_out/pmc_${TAG}_busy.log 2>&1
+bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1                       # default bench: one step in flight
+bash scripts/collect_profiles.sh ${TAG}_inflight3 "--inflight 3" > gpurun_out/collect_${TAG}_inflight3.log 2>&1
+bash scripts/pmc_pass.sh ${TAG}_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" --no-modes > gpurun_out/pmc_${TAG}_insts.log 2>&1
+bash scripts/pmc_pass.sh ${TAG}_busy "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" --no-modes > gpurun_out/pmc_${TAG}_busy.log 2>&1
 OUT=gpurun_out/profiles_$TAG; mkdir -p $OUT
 cp gpurun_out/prof_$TAG/bench_line.json $OUT/${TAG}_bench_line.json
-cp gpurun_out/prof_$TAG/trace/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
+cp gpurun_out/prof_$TAG/trace/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp $(find gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 cp gpurun_out/prof_$TAG/traffic.json $OUT/${TAG}_traffic.json
-cp gpurun_out/prof_${TAG}_alone/bench_line.json $OUT/${TAG}_alone_inflight1_bench_line.json
-cp gpurun_out/prof_${TAG}_alone/trace/*kernel_stats.csv $OUT/${TAG}_alone_inflight1_kernel_stats.csv
-python scripts/summarize_pmc.py gpurun_out/prof_$TAG/pmc_fetch/*counter_collection.csv $OUT/${TAG}_pmc_fetch_per_kernel.csv
-python scripts/summarize_pmc.py gpurun_out/prof_$TAG/pmc_write/*counter_collection.csv $OUT/${TAG}_pmc_write_per_kernel.csv
-python scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_insts/*counter_collection.csv $OUT/${TAG}_pmc_sq_insts_per_kernel.csv
-python scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_busy/*counter_collection.csv $OUT/${TAG}_pmc_sq_busy_per_kernel.csv
-ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-400
+cp gpurun_out/prof_${TAG}_inflight3/bench_line.json $OUT/${TAG}_inflight3_bench_line.json
+cp $(find gpurun_out/prof_${TAG}_inflight3/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_inflight3_kernel_stats.csv
+python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_fetch -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_fetch_per_kernel.csv
+python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_write_per_kernel.csv
+python scripts/summarize_pmc.py $(find gpurun_out/pmc_${TAG}_insts -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq_insts_per_kernel.csv
+python scripts/summarize_pmc.py $(find gpurun_out/pmc_${TAG}_busy -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq_busy_per_kernel.csv
+# the VALU axis of bench.py's roofline block: per kernel, from the SQ pass (quad-cycle counters summed over the waves of a launch)
+python - "$OUT" "$TAG" <<'PY'
+import csv, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {}
+for r in csv.DictReader(open(f"{out}/{tag}_pmc_sq_busy_per_kernel.csv")):
+    k = r["Kernel_Name"]
+    if "anonymous namespace" not in k: continue
+    name = k.split("::")[1].split("(")[0].split("<")[0]
+    name = {"k_tile_rank": "k_sort", "k_seg_bwd_pair": "k_seg_bwd"}.get(name, name)
+    g = lambda c: float(r.get(c + "_avg_per_launch") or 0.0)
+    wc = g("SQ_WAVE_CYCLES")
+    if not wc: continue
+    res[name] = {"valu_insts_per_launch": round(g("SQ_INSTS_VALU")), "wave_quadcycles": round(wc),
+                 "wave_parked_frac": round(g("SQ_WAIT_ANY") / wc, 4),          # at s_waitcnt / s_barrier
+                 "issue_stall_frac": round(g("SQ_WAIT_INST_ANY") / wc, 4),
+                 "inst_active_frac": round(g("SQ_ACTIVE_INST_ANY") / wc, 4),
+                 "valu_active_frac_of_wave_time": round(g("SQ_ACTIVE_INST_VALU") / wc, 4),
+                 "valu_active_over_busy": round(g("SQ_ACTIVE_INST_VALU") / max(g("SQ_BUSY_CYCLES"), 1.0), 4)}   # SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES as counted (quad-cycles over SE-cycles)
+json.dump(res, open(f"{out}/{tag}_valu.json", "w"), indent=1)
+print(json.dumps(res.get("k_seg_bwd"), indent=1))
+PY
+ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-600

@@ -1,0 +1,88 @@
+"""SURVEY.md 8(c) harness goldens: three seeded training steps (train.py:309-349) and one eval frame (eval.py:336-361) of the CPU
+oracle in float64 (scripts/make_train_goldens.py -> tests/golden/train_steps.npz; S body: 13 776 Gaussians, 128 x 128) replayed
+through the product: gomavatar_amd.model.Model + train_util.train_iteration / eval_frame + LPIPS (fp32 trunk, same seeded weights)."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from gomavatar_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_training_steps_and_eval_frame_match_the_oracle_goldens(golden_dir, capsys):
+    from gomavatar_amd.model import Model
+    from gomavatar_amd.lpips import LPIPS
+    from gomavatar_amd import train_util as tu
+    g = np.load(os.path.join(golden_dir, "train_steps.npz"))
+    img, steps = int(g["img"]), int(g["steps"])
+    cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
+             normal_renderer=NS(sigma=1e-5, soft_mask=True), shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)),
+             lbs_weights=NS(refine=False))
+    train_cfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, canonical_geometry_xyz=0.0005, shadow=0.0005), lr_decay_steps=100000,
+                   losses=NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=1.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                             normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05)))      # exps/zju-mocap_377.yaml
+    body = syn.make_body(0)
+
+    def make(seed):
+        m = Model(cfg, body).train()
+        gp = syn.make_gaussian_params(m.faces.shape[0], seed)
+        with torch.no_grad():
+            m.so3.copy_(torch.from_numpy(gp["so3"])); m.scale.copy_(torch.from_numpy(gp["scale"])); m.appearance.copy_(torch.from_numpy(gp["appearance"]))
+            lin = [l for l in m.shadow_module.block_mlps if isinstance(l, torch.nn.Linear)]
+            for i, l in enumerate(lin):
+                l.weight.copy_(torch.from_numpy(g[f"shadow_wb{2 * i}"])); l.bias.copy_(torch.from_numpy(g[f"shadow_wb{2 * i + 1}"]))
+        return m
+    teacher, student = make(2), make(1)
+    lp = LPIPS(trunk_seed=0, trunk_dtype=torch.float32, device="cuda")
+    lp_fn = lambda a, b: lp(a, b)
+    frames = []
+    for i in range(steps + 1):
+        fr = {k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(i, img).items()}
+        with torch.no_grad():
+            teacher.eval()
+            rgbs, masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            fr["target_rgbs"], fr["target_masks"] = tu.unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
+        frames.append(fr)
+    opt = torch.optim.Adam(student.get_param_groups(train_cfg), betas=(0.9, 0.999))
+    names = [pg["name"] for pg in opt.param_groups]
+    assert names == ["lbs_weights", "appearance", "canonical_geometry_xyz", "canonical_geometry", "canonical_geometry", "shadow"]
+    report = []
+    for it in range(steps):
+        loss, items, rgb, mask = tu.train_iteration(student, opt, frames[it], train_cfg, it, lpips_func=lp_fn)
+        for k in ("rgb", "mask", "lpips", "laplacian_observation", "normal_mask", "normal_consist", "color_consist"):
+            got, ref = float(items[k]["unscaled"].detach()), float(g[f"s{it}_loss_{k}"])
+            report.append((it, k, got, ref))
+            tol = 2e-3 if k == "lpips" else 5e-4          # LPIPS: fp32 convolutions of a deep random trunk against float64
+            assert abs(got - ref) <= tol * abs(ref) + 1e-6, (it, k, got, ref)      # (the mask term is ~5e-4: its fp32 / threshold-flip noise is ~2e-7)
+        assert abs(float(loss.detach()) - float(g[f"s{it}_loss_total"])) <= 1e-3 * float(g[f"s{it}_loss_total"])
+        assert abs(float(rgb.detach().mean()) - float(g[f"s{it}_rgb_mean"])) <= 2e-5 and abs(float(mask.detach().mean()) - float(g[f"s{it}_mask_mean"])) <= 2e-5
+        assert abs(float(rgb.detach().norm()) - float(g[f"s{it}_rgb_l2"])) <= 1e-4 * float(g[f"s{it}_rgb_l2"])
+        # gradient norm per parameter group (recorded before the Adam step; p.grad still holds it) and parameter norms after the step;
+        # the product has the reference's extra leading lbs_weights group (a buffer, no gradient)
+        for gi, pg in enumerate(opt.param_groups[1:]):
+            gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in pg["params"])))
+            ref = float(g[f"s{it}_gradnorm_{gi}_{pg['name']}"])
+            report.append((it, "gradnorm " + pg["name"], gn, ref))
+            assert abs(gn - ref) <= 2e-2 * ref, (it, gi, pg["name"], gn, ref)
+            pn = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in pg["params"])))
+            assert abs(pn - float(g[f"s{it}_paramnorm_{gi}_{pg['name']}"])) <= 1e-5 * pn, (it, gi, pg["name"])
+        assert abs(opt.param_groups[1]["lr"] - 0.0005 * 0.1 ** (it / 100000)) < 1e-12            # update_lr (train.py:166-175)
+    # eval frame (eval.py:336-361): 8-bit PSNR of the student's render against the teacher's, white background
+    student.eval(); teacher.eval()
+    fr = dict(frames[steps])
+    with torch.no_grad():
+        t_rgbs, t_masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+        fr["target_rgbs"] = tu.unpack(t_rgbs, t_masks, torch.ones(1, 3, device="cuda"))
+    pred8, value = tu.eval_frame(student, fr)
+    assert pred8.dtype == torch.uint8 and pred8.shape == (img, img, 3)
+    truth8 = torch.from_numpy(g["eval_truth_8b"])
+    from gomavatar_amd.metrics import to_8b
+    d8 = (to_8b(fr["target_rgbs"][0]).cpu().int() - truth8.int()).abs()
+    assert int((d8 > 1).sum()) <= 5 and float((d8 > 0).float().mean()) < 2e-3      # the teacher's 8-bit frame: truncation flips at x.9999 only
+    assert abs(value - float(g["eval_psnr"])) <= 0.02, (value, float(g["eval_psnr"]))
+    with capsys.disabled():
+        print("\n[train-step goldens] " + "; ".join(f"s{it} {k}: {a:.6g} vs {b:.6g}" for it, k, a, b in report if it == steps - 1) + f"; eval PSNR {value:.3f} vs {float(g['eval_psnr']):.3f}")
