@@ -1050,8 +1050,11 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 //   (Measured and dropped on the way here: one task per SEGMENT with the next piece's entries prefetched -- 276 us instead of 205:
 //    a quarter of the tasks, and these kernels live on many short independent chains; one WAVE per task walking its four quadrants
 //    without any barrier -- 218-259 us: it needs ~100 VGPRs, and at five waves per SIMD with spills the gain is gone.)
+#ifndef GOM_BWDP_WAVES
+#define GOM_BWDP_WAVES 5   // (at 6 waves per SIMD = 80 registers, 7 of them spill: same speed, +40 MB of scratch traffic per launch)
+#endif
 template <int C>
-__global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd_pair(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                   const GomCamera *__restrict__ cams,
                                                   const uint4 *__restrict__ seg_desc, const uint4 *__restrict__ seg_qmax,
                                                   const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col,

@@ -56,6 +56,7 @@ class FrameParallel:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.average = average
         self._native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._host = None
         self.params = FlatBuffer(shapes, device)
         self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
 
@@ -73,6 +74,16 @@ class FrameParallel:
         if self.world > 1:
             if self.average and self._native_avg:
                 dist.all_reduce(self.grads.flat, op=dist.ReduceOp.AVG, group=self.group)
+            elif self.grads.flat.is_cuda and not self._native_avg:
+                # gloo with device tensors (ranks sharing one GPU on a development lease): staged through one pinned host buffer --
+                # gloo's plain host path -- rather than through its device-tensor path
+                if self._host is None:
+                    self._host = torch.empty(self.grads.flat.shape, dtype=torch.float32).pin_memory()
+                self._host.copy_(self.grads.flat, non_blocking=False)
+                dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    self._host.mul_(1.0 / self.world)
+                self.grads.flat.copy_(self._host, non_blocking=False)
             else:
                 dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
                 if self.average:

@@ -7,11 +7,11 @@ frame-parallel trainer and by smoke().
        -> splat backward -> face backward -> vertex gather + LBS backward
 
 i.e. reference models/model.py:213-250 + models/modules/renderer/gaussian.py:22-100
-+ train.py:53-55,101-111 and the autograd backward of all of it, as 17 kernel
++ train.py:53-55,101-111 and the autograd backward of all of it, as 18 kernel
 launches on one stream.  Gradients land in `self.grads` (vertices (3,N), so3
 (3,F), scale (3,F), appearance (3,F)) and are bitwise reproducible.
 
-`batch=B > 1` runs B frames through the SAME 17 launches (every kernel covers
+`batch=B > 1` runs B frames through the SAME launches (every kernel covers
 all B frames; `gom_batch_forward_backward`): per-frame tensors get a leading B
 dimension, the gradients are the sum over the B frames.
 """
@@ -120,7 +120,7 @@ class RenderStep:
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
                          target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False,
                          image_grad_hook=None) -> None:
-        """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 17 kernels.
+        """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 18 kernels (19 for a batch).
         params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
         frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
         target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors.

@@ -42,3 +42,6 @@ json.dump(res, open(f"{out}/{tag}_valu.json", "w"), indent=1)
 print(json.dumps(res.get("k_seg_bwd"), indent=1))
 PY
 ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-600
+# gpurun merges at most 64 MiB back: drop the raw traces / counter dumps, the summaries above are what is kept
+rm -rf gpurun_out/prof_${TAG}/trace gpurun_out/prof_${TAG}/pmc_fetch gpurun_out/prof_${TAG}/pmc_write gpurun_out/prof_${TAG}_inflight3/trace \
+       gpurun_out/prof_${TAG}_inflight3/pmc_fetch gpurun_out/prof_${TAG}_inflight3/pmc_write gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_busy
