@@ -1068,7 +1068,9 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
     __shared__ unsigned long long s_done[2][4];
     __shared__ uint32_t s_task[2];
-    __shared__ float4 s_e0[4][64];
+    // survivors' attributes through wave-private LDS broadcast slabs, the colours included (four v_readlane at ~6.7 issue cycles each in
+    // k_seg_bwd, which has no LDS to spare at six workgroups per CU; this kernel runs five)
+    __shared__ float4 s_e0[4][64], s_e2[4][64];
     __shared__ float2 s_e1[4][64];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
@@ -1151,6 +1153,13 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                 unsigned long long mask = __ballot(r.keep);
                 s_e0[wv][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
                 s_e1[wv][lane] = make_float2(r.c, r.o);
+                {
+                    float4 cl = make_float4(r.col[0], 0.f, 0.f, 0.f);
+                    if (C > 1) cl.y = r.col[1 % C];
+                    if (C > 2) cl.z = r.col[2 % C];
+                    if (C > 3) cl.w = r.col[3 % C];
+                    s_e2[wv][lane] = cl;
+                }
                 while (mask) {
                     int kk[GOM_BWD_EPT];
                     bool kv[GOM_BWD_EPT];
@@ -1161,12 +1170,15 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                         const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
                         mask &= ~(1ull << k);
                         kk[u] = k;
-                        const float4 g0 = s_e0[wv][k];
+                        const float4 g0 = s_e0[wv][k], c4 = s_e2[wv][k];
                         const float2 g1 = s_e1[wv][k];
                         const float o_ = kv[u] ? g1.y : 0.f;
                         const float dx = g0.x - pfx, dy = g0.y - pfy;
+                        {
+                            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-                        for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
+                            for (int ch = 0; ch < C; ch++) ecol[u][ch] = cv[ch];
+                        }
                         const float power = gauss_power(g0.z, g0.w, g1.x, dx, dy);
                         const float g = __expf(power);
                         float a = fminf(kMaxAlpha, o_ * g);
