@@ -55,7 +55,8 @@ class FrameParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.average = average
-        self._native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._native_avg = self._nccl
         self._host = None
         self.params = FlatBuffer(shapes, device)
         self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
@@ -71,23 +72,33 @@ class FrameParallel:
     def all_reduce_grads(self) -> None:
         """ONE collective on the flat buffer (enqueued on the current stream).  RCCL averages inside the collective
         (ReduceOp.AVG: no separate scaling launch); gloo (CPU tests, ranks sharing a device) sums and scales."""
-        if self.world > 1:
+        if self.world <= 1:
+            return
+        flat = self.grads.flat
+        if self._nccl:
             if self.average and self._native_avg:
-                dist.all_reduce(self.grads.flat, op=dist.ReduceOp.AVG, group=self.group)
-            elif self.grads.flat.is_cuda and not self._native_avg:
-                # gloo with device tensors (ranks sharing one GPU on a development lease): staged through one pinned host buffer --
-                # gloo's plain host path -- rather than through its device-tensor path
-                if self._host is None:
-                    self._host = torch.empty(self.grads.flat.shape, dtype=torch.float32).pin_memory()
-                self._host.copy_(self.grads.flat, non_blocking=False)
-                dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
-                if self.average:
-                    self._host.mul_(1.0 / self.world)
-                self.grads.flat.copy_(self._host, non_blocking=False)
-            else:
-                dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
-                if self.average:
-                    self.grads.flat.mul_(1.0 / self.world)
+                try:
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+                    return
+                except (RuntimeError, ValueError):      # a collective library without ncclAvg: sum + scale from now on (same on every rank)
+                    self._native_avg = False
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                flat.mul_(1.0 / self.world)
+        elif flat.is_cuda:
+            # gloo with device tensors (ranks sharing one GPU on a development lease): staged through one pinned host buffer --
+            # gloo's plain host path -- rather than through its device-tensor path
+            if self._host is None:
+                self._host = torch.empty(flat.shape, dtype=torch.float32).pin_memory()
+            self._host.copy_(flat, non_blocking=False)
+            dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                self._host.mul_(1.0 / self.world)
+            flat.copy_(self._host, non_blocking=False)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                flat.mul_(1.0 / self.world)
 
     def make_adam(self, lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8) -> torch.optim.Adam:
         """Adam with one param group per tensor (the reference uses per-group
