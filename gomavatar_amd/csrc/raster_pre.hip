@@ -466,7 +466,10 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 // unique sort key), then conic -> cov2D -> (cov3D, mean3D) and the projection
 // term of the screen-space mean gradient.
 #ifndef GOM_PB_W
-#define GOM_PB_W 4
+#define GOM_PB_W 8   // live records in flight per trip of k_preprocess_bwd (4: 54 us, 8: 49 us on the metric workload)
+#endif
+#ifndef GOM_PB_MB
+#define GOM_PB_MB 16  // liveness lookups in flight per trip (4, 8, 16 measure the same: nine Gaussians in ten need one trip)
 #endif
 template <int C, bool RANK>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
@@ -504,34 +507,55 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         // beyond the tile's last contributor: about half of all pairs on a body (back-facing surface).  With the depth ranking that
         // is a comparison of the Gaussian's rank with the rank of the tile's last contributor (tile_qlim, from the forward's combine
         // pass); with the per-tile merge sort, of its list index (pair_pos) with tile_nmax.
-        // GOM_PB_W records in flight per trip (a Gaussian touches 2.7 tiles on average: 4 covers nine in ten in one trip, and 8 cost
-        // twice the load instructions and 126 VGPRs for nothing); fixed k order keeps the sum reproducible.
+        // Two passes per window of 64 tiles: a few Gaussians close to the camera own a hundred records (the metric workload: up to
+        // 121, fifty beyond 64 in one frame) and every dependent trip of such a lane is a memory latency the kernel's tail waits for
+        // (with liveness and record of four tiles per trip: 31 trips of two dependent loads, 62 us; without the gather 18 us):
+        // (1) the liveness bits, GOM_PB_MB tiles per trip (independent loads; lanes past their last tile re-read their first one);
+        // (2) the LIVE records only, GOM_PB_W per trip, in ascending k (fixed summation order).
         const uint32_t nt = tiles_touched[i];
         const uint32_t po = pair_off[i];
         const ushort4 rc = rect[i];
         const uint32_t rw = (uint32_t)(rc.z - rc.x);
         const uint32_t myq = RANK ? rank_of[(size_t)fr * P + i] : 0u;
-        for (uint32_t k0 = 0; k0 < nt; k0 += GOM_PB_W) {
-            bool live[GOM_PB_W];
+        const uint32_t tile0 = (uint32_t)rc.y * (uint32_t)gx + (uint32_t)rc.x;   // (stacked tile rows: rect carries the frame offset)
+        uint32_t kx = 0, trow = tile0;   // column inside the rect and first tile of the row of tile k
+        for (uint32_t w0 = 0; w0 < nt; w0 += 64) {
+            const uint32_t wn = min(64u, nt - w0);
+            unsigned long long m = 0ull;
+            for (uint32_t b0 = 0; b0 < wn; b0 += GOM_PB_MB) {
+                uint32_t lim[GOM_PB_MB], pos[GOM_PB_MB];
 #pragma unroll
-            for (int u = 0; u < GOM_PB_W; u++) {
-                const uint32_t k = k0 + u < nt ? k0 + u : k0;
-                const uint32_t tile = ((uint32_t)rc.y + k / rw) * (uint32_t)gx + (uint32_t)rc.x + k % rw;   // (stacked tile rows: rect carries the frame offset)
-                live[u] = k0 + u < nt && (RANK ? myq < tile_qlim[tile] : pair_pos[po + k] - tile_base[tile] < tile_nmax[tile]);
+                for (int u = 0; u < GOM_PB_MB; u++) {
+                    const bool in = b0 + u < wn;
+                    const uint32_t tile = in ? trow + kx : tile0;
+                    if (RANK) { lim[u] = tile_qlim[tile]; pos[u] = myq; }
+                    else { lim[u] = tile_nmax[tile]; pos[u] = pair_pos[po + (in ? w0 + b0 + u : 0u)] - tile_base[tile]; }
+                    if (!in) lim[u] = 0u;
+                    if (++kx == rw) { kx = 0; trow += (uint32_t)gx; }
+                }
+#pragma unroll
+                for (int u = 0; u < GOM_PB_MB; u++)
+                    if (pos[u] < lim[u]) m |= 1ull << (b0 + u);
             }
-            float4 q0[GOM_PB_W], q1[GOM_PB_W], q2[GOM_PB_W];
+            const float *run = partial + (size_t)(po + w0) * GOM_PARTIAL_STRIDE;
+            while (m) {
+                bool live[GOM_PB_W];
+                float4 q0[GOM_PB_W], q1[GOM_PB_W], q2[GOM_PB_W];
 #pragma unroll
-            for (int u = 0; u < GOM_PB_W; u++) {
-                // (a dead entry re-reads the Gaussian's first slot -- same cache line, no branch around the loads -- and is masked below)
-                const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)(po + (live[u] ? k0 + u : 0u)) * GOM_PARTIAL_STRIDE);
-                q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
-            }
+                for (int u = 0; u < GOM_PB_W; u++) {
+                    live[u] = m != 0ull;
+                    const uint32_t k = live[u] ? (uint32_t)__builtin_ctzll(m) : 0u;   // (spent lanes re-read the window's first slot, masked below)
+                    m &= m - 1ull;
+                    const float4 *rec = reinterpret_cast<const float4 *>(run + (size_t)k * GOM_PARTIAL_STRIDE);
+                    q0[u] = rec[0]; q1[u] = rec[1]; q2[u] = rec[2];
+                }
 #pragma unroll
-            for (int u = 0; u < GOM_PB_W; u++) {
-                if (live[u]) {
-                    acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
-                    acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;
-                    acc[8] += q2[u].x; acc[9] += q2[u].y;
+                for (int u = 0; u < GOM_PB_W; u++) {
+                    if (live[u]) {
+                        acc[0] += q0[u].x; acc[1] += q0[u].y; acc[2] += q0[u].z; acc[3] += q0[u].w;
+                        acc[4] += q1[u].x; acc[5] += q1[u].y; acc[6] += q1[u].z; acc[7] += q1[u].w;
+                        acc[8] += q2[u].x; acc[9] += q2[u].y;
+                    }
                 }
             }
         }
