@@ -21,7 +21,7 @@ GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
 (BUF_DEPTH, BUF_XY, BUF_CONIC_OPACITY, BUF_TILES_TOUCHED, BUF_RECT, BUF_TILE_BASE, BUF_KEYS, BUF_POINT_LIST, BUF_FINAL_T,
  BUF_N_CONTRIB, BUF_STATUS) = range(11)
-OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE, OPT_SEG_SHIFT, OPT_TASK_GRID_PCT, OPT_SORT_MODE, OPT_BWD_MODE = 0, 1, 2, 3, 4, 5, 6
+OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE, OPT_SEG_SHIFT, OPT_TASK_GRID_PCT, OPT_SORT_MODE, OPT_BWD_MODE, OPT_FUSE_FACE = 0, 1, 2, 3, 4, 5, 6, 7
 SORT_AUTO, SORT_TILE_MERGE, SORT_DEPTH_RANK = 0, 1, 2
 KERNEL_NAMES = ("preprocess", "scan_tiles", "emit", "sort", "seg_T", "seg_fwd", "combine", "seg_bwd", "preprocess_bwd", "depth_hist", "depth_rank")
 

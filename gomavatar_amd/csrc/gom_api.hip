@@ -85,6 +85,14 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value < -1 || value > 1) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges) or 1 (one sub-range per barrier)"); return -1; }
             s->bwdMode = (int)value;
             return 0;
+        case GOM_OPT_FUSE_FACE:
+            if (value != 0 && value != 1) { gom_set_error("GOM_OPT_FUSE_FACE is 0 or 1"); return -1; }
+            if ((value != 0) != s->fuseFace) {   // recorded graphs hold the other launch sequence
+                for (auto &g : s->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+                s->graphs.clear();
+            }
+            s->fuseFace = value != 0;
+            return 0;
         case GOM_OPT_SORT_MODE:
             if (value < 0 || value > 2) { gom_set_error("sort mode must be 0 (auto), 1 (per-tile merge sort) or 2 (depth ranking)"); return -1; }
             s->sortMode = (int)value;
@@ -201,7 +209,7 @@ static bool valid_dims(int P, int C, const GomCamera *cam) {
 // All tensors then carry a leading B dimension.
 static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamera *cams, int B, int P, int C, const float *means3D,
                                const float *cov6, const float *colors, const float *opacity, float *out_color, int32_t *radii,
-                               uint32_t flags, void *stream) {
+                               uint32_t flags, void *stream, const GomFaceArgs *face = nullptr) {
     if (!s) { gom_set_error("null state"); return -1; }
     if (!valid_dims(P, C, cam)) return -1;
     if (!out_color || (P > 0 && (!means3D || !cov6 || !colors || !opacity))) { gom_set_error("null tensor pointer"); return -1; }
@@ -220,7 +228,7 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         const bool rank_fits = (int64_t)s->gx * s->gy * B < (1 << 24);   // (k_tile_rank's work items carry the tile in 24 bits)
         s->rankSort = rank_fits && (s->sortMode == 2 || (s->sortMode == 0 && P <= (1 << 18)));
         if (s->rankSort && P > 393216) { gom_set_error("GOM_OPT_SORT_MODE 2 needs P <= 393216 per frame (the frame's rank bitmap lives in 64 KiB of LDS)"); return -1; }
-        if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st)) return rc;
+        if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st, face)) return rc;
         if (s->rankSort) {
             if (int rc = gom_launch_depth_hist(s, P, st)) return rc;
             if (int rc = gom_launch_scan_emit(s, P, st, true)) return rc;
@@ -246,7 +254,7 @@ extern "C" int gom_raster_forward(GomState *s, const GomCamera *cam, int P, int 
 static int raster_backward_impl(GomState *s, const GomCamera *cam, const GomCamera *cams, int B, int P, int C, const float *means3D,
                                 const float *cov6, const float *colors, const float *opacity, const float *dL_dcolor,
                                 float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans2D,
-                                uint32_t flags, void *stream) {
+                                uint32_t flags, void *stream, const GomFaceArgs *face = nullptr) {
     (void)opacity;
     if (!s) { gom_set_error("null state"); return -1; }
     if (!valid_dims(P, C, cam)) return -1;
@@ -254,14 +262,14 @@ static int raster_backward_impl(GomState *s, const GomCamera *cam, const GomCame
         gom_set_error("gom_raster_backward without a matching forward on this state");
         return -1;
     }
-    if (!dL_dcolor || !dL_dmeans3D || !dL_dcov6 || !dL_dcolors || !dL_dopacity) { gom_set_error("null gradient pointer"); return -1; }
+    if (!dL_dcolor || (!face && (!dL_dmeans3D || !dL_dcov6 || !dL_dcolors || !dL_dopacity))) { gom_set_error("null gradient pointer"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     if (flags & GOM_BWD_RECOMPUTE_FORWARD) {
         if (int rc = gom_launch_render_forward(s, *cam, C, colors, s->scratch_img, true, st)) return rc;
     }
     if (int rc = gom_launch_render_backward(s, *cam, C, colors, dL_dcolor, st)) return rc;
     if (int rc = gom_launch_preprocess_backward(s, *cam, P, C, means3D, cov6, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity,
-                                                dL_dmeans2D, st))
+                                                dL_dmeans2D, st, face))
         return rc;
     return 0;
 }
@@ -421,14 +429,27 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     const int N = f->N, F = f->F, H = f->H, W = f->W, J = 24;
     int rc;
     if ((flags & GOM_FRAME_FORWARD_ONLY) && (flags & GOM_FRAME_BACKWARD_ONLY)) { gom_set_error("FORWARD_ONLY and BACKWARD_ONLY together"); return -1; }
+    // The per-face frame runs inside the rasterizer's per-Gaussian kernels (GomFaceArgs) unless GOM_OPT_FUSE_FACE is 0.
+    const size_t F3 = 3 * (size_t)F, N3 = 3 * (size_t)N;
+    float *b_so3 = B > 1 ? s->batch_grads : f->g_so3;   // B > 1: every frame writes its own slice, one more launch sums them in frame order (no atomics: reproducible)
+    float *b_scale = B > 1 ? s->batch_grads + B * F3 : f->g_scale;
+    float *b_app = B > 1 ? s->batch_grads + 2 * B * F3 : f->g_appearance;
+    float *b_vert = B > 1 ? s->batch_grads + 3 * B * F3 : f->g_vertices;
+    GomFaceArgs fa{};
+    fa.N = N; fa.verts = f->work_vobs; fa.faces = f->faces; fa.so3 = f->so3; fa.scale = f->scale; fa.sigma = f->sigma;
+    fa.appearance = f->appearance; fa.feat4 = f->work_feat;
+    fa.d_corner = f->work_dcorner; fa.d_so3 = b_so3; fa.d_scale = b_scale; fa.d_appearance = b_app;
+    const GomFaceArgs *face = s->fuseFace ? &fa : nullptr;
     if (!(flags & GOM_FRAME_BACKWARD_ONLY)) {
         if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
         if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
-        if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
-                                         f->work_feat, stream)))
-            return rc;
+        if (!face) {
+            if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
+                                             f->work_feat, stream)))
+                return rc;
+        }
         if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
-                                      f->work_radii, 0, stream)))
+                                      f->work_radii, 0, stream, face)))
             return rc;
         if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
                                     nullptr, f->loss_partials, stream)))
@@ -436,17 +457,13 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     }
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
     if ((rc = raster_backward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage,
-                                   f->work_dxyz, f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream)))
+                                   f->work_dxyz, f->work_dcov6, f->work_dfeat, f->work_dopacity, nullptr, 0, stream, face)))
         return rc;
-    // B > 1: every frame writes its own slice, one more launch sums them in frame order (no atomics: reproducible)
-    const size_t F3 = 3 * (size_t)F, N3 = 3 * (size_t)N;
-    float *b_so3 = B > 1 ? s->batch_grads : f->g_so3;
-    float *b_scale = B > 1 ? s->batch_grads + B * F3 : f->g_scale;
-    float *b_app = B > 1 ? s->batch_grads + 2 * B * F3 : f->g_appearance;
-    float *b_vert = B > 1 ? s->batch_grads + 3 * B * F3 : f->g_vertices;
-    if ((rc = gom_face_backward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_dxyz, f->work_dcov6,
-                                      f->work_dcorner, b_so3, b_scale, f->work_dfeat, b_app, stream)))
-        return rc;
+    if (!face) {
+        if ((rc = gom_face_backward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_dxyz, f->work_dcov6,
+                                          f->work_dcorner, b_so3, b_scale, f->work_dfeat, b_app, stream)))
+            return rc;
+    }
     if ((rc = gom_vertex_backward_batch(B, F, N, J, f->vertices, f->lbs_weights, f->work_RT, f->csr_off, f->csr_idx, f->work_dcorner,
                                         nullptr, nullptr, b_vert, nullptr, stream)))
         return rc;

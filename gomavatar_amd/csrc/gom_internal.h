@@ -60,6 +60,7 @@ struct GomState {
     int B = 1;
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
+    bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
     int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 0 = two sub-ranges between barriers with opposite quadrants per wave, 1 = one sub-range per
                                       // barrier (round 1); -1 = auto: 0 for a batched launch (+2 %), 1 for a single frame (+1 %)
     int segShift = 7;                 // log2 of the segment size of the current binning: 7 for one frame, 8 for a batch
@@ -173,9 +174,23 @@ void gom_set_error(const char *fmt, ...);
 
 int gom_ensure_capacity(GomState *s, int P_frame, int H, int W, int B);
 
+// The frame step's geometry around the rasterizer's per-Gaussian kernels (frame_enqueue, gom_api.hip): with it k_preprocess builds the
+// Gaussian from its posed triangle itself (means3D / cov6 become outputs) and k_preprocess_bwd runs the frame's backward in the same thread.
+struct GomFaceArgs {
+    int N;                       // vertices per frame
+    const float *verts;          // (B, 3, N) posed vertices
+    const int32_t *faces;        // (F, 3)
+    const float *so3, *scale;    // (3, F)
+    float sigma;
+    const float *appearance;     // (3, F)
+    float *feat4;                // (B, F, 4) rasterizer features [r g b 1], written by the forward
+    float *d_corner;             // (B, F, 9)      written by the backward
+    float *d_so3, *d_scale, *d_appearance;   // (B, 3, F) per-frame slices
+};
+
 // ---- launchers (one per kernel family; defined in the .hip files) ----------
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
-                          const float *opacity, int32_t *radii_out, hipStream_t st);
+                          const float *opacity, int32_t *radii_out, hipStream_t st, const GomFaceArgs *face = nullptr);
 int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false);
 int gom_launch_depth_hist(GomState *s, int P, hipStream_t st);
 int gom_launch_depth_rank(GomState *s, int P, hipStream_t st);
@@ -206,4 +221,4 @@ int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, con
                     float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
                                    const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
-                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st);
+                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st, const GomFaceArgs *face = nullptr);

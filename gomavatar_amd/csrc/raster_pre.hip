@@ -20,6 +20,7 @@
 //    render backward through a position table (pair_pos) the sort fills in
 //    (no float atomics anywhere -> bitwise reproducible, no searching).
 #include "gom_internal.h"
+#include "geom_face.hpp"
 
 namespace {
 
@@ -103,9 +104,12 @@ __device__ __forceinline__ GomCamera pick_camera(const GomCamera &cam, const Gom
     return c;
 }
 
-template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
-                                                    const float *__restrict__ cov6, const float *__restrict__ opacity,
+// FACE: the Gaussian is made here too, from its posed triangle (geom_face.hpp; the frame step, gom_api.hip): `means` / `cov6` are
+// then OUTPUTS of this kernel (the backward and the exports read them) -- one launch, and one trip of nine floats per Gaussian
+// through HBM, less than the face kernel followed by this one.
+template <bool LDS_HIST, bool FACE>
+__global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCamera *__restrict__ cams, int P, float *__restrict__ means,
+                                                    float *__restrict__ cov6, const float *__restrict__ opacity, GomFaceArgs face,
                                                     float *__restrict__ depth, float2 *__restrict__ xy,
                                                     float4 *__restrict__ conic_opacity, uint32_t *__restrict__ tiles_touched,
                                                     ushort4 *__restrict__ rect, int32_t *__restrict__ radii,
@@ -144,7 +148,21 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         uint32_t o_tiles = 0;
         const float fx = (float)cam.W / (2.0f * cam.tanfovx);
         const float fy = (float)cam.H / (2.0f * cam.tanfovy);
-        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        float p[3], c6[6];
+        if (FACE) {
+            gom_face::FaceFwd o;
+            float s3[3];
+            gom_face::face_forward(face.verts + (size_t)fr * 3 * face.N, face.N, face.faces, face.so3, face.scale, P, i, face.sigma, o, p, s3);
+            gom_face::face_cov6(o, c6);
+            means[3 * i] = p[0]; means[3 * i + 1] = p[1]; means[3 * i + 2] = p[2];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov6[6 * i + k] = c6[k];
+            if (face.feat4)   // (3,F) colour parameter -> (F,4) rasterizer features [r g b 1] (gaussian.py:49)
+                *reinterpret_cast<float4 *>(face.feat4 + 4 * ((size_t)fr * P + i)) =
+                    make_float4(face.appearance[i], face.appearance[(size_t)P + i], face.appearance[2 * (size_t)P + i], 1.0f);
+        } else {
+            p[0] = means[3 * i]; p[1] = means[3 * i + 1]; p[2] = means[3 * i + 2];
+        }
         float pv[3];
         xform4x3(cam.view, p, pv);
         if (pv[2] > 0.2f) {
@@ -154,9 +172,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
             const float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
             ProjJac pj;
             proj_jacobian(cam, p, fx, fy, pj);
-            float c6[6];
+            if (!FACE) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
+                for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
+            }
             float a, b, c, SM0[3], SM1[3];
             cov2d_from(c6, pj, a, b, c, SM0, SM1);
             const float det = a * c - b * b;
@@ -471,8 +490,10 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
 #ifndef GOM_PB_MB
 #define GOM_PB_MB 16  // liveness lookups in flight per trip (4, 8, 16 measure the same: nine Gaussians in ten need one trip)
 #endif
-template <int C, bool RANK>
-__global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, int P, const float *__restrict__ means,
+// FACE: the gradients of mean and covariance go straight through the backward of the per-face frame (geom_face.hpp) in the same thread:
+// corner / so3 / scale / appearance gradients out, nothing per Gaussian written in between.
+template <int C, bool RANK, bool FACE>
+__global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const GomCamera *__restrict__ cams, GomFaceArgs face, int P, const float *__restrict__ means,
                                                         const float *__restrict__ cov6, const int32_t *__restrict__ radii,
                                                         const uint32_t *__restrict__ tiles_touched,
                                                         const float4 *__restrict__ conic_opacity,
@@ -491,7 +512,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
     {
         const size_t go = (size_t)fr * P;
         means += 3 * go; cov6 += 6 * go; radii += go; tiles_touched += go; conic_opacity += go; pair_off += go; rect += go;
-        dL_dmeans += 3 * go; dL_dcov6 += 6 * go; dL_dcolors += C * go; dL_dopacity += go;
+        if (!FACE) { dL_dmeans += 3 * go; dL_dcov6 += 6 * go; dL_dcolors += C * go; dL_dopacity += go; }
         if (dL_dmeans2D) dL_dmeans2D += 3 * go;
     }
     float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -630,6 +651,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         for (int k = 0; k < 4; k++) acc[k] = nanv;
         gop = g2x = g2y = nanv;
     }
+    if (FACE) {   // blockIdx.y = frame: the parameter gradients go to per-frame slices (summed by k_sum_frames)
+        gom_face::FaceFwd o;
+        float cdummy[3], s3[3], dcr[9], dw[3], dS[3];
+        gom_face::face_forward(face.verts + (size_t)fr * 3 * face.N, face.N, face.faces, face.so3, face.scale, P, i, face.sigma, o, cdummy, s3);
+        gom_face::face_backward(o, s3, face.sigma, gm, gc, dcr, dw, dS);
+        const size_t P3 = 3 * (size_t)P;
+        float *dc = face.d_corner + (size_t)fr * 9 * P + 9 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dc[k] = dcr[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            face.d_so3[fr * P3 + (size_t)k * P + i] = dw[k];
+            face.d_scale[fr * P3 + (size_t)k * P + i] = dS[k];
+            face.d_appearance[fr * P3 + (size_t)k * P + i] = acc[k];
+        }
+        return;
+    }
     dL_dmeans[3 * i] = gm[0];
     dL_dmeans[3 * i + 1] = gm[1];
     dL_dmeans[3 * i + 2] = gm[2];
@@ -650,21 +688,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
 #define GOM_LDS_TILE_LIMIT 8192
 
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
-                          const float *opacity, int32_t *radii_out, hipStream_t st) {
+                          const float *opacity, int32_t *radii_out, hipStream_t st, const GomFaceArgs *face) {
     const int n_tiles = s->gx * s->gy;
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_PREPROCESS, st);
     const dim3 grid(blocks, s->B);
     const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
-    if (n_tiles <= GOM_LDS_TILE_LIMIT)
-        hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), n_tiles * sizeof(uint32_t), st, cam, s->cams, P, means3D, cov6,
-                           opacity, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out,
-                           s->tile_count, s->pair_off, s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr);
-    else
-        hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, opacity, s->depth,
-                           s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,
-                           s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr);
+    const bool lds = n_tiles <= GOM_LDS_TILE_LIMIT;
+    const GomFaceArgs fa = face ? *face : GomFaceArgs{};
+    // (with `face` the two arrays are this kernel's outputs: the frame step owns them)
+    float *m = const_cast<float *>(means3D), *c = const_cast<float *>(cov6);
+#define GOM_PP(LDSH, FACEV) hipLaunchKernelGGL((k_preprocess<LDSH, FACEV>), grid, dim3(256), LDSH ? n_tiles * sizeof(uint32_t) : 0, st, cam, s->cams, P, m, c, opacity, fa, \
+                                               s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,  \
+                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr)
+    if (lds) { if (face) GOM_PP(true, true); else GOM_PP(true, false); }
+    else { if (face) GOM_PP(false, true); else GOM_PP(false, false); }
+#undef GOM_PP
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -702,16 +742,19 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank) {
 
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
                                    const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
-                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st) {
+                                   float *dL_dopacity, float *dL_dmeans2D, hipStream_t st, const GomFaceArgs *face) {
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
+    if (face && C != 4) { gom_set_error("the fused face backward carries [r g b 1] features (C = 4)"); return -1; }
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
     const dim3 grid(blocks, s->B);
-#define GOM_PB(CC, RK) hipLaunchKernelGGL((k_preprocess_bwd<CC, RK>), grid, dim3(256), 0, st, cam, s->cams, P, means3D, cov6, s->radii, s->tiles_touched,         \
-                                          s->conic_opacity, s->pair_off, s->pair_pos, s->rect, s->tile_base, s->tile_nmax, s->rank_of, s->tile_qlim, s->gx, s->partial, \
-                                          s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D)
-    if (C == 3) { if (s->rankSort) GOM_PB(3, true); else GOM_PB(3, false); }
-    else { if (s->rankSort) GOM_PB(4, true); else GOM_PB(4, false); }
+    const GomFaceArgs fa = face ? *face : GomFaceArgs{};
+#define GOM_PB(CC, RK, FC) hipLaunchKernelGGL((k_preprocess_bwd<CC, RK, FC>), grid, dim3(256), 0, st, cam, s->cams, fa, P, means3D, cov6, s->radii, s->tiles_touched,    \
+                                              s->conic_opacity, s->pair_off, s->pair_pos, s->rect, s->tile_base, s->tile_nmax, s->rank_of, s->tile_qlim, s->gx, s->partial, \
+                                              s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D)
+    if (face) { if (s->rankSort) GOM_PB(4, true, true); else GOM_PB(4, false, true); }
+    else if (C == 3) { if (s->rankSort) GOM_PB(3, true, false); else GOM_PB(3, false, false); }
+    else { if (s->rankSort) GOM_PB(4, true, false); else GOM_PB(4, false, false); }
 #undef GOM_PB
     GOM_LAUNCH_CHECK();
     return 0;

@@ -97,9 +97,12 @@ enum {
     GOM_OPT_BWD_MODE = 6,      /* render backward: 0 = a workgroup replays two consecutive sub-ranges between barriers, every wave taking
                                   diagonally opposite 8x8 quadrants in the two (evens out the quadrant imbalance of a tile); 1 = one
                                   sub-range per barrier (round 1); -1 (default) = 0 for a batched launch, 1 for a single frame.  Same gradients, bitwise. */
-    GOM_OPT_SORT_MODE = 5      /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
+    GOM_OPT_SORT_MODE = 5,     /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
                                   frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
                                   bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */
+    GOM_OPT_FUSE_FACE = 7      /* frame step (gom_frame_forward_backward / gom_batch_forward_backward) only: 1 (default) = the per-face
+                                  Gaussian frame and its backward run inside the rasterizer's per-Gaussian kernels (two launches and a
+                                  round trip of the means / covariances / their gradients through HBM less); 0 = separate face kernels. */
 };
 
 /* kernel ids for gom_state_kernel_times */

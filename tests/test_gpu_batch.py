@@ -229,3 +229,41 @@ def test_batch_with_small_segments_equals_single_frames_bitwise():
     assert torch.equal(batch.image, torch.stack(imgs))
     for k in ("vertices", "so3", "scale", "appearance"):
         assert torch.equal(batch.grads[k], grads[0][k] + grads[1][k]), k
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_face_frame_inside_the_per_gaussian_kernels_matches_the_separate_face_kernels(B):
+    """GOM_OPT_FUSE_FACE (default 1): the per-face Gaussian frame and its backward run inside k_preprocess / k_preprocess_bwd.
+    Same device functions as the stand-alone face kernels (geom_face.hpp, contraction pinned there): the two launch sequences
+    agree bitwise."""
+    from gomavatar_amd.pipeline import RenderStep
+    from gomavatar_amd import _lib
+    img = 128
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B, smpl_like=True)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    sq = (lambda t: t[0].contiguous()) if B == 1 else (lambda t: t)
+    out = []
+    for fuse in (0, 1):
+        step = RenderStep(faces, N, (img, img), w25, batch=B)
+        step.state.set_option(_lib.OPT_FUSE_FACE, fuse)
+        if B == 1:
+            step.set_camera(frames[0]["K"][0], frames[0]["E"][0], (0.1, 0.2, 0.3, 0.0))
+        else:
+            step.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames], (0.1, 0.2, 0.3, 0.0))
+        for graph in (False, True, True):
+            step.forward_backward(params, {k: sq(v) for k, v in fr_b.items()}, sq(gt_rgb), sq(gt_mask), sq(bg_b), graph=graph)
+            torch.cuda.synchronize()
+        out.append(dict(image=step.image.clone(), radii=step.radii.clone(), loss=step.loss_partials.clone(), D=step.state.poll()[0],
+                        grads={k: v.clone() for k, v in step.grads.items()}))
+    a, b = out
+    assert a["D"] == b["D"] and torch.equal(a["radii"], b["radii"])
+    d_img = float((a["image"] - b["image"]).abs().max())
+    print(f"\n[fused face kernels, B={B}] max |image difference| {d_img:.2e}  bitwise: {torch.equal(a['image'], b['image'])}")
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["loss"], b["loss"])
+    for k in a["grads"]:
+        ga, gb = a["grads"][k], b["grads"][k]
+        rel = float((ga - gb).abs().max() / ga.abs().max())
+        print(f"[fused face kernels, B={B}] d{k}: max |difference| / max |g| = {rel:.2e}  bitwise: {torch.equal(ga, gb)}")
+        assert float(ga.abs().max()) > 0 and torch.equal(ga, gb)
