@@ -381,9 +381,16 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 //   * request() is issued AFTER the task's own loads (returns are in order: a load behind the atomic would wait for
 //     it), publish() hands the result to the other waves through LDS before the task's last __syncthreads() --
 //     every path through a task must call both and then pass a barrier.
+//   * A workgroup whose shard is drained tries GOM_TQ_STEAL more shards and leaves.  Stealing is only balance between XCDs: every
+//     task is drawn by the workgroups of its own shard whatever the others do.  (Walking all eight was ~7 failing device-scope
+//     dequeues per workgroup at the moment all shards drain together: 14 000 of them at ~88 per us and address, the last task of
+//     every workgroup took 16 us instead of 7 -- scripts/wg_timeline_T.py; k_seg_T 94 -> 87 us.  0, 1, 2, 3 measure the same.)
 //   * The last workgroup to leave zeroes the heads for the next launch (graph replays included).
 // ctr layout: head of shard x at ctr[32 * x], workgroups that have left at ctr[32 * 8].
 #define GOM_TQ_WORDS (32 * GOM_TQ_SHARDS + 32)
+#ifndef GOM_TQ_STEAL
+#define GOM_TQ_STEAL 2   // shards a workgroup tries after its own before it leaves
+#endif
 template <int PER_SEG>
 struct TaskQueueT {
     uint32_t *ctr;
@@ -396,7 +403,7 @@ struct TaskQueueT {
     // thread 0 only: local index j on the current shard -> task, moving to the next shards while the current one is empty
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {
         while (j >= shard_tasks(shard)) {
-            if (++tried >= GOM_TQ_SHARDS) return 0xffffffffu;
+            if (++tried > GOM_TQ_STEAL) return 0xffffffffu;
             shard = (shard + 1) % GOM_TQ_SHARDS;
             j = per_shard_wgs + atomicAdd(ctr + 32 * shard, 1u);
         }
