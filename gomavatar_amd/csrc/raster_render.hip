@@ -165,6 +165,58 @@ __device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float
     return a;
 }
 
+// Two entries at one pixel, the same operations in the same order as entry_alpha, on register PAIRS: the products and sums become
+// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (one issue slot for both entries; the body of the segment kernels is bound by VALU
+// issue -- profiles/r02_valu.json, scripts/wg_timeline_T.py -- and a wave64 instruction occupies its SIMD for four cycles).
+// Bit-identical to two entry_alpha calls: packed fp32 operations round like the scalar ones, and nothing is left to contraction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct PairGeo { v2f x, y, a, b, c, o; };
+__device__ __forceinline__ v2f pair_alpha(const PairGeo &e, float pfx, float pfy) {
+#pragma clang fp contract(off)
+    const v2f px = {pfx, pfx}, py = {pfy, pfy};
+    const v2f dx = e.x - px, dy = e.y - py;
+    const v2f q = __builtin_elementwise_fma(dx, e.a * dx, dy * (e.c * dy));
+    const v2f mh = {-0.5f, -0.5f};
+    const v2f power = mh * q - dx * (e.b * dy);
+    const v2f l2e = {1.44269504088896340736f, 1.44269504088896340736f};   // __expf(x) = v_exp_f32(x * log2 e)
+    const v2f t = power * l2e;
+    const v2f g = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const v2f og = e.o * g;
+    v2f al;
+    al.x = (power.x <= 0.f) ? fminf(kMaxAlpha, og.x) : 0.f;
+    al.y = (power.y <= 0.f) ? fminf(kMaxAlpha, og.y) : 0.f;
+    al.x = (al.x >= kMinAlpha) ? al.x : 0.f;
+    al.y = (al.y >= kMinAlpha) ? al.y : 0.f;
+    return al;
+}
+
+// Survivors of a sub-range, compacted in list order into PAIR records in a wave-private LDS slab: pair j = survivors 2j and
+// 2j + 1 as (x0 x1 y0 y1)(a0 a1 b0 b1)(c0 c1 o0 o1), so that three broadcast ds_read_b128 deliver both entries already laid
+// out as register pairs.  The slab is padded with null entries (opacity 0 -> alpha 0) up to a multiple of four survivors.
+#define GOM_PAIR_F4 (3 * (GOM_SUB_MAX / 2 + 2))   // float4 per wave slab
+__device__ __forceinline__ uint32_t stage_pairs(float4 *slab, bool keep, unsigned long long mask, int lane, float x, float y, float a, float b, float c,
+                                                float o) {
+    float *f = reinterpret_cast<float *>(slab);
+    const uint32_t n = (uint32_t)__popcll(mask), n4 = (n + 3u) & ~3u;
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (keep) {
+        float *d = f + 12u * (pos >> 1) + (pos & 1u);
+        d[0] = x; d[2] = y; d[4] = a; d[6] = b; d[8] = c; d[10] = o;
+    }
+    if (lane < 3 && n + (uint32_t)lane < n4) {
+        const uint32_t pp = n + (uint32_t)lane;
+        float *d = f + 12u * (pp >> 1) + (pp & 1u);
+        d[0] = 0.f; d[2] = 0.f; d[4] = 0.f; d[6] = 0.f; d[8] = 0.f; d[10] = 0.f;
+    }
+    return n4;
+}
+__device__ __forceinline__ PairGeo load_pair(const float4 *slab, uint32_t j) {
+    const float4 p0 = slab[3 * j], p1 = slab[3 * j + 1], p2 = slab[3 * j + 2];
+    PairGeo e;
+    e.x = v2f{p0.x, p0.y}; e.y = v2f{p0.z, p0.w}; e.a = v2f{p1.x, p1.y}; e.b = v2f{p1.z, p1.w}; e.c = v2f{p2.x, p2.y}; e.o = v2f{p2.z, p2.w};
+    return e;
+}
+
 // ---------------------------------------------------------------- sort ------
 // (merge-sort building blocks: sort_util.hpp)
 using namespace gom_sort;
@@ -451,14 +503,17 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
                                                 const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr) {
     __shared__ float s_P[2][GOM_NSUB][64];
     __shared__ uint32_t s_task[2];
-    // Survivors' attributes reach the lanes through a wave-private LDS slab (uniform address = one broadcast ds_read_b128 +
-    // ds_read_b64 per entry) instead of six v_readlane (~6.6 issue cycles each): k_seg_T 117 -> 100 us.
-    __shared__ float4 s_e0[GOM_NSUB][64];
-    __shared__ float2 s_e1[GOM_NSUB][64];
+    // Survivors' attributes reach the lanes through a wave-private LDS slab (uniform addresses = broadcast reads) instead of six
+    // v_readlane (~6.6 issue cycles each): k_seg_T 117 -> 100 us; as PAIR records (stage_pairs) for the packed evaluation.
+    __shared__ float4 s_pr[GOM_NSUB][GOM_PAIR_F4];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
+#ifdef GOM_PHASE_PROF   // (scripts/wg_timeline_T.py: lifetime, number of tasks, longest and last task of every workgroup)
+    const unsigned long long ph_w0 = wall_clock64();
+    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64(), ph_lastsurv = 0, ph_maxsurv = 0;
+#endif
     TaskQueue tq;
     for (tq.init(task_ctr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
@@ -485,21 +540,17 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             tq.request();
             unsigned long long mask = __ballot(r.keep);
-            s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
-            s_e1[sub][lane] = make_float2(r.c, r.o);
-            while (mask) {
-                float al[GOM_FWD_EPT];
-#pragma unroll
-                for (int u = 0; u < GOM_FWD_EPT; u++) {
-                    const bool kv = mask != 0ull;
-                    const int k = kv ? __builtin_ctzll(mask) : 0;
-                    mask &= mask - 1;
-                    const float4 e0 = s_e0[sub][k];
-                    const float2 e1 = s_e1[sub][k];
-                    al[u] = entry_alpha(e0.x, e0.y, e0.z, e0.w, e1.x, kv ? e1.y : 0.f, pfx, pfy);
-                }
-#pragma unroll
-                for (int u = 0; u < GOM_FWD_EPT; u++) T = T * (1.f - al[u]);
+#ifdef GOM_PHASE_PROF
+            ph_lastsurv = __popcll(mask);
+#endif
+            const uint32_t n4 = stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o);   // (LDS operations of one wave execute in order: no barrier)
+            for (uint32_t j = 0; j < n4 / 2; j += 2) {
+                const v2f a0 = pair_alpha(load_pair(s_pr[sub], j), pfx, pfy);
+                const v2f a1 = pair_alpha(load_pair(s_pr[sub], j + 1), pfx, pfy);
+                T = T * (1.f - a0.x);
+                T = T * (1.f - a0.y);
+                T = T * (1.f - a1.x);
+                T = T * (1.f - a1.y);
             }
         }
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
@@ -508,7 +559,16 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         tq.publish(s_task);
         __syncthreads();
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
+#ifdef GOM_PHASE_PROF
+        { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) { ph_max = ph_last; ph_maxsurv = ph_lastsurv; } }
+#endif
     }
+#ifdef GOM_PHASE_PROF
+    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
+        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = wall_clock64();
+        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | (ph_maxsurv << 24) | (ph_lastsurv << 16) | ph_tasks;
+    }
+#endif
     tq.finish();
 }
 
@@ -1040,9 +1100,11 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
     tq.finish();
 #ifdef GOM_PHASE_PROF
     if (threadIdx.x == 0) {
+#ifdef GOM_PHASE_PROF_BWD   // (the arrays are shared with k_seg_T's instrumentation: one kernel at a time)
         g_wg_busy[blockIdx.x] += __builtin_readcyclecounter() - ph_k0;
         g_wg_t0[blockIdx.x] = ph_w0;   // timeline of the last launch (100 MHz wall clock, common to all XCDs)
         g_wg_t1[blockIdx.x] = wall_clock64();
+#endif
     }
 #endif
 }
