@@ -51,7 +51,7 @@
 #include "sort_util.hpp"
 #include <cstdlib>
 
-#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py ... -DGOM_PHASE_PROF): cycles per phase of k_seg_bwd
+#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2): workgroup timeline of k_seg_T (1) or k_seg_bwd_pair (2), scripts/wg_timeline_T.py
 __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_wg_busy[GOM_SEG_GRID * 4];
 extern "C" int gom_debug_phase_counters(unsigned long long *out, unsigned long long *wg, int reset) {
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
-#ifdef GOM_PHASE_PROF   // (scripts/wg_timeline_T.py: lifetime, number of tasks, longest and last task of every workgroup)
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1   // (scripts/wg_timeline_T.py: lifetime, number of tasks, longest and last task of every workgroup)
     const unsigned long long ph_w0 = wall_clock64();
     unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64(), ph_lastsurv = 0, ph_maxsurv = 0;
 #endif
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             tq.request();
             unsigned long long mask = __ballot(r.keep);
-#ifdef GOM_PHASE_PROF
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
             ph_lastsurv = __popcll(mask);
 #endif
             const uint32_t n4 = stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o);   // (LDS operations of one wave execute in order: no barrier)
@@ -559,11 +559,11 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         tq.publish(s_task);
         __syncthreads();
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
-#ifdef GOM_PHASE_PROF
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
         { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) { ph_max = ph_last; ph_maxsurv = ph_lastsurv; } }
 #endif
     }
-#ifdef GOM_PHASE_PROF
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
     if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
         g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = wall_clock64();
         g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | (ph_maxsurv << 24) | (ph_lastsurv << 16) | ph_tasks;
@@ -1147,6 +1147,10 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);
     const size_t HW = (size_t)H * W;
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2   // (scripts/wg_timeline_T.py)
+    const unsigned long long ph_w0 = wall_clock64();
+    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
+#endif
     TaskQueueT<2> tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
@@ -1327,7 +1331,16 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
             }
         }
         __syncthreads();   // the next pair overwrites s_acc / s_done
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2
+        { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) ph_max = ph_last; }
+#endif
     }
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2
+    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
+        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = wall_clock64();
+        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | ph_tasks;
+    }
+#endif
     tq.finish();
 }
 

@@ -1,4 +1,6 @@
-"""Development aid (prof variant built from an instrumented k_seg_T): per-workgroup lifetime, number of tasks, longest and last task."""
+"""Development aid: per-workgroup lifetime, number of tasks, longest and last task of a persistent segment kernel.
+    python scripts/exp_build.py prof -DGOM_PHASE_PROF=1      # k_seg_T (resident grid 2048); =2: k_seg_bwd_pair (GOM_TL_GRID=1280)
+    GOM_HIP_LIB=gomavatar_amd/_variants/libgom_hip_prof.so [GOM_TL_GRID=1280] python scripts/wg_timeline_T.py"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -7,7 +9,7 @@ import bench
 lib = ctypes.CDLL(_lib.LIB_PATH)
 sys.argv = ["bench.py", "--inflight", "1", "--no-cpu-baseline", "--no-modes", "--steps", "20", "--warmup", "4"]
 bench.main()
-n = 2048
+n = int(os.environ.get("GOM_TL_GRID", "2048"))
 t0 = np.zeros(4096 * 4, np.uint64); t1 = np.zeros(4096 * 4, np.uint64); wg = np.zeros(4096 * 4, np.uint64)
 lib.gom_debug_wg_timeline(t0.ctypes.data_as(ctypes.c_void_p), t1.ctypes.data_as(ctypes.c_void_p))
 lib.gom_debug_phase_counters(None, wg.ctypes.data_as(ctypes.c_void_p), 0)
