@@ -231,15 +231,18 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st, face)) return rc;
         if (s->rankSort) {
             if (int rc = gom_launch_depth_hist(s, P, st)) return rc;
-            if (int rc = gom_launch_scan_emit(s, P, st, true)) return rc;
+            if (int rc = gom_launch_scan_emit(s, P, st, true, out_color, C, cam->bg)) return rc;
             if (int rc = gom_launch_tile_rank(s, st)) return rc;
         } else {
-            if (int rc = gom_launch_scan_emit(s, P, st)) return rc;
+            if (int rc = gom_launch_scan_emit(s, P, st, false, out_color, C, cam->bg)) return rc;
             if (int rc = gom_launch_sort(s, st)) return rc;
         }
+        s->emptyFilled = P > 0;   // (no Gaussians: no emit launch)
     }
     s->C = C;
-    if (int rc = gom_launch_render_forward(s, *cam, C, colors, out_color, reuse, st)) return rc;
+    const int rrc = gom_launch_render_forward(s, *cam, C, colors, out_color, reuse, st);
+    s->emptyFilled = false;       // (a later pass over this binning -- other colours, other image -- paints its own)
+    if (rrc) return rrc;
     if (reuse && radii) GOM_HIP_CHECK(hipMemcpyAsync(radii, s->radii, (size_t)P * B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     s->haveForward = true;
     return 0;

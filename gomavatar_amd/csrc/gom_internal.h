@@ -60,6 +60,7 @@ struct GomState {
     int B = 1;
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
+    bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write
     bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
     int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 0 = two sub-ranges between barriers with opposite quadrants per wave, 1 = one sub-range per
                                       // barrier (round 1); -1 = auto: 0 for a batched launch (+2 %), 1 for a single frame (+1 %)
@@ -191,7 +192,19 @@ struct GomFaceArgs {
 // ---- launchers (one per kernel family; defined in the .hip files) ----------
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
                           const float *opacity, int32_t *radii_out, hipStream_t st, const GomFaceArgs *face = nullptr);
-int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false);
+// Background of the tiles no Gaussian touches, painted by spare blocks of k_emit (see there); first_block = blocks that emit.
+#define GOM_FILL_TILES 4
+struct GomEmptyFill {
+    int first_block, H, W, C;
+    float bg[4];
+    const GomCamera *cams;
+    const uint32_t *tile_base;
+    float *out_color, *final_T;
+    uint32_t *n_contrib;
+};
+// fill_out: the image this forward writes (C planes per frame) -- the emit kernel then also paints the empty tiles and the compositing
+// assembly skips them (GomState::emptyFilled).
+int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false, float *fill_out = nullptr, int fill_C = 0, const float *fill_bg = nullptr);
 int gom_launch_depth_hist(GomState *s, int P, hipStream_t st);
 int gom_launch_depth_rank(GomState *s, int P, hipStream_t st);
 int gom_launch_tile_rank(GomState *s, hipStream_t st);

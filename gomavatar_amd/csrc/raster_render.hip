@@ -764,8 +764,8 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
                                                      const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
-                                                     uint32_t *__restrict__ tile_qlim) {
-    __shared__ uint32_t s_nmax[4];
+                                                     uint32_t *__restrict__ tile_qlim, int skip_empty) {
+    __shared__ uint32_t s_nmax[4], s_qmax[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -794,6 +794,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
         return;
     }
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
+    if (nseg == 0 && skip_empty) return;   // this forward's k_emit painted the tile (background, T = 1, no contributor; tile_nmax zeroed by the scan)
     float T = 1.f, acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
@@ -802,6 +803,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
     bool going = true;
     // 8 segments per trip: all loads of a trip are issued before the (cheap, serial) fold, so the list of
     // segments costs one memory latency per 8 instead of one per segment.
+    float cs0[8][C];   // the colours of the first trip: tiles of up to 8 segments (nearly all) make their second pass from registers
     for (uint32_t s0 = 0; s0 < nseg; s0 += 8) {
         float te[8], cs[8][C];
         uint32_t ll[8];
@@ -812,6 +814,12 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
             te[u] = seg_Tend[o];
             ll[u] = seg_last[o];
             ld4<C>(seg_C, sb + sl, threadIdx.x, cs[u]);
+        }
+        if (s0 == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) cs0[u][ch] = cs[u][ch];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -837,26 +845,44 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
             }
         }
     }
+    // depth ranking: 1 + rank of the pixel's last contributor.  The tile's maximum (= the rank of its last contributing entry: ranks grow
+    // along the list) is what the per-Gaussian backward compares a Gaussian's own rank with.  Every lane fetches its own -- two dependent
+    // gathers issued HERE, in the shadow of the second pass -- where thread 0 used to walk tile_base -> point_list -> rank_of alone
+    // behind the barrier at the end.
+    uint32_t qrank = 0;
+    if (rank_of && inside && last) qrank = rank_of[point_list[tile_base[tile] + last - 1u]] + 1u;
     // colour still to come behind each segment (small terms first: accurate suffix sums)
     {
         float S[C];
 #pragma unroll
         for (int ch = 0; ch < C; ch++) S[ch] = 0.f;
-        for (int s1 = (int)nseg; s1 > 0; s1 -= 8) {
-            float cs[8][C];
+        if (nseg <= 8) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int sl = max(s1 - 1 - u, 0);
-                ld4<C>(seg_C, (size_t)(sb + sl), threadIdx.x, cs[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int sl = s1 - 1 - u;
-                if (sl >= 0) {
-                    st4<C>(seg_Sbehind, (size_t)(sb + sl), threadIdx.x, S);
+            for (int u = 7; u >= 0; u--) {
+                if (u < (int)nseg) {
+                    st4<C>(seg_Sbehind, (size_t)(sb + u), threadIdx.x, S);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++)
-                        if (sl <= s_stop) S[ch] += cs[u][ch];
+                        if (u <= s_stop) S[ch] += cs0[u][ch];
+                }
+            }
+        } else {
+            for (int s1 = (int)nseg; s1 > 0; s1 -= 8) {
+                float cs[8][C];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int sl = max(s1 - 1 - u, 0);
+                    ld4<C>(seg_C, (size_t)(sb + sl), threadIdx.x, cs[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int sl = s1 - 1 - u;
+                    if (sl >= 0) {
+                        st4<C>(seg_Sbehind, (size_t)(sb + sl), threadIdx.x, S);
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++)
+                            if (sl <= s_stop) S[ch] += cs[u][ch];
+                    }
                 }
             }
         }
@@ -868,14 +894,12 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = acc[ch] + T * bg[ch];
     }
     const uint32_t wmax = wave_max_u32(inside ? last : 0u);
-    if (lane == 0) s_nmax[wave] = wmax;
+    const uint32_t wq = rank_of ? wave_max_u32(qrank) : 0u;
+    if (lane == 0) { s_nmax[wave] = wmax; s_qmax[wave] = wq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t nm = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
-        tile_nmax[tile] = nm;
-        // depth ranking: 1 + rank of the tile's last contributing entry -- the per-Gaussian backward compares a Gaussian's own rank
-        // with it instead of looking up its list position
-        if (rank_of) tile_qlim[tile] = nm ? rank_of[point_list[tile_base[tile] + nm - 1u]] + 1u : 0u;
+        tile_nmax[tile] = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
+        if (rank_of) tile_qlim[tile] = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
     }
     // the four quadrant maxima once per SEGMENT of the tile: the backward finds them with the segment index alone
     for (uint32_t i = threadIdx.x; i < nseg; i += 256) seg_qmax[sb + i] = make_uint4(s_nmax[0], s_nmax[1], s_nmax[2], s_nmax[3]);
@@ -1417,7 +1441,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 #define GOM_CF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
-                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim)
+                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim, s->emptyFilled ? 1 : 0)
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }

@@ -221,12 +221,23 @@ def test_linear_weight_gradient_kernel_matches_torch(n, i, o):
 def test_shadow_module_gradients_match_the_plain_torch_module():
     from gomavatar_amd.model import ShadowModule
     import copy
+    torch.manual_seed(11)
     sm = ShadowModule(multires=6).cuda()
     with torch.no_grad():
         sm.block_mlps[-1].weight.normal_(0, 0.3)
     ref = copy.deepcopy(sm).cpu()
     x = torch.randn(1, 3000, 3)
     w = torch.randn(1, 3000, 1)
+    # rows with a pre-activation within rounding of the ReLU kink get loss weight 0 (see the next test: which side they land on is a
+    # matter of summation order, and the library GEMMs of the layer-wise path do not order their sums the same way on every call)
+    with torch.no_grad():
+        refd, pre = copy.deepcopy(ref).double(), []
+        hooks = [m.register_forward_hook(lambda _m, _i, o: pre.append(o.abs().min(-1).values.reshape(-1))) for m in list(refd.block_mlps)[:-1]
+                 if isinstance(m, torch.nn.Linear)]
+        refd(x.double())
+        for h in hooks:
+            h.remove()
+        w[0, torch.stack(pre).min(0).values < 1e-5] = 0.0
     xr = x.clone().requires_grad_(); (ref(xr) * w).sum().backward()
     xg = x.cuda().requires_grad_(); (sm(xg) * w.cuda()).sum().backward()
     assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
