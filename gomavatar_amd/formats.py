@@ -129,11 +129,17 @@ def apply_global_tfm_to_camera(E: np.ndarray, Rh: np.ndarray, Th: np.ndarray):
 
 
 class ReferenceDataset:
-    """Frames of a dataset directory prepared by the reference's scripts, as the dict `dataset/train.py:209-287` returns
-    (without the random crop; images need Pillow and are optional)."""
+    """Frames of a dataset directory prepared by the reference's scripts, as the dict `dataset/train.py:209-287` returns: lens
+    undistortion, resizing (`target_size` = (w, h) or `resize_img_scale` = (sx, sy)) and the random crop (`crop_size` = (w, h)) as
+    `dataset/train.py:138-200` does them, through the numpy restatements of the OpenCV calls in `imageops.py` (OpenCV absent: parity
+    unpinned).  Images need Pillow and are optional."""
 
-    def __init__(self, dataset_path: str, bgcolor=None, load_images: bool = True):
+    def __init__(self, dataset_path: str, bgcolor=None, load_images: bool = True, target_size=None, resize_img_scale=(1.0, 1.0),
+                 crop_size=(-1, -1)):
         self.path = dataset_path
+        self.target_size = tuple(target_size) if target_size is not None else None
+        self.resize_img_scale = (float(resize_img_scale[0]), float(resize_img_scale[1])) if np.ndim(resize_img_scale) else (float(resize_img_scale),) * 2
+        self.crop_size = tuple(crop_size)
         with open(os.path.join(dataset_path, "canonical_joints.pkl"), "rb") as f:
             cj = pickle.load(f)
         self.canonical_joints = cj["joints"].astype("float32")
@@ -163,21 +169,42 @@ class ReferenceDataset:
     def __getitem__(self, idx: int) -> Dict[str, np.ndarray]:
         name = self.framelist[idx]
         mi, cam = self.mesh_infos[name], self.cameras[name]
-        if "distortions" in cam and np.any(np.asarray(cam["distortions"]) != 0):
-            raise NotImplementedError("lens undistortion needs OpenCV (dataset/train.py:151-155)")
         bg = (np.random.rand(3) * 255.0).astype("float32") if self.bgcolor is None else np.asarray(self.bgcolor, dtype="float32")
         poses, tpose = mi["poses"].astype("float32"), mi["tpose_joints"].astype("float32")
         E, gt = apply_global_tfm_to_camera(cam["extrinsics"], mi["Rh"].astype("float32"), mi["Th"].astype("float32"))
         dst_Rs, dst_Ts = _syn.pose_to_body_RTs(poses.reshape(-1), tpose)
-        out = {"frame_name": name, "bgcolor": bg / 255.0, "K": cam["intrinsics"][:3, :3].astype(np.float32), "E": E.astype(np.float32),
+        K = cam["intrinsics"][:3, :3].astype(np.float64).copy()
+        out = {"frame_name": name, "bgcolor": bg / 255.0, "K": K.astype(np.float32), "E": E.astype(np.float32),
                "global_tfms": gt, "dst_poses": poses, "dst_Rs": dst_Rs, "dst_Ts": dst_Ts,
                "cnl_gtfms": _syn.canonical_global_tfms(self.canonical_joints), "dst_posevec": poses.reshape(-1)[3:] + 1e-2,
                "dst_tpose_joints": tpose}
         if self.load_images:
             from PIL import Image
-            img = np.asarray(Image.open(os.path.join(self.path, "images", name + ".png")).convert("RGB"), dtype=np.float32)
-            alpha = np.asarray(Image.open(os.path.join(self.path, "masks", name + ".png")).convert("RGB"), dtype=np.float32) / 255.0
-            out["target_rgbs"] = ((alpha * img + (1.0 - alpha) * bg[None, None, :]) / 255.0).astype(np.float32)
+            from . import imageops as iop
+            img8 = np.asarray(Image.open(os.path.join(self.path, "images", name + ".png")).convert("RGB"))
+            mask8 = np.asarray(Image.open(os.path.join(self.path, "masks", name + ".png")).convert("RGB"))
+            orig_H, orig_W = img8.shape[:2]
+            if "distortions" in cam:                                      # dataset/train.py:151-155
+                img8 = iop.undistort(img8, cam["intrinsics"], cam["distortions"])
+                mask8 = iop.undistort(mask8, cam["intrinsics"], cam["distortions"])
+            alpha = mask8 / 255.0                                          # float64, like the reference's numpy arithmetic
+            img = alpha * img8 + (1.0 - alpha) * bg[None, None, :]
+            if self.target_size is not None:                               # dataset/train.py:158-163
+                img = iop.resize(img, self.target_size, interpolation=iop.INTER_LANCZOS4)
+                alpha = iop.resize(alpha, self.target_size, interpolation=iop.INTER_LINEAR)
+                scale_w, scale_h = self.target_size[0] / orig_W, self.target_size[1] / orig_H
+            else:
+                scale_w, scale_h = self.resize_img_scale
+                if self.resize_img_scale != (1.0, 1.0):                    # dataset/train.py:165-173
+                    img = iop.resize(img, None, fx=scale_w, fy=scale_h, interpolation=iop.INTER_LANCZOS4)
+                    alpha = iop.resize(alpha, None, fx=scale_w, fy=scale_h, interpolation=iop.INTER_LINEAR)
+            img = (img / 255.0).astype(np.float32)
+            K[:1] *= scale_w                                               # dataset/train.py:239-244
+            K[1:2] *= scale_h
+            if self.crop_size != (-1, -1):                                 # dataset/train.py:255-256
+                img, alpha, K = iop.crop_image(img, alpha, K, self.crop_size)
+            out["K"] = K.astype(np.float32)
+            out["target_rgbs"] = img
             out["target_masks"] = alpha[:, :, 0].astype(np.float32)
         return out
 

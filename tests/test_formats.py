@@ -3,6 +3,7 @@ import os
 from types import SimpleNamespace as NS
 
 import numpy as np
+import pytest
 import torch
 
 from gomavatar_amd import formats, synthetic as syn
@@ -98,6 +99,43 @@ def test_dataset_directory_round_trip(tmp_path):
     # Rh / Th are folded into the extrinsics (camera_util.py:111-131)
     E2, g = formats.apply_global_tfm_to_camera(np.eye(4), np.array([0.0, 0.3, 0.0]), np.array([0.1, 0.0, 0.0]))
     np.testing.assert_allclose(E2 @ g, np.eye(4), atol=1e-12)
+
+
+def test_dataset_reader_undistorts_resizes_and_crops_like_the_reference(tmp_path):
+    """dataset/train.py:138-200, 239-256: undistort both images when the camera has `distortions`, composite on the background in
+    floating point, LANCZOS4 for the image and LINEAR for the mask (target_size or resize_img_scale), K scaled, crop shifts the
+    principal point.  (The image operations themselves: tests/test_imageops.py.)"""
+    pytest.importorskip("PIL")
+    import pickle, os
+    formats.write_synthetic_dataset(str(tmp_path), n_frames=2, img=64, level=1)
+    plain = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0])[0]
+    # zero distortion coefficients: the undistortion branch runs and changes nothing
+    with open(os.path.join(tmp_path, "cameras.pkl"), "rb") as f:
+        cams = pickle.load(f)
+    for c in cams.values():
+        c["distortions"] = np.zeros(5)
+    with open(os.path.join(tmp_path, "cameras.pkl"), "wb") as f:
+        pickle.dump(cams, f)
+    same = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0])[0]
+    assert np.array_equal(same["target_rgbs"], plain["target_rgbs"]) and np.array_equal(same["target_masks"], plain["target_masks"])
+    # half size through both spellings: K scales, shapes follow, the mask stays a mask, the background stays the background
+    for kw in (dict(target_size=(32, 32)), dict(resize_img_scale=(0.5, 0.5))):
+        half = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0], **kw)[0]
+        assert half["target_rgbs"].shape == (32, 32, 3) and half["target_masks"].shape == (32, 32) and half["target_rgbs"].dtype == np.float32
+        np.testing.assert_allclose(half["K"][:2], plain["K"][:2] * 0.5, rtol=1e-6)
+        assert half["target_masks"].min() >= 0.0 and half["target_masks"].max() <= 1.0 and half["target_masks"][16, 16] == 1.0
+        np.testing.assert_allclose(half["target_rgbs"][0, 0], [0.0, 1.0, 0.0], atol=1e-5)
+    # a real distortion moves pixels; the crop keeps at least 20 mask units and moves the principal point by the crop offset
+    for c in cams.values():
+        c["distortions"] = np.array([0.3, 0.0, 0.0, 0.0, 0.0])
+    with open(os.path.join(tmp_path, "cameras.pkl"), "wb") as f:
+        pickle.dump(cams, f)
+    np.random.seed(0)
+    warped = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0], crop_size=(40, 32))[0]
+    assert warped["target_rgbs"].shape == (32, 40, 3) and warped["target_masks"].sum() >= 20
+    assert plain["K"][0, 2] - warped["K"][0, 2] >= 0 and plain["K"][1, 2] - warped["K"][1, 2] >= 0
+    full = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0])[0]
+    assert not np.array_equal(full["target_masks"], plain["target_masks"])
 
 
 def test_shadow_module_and_color_consistency_match_reference_goldens(golden_dir):
