@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "gom_internal.h"
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -30,6 +31,7 @@ static int grow(T **p, size_t count) {
 
 extern "C" GomState *gom_state_create(void) {
     GomState *s = new GomState();
+    if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // development switch (A/B of the cost-ordered backward queue)
     if (hipGetDevice(&s->device) != hipSuccess) {
         gom_set_error("hipGetDevice failed (no HIP device?)");
         delete s;
@@ -50,7 +52,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -184,7 +186,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow(&s->seg_desc, n) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
+        if (grow(&s->seg_desc, n) || grow(&s->seg_cost, 2 * n) || grow(&s->bwd_order, 2 * n) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
             grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX) || grow(&s->sub_T, n * 4 * GOM_TPX) ||
             grow(&s->sub_C, n * 16 * GOM_TPX) || grow(&s->sub_Tend, n * 4 * GOM_TPX))
             return -2;
@@ -270,7 +272,9 @@ static int raster_backward_impl(GomState *s, const GomCamera *cam, const GomCame
     if (flags & GOM_BWD_RECOMPUTE_FORWARD) {
         if (int rc = gom_launch_render_forward(s, *cam, C, colors, s->scratch_img, true, st)) return rc;
     }
-    if (int rc = gom_launch_render_backward(s, *cam, C, colors, dL_dcolor, st)) return rc;
+    const int brc = gom_launch_render_backward(s, *cam, C, colors, dL_dcolor, st);
+    s->bwdOrderReady = false;   // (the order belongs to ONE forward / backward pair)
+    if (brc) return brc;
     if (int rc = gom_launch_preprocess_backward(s, *cam, P, C, means3D, cov6, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity,
                                                 dL_dmeans2D, st, face))
         return rc;
@@ -454,9 +458,13 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
         if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
                                       f->work_radii, 0, stream, face)))
             return rc;
+        // batched launches: the loss kernel carries the rider that orders the backward's task queue by the cost the forward counted
+        GomBwdOrderRider rider{s->status, s->seg_cost, s->bwd_order};
+        const bool ride = B > 1 && s->bwdOrder && s->rankSort;   // (the tile pass of the depth ranking zeroes the cost words)
         if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
-                                    nullptr, f->loss_partials, stream)))
+                                    nullptr, f->loss_partials, stream, ride ? &rider : nullptr)))
             return rc;
+        s->bwdOrderReady = ride;
     }
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
     if ((rc = raster_backward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage,

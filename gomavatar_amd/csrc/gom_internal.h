@@ -61,6 +61,7 @@ struct GomState {
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
     bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write
+    bool bwdOrder = true;             // development switch: cost-ordered backward queue in the frame step
     bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
     int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 0 = two sub-ranges between barriers with opposite quadrants per wave, 1 = one sub-range per
                                       // barrier (round 1); -1 = auto: 0 for a batched launch (+2 %), 1 for a single frame (+1 %)
@@ -103,6 +104,9 @@ struct GomState {
     // per segment (x 256 pixels of the tile, quadrant-major)
     int64_t capSegs = 0;
     uint4 *seg_qmax = nullptr;        // [capSegs] max n_contrib over each 8x8 quadrant of the segment's tile (combine pass, for the backward)
+    uint32_t *seg_cost = nullptr;     // [capSegs][2] entries that survived the cull in the alive pieces of each sub-range PAIR (k_seg_fwd) = cost estimate of the backward's task
+    uint32_t *bwd_order = nullptr;    // [capSegs * 2] the backward's (segment, pair) tasks, most expensive first (rider block of the loss kernel)
+    bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
     float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
     float *ent_col = nullptr;         // [capPairs][4] list-ordered colours
@@ -227,9 +231,17 @@ int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32
 int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
                               const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
                               float *d_xyz, float *dRT, void *stream);
+// Riders of the loss kernel in the frame step: eight extra workgroups, one per shard of the render backward's task queue, order its tasks
+// by the cost the forward counted (counting sort, 512 levels, most expensive first).  It runs in the shadow of the loss blocks -- between the forward and the backward there
+// is no other launch to hide them in.
+struct GomBwdOrderRider {
+    const GomDevStatus *status;
+    const uint32_t *seg_cost;
+    uint32_t *bwd_order;
+};
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream);
+                      float *loss_partials, void *stream, const GomBwdOrderRider *rider = nullptr);
 int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
                     float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,

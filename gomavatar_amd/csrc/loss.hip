@@ -16,18 +16,58 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0
 __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict__ pred, const float *__restrict__ shade,
                                                  const float *__restrict__ gt_rgb, const float *__restrict__ gt_mask,
                                                  const float *__restrict__ bg, float k_rgb, float k_mask,
-                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials) {
+                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials, GomBwdOrderRider rider) {
     __shared__ float s_red[2][4];
+    if (blockIdx.x >= GOM_LOSS_BLOCKS) {   // the riders (eight workgroups, frame 0's row of the grid only): see GomBwdOrderRider
+        if (blockIdx.y != 0 || rider.status->overflow) return;
+        // Rider x orders the tasks of queue shard x (the segments with seg mod 8 = x, two tasks each, queue position j <-> task
+        // ((j >> 1) * 8 + x) << 1 | (j & 1), as TaskQueueT<2>::task_of): a counting sort over 512 cost levels, most expensive first.
+        __shared__ uint32_t s_lvl[512];
+        const uint32_t x = blockIdx.x - GOM_LOSS_BLOCKS, nsegs = rider.status->num_segs;
+        const uint32_t n = nsegs > x ? 2u * ((nsegs - x + 7u) / 8u) : 0u;
+        auto task_of = [x](uint32_t j) { return (((j >> 1) * 8u + x) << 1) | (j & 1u); };
+        for (int k = threadIdx.x; k < 512; k += 256) s_lvl[k] = 0u;
+        __syncthreads();
+        for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * 256) {   // 8 independent loads in flight per thread
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * 256; c[u] = j < n ? rider.seg_cost[task_of(j)] : 0xffffffffu; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (c[u] != 0xffffffffu) atomicAdd(&s_lvl[511u - min(c[u], 511u)], 1u);   // level 0 = the most expensive
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {   // exclusive scan of the 512 level counts: 8 per lane + a wave scan
+            uint32_t c[8], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { c[k] = s_lvl[8 * threadIdx.x + k]; tot += c[k]; }
+            uint32_t y = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t z = __shfl_up(y, d, 64); if ((int)threadIdx.x >= d) y += z; }
+            uint32_t run = y - tot;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s_lvl[8 * threadIdx.x + k] = run; run += c[k]; }
+        }
+        __syncthreads();
+        for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * 256) {
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * 256; c[u] = j < n ? rider.seg_cost[task_of(j)] : 0xffffffffu; }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (c[u] != 0xffffffffu) rider.bwd_order[task_of(atomicAdd(&s_lvl[511u - min(c[u], 511u)], 1u))] = task_of(j0 + u * 256);   // (order inside a level: any)
+        }
+        return;
+    }
     {  // blockIdx.y = frame of a batched launch: [B][4][HW] images, [B][HW][3] targets, [B][3] backgrounds
         const size_t fr = blockIdx.y;
         pred += fr * 4 * HW; gt_rgb += fr * 3 * HW; gt_mask += fr * HW; bg += fr * 3; dpred += fr * 4 * HW;
-        partials += fr * 2 * gridDim.x;
+        partials += fr * 2 * GOM_LOSS_BLOCKS;   // (the grid's x extent may carry one rider block more)
         if (shade) shade += fr * HW;
         if (dshade) dshade += fr * HW;
     }
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     float sum_rgb = 0.f, sum_mask = 0.f;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += GOM_LOSS_BLOCKS * 256) {
         const float m = pred[3 * (size_t)HW + p];
         const float s = shade ? shade[p] : 1.f;
         const float a0 = pred[p], a1 = pred[(size_t)HW + p], a2 = pred[2 * (size_t)HW + p];
@@ -62,14 +102,14 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
 
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream) {
+                      float *loss_partials, void *stream, const GomBwdOrderRider *rider) {
     if (H <= 0 || W <= 0) { gom_set_error("gom_l1_loss: bad image size"); return -1; }
     if (!pred || !gt_rgb || !gt_mask || !bg || !dL_dpred || !loss_partials) { gom_set_error("gom_l1_loss: null pointer"); return -1; }
     const int HW = H * W;
     const float k_rgb = grad_scale * c_rgb / (3.0f * (float)HW);
     const float k_mask = grad_scale * c_mask / (float)HW;
-    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
-                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials);
+    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS + (rider ? 8 : 0), B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
+                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials, rider ? *rider : GomBwdOrderRider{});
     GOM_LAUNCH_CHECK();
     return 0;
 }

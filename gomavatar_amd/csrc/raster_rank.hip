@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
                                                   const uint32_t *__restrict__ order, const float4 *__restrict__ rec_g,
                                                   uint32_t *__restrict__ point_list, uint4 *__restrict__ seg_desc,
                                                   uint32_t *__restrict__ ent_slot, float2 *__restrict__ ent_geo,
-                                                  const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words, uint32_t *__restrict__ seg_cost) {
     extern __shared__ uint32_t s_mem[];
     __shared__ uint32_t s_wsum[NT / 64];
     uint32_t *s_bm = s_mem, *s_stage = s_mem + bm_words;
@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
         if (c0 == 0) {
             const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
             for (uint32_t i = t; i < nseg; i += NT)
+            {
                 seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
+                if (seg_cost) { seg_cost[2 * (sb + i)] = 0u; seg_cost[2 * (sb + i) + 1] = 0u; }
+            }
         }
         const int fr = tile / (gx * gy);
         const int tx = tile % gx, ty = tile / gx;                 // ty: row in the STACKED grid (rects carry the same offset)
@@ -317,7 +320,7 @@ int gom_launch_tile_rank(GomState *s, hipStream_t st) {
     const int cap_items = n_tiles + (int)(s->capPairs / GOM_RANK_WIN < 0x7fffffff ? s->capPairs / GOM_RANK_WIN : 0x7fffffff);
     const int grid = cap_items < 2048 ? cap_items : 2048;   // a resident grid striding over the work items of the scan kernel
     hipLaunchKernelGGL((k_tile_rank<256>), dim3(grid), dim3(256), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, s->work_items, &s->status->n_work_items,
-                       s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words);
+                       s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words, s->seg_cost);
     GOM_LAUNCH_CHECK();
     return 0;
 }

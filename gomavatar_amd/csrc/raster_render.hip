@@ -446,13 +446,15 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 template <int PER_SEG>
 struct TaskQueueT {
     uint32_t *ctr;
-    uint32_t nsegs, per_shard_wgs, shard, tried, pend, it;
+    const uint32_t *order;   // optional: position in the queue -> task (the backward's cost-ordered list); null = identity
+    uint32_t nsegs, per_shard_wgs, shard, tried, pend, it, next;
+    bool have_next;
     __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? (uint32_t)PER_SEG * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
     __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const {
         constexpr uint32_t SH = PER_SEG == 4 ? 2u : (PER_SEG == 2 ? 1u : 0u);   // PER_SEG queue items per segment: (segment << SH) | piece
         return (((j >> SH) * GOM_TQ_SHARDS + x) << SH) | (j & ((1u << SH) - 1u));
     }
-    // thread 0 only: local index j on the current shard -> task, moving to the next shards while the current one is empty
+    // thread 0 only: local index j on the current shard -> queue item, moving to the next shards while the current one is empty
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {
         while (j >= shard_tasks(shard)) {
             if (++tried > GOM_TQ_STEAL) return 0xffffffffu;
@@ -461,12 +463,13 @@ struct TaskQueueT {
         }
         return task_of(shard, j);
     }
-    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task) {
-        ctr = c; nsegs = n_segs; it = 0; tried = 0; pend = 0;
+    __device__ __forceinline__ uint32_t to_task(uint32_t item) const { return (item == 0xffffffffu || !order) ? item : order[item]; }
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task, const uint32_t *task_order = nullptr) {
+        ctr = c; order = task_order; nsegs = n_segs; it = 0; tried = 0; pend = 0; next = 0; have_next = false;
         if (!ctr) return;  // static mode: plain grid-stride (single-frame launches, see the launchers)
         per_shard_wgs = gridDim.x / GOM_TQ_SHARDS;  // the launchers round the grid to a multiple of the shard count
         shard = blockIdx.x % GOM_TQ_SHARDS;
-        if (threadIdx.x == 0) s_task[0] = resolve(blockIdx.x / GOM_TQ_SHARDS);
+        if (threadIdx.x == 0) s_task[0] = to_task(resolve(blockIdx.x / GOM_TQ_SHARDS));
         __syncthreads();
     }
     __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
@@ -479,8 +482,14 @@ struct TaskQueueT {
     __device__ __forceinline__ void request() {
         if (ctr && threadIdx.x == 0) pend = atomicAdd(ctr + 32 * shard, 1u);
     }
+    // optional, between request() and publish(): turn the dequeue into the next task now, so that the order-table load it issues has
+    // the rest of the task to arrive (publish() would otherwise wait for it in front of the barrier)
+    __device__ __forceinline__ void look_ahead() {
+        if (ctr && threadIdx.x == 0 && !have_next) { next = to_task(resolve(per_shard_wgs + pend)); have_next = true; }
+    }
     __device__ __forceinline__ void publish(uint32_t *s_task) {
-        if (ctr && threadIdx.x == 0) s_task[(it + 1) & 1] = resolve(per_shard_wgs + pend);
+        look_ahead();
+        if (ctr && threadIdx.x == 0) { s_task[(it + 1) & 1] = next; have_next = false; }
     }
     __device__ __forceinline__ void advance() { it++; }
     __device__ __forceinline__ void finish() {
@@ -579,11 +588,11 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
 // contribution, T after it (negated if the stop rule fired inside) and the last contributor; the per-sub-range
 // pieces are kept as checkpoints for the backward.
 template <int C>
-__global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+__global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
-                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, uint32_t *__restrict__ seg_cost) {
     __shared__ float s_c[GOM_NSUB][C][64];
     __shared__ float s_t[GOM_NSUB][64];
     __shared__ uint32_t s_l[GOM_NSUB][64];
@@ -659,6 +668,8 @@ __global__ void __launch_bounds__(256) k_seg_fwd(uint32_t seg_shift, int gx, int
         uint32_t last = 0;
         if (__ballot(wl != 0.f) != 0ull) {
             unsigned long long mask = __ballot(r.keep);
+            // what the backward will pay for this piece, roughly: the entries that reach alive pixels here (GomBwdOrderRider)
+            if (seg_cost && lane == 0 && mask) atomicAdd(&seg_cost[2 * seg + (sub >> 1)], (uint32_t)__popcll(mask));
             s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
             s_e1[sub][lane] = make_float2(r.c, r.o);
             {
@@ -1155,7 +1166,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
-                                                  uint32_t *__restrict__ task_ctr) {
+                                                  uint32_t *__restrict__ task_ctr, const uint32_t *__restrict__ task_order) {
     constexpr int NV = 6 + C;
     // [half of the pair][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote
     __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
@@ -1176,7 +1187,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
 #endif
     TaskQueueT<2> tq;
-    for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
+    for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task, task_order);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
         if (task == 0xffffffffu) break;
         const uint32_t seg = task >> 1;
@@ -1330,6 +1341,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                 }
             }
             if (lane == 0) s_done[half][q] = done;
+            if (half == 0 && requested) tq.look_ahead();   // (the dequeue went out with the first half's loads: it is back)
         }
         if (!requested) tq.request();
         tq.publish(s_task);
@@ -1431,7 +1443,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_RESIDENT(k_seg_fwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
-                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR)
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
     }
@@ -1459,7 +1471,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 #define GOM_SBW(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_pair<CC>), dim3(GOM_RESIDENT(k_seg_bwd_pair<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, s->B > 1 && s->bwdOrderReady ? s->bwd_order : nullptr)
         if (C == 3) GOM_SBW(3); else GOM_SBW(4);
 #undef GOM_SBW
         GOM_LAUNCH_CHECK();
