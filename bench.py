@@ -499,6 +499,9 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        # leave together: a rank that tears its sockets down while another is still inside its last collective takes that one down with it
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 

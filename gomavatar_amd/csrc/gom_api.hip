@@ -186,7 +186,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow(&s->seg_desc, n) || grow(&s->seg_cost, 2 * n) || grow(&s->bwd_order, 2 * n) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
+        if (grow(&s->seg_desc, n) || grow(&s->seg_cost, 16 * n) || grow(&s->bwd_order, 4 * n + 64) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
             grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX) || grow(&s->sub_T, n * 4 * GOM_TPX) ||
             grow(&s->sub_C, n * 16 * GOM_TPX) || grow(&s->sub_Tend, n * 4 * GOM_TPX))
             return -2;

@@ -104,8 +104,8 @@ struct GomState {
     // per segment (x 256 pixels of the tile, quadrant-major)
     int64_t capSegs = 0;
     uint4 *seg_qmax = nullptr;        // [capSegs] max n_contrib over each 8x8 quadrant of the segment's tile (combine pass, for the backward)
-    uint32_t *seg_cost = nullptr;     // [capSegs][2] entries that survived the cull in the alive pieces of each sub-range PAIR (k_seg_fwd) = cost estimate of the backward's task
-    uint32_t *bwd_order = nullptr;    // [capSegs * 2] the backward's (segment, pair) tasks, most expensive first (rider block of the loss kernel)
+    uint32_t *seg_cost = nullptr;     // [capSegs][4 sub-ranges][4 quadrants] entries that survived the cull in the pieces k_seg_fwd found alive = cost estimate of the backward's tasks
+    uint32_t *bwd_order = nullptr;    // the backward's tasks per queue shard, most expensive first (riders of the loss kernel): GOM_BWD_ORDER_* below
     bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
     float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
@@ -231,6 +231,13 @@ int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32
 int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, const float *weights, const float *RT, const int32_t *csr_off,
                               const int32_t *csr_idx, const float *d_corner, const float *d_verts_extra, float *d_verts_obs,
                               float *d_xyz, float *dRT, void *stream);
+// The backward's task word: (segment << 3) | code, code 0 / 1 = the pair of sub-ranges (0,1) / (2,3), code 4 + j = sub-range j alone (the riders
+// split a pair whose busiest wave would see more than GOM_BWD_SPLIT_COST surviving entries: the densest pairs are 120 us tasks).
+// Order table: [0, 8) tasks of shard x; then shard x's tasks at GOM_BWD_ORDER_BASE + x * region, region = 4 * ceil(nsegs / 8) entries.
+#ifndef GOM_BWD_SPLIT_COST
+#define GOM_BWD_SPLIT_COST 110u
+#endif
+#define GOM_BWD_ORDER_BASE 64u
 // Riders of the loss kernel in the frame step: eight extra workgroups, one per shard of the render backward's task queue, order its tasks
 // by the cost the forward counted (counting sort, 512 levels, most expensive first).  It runs in the shadow of the loss blocks -- between the forward and the backward there
 // is no other launch to hide them in.

@@ -20,41 +20,65 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
     __shared__ float s_red[2][4];
     if (blockIdx.x >= GOM_LOSS_BLOCKS) {   // the riders (eight workgroups, frame 0's row of the grid only): see GomBwdOrderRider
         if (blockIdx.y != 0 || rider.status->overflow) return;
-        // Rider x orders the tasks of queue shard x (the segments with seg mod 8 = x, two tasks each, queue position j <-> task
-        // ((j >> 1) * 8 + x) << 1 | (j & 1), as TaskQueueT<2>::task_of): a counting sort over 512 cost levels, most expensive first.
+        // Rider x orders the tasks of queue shard x (the segments with seg mod 8 = x): a counting sort over 512 cost levels, most
+        // expensive first; a pair of sub-ranges above GOM_BWD_SPLIT_COST becomes two single-sub-range tasks.
         __shared__ uint32_t s_lvl[512];
         const uint32_t x = blockIdx.x - GOM_LOSS_BLOCKS, nsegs = rider.status->num_segs;
-        const uint32_t n = nsegs > x ? 2u * ((nsegs - x + 7u) / 8u) : 0u;
-        auto task_of = [x](uint32_t j) { return (((j >> 1) * 8u + x) << 1) | (j & 1u); };
+        const uint32_t npairs = nsegs > x ? 2u * ((nsegs - x + 7u) / 8u) : 0u;       // (segment, pair) units of this shard
+        const uint32_t region = 4u * ((nsegs + 7u) / 8u);
+        uint32_t *out = rider.bwd_order + GOM_BWD_ORDER_BASE + (size_t)x * region;
         for (int k = threadIdx.x; k < 512; k += 256) s_lvl[k] = 0u;
         __syncthreads();
-        for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * 256) {   // 8 independent loads in flight per thread
-            uint32_t c[8];
+        auto level = [](uint32_t c) { return 511u - min(c, 511u); };                  // level 0 = the most expensive
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t j0 = threadIdx.x; j0 < npairs; j0 += 2 * 256) {            // 2 units = 4 independent 16-byte loads in flight per thread
+                uint2 c[2];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * 256; c[u] = j < n ? rider.seg_cost[task_of(j)] : 0xffffffffu; }
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t j = j0 + u * 256, seg = (j >> 1) * 8u + x;
+                    c[u] = make_uint2(0xffffffffu, 0u);
+                    if (j < npairs && seg < nsegs) {
+                        // what the pair costs its workgroup: wave w takes quadrant w of the first sub-range, then quadrant 3 - w of the second
+                        // (k_seg_bwd_pair), and the task lasts as long as its busiest wave; a sub-range alone: its busiest quadrant
+                        const uint4 a = *reinterpret_cast<const uint4 *>(rider.seg_cost + 16 * (size_t)seg + 8 * (j & 1u));
+                        const uint4 b = *reinterpret_cast<const uint4 *>(rider.seg_cost + 16 * (size_t)seg + 8 * (j & 1u) + 4);
+                        const uint32_t both = max(max(a.x + b.w, a.y + b.z), max(a.z + b.y, a.w + b.x));
+                        c[u] = make_uint2(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w)));
+                        if (both <= GOM_BWD_SPLIT_COST) c[u] = make_uint2(both, 0xfffffffeu);   // (.y = marker: not split)
+                    }
+                }
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (c[u] != 0xffffffffu) atomicAdd(&s_lvl[511u - min(c[u], 511u)], 1u);   // level 0 = the most expensive
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {   // exclusive scan of the 512 level counts: 8 per lane + a wave scan
-            uint32_t c[8], tot = 0;
+                for (int u = 0; u < 2; u++) {
+                    if (c[u].x == 0xffffffffu) continue;
+                    const uint32_t j = j0 + u * 256, seg = (j >> 1) * 8u + x, pair = j & 1u, tot = c[u].x;
+                    if (c[u].y != 0xfffffffeu) {
+                        if (pass == 0) { atomicAdd(&s_lvl[level(c[u].x)], 1u); atomicAdd(&s_lvl[level(c[u].y)], 1u); }
+                        else {
+                            out[atomicAdd(&s_lvl[level(c[u].x)], 1u)] = (seg << 3) | (4u + 2u * pair);
+                            out[atomicAdd(&s_lvl[level(c[u].y)], 1u)] = (seg << 3) | (5u + 2u * pair);
+                        }
+                    } else {
+                        if (pass == 0) atomicAdd(&s_lvl[level(tot)], 1u);
+                        else out[atomicAdd(&s_lvl[level(tot)], 1u)] = (seg << 3) | pair;    // (order inside a level: any)
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (threadIdx.x < 64) {   // exclusive scan of the 512 level counts: 8 per lane + a wave scan
+                    uint32_t c8[8], tot = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { c[k] = s_lvl[8 * threadIdx.x + k]; tot += c[k]; }
-            uint32_t y = tot;
+                    for (int k = 0; k < 8; k++) { c8[k] = s_lvl[8 * threadIdx.x + k]; tot += c8[k]; }
+                    uint32_t y = tot;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t z = __shfl_up(y, d, 64); if ((int)threadIdx.x >= d) y += z; }
-            uint32_t run = y - tot;
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t z = __shfl_up(y, d, 64); if ((int)threadIdx.x >= d) y += z; }
+                    uint32_t run = y - tot;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { s_lvl[8 * threadIdx.x + k] = run; run += c[k]; }
-        }
-        __syncthreads();
-        for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * 256) {
-            uint32_t c[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * 256; c[u] = j < n ? rider.seg_cost[task_of(j)] : 0xffffffffu; }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (c[u] != 0xffffffffu) rider.bwd_order[task_of(atomicAdd(&s_lvl[511u - min(c[u], 511u)], 1u))] = task_of(j0 + u * 256);   // (order inside a level: any)
+                    for (int k = 0; k < 8; k++) { s_lvl[8 * threadIdx.x + k] = run; run += c8[k]; }
+                    if (threadIdx.x == 63) rider.bwd_order[x] = run;   // tasks of this shard
+                }
+                __syncthreads();
+            }
         }
         return;
     }

@@ -189,7 +189,10 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
             for (uint32_t i = t; i < nseg; i += NT)
             {
                 seg_desc[sb + i] = make_uint4((uint32_t)tile, base + (i << seg_shift), min(1u << seg_shift, n - (i << seg_shift)), i);
-                if (seg_cost) { seg_cost[2 * (sb + i)] = 0u; seg_cost[2 * (sb + i) + 1] = 0u; }
+                if (seg_cost) {   // [sub-range][quadrant] survivor counts, filled by the pieces of k_seg_fwd that find pixels alive
+                    uint4 *c = reinterpret_cast<uint4 *>(seg_cost + 16 * (size_t)(sb + i));
+                    c[0] = c[1] = c[2] = c[3] = make_uint4(0u, 0u, 0u, 0u);
+                }
             }
         }
         const int fr = tile / (gx * gy);

@@ -446,7 +446,6 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 template <int PER_SEG>
 struct TaskQueueT {
     uint32_t *ctr;
-    const uint32_t *order;   // optional: position in the queue -> task (the backward's cost-ordered list); null = identity
     uint32_t nsegs, per_shard_wgs, shard, tried, pend, it, next;
     bool have_next;
     __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? (uint32_t)PER_SEG * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
@@ -463,13 +462,12 @@ struct TaskQueueT {
         }
         return task_of(shard, j);
     }
-    __device__ __forceinline__ uint32_t to_task(uint32_t item) const { return (item == 0xffffffffu || !order) ? item : order[item]; }
-    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task, const uint32_t *task_order = nullptr) {
-        ctr = c; order = task_order; nsegs = n_segs; it = 0; tried = 0; pend = 0; next = 0; have_next = false;
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task) {
+        ctr = c; nsegs = n_segs; it = 0; tried = 0; pend = 0; next = 0; have_next = false;
         if (!ctr) return;  // static mode: plain grid-stride (single-frame launches, see the launchers)
         per_shard_wgs = gridDim.x / GOM_TQ_SHARDS;  // the launchers round the grid to a multiple of the shard count
         shard = blockIdx.x % GOM_TQ_SHARDS;
-        if (threadIdx.x == 0) s_task[0] = to_task(resolve(blockIdx.x / GOM_TQ_SHARDS));
+        if (threadIdx.x == 0) s_task[0] = resolve(blockIdx.x / GOM_TQ_SHARDS);
         __syncthreads();
     }
     __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
@@ -485,7 +483,7 @@ struct TaskQueueT {
     // optional, between request() and publish(): turn the dequeue into the next task now, so that the order-table load it issues has
     // the rest of the task to arrive (publish() would otherwise wait for it in front of the barrier)
     __device__ __forceinline__ void look_ahead() {
-        if (ctr && threadIdx.x == 0 && !have_next) { next = to_task(resolve(per_shard_wgs + pend)); have_next = true; }
+        if (ctr && threadIdx.x == 0 && !have_next) { next = resolve(per_shard_wgs + pend); have_next = true; }
     }
     __device__ __forceinline__ void publish(uint32_t *s_task) {
         look_ahead();
@@ -500,6 +498,64 @@ struct TaskQueueT {
 };
 
 using TaskQueue = TaskQueueT<4>;
+
+// The queue of k_seg_bwd_pair: the same sharded dequeue, but the tasks are the words of gom_internal.h ((segment << 3) | code) and, when the
+// riders of the loss kernel have run, come from the cost-ordered table (its own count per shard) instead of the (segment, pair) grid.
+struct PairQueue {
+    uint32_t *ctr;
+    const uint32_t *order;
+    uint32_t nsegs, region, per_shard_wgs, shard, ntasks, tried, pend, it, next;
+    bool have_next;
+    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const {
+        if (order) return order[x];
+        return nsegs > x ? 2u * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u;
+    }
+    __device__ __forceinline__ uint32_t task_at(uint32_t x, uint32_t j) const {
+        if (order) return order[GOM_BWD_ORDER_BASE + (size_t)x * region + j];
+        return (((j >> 1) * GOM_TQ_SHARDS + x) << 3) | (j & 1u);
+    }
+    __device__ __forceinline__ uint32_t resolve(uint32_t j) {   // thread 0 only
+        while (j >= ntasks) {
+            if (++tried > GOM_TQ_STEAL) return 0xffffffffu;
+            shard = (shard + 1) % GOM_TQ_SHARDS;
+            ntasks = shard_tasks(shard);
+            j = per_shard_wgs + atomicAdd(ctr + 32 * shard, 1u);
+        }
+        return task_at(shard, j);
+    }
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task, const uint32_t *task_order) {
+        ctr = c; order = c ? task_order : nullptr; nsegs = n_segs; region = 4u * ((n_segs + 7u) / 8u); it = 0; tried = 0; pend = 0; next = 0; have_next = false;
+        if (!ctr) return;  // static mode: plain grid-stride over the (segment, pair) grid
+        per_shard_wgs = gridDim.x / GOM_TQ_SHARDS;
+        shard = blockIdx.x % GOM_TQ_SHARDS;
+        ntasks = 0;
+        if (threadIdx.x == 0) { ntasks = shard_tasks(shard); s_task[0] = resolve(blockIdx.x / GOM_TQ_SHARDS); }
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
+        if (!ctr) {
+            const uint32_t t = blockIdx.x + it * gridDim.x;
+            return t < nsegs * 2u ? ((t >> 1) << 3) | (t & 1u) : 0xffffffffu;
+        }
+        return s_task[it & 1];
+    }
+    __device__ __forceinline__ void request() {
+        if (ctr && threadIdx.x == 0) pend = atomicAdd(ctr + 32 * shard, 1u);
+    }
+    __device__ __forceinline__ void look_ahead() {   // optional, between request() and publish(): the table loads get the rest of the task to arrive
+        if (ctr && threadIdx.x == 0 && !have_next) { next = resolve(per_shard_wgs + pend); have_next = true; }
+    }
+    __device__ __forceinline__ void publish(uint32_t *s_task) {
+        look_ahead();
+        if (ctr && threadIdx.x == 0) { s_task[(it + 1) & 1] = next; have_next = false; }
+    }
+    __device__ __forceinline__ void advance() { it++; }
+    __device__ __forceinline__ void finish() {
+        if (ctr && threadIdx.x == 0 && atomicAdd(ctr + 32 * GOM_TQ_SHARDS, 1u) == gridDim.x - 1) {
+            for (int x = 0; x <= GOM_TQ_SHARDS; x++) ctr[32 * x] = 0;
+        }
+    }
+};
 
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
@@ -669,7 +725,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
         if (__ballot(wl != 0.f) != 0ull) {
             unsigned long long mask = __ballot(r.keep);
             // what the backward will pay for this piece, roughly: the entries that reach alive pixels here (GomBwdOrderRider)
-            if (seg_cost && lane == 0 && mask) atomicAdd(&seg_cost[2 * seg + (sub >> 1)], (uint32_t)__popcll(mask));
+            if (seg_cost && lane == 0 && mask) seg_cost[16 * (size_t)seg + 4 * sub + q] = (uint32_t)__popcll(mask);   // (one writer per word)
             s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
             s_e1[sub][lane] = make_float2(r.c, r.o);
             {
@@ -1186,12 +1242,13 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     const unsigned long long ph_w0 = wall_clock64();
     unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
 #endif
-    TaskQueueT<2> tq;
+    PairQueue tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task, task_order);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
         if (task == 0xffffffffu) break;
-        const uint32_t seg = task >> 1;
-        const int sub_a = (int)(task & 1u) * 2;
+        const uint32_t seg = task >> 3, code = task & 7u;
+        const int nhalf = code < 4u ? 2 : 1;                                   // a pair of sub-ranges, or one alone (split by the riders)
+        const int sub_a = code < 4u ? (int)code * 2 : (int)code - 4;
         const uint4 d = seg_desc[seg];
         const uint4 qm4 = seg_qmax[seg];
         const uint32_t tile = d.x, start = d.y, cnt = d.z;
@@ -1217,7 +1274,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         for (int half = 0; half < 2; half++) {
             const int sub = sub_a + half;
             const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;
-            const bool empty = (uint32_t)sub * sub_sz >= cnt;
+            const bool empty = half >= nhalf || (uint32_t)sub * sub_sz >= cnt;
             scnt_h[half] = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
             live_h[half] = !empty && s0 < tmax;
             const int q = half == 0 ? wv : 3 - wv;   // the diagonally opposite quadrant in the second sub-range

@@ -41,7 +41,15 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_launches_itself_for_two_ranks():
-    d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
+    try:
+        d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
+    except AssertionError as e:
+        # Two ranks on ONE device over gloo is a stand-in for RCCL (module docstring): once in a few dozen runs a rank's TCP pair is torn
+        # down under the other ("Connection closed by peer", SIGABRT inside gloo).  That is the stand-in's transport, not the code under
+        # test: one more attempt; anything else, or a second failure, fails the test.
+        if "Connection closed by peer" not in str(e) and "connection closed" not in str(e).lower():
+            raise
+        d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 16 and d["config"]["allreduce_floats"] == 951023
     assert d["config"]["allreduce_us"] > 0 and d["config"]["parallelism"] == "frame-dp2" and d["value"] > 0
     assert "cpu_baseline" not in d     # rank 0 at N = 1 only
