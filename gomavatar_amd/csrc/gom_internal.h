@@ -34,7 +34,9 @@ struct GomDevStatus {
     // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
     uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
     uint32_t n_work_items;     // length of the work list of k_tile_rank
-    uint32_t pad_[26];
+    uint32_t n_big;            // Gaussians with more than GOM_BIG_NT tiles in this forward (list: GomState::big_list), published by the scan kernel
+    uint32_t n_big_build;      // ... being counted by k_preprocess
+    uint32_t pad_[24];
     uint32_t shard_cursor[8][32];   // [shard][0] used
 };
 
@@ -107,6 +109,7 @@ struct GomState {
     uint32_t *seg_cost = nullptr;     // [capSegs][4 sub-ranges][4 quadrants] entries that survived the cull in the pieces k_seg_fwd found alive = cost estimate of the backward's tasks
     uint32_t *bwd_order = nullptr;    // the backward's tasks per queue shard, most expensive first (riders of the loss kernel): GOM_BWD_ORDER_* below
     bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
+    uint32_t *big_list = nullptr;     // [GOM_BIG_CAP] frame * P + index of the Gaussians that touch more than GOM_BIG_NT tiles (k_preprocess_bwd gives each a whole wave)
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
     float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
     float *ent_col = nullptr;         // [capPairs][4] list-ordered colours
@@ -197,6 +200,10 @@ struct GomFaceArgs {
 int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float *means3D, const float *cov6,
                           const float *opacity, int32_t *radii_out, hipStream_t st, const GomFaceArgs *face = nullptr);
 // Background of the tiles no Gaussian touches, painted by spare blocks of k_emit (see there); first_block = blocks that emit.
+// A Gaussian close to the camera touches a hundred tiles; its gradient records are summed by one WAVE (rider blocks of k_preprocess_bwd)
+// instead of one lane walking them while the kernel waits (13 of its 62 us on the metric workload).
+#define GOM_BIG_NT 32u
+#define GOM_BIG_CAP 2048u
 #define GOM_FILL_TILES 4
 struct GomEmptyFill {
     int first_block, H, W, C;

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
                                                     int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax,
-                                                    float4 *__restrict__ rec_g) {
+                                                    float4 *__restrict__ rec_g, uint32_t *__restrict__ big_list) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_dmin[4], s_dmax[4];
@@ -213,6 +213,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         xy[i] = make_float2(o_x, o_y);
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
+        if (big_list && o_tiles > GOM_BIG_NT) {   // (a few hundred per frame at most: one counter is enough)
+            const uint32_t bi = atomicAdd(&status->n_big_build, 1u);
+            if (bi < GOM_BIG_CAP) big_list[bi] = (uint32_t)fr * (uint32_t)P + (uint32_t)i;
+        }
         my_tiles = o_tiles;
         my_depth = o_depth;
         rect[i] = make_ushort4((unsigned short)x0, (unsigned short)(y0 + ty_off), (unsigned short)x1, (unsigned short)(y1 + ty_off));
@@ -417,6 +421,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         status->pair_cursor = 0;
         status->shard_overflow = 0;
         status->n_work_items = over ? 0u : wi_carry;
+        status->n_big = status->n_big_build;   // (more than GOM_BIG_CAP: the list is incomplete and k_preprocess_bwd ignores it)
+        status->n_big_build = 0;
         for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
@@ -527,10 +533,25 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
                                                         const GomDevStatus *__restrict__ status,
                                                         float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
                                                         float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
-                                                        float *__restrict__ dL_dmeans2D) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const int fr = blockIdx.y;
+                                                        float *__restrict__ dL_dmeans2D, const uint32_t *__restrict__ big_list) {
+    // Blocks behind the per-Gaussian grid (row 0 of the grid only) are RIDERS: each of their waves takes one Gaussian of big_list -- more than
+    // GOM_BIG_NT tiles, i.e. close to the camera -- sums its records with all 64 lanes and lets lane 0 finish it; the lane that owns such a
+    // Gaussian in the per-Gaussian grid leaves it alone.  (A lane walking 121 records in dependent trips was the kernel's tail.)
+    const int main_blocks = (P + 255) / 256;
+    const bool rider = (int)blockIdx.x >= main_blocks;
+    const uint32_t n_big = big_list ? status->n_big : GOM_BIG_CAP + 1u;
+    const bool use_big = n_big <= GOM_BIG_CAP;
+    int i, fr;
+    if (rider) {
+        const uint32_t w = ((uint32_t)blockIdx.x - (uint32_t)main_blocks) * 4u + (threadIdx.x >> 6);
+        if (blockIdx.y != 0 || !use_big || w >= n_big) return;
+        const uint32_t gi = big_list[w];
+        fr = (int)(gi / (uint32_t)P); i = (int)(gi % (uint32_t)P);
+    } else {
+        i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= P) return;
+        fr = blockIdx.y;
+    }
     const GomCamera cam = pick_camera(cam1, cams, fr);
     {
         const size_t go = (size_t)fr * P;
@@ -557,13 +578,34 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         // (1) the liveness bits, GOM_PB_MB tiles per trip (independent loads; lanes past their last tile re-read their first one);
         // (2) the LIVE records only, GOM_PB_W per trip, in ascending k (fixed summation order).
         const uint32_t nt = tiles_touched[i];
+        if (!rider && use_big && nt > GOM_BIG_NT) return;   // a rider wave has it
         const uint32_t po = pair_off[i];
         const ushort4 rc = rect[i];
         const uint32_t rw = (uint32_t)(rc.z - rc.x);
         const uint32_t myq = RANK ? rank_of[(size_t)fr * P + i] : 0u;
         const uint32_t tile0 = (uint32_t)rc.y * (uint32_t)gx + (uint32_t)rc.x;   // (stacked tile rows: rect carries the frame offset)
+        if (rider) {   // lane l sums the records l, l + 64, ... (liveness as below), then the wave adds the 64 partial sums
+            const uint32_t lane = threadIdx.x & 63u;
+            for (uint32_t k = lane; k < nt; k += 64) {
+                const uint32_t tile = tile0 + (k / rw) * (uint32_t)gx + k % rw;
+                const bool lv = RANK ? myq < tile_qlim[tile] : pair_pos[po + k] - tile_base[tile] < tile_nmax[tile];
+                if (lv) {
+                    const float4 *rec = reinterpret_cast<const float4 *>(partial + (size_t)(po + k) * GOM_PARTIAL_STRIDE);
+                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                    acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
+                    acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
+                    acc[8] += q2.x; acc[9] += q2.y;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 10; v++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) acc[v] += __shfl_xor(acc[v], d, 64);
+            }
+            if (lane != 0) return;   // lane 0 finishes the Gaussian
+        }
         uint32_t kx = 0, trow = tile0;   // column inside the rect and first tile of the row of tile k
-        for (uint32_t w0 = 0; w0 < nt; w0 += 64) {
+        for (uint32_t w0 = 0; w0 < (rider ? 0u : nt); w0 += 64) {
             const uint32_t wn = min(64u, nt - w0);
             unsigned long long m = 0ull;
             for (uint32_t b0 = 0; b0 < wn; b0 += GOM_PB_MB) {
@@ -724,7 +766,7 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     float *m = const_cast<float *>(means3D), *c = const_cast<float *>(cov6);
 #define GOM_PP(LDSH, FACEV) hipLaunchKernelGGL((k_preprocess<LDSH, FACEV>), grid, dim3(256), LDSH ? n_tiles * sizeof(uint32_t) : 0, st, cam, s->cams, P, m, c, opacity, fa, \
                                                s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,  \
-                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr)
+                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr, s->big_list)
     if (lds) { if (face) GOM_PP(true, true); else GOM_PP(true, false); }
     else { if (face) GOM_PP(false, true); else GOM_PP(false, false); }
 #undef GOM_PP
@@ -777,11 +819,11 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
     if (blocks == 0) return 0;
     if (face && C != 4) { gom_set_error("the fused face backward carries [r g b 1] features (C = 4)"); return -1; }
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
-    const dim3 grid(blocks, s->B);
+    const dim3 grid(blocks + GOM_BIG_CAP / 4, s->B);   // + the rider blocks (one wave per big Gaussian; row 0 only, the others leave at once)
     const GomFaceArgs fa = face ? *face : GomFaceArgs{};
 #define GOM_PB(CC, RK, FC) hipLaunchKernelGGL((k_preprocess_bwd<CC, RK, FC>), grid, dim3(256), 0, st, cam, s->cams, fa, P, means3D, cov6, s->radii, s->tiles_touched,    \
                                               s->conic_opacity, s->pair_off, s->pair_pos, s->rect, s->tile_base, s->tile_nmax, s->rank_of, s->tile_qlim, s->gx, s->partial, \
-                                              s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D)
+                                              s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D, s->big_list)
     if (face) { if (s->rankSort) GOM_PB(4, true, true); else GOM_PB(4, false, true); }
     else if (C == 3) { if (s->rankSort) GOM_PB(3, true, false); else GOM_PB(3, false, false); }
     else { if (s->rankSort) GOM_PB(4, true, false); else GOM_PB(4, false, false); }

@@ -167,6 +167,31 @@ def test_backward_matches_oracle(C, sort_mode):
         assert np.median(err) <= 1e-6 * scale, (name, np.median(err), scale)
 
 
+@pytest.mark.parametrize("P", [300, 2600])
+def test_backward_with_gaussians_over_many_tiles(P):
+    """Gaussians touching more than 32 tiles get a whole wave each in k_preprocess_bwd (rider blocks fed from a list the forward
+    builds, capacity 2 048); beyond the capacity the per-lane walk takes all of them.  Both paths against the float64 oracle."""
+    from gpu_util import hip_forward
+    from gomavatar_amd import _lib
+    cam, means, cov6, colors, op = small_scene(seed=77, P=P, H=256, W=256, opacity=(0.02, 0.2), spread=0.5, scale=0.12, C=3)
+    rng = np.random.default_rng(2)
+    wimg = rng.normal(size=(3, 256, 256)).astype(np.float32)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True)
+    (out * torch.from_numpy(wimg).cuda()).sum().backward()
+    tt = st.export(_lib.BUF_TILES_TOUCHED, torch.empty(P, dtype=torch.int32, device="cuda")).cpu().numpy()
+    n_big = int((tt > 32).sum())
+    assert (n_big > 2048) == (P > 2048) and n_big > 0.7 * P, n_big
+    f = orast.forward(cam, means, cov6, colors, op, dtype=np.float64)
+    g = orast.backward(f, wimg.astype(np.float64))
+    for name, got, ref in (("means3D", t[0].grad, g["dL_dmeans3D"]), ("cov6", t[1].grad, g["dL_dcov6"]),
+                           ("colors", t[2].grad, g["dL_dcolors"]), ("opacity", t[3].grad, g["dL_dopacity"])):
+        got = got.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref)
+        assert np.quantile(err, 0.999) <= 2e-4 * scale, (name, np.quantile(err, 0.999), scale)
+        assert np.median(err) <= 2e-6 * scale, (name, np.median(err), scale)
+
+
 def test_backward_is_bitwise_reproducible():
     from gpu_util import hip_forward
     cam, means, cov6, colors, op = small_scene(seed=32, P=1500, H=64, W=64, opacity=(0.3, 1.0))
