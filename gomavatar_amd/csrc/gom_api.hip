@@ -130,7 +130,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const int cap = P + P / 8 + 256;
         if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
             grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap) || grow(&s->bkeys, cap) || grow(&s->bkeys_scratch, cap) ||
-            grow(&s->rec_g, (size_t)cap * 3) || grow(&s->order, cap) || grow(&s->rank_of, cap))
+            grow(&s->rec_g, (size_t)cap * 2) || grow(&s->order, cap) || grow(&s->rank_of, cap))
             return -2;
         s->capP = cap;
     }
@@ -228,7 +228,8 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         s->P = P; s->H = cam->H; s->W = cam->W; s->cams = cams;
         // Tile-list order: rank the frame's Gaussians by depth once + a linear bitmap pass per tile (raster_rank.hip), unless
         // the frame's bitmap would not fit in LDS (P > 2^19) or the caller asked for the per-tile merge sort.
-        const bool rank_fits = (int64_t)s->gx * s->gy * B < (1 << 24);   // (k_tile_rank's work items carry the tile in 24 bits)
+        // (k_tile_rank's work items carry the tile in 24 bits; the Gaussian record packs its rect as 10-bit x0 / width and 12-bit stacked y0)
+        const bool rank_fits = (int64_t)s->gx * s->gy * B < (1 << 24) && s->gx < 1024 && (int64_t)s->gy * B < 4096;
         s->rankSort = rank_fits && (s->sortMode == 2 || (s->sortMode == 0 && P <= (1 << 18)));
         if (s->rankSort && P > 393216) { gom_set_error("GOM_OPT_SORT_MODE 2 needs P <= 393216 per frame (the frame's rank bitmap lives in 64 KiB of LDS)"); return -1; }
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st, face)) return rc;

@@ -132,7 +132,7 @@ struct GomState {
     uint32_t *depth_minmax = nullptr; // [capFrames = frames x preprocess blocks][2] bit patterns of the min / max visible depth of a block
     uint32_t *bucket_count = nullptr, *bucket_base = nullptr, *bucket_cursor = nullptr;   // [capBuckets (+1)]
     uint64_t *bkeys = nullptr, *bkeys_scratch = nullptr;   // [capP] (depth_bits << 32 | index in frame), bucket-major
-    float4 *rec_g = nullptr;          // [capP][3] 48-byte record of a Gaussian: (x, y, conic a, b) (conic c, opacity, -, depth bits) (rect lo, rect hi, pair_off, -)
+    float4 *rec_g = nullptr;          // [capP][2] 32-byte record of a Gaussian: (x, y, conic a, b) (conic c, opacity, pair_off, rect x0 | width << 10 | y0 << 20)
     uint32_t *order = nullptr;        // [capP] Gaussian at packed depth rank q
     uint32_t *rank_of = nullptr;      // [capP] packed rank of a (visible) Gaussian
     uint32_t *keys32 = nullptr;       // [capPairs] emitted ranks, tile-major

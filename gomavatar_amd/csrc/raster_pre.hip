@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         means += 3 * go; cov6 += 6 * go; opacity += go; depth += go; xy += go; conic_opacity += go; tiles_touched += go;
         rect += go; radii += go; pair_off += go;
         if (radii_user) radii_user += go;
-        if (rec_g) rec_g += 3 * go;
+        if (rec_g) rec_g += 2 * go;
         tile_count += (size_t)fr * n_tiles;
     }
     const int ty_off = fr * gy;  // tile rows of this frame in the stacked grid
@@ -274,11 +274,12 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         if (i < P) {
             const uint32_t po = s_blockbase + woff + (x - my_tiles);
             pair_off[i] = po;
-            if (rec_g) {   // everything the tile pass of the depth ranking needs of this Gaussian, in one 48-byte record
-                float4 *d = rec_g + 3 * (size_t)i;
+            if (rec_g) {   // everything the tile pass of the depth ranking needs of this Gaussian, in one 32-byte record (one sector per gather):
+                // (x, y, conic a, b) (conic c, opacity, first slot, rect: x0 | width << 10 | y0 << 20 in tiles, y0 in the stacked grid)
+                float4 *d = rec_g + 2 * (size_t)i;
+                const uint32_t rx0 = my_rlo & 0xffffu, ry0 = my_rlo >> 16, rw = (my_rhi & 0xffffu) - rx0;
                 d[0] = my_r0;
-                d[1] = make_float4(my_r1.x, my_r1.y, 0.f, my_depth);
-                d[2] = make_float4(__uint_as_float(my_rlo), __uint_as_float(my_rhi), __uint_as_float(po), 0.f);
+                d[1] = make_float4(my_r1.x, my_r1.y, __uint_as_float(po), __uint_as_float(rx0 | (rw << 10) | (ry0 << 20)));
             }
         }
     }

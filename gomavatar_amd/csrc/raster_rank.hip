@@ -15,7 +15,7 @@
 //                     packed (frame, depth, index) order: order[q] = Gaussian, rank_of[Gaussian] = q.
 //   k_emit<RANK>      (raster_pre.hip) writes q instead of a 64-bit key into the tile's range, in arbitrary order.
 //   k_tile_rank       per tile: the ranks of its entries set bits of a P-bit bitmap in LDS; a popcount scan turns the bitmap
-//                     into the sorted list; the entries' 48-byte records (rec_g, left by k_preprocess) are gathered through
+//                     into the sorted list; the entries' 32-byte records (rec_g, left by k_preprocess) are gathered through
 //                     order[] and written in LIST order (point_list, ent_geo, ent_slot, segment descriptors).  No comparison,
 //                     no log factor, no limit on the list length.
 //
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, cons
 
 // ---- per bucket: sort -> rank of every visible Gaussian ---------------------------------------------------------------
 // order[q] = global Gaussian id at packed rank q, rank_of[g] = q.  Nothing else moves here: the tile pass fetches a Gaussian's
-// 48-byte record (rec_g, written by k_preprocess in Gaussian order) through order[] -- the entries of one tile are neighbours on
+// 32-byte record (rec_g, written by k_preprocess in Gaussian order) through order[] -- the entries of one tile are neighbours on
 // the mesh, so their records are neighbours in memory, where a copy in rank order (first version: 113 MB of sector traffic to
 // build it, 30 us) scattered them by depth.  A bucket is ~200 keys: 2-wave workgroups, 8 keys per thread.
 #define GOM_BSORT_NT 128
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
         __syncthreads();
         const uint32_t cnt = c1 - c0;
         for (uint32_t i0 = t; i0 < cnt; i0 += 4 * NT) {       // 4 entries per trip: their record gathers are issued before the first store
-            float4 r0[4], r1[4], r2[4];
+            float4 r0[4], r1[4];
             uint32_t g4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -250,17 +250,17 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float4 *rec = rec_g + 3 * (size_t)g4[u];
-                r0[u] = rec[0]; r1[u] = rec[1]; r2[u] = rec[2];
+                const float4 *rec = rec_g + 2 * (size_t)g4[u];
+                r0[u] = rec[0]; r1[u] = rec[1];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t i = i0 + u * NT;
                 if (i < cnt) {
                     const uint32_t li = base + c0 + i;
-                    const uint32_t rlo = __float_as_uint(r2[u].x), rhi = __float_as_uint(r2[u].y), po = __float_as_uint(r2[u].z);
-                    const uint32_t rx0 = rlo & 0xffffu, ry0 = rlo >> 16, rx1 = rhi & 0xffffu;
-                    const uint32_t k = ((uint32_t)ty - ry0) * (rx1 - rx0) + ((uint32_t)tx - rx0);
+                    const uint32_t po = __float_as_uint(r1[u].z), pk = __float_as_uint(r1[u].w);
+                    const uint32_t rx0 = pk & 1023u, rw = (pk >> 10) & 1023u, ry0 = pk >> 20;
+                    const uint32_t k = ((uint32_t)ty - ry0) * rw + ((uint32_t)tx - rx0);
                     point_list[li] = g4[u];
                     ent_slot[li] = po + k;
                     float2 *dst = ent_geo + 3 * (size_t)li;
