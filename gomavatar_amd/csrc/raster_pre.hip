@@ -325,11 +325,14 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
                                                      uint32_t *__restrict__ work_items) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
+    // two workgroups: block 0 scans the tiles (and lists the work items), block 1 -- launched with the depth ranking -- the buckets: the two
+    // chains (load, block scans, stores) are independent and this kernel is nothing but their latency
+    const bool do_tiles = blockIdx.x == 0, do_buckets = bucket_count != nullptr && blockIdx.x == gridDim.x - 1;
     uint32_t carry = 0, seg_carry = 0, wi_carry = 0;
     // 8 consecutive tiles per thread and trip: a batched launch (8 192 tiles at 8 x 512x512) is ONE trip = one load latency and
     // two block scans, where one tile per thread took eight dependent trips (20 us of a single workgroup's latency chain).
     constexpr int kPer = 8;
-    for (int base = 0; base < n_tiles; base += 1024 * kPer) {
+    for (int base = 0; do_tiles && base < n_tiles; base += 1024 * kPer) {
         const int i0 = base + tid * kPer;
         const bool full = i0 + kPer <= n_tiles;   // (arrays come from hipMalloc and i0 is a multiple of 8: 16-byte accesses are aligned)
         uint32_t v[kPer];
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
     }
     // depth ranking (raster_rank.hip): exclusive scan of the (frame, bucket) counts = packed ranks at which the buckets start
-    if (bucket_count) {
+    if (do_buckets) {
         uint32_t bcarry = 0;
         for (int base = 0; base < n_buckets; base += 1024 * kPer) {
             const int i0 = base + tid * kPer;
@@ -412,7 +415,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
         if (tid == 0) bucket_base[n_buckets] = bcarry;
     }
-    if (tid == 0) {
+    if (tid == 0 && do_tiles) {
         tile_base[n_tiles] = carry;
         seg_base[n_tiles] = seg_carry;
         const bool over = carry > cap_pairs || status->shard_overflow != 0u;
@@ -782,7 +785,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
     const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
+        hipLaunchKernelGGL(k_scan_tiles, dim3(rank ? 2 : 1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
                            s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
                            s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr);
     }
