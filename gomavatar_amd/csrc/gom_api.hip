@@ -39,7 +39,6 @@ extern "C" GomState *gom_state_create(void) {
     }
     if (hipMalloc((void **)&s->status, sizeof(GomDevStatus)) != hipSuccess ||
         hipMemset(s->status, 0, sizeof(GomDevStatus)) != hipSuccess ||
-        hipMalloc((void **)&s->big_list, GOM_BIG_CAP * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&s->task_ctr, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess || hipMemset(s->task_ctr, 0, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess) {
         gom_set_error("hipMalloc(status) failed");
         delete s;
@@ -53,7 +52,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -150,6 +149,11 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
             if (grow(&s->depth_minmax, (size_t)nmm * 2)) return -2;
             s->capFrames = (int)nmm;
         }
+    }
+    if (B > s->capBigFrames) {
+        if (grow(&s->big_list, (size_t)B * GOM_BIG_CAP) || grow(&s->big_count, (size_t)2 * B)) return -2;
+        GOM_HIP_CHECK(hipMemset(s->big_count, 0, (size_t)2 * B * sizeof(uint32_t)));
+        s->capBigFrames = B;
     }
     if (tiles > s->capTiles) {
         if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||

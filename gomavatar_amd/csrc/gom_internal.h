@@ -34,9 +34,7 @@ struct GomDevStatus {
     // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
     uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
     uint32_t n_work_items;     // length of the work list of k_tile_rank
-    uint32_t n_big;            // Gaussians with more than GOM_BIG_NT tiles in this forward (list: GomState::big_list), published by the scan kernel
-    uint32_t n_big_build;      // ... being counted by k_preprocess
-    uint32_t pad_[24];
+    uint32_t pad_[26];
     uint32_t shard_cursor[8][32];   // [shard][0] used
 };
 
@@ -109,7 +107,9 @@ struct GomState {
     uint32_t *seg_cost = nullptr;     // [capSegs][4 sub-ranges][4 quadrants] entries that survived the cull in the pieces k_seg_fwd found alive = cost estimate of the backward's tasks
     uint32_t *bwd_order = nullptr;    // the backward's tasks per queue shard, most expensive first (riders of the loss kernel): GOM_BWD_ORDER_* below
     bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
-    uint32_t *big_list = nullptr;     // [GOM_BIG_CAP] frame * P + index of the Gaussians that touch more than GOM_BIG_NT tiles (k_preprocess_bwd gives each a whole wave)
+    uint32_t *big_list = nullptr;     // [frames][GOM_BIG_CAP] the Gaussians of each frame that touch more than GOM_BIG_NT tiles (k_preprocess_bwd gives each a whole wave)
+    uint32_t *big_count = nullptr;    // [2][frames] their number per frame: [0] published by the scan kernel, [1] being counted by k_preprocess
+    int capBigFrames = 0;
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
     float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
     float *ent_col = nullptr;         // [capPairs][4] list-ordered colours
@@ -203,7 +203,7 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
 // A Gaussian close to the camera touches a hundred tiles; its gradient records are summed by one WAVE (rider blocks of k_preprocess_bwd)
 // instead of one lane walking them while the kernel waits (13 of its 62 us on the metric workload).
 #define GOM_BIG_NT 32u
-#define GOM_BIG_CAP 2048u
+#define GOM_BIG_CAP 512u    // per FRAME (a frame with more keeps the per-lane walk: the choice never depends on what else is in the batch)
 #define GOM_FILL_TILES 4
 struct GomEmptyFill {
     int first_block, H, W, C;

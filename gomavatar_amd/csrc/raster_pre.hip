@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
                                                     int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax,
-                                                    float4 *__restrict__ rec_g, uint32_t *__restrict__ big_list) {
+                                                    float4 *__restrict__ rec_g, uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, int big_frames) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_dmin[4], s_dmax[4];
@@ -213,9 +213,9 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         xy[i] = make_float2(o_x, o_y);
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
-        if (big_list && o_tiles > GOM_BIG_NT) {   // (a few hundred per frame at most: one counter is enough)
-            const uint32_t bi = atomicAdd(&status->n_big_build, 1u);
-            if (bi < GOM_BIG_CAP) big_list[bi] = (uint32_t)fr * (uint32_t)P + (uint32_t)i;
+        if (big_list && o_tiles > GOM_BIG_NT) {   // (a few hundred per frame at most: one counter per frame is enough)
+            const uint32_t bi = atomicAdd(&big_count[big_frames + fr], 1u);   // ([0, big_frames): last forward's counts, published by the scan kernel)
+            if (bi < GOM_BIG_CAP) big_list[(size_t)fr * GOM_BIG_CAP + bi] = (uint32_t)i;
         }
         my_tiles = o_tiles;
         my_depth = o_depth;
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
                                                      GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift,
                                                      uint32_t *__restrict__ bucket_count, uint32_t *__restrict__ bucket_base,
                                                      uint32_t *__restrict__ bucket_cursor, int n_buckets,
-                                                     uint32_t *__restrict__ work_items) {
+                                                     uint32_t *__restrict__ work_items, uint32_t *__restrict__ big_count, int n_frames, int big_frames) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
     // two workgroups: block 0 scans the tiles (and lists the work items), block 1 -- launched with the depth ranking -- the buckets: the two
@@ -415,6 +415,9 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         }
         if (tid == 0) bucket_base[n_buckets] = bcarry;
     }
+    if (do_tiles && big_count) {   // publish the per-frame counts of the many-tile Gaussians (more than GOM_BIG_CAP: that frame's list is incomplete and unused)
+        for (int f = tid; f < n_frames; f += 1024) { big_count[f] = big_count[big_frames + f]; big_count[big_frames + f] = 0u; }
+    }
     if (tid == 0 && do_tiles) {
         tile_base[n_tiles] = carry;
         seg_base[n_tiles] = seg_carry;
@@ -425,8 +428,6 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         status->pair_cursor = 0;
         status->shard_overflow = 0;
         status->n_work_items = over ? 0u : wi_carry;
-        status->n_big = status->n_big_build;   // (more than GOM_BIG_CAP: the list is incomplete and k_preprocess_bwd ignores it)
-        status->n_big_build = 0;
         for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
@@ -537,24 +538,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
                                                         const GomDevStatus *__restrict__ status,
                                                         float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
                                                         float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
-                                                        float *__restrict__ dL_dmeans2D, const uint32_t *__restrict__ big_list) {
-    // Blocks behind the per-Gaussian grid (row 0 of the grid only) are RIDERS: each of their waves takes one Gaussian of big_list -- more than
+                                                        float *__restrict__ dL_dmeans2D, const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
+    // Blocks behind the per-Gaussian grid are RIDERS: each of their waves takes one Gaussian of its frame's big_list -- more than
     // GOM_BIG_NT tiles, i.e. close to the camera -- sums its records with all 64 lanes and lets lane 0 finish it; the lane that owns such a
     // Gaussian in the per-Gaussian grid leaves it alone.  (A lane walking 121 records in dependent trips was the kernel's tail.)
     const int main_blocks = (P + 255) / 256;
     const bool rider = (int)blockIdx.x >= main_blocks;
-    const uint32_t n_big = big_list ? status->n_big : GOM_BIG_CAP + 1u;
-    const bool use_big = n_big <= GOM_BIG_CAP;
-    int i, fr;
+    const int fr = blockIdx.y;
+    const uint32_t n_big = big_list ? big_count[fr] : GOM_BIG_CAP + 1u;
+    const bool use_big = n_big <= GOM_BIG_CAP;   // per frame: a frame is treated the same alone and in a batch
+    int i;
     if (rider) {
         const uint32_t w = ((uint32_t)blockIdx.x - (uint32_t)main_blocks) * 4u + (threadIdx.x >> 6);
-        if (blockIdx.y != 0 || !use_big || w >= n_big) return;
-        const uint32_t gi = big_list[w];
-        fr = (int)(gi / (uint32_t)P); i = (int)(gi % (uint32_t)P);
+        if (!use_big || w >= n_big) return;
+        i = (int)big_list[(size_t)fr * GOM_BIG_CAP + w];
     } else {
         i = blockIdx.x * 256 + threadIdx.x;
         if (i >= P) return;
-        fr = blockIdx.y;
     }
     const GomCamera cam = pick_camera(cam1, cams, fr);
     {
@@ -770,7 +770,7 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     float *m = const_cast<float *>(means3D), *c = const_cast<float *>(cov6);
 #define GOM_PP(LDSH, FACEV) hipLaunchKernelGGL((k_preprocess<LDSH, FACEV>), grid, dim3(256), LDSH ? n_tiles * sizeof(uint32_t) : 0, st, cam, s->cams, P, m, c, opacity, fa, \
                                                s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,  \
-                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr, s->big_list)
+                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr, s->big_list, s->big_count, s->capBigFrames)
     if (lds) { if (face) GOM_PP(true, true); else GOM_PP(true, false); }
     else { if (face) GOM_PP(false, true); else GOM_PP(false, false); }
 #undef GOM_PP
@@ -787,7 +787,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
         GomKernelTimer timer(s, GOM_K_SCAN, st);
         hipLaunchKernelGGL(k_scan_tiles, dim3(rank ? 2 : 1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
                            s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
-                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr);
+                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr, s->big_count, s->B, s->capBigFrames);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;
@@ -823,11 +823,11 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
     if (blocks == 0) return 0;
     if (face && C != 4) { gom_set_error("the fused face backward carries [r g b 1] features (C = 4)"); return -1; }
     GomKernelTimer timer(s, GOM_K_PREPROCESS_BWD, st);
-    const dim3 grid(blocks + GOM_BIG_CAP / 4, s->B);   // + the rider blocks (one wave per big Gaussian; row 0 only, the others leave at once)
+    const dim3 grid(blocks + GOM_BIG_CAP / 4, s->B);   // + the rider blocks (one wave per many-tile Gaussian of the frame)
     const GomFaceArgs fa = face ? *face : GomFaceArgs{};
 #define GOM_PB(CC, RK, FC) hipLaunchKernelGGL((k_preprocess_bwd<CC, RK, FC>), grid, dim3(256), 0, st, cam, s->cams, fa, P, means3D, cov6, s->radii, s->tiles_touched,    \
                                               s->conic_opacity, s->pair_off, s->pair_pos, s->rect, s->tile_base, s->tile_nmax, s->rank_of, s->tile_qlim, s->gx, s->partial, \
-                                              s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D, s->big_list)
+                                              s->status, dL_dmeans3D, dL_dcov6, dL_dcolors, dL_dopacity, dL_dmeans2D, s->big_list, s->big_count)
     if (face) { if (s->rankSort) GOM_PB(4, true, true); else GOM_PB(4, false, true); }
     else if (C == 3) { if (s->rankSort) GOM_PB(3, true, false); else GOM_PB(3, false, false); }
     else { if (s->rankSort) GOM_PB(4, true, false); else GOM_PB(4, false, false); }

@@ -27,9 +27,11 @@ def _scene(img, B, smpl_like=False):
     return faces, N, w25, params, frames, gt_rgb, gt_mask
 
 
-@pytest.mark.parametrize("B,img,graph,smpl_like", [(3, 128, False, False), (4, 96, True, False), (2, 256, False, True)])
+@pytest.mark.parametrize("B,img,graph,smpl_like", [(3, 128, False, False), (4, 96, True, False), (2, 256, False, True), (5, 256, True, False)])
 def test_batch_equals_single_frames_bitwise(B, img, graph, smpl_like):
-    """smpl_like: the 13 776-face body at 256x256 has tile lists on both sides of the 2048-entry split between the
+    """(5, 256): hundreds of Gaussians over more than 32 tiles per frame -- every frame must make the same choices (k_preprocess_bwd's
+    rider waves) alone and in a batch; a list shared by the batch once overflowed where the single frames' did not (scripts/soak.py).
+    smpl_like: the 13 776-face body at 256x256 has tile lists on both sides of the 2048-entry split between the
     two k_sort instantiations of a batched launch."""
     from gomavatar_amd.pipeline import RenderStep
     faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B, smpl_like)
