@@ -51,7 +51,7 @@
 #include "sort_util.hpp"
 #include <cstdlib>
 
-#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2): workgroup timeline of k_seg_T (1) or k_seg_bwd_pair (2), scripts/wg_timeline_T.py
+#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2) or k_seg_fwd (3), scripts/wg_timeline_T.py
 __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_wg_busy[GOM_SEG_GRID * 4];
 extern "C" int gom_debug_phase_counters(unsigned long long *out, unsigned long long *wg, int reset) {
@@ -659,11 +659,18 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3   // (scripts/wg_timeline_T.py)
+    const unsigned long long ph_w0 = wall_clock64();
+    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
+#endif
     TaskQueue tq;
     for (tq.init(task_ctr ? task_ctr + GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
         if (task == 0xffffffffu) break;
         const uint32_t seg = task >> 2;
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3
+        { const unsigned long long t = wall_clock64(); if (ph_tasks) { ph_last = t - ph_t; if (ph_last > ph_max) ph_max = ph_last; } ph_t = t; ph_tasks++; }
+#endif
         const int q = (int)(task & 3);
         const int pxi = q * 64 + lane;
         const uint4 d = seg_desc[seg];
@@ -817,6 +824,14 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
             st4<C>(seg_C, seg, pxi, tot);
         }
     }
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3
+    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
+        const unsigned long long t = wall_clock64();
+        ph_last = t - ph_t; if (ph_last > ph_max) ph_max = ph_last;
+        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = t;
+        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | ph_tasks;
+    }
+#endif
     tq.finish();
 }
 
