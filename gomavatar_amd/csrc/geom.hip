@@ -43,14 +43,12 @@ __device__ void invert4x4(const float *m, float *inv) {
 
 // ---- forward kinematics: one wave ------------------------------------------
 // RT[j] = top 3 rows of (prod_{chain} local[k]) * inverse(cnl_gtfms[j]).
-__global__ void __launch_bounds__(64) k_fk_fwd(const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
-                                               float *__restrict__ RT, float *__restrict__ save) {
-    __shared__ float L[24][16], G[24][16], Ci[24][16];
-    const int t = threadIdx.x;
-    {  // blockIdx.x = frame of a batched launch
-        const size_t fr = blockIdx.x;
-        cnl += fr * 24 * 16; Rs += fr * 24 * 9; Ts += fr * 24 * 3; RT += fr * 24 * 12; save += fr * 24 * 32;
-    }
+// The chain itself, for one frame, by the first 24 / 16 threads of a workgroup of NT threads (every thread takes the barriers): local
+// [R | T] matrices into L, inverse canonical transforms into Ci, global transforms G, and the skinning rows RT (24 x 12) into LDS.
+template <int NT>
+__device__ __forceinline__ void fk_forward_block(int t, const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
+                                                 float (*L)[16], float (*G)[16], float (*Ci)[16], float *rt) {
+#pragma clang fp contract(on)
     if (t < 24) {
         for (int r = 0; r < 3; r++) {
             for (int c = 0; c < 3; c++) L[t][4 * r + c] = Rs[9 * t + 3 * r + c];
@@ -72,11 +70,24 @@ __global__ void __launch_bounds__(64) k_fk_fwd(const float *__restrict__ cnl, co
         }
         __syncthreads();
     }
-    for (int o = t; o < 24 * 12; o += 64) {
+    for (int o = t; o < 24 * 12; o += NT) {
         const int j = o / 12, e = o % 12;
         const int r = e < 9 ? e / 3 : e - 9, c = e < 9 ? e % 3 : 3;
-        RT[o] = G[j][4 * r + 0] * Ci[j][c] + G[j][4 * r + 1] * Ci[j][4 + c] + G[j][4 * r + 2] * Ci[j][8 + c] + G[j][4 * r + 3] * Ci[j][12 + c];
+        rt[o] = G[j][4 * r + 0] * Ci[j][c] + G[j][4 * r + 1] * Ci[j][4 + c] + G[j][4 * r + 2] * Ci[j][8 + c] + G[j][4 * r + 3] * Ci[j][12 + c];
     }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64) k_fk_fwd(const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
+                                               float *__restrict__ RT, float *__restrict__ save) {
+    __shared__ float L[24][16], G[24][16], Ci[24][16], s_rt[24 * 12];
+    const int t = threadIdx.x;
+    {  // blockIdx.x = frame of a batched launch
+        const size_t fr = blockIdx.x;
+        cnl += fr * 24 * 16; Rs += fr * 24 * 9; Ts += fr * 24 * 3; RT += fr * 24 * 12; save += fr * 24 * 32;
+    }
+    fk_forward_block<64>(t, cnl, Rs, Ts, L, G, Ci, s_rt);
+    for (int o = t; o < 24 * 12; o += 64) RT[o] = s_rt[o];
     for (int o = t; o < 24 * 16; o += 64) {
         save[(o / 16) * 32 + (o % 16)] = G[o / 16][o % 16];
         save[(o / 16) * 32 + 16 + (o % 16)] = Ci[o / 16][o % 16];
@@ -133,15 +144,10 @@ __global__ void __launch_bounds__(64) k_fk_bwd(const float *__restrict__ Rs, con
 }
 
 // ---- LBS: one thread per vertex ---------------------------------------------
-__global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
-                                                 const float *__restrict__ RT, float *__restrict__ out) {
-    extern __shared__ float s_rt[];
-    RT += (size_t)blockIdx.y * J * 12;  // blockIdx.y = frame of a batched launch (shared canonical vertices and weights)
-    out += (size_t)blockIdx.y * 3 * N;
-    for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
-    __syncthreads();
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// v' = sum_j w_j (R_j v + T_j) for vertex n, from the skinning rows in LDS (contraction pinned: k_lbs_fwd and k_fk_lbs_fwd give the same bits)
+__device__ __forceinline__ void lbs_blend(int N, int J, int n, const float *__restrict__ xyz, const float *__restrict__ w, const float *s_rt,
+                                          float *__restrict__ out) {
+#pragma clang fp contract(on)
     const float x = xyz[n], y = xyz[(size_t)N + n], z = xyz[2 * (size_t)N + n];
     float ox = 0.f, oy = 0.f, oz = 0.f;
     for (int j = 0; j < J; j++) {
@@ -156,6 +162,43 @@ __global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__re
     out[n] = ox;
     out[(size_t)N + n] = oy;
     out[2 * (size_t)N + n] = oz;
+}
+
+__global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
+                                                 const float *__restrict__ RT, float *__restrict__ out) {
+    extern __shared__ float s_rt[];
+    RT += (size_t)blockIdx.y * J * 12;  // blockIdx.y = frame of a batched launch (shared canonical vertices and weights)
+    out += (size_t)blockIdx.y * 3 * N;
+    for (int i = threadIdx.x; i < J * 12; i += 256) s_rt[i] = RT[i];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    lbs_blend(N, J, n, xyz, w, s_rt, out);
+}
+
+// FK + LBS in one launch (the frame step): every workgroup runs the frame's 24-joint chain itself (two microseconds of barriers next to a
+// launch and a dependent kernel's latency) and skins its 256 vertices from the rows it holds in LDS; the first workgroup of a frame
+// also leaves RT and the FK state for the backward.  Same arithmetic as k_fk_fwd + k_lbs_fwd.
+__global__ void __launch_bounds__(256) k_fk_lbs_fwd(int N, const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
+                                                    const float *__restrict__ xyz, const float *__restrict__ w, float *__restrict__ RT,
+                                                    float *__restrict__ save, float *__restrict__ out) {
+    __shared__ float L[24][16], G[24][16], Ci[24][16], s_rt[24 * 12];
+    const int t = threadIdx.x;
+    {
+        const size_t fr = blockIdx.y;
+        cnl += fr * 24 * 16; Rs += fr * 24 * 9; Ts += fr * 24 * 3; RT += fr * 24 * 12; save += fr * 24 * 32; out += fr * 3 * N;
+    }
+    fk_forward_block<256>(t, cnl, Rs, Ts, L, G, Ci, s_rt);
+    if (blockIdx.x == 0) {
+        for (int o = t; o < 24 * 12; o += 256) RT[o] = s_rt[o];
+        for (int o = t; o < 24 * 16; o += 256) {
+            save[(o / 16) * 32 + (o % 16)] = G[o / 16][o % 16];
+            save[(o / 16) * 32 + 16 + (o % 16)] = Ci[o / 16][o % 16];
+        }
+    }
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    lbs_blend(N, 24, n, xyz, w, s_rt, out);
 }
 
 // ---- per-face Gaussian frame: geom_face.hpp ------------------------------------
@@ -388,6 +431,15 @@ extern "C" int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const f
                                float *d_dst_Ts, void *stream) {
     if (!dst_Rs || !dst_Ts || !fk_save || !dRT || !d_dst_Rs || !d_dst_Ts) { gom_set_error("gom_fk_backward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_fk_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_Rs, dst_Ts, fk_save, dRT, d_dst_Rs, d_dst_Ts);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_fk_lbs_forward_batch(int B, int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights,
+                             float *RT, float *fk_save, float *out, void *stream) {
+    if (!cnl_gtfms || !dst_Rs || !dst_Ts || !RT || !fk_save || !xyz || !weights || !out) { gom_set_error("gom_fk_lbs_forward: null pointer"); return -1; }
+    if (N <= 0) return gom_fk_forward_batch(B, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save, stream);
+    hipLaunchKernelGGL(k_fk_lbs_fwd, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, cnl_gtfms, dst_Rs, dst_Ts, xyz, weights, RT, fk_save, out);
     GOM_LAUNCH_CHECK();
     return 0;
 }

@@ -454,8 +454,12 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     fa.d_corner = f->work_dcorner; fa.d_so3 = b_so3; fa.d_scale = b_scale; fa.d_appearance = b_app;
     const GomFaceArgs *face = s->fuseFace ? &fa : nullptr;
     if (!(flags & GOM_FRAME_BACKWARD_ONLY)) {
-        if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
-        if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
+        if (face) {   // (GOM_OPT_FUSE_FACE also fuses the kinematic chain into the skinning launch)
+            if ((rc = gom_fk_lbs_forward_batch(B, N, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->vertices, f->lbs_weights, f->work_RT, f->work_fk, f->work_vobs, stream))) return rc;
+        } else {
+            if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
+            if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;
+        }
         if (!face) {
             if ((rc = gom_face_forward_batch(B, N, F, f->work_vobs, f->faces, f->so3, f->scale, f->sigma, f->work_xyz, f->work_cov6, f->appearance,
                                              f->work_feat, stream)))

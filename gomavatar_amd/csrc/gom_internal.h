@@ -230,6 +230,8 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 // batched (B frames per launch) geometry / loss launches behind the single-frame C-ABI entry points
 int gom_fk_forward_batch(int B, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream);
 int gom_lbs_forward_batch(int B, int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream);
+int gom_fk_lbs_forward_batch(int B, int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights,
+                             float *RT, float *fk_save, float *out, void *stream);
 int gom_face_forward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                            float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream);
 int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,

@@ -15,8 +15,8 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
 names = [short(r["Kernel_Name"]) for r in rows]
-# a step = from one k_fk_fwd to the next; take the 10th step from the end
-starts = [i for i, n in enumerate(names) if n.startswith("k_fk_fwd")]
+# a step = from one k_fk* launch to the next; take the 10th step from the end
+starts = [i for i, n in enumerate(names) if n.startswith("k_fk")]   # k_fk_fwd or k_fk_lbs_fwd: the first kernel of a step
 a, b = starts[-10], starts[-9]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
 out = []
