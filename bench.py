@@ -222,7 +222,9 @@ class Runner:
         for sl in self.slots:
             sl["step"].state.set_option(_lib.OPT_PROFILE, 0)
         torch.cuda.synchronize()
-        return {k: acc[k] / n for k in _lib.KERNEL_NAMES}, D / n
+        # (a kernel id that no launch carried this time -- e.g. the depth histogram, which the frame step builds inside k_preprocess -- reports
+        #  -1 ms: it is left out)
+        return {k: acc[k] / n for k in _lib.KERNEL_NAMES if acc.get(k, -1.0) >= 0.0}, D / n
 
 
 def timeit(torch, fn, min_s=MIN_TIMED_S, warm=5, chunk=10):

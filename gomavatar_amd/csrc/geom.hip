@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) k_fk_bwd(const float *__restrict__ Rs, con
 // ---- LBS: one thread per vertex ---------------------------------------------
 // v' = sum_j w_j (R_j v + T_j) for vertex n, from the skinning rows in LDS (contraction pinned: k_lbs_fwd and k_fk_lbs_fwd give the same bits)
 __device__ __forceinline__ void lbs_blend(int N, int J, int n, const float *__restrict__ xyz, const float *__restrict__ w, const float *s_rt,
-                                          float *__restrict__ out) {
+                                          float *__restrict__ out, float (&pos)[3]) {
 #pragma clang fp contract(on)
     const float x = xyz[n], y = xyz[(size_t)N + n], z = xyz[2 * (size_t)N + n];
     float ox = 0.f, oy = 0.f, oz = 0.f;
@@ -162,6 +162,7 @@ __device__ __forceinline__ void lbs_blend(int N, int J, int n, const float *__re
     out[n] = ox;
     out[(size_t)N + n] = oy;
     out[2 * (size_t)N + n] = oz;
+    pos[0] = ox; pos[1] = oy; pos[2] = oz;
 }
 
 __global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__restrict__ xyz, const float *__restrict__ w,
@@ -173,7 +174,8 @@ __global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__re
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    lbs_blend(N, J, n, xyz, w, s_rt, out);
+    float pos[3];
+    lbs_blend(N, J, n, xyz, w, s_rt, out, pos);
 }
 
 // FK + LBS in one launch (the frame step): every workgroup runs the frame's 24-joint chain itself (two microseconds of barriers next to a
@@ -181,8 +183,10 @@ __global__ void __launch_bounds__(256) k_lbs_fwd(int N, int J, const float *__re
 // also leaves RT and the FK state for the backward.  Same arithmetic as k_fk_fwd + k_lbs_fwd.
 __global__ void __launch_bounds__(256) k_fk_lbs_fwd(int N, const float *__restrict__ cnl, const float *__restrict__ Rs, const float *__restrict__ Ts,
                                                     const float *__restrict__ xyz, const float *__restrict__ w, float *__restrict__ RT,
-                                                    float *__restrict__ save, float *__restrict__ out) {
+                                                    float *__restrict__ save, float *__restrict__ out, GomCamera cam1, const GomCamera *__restrict__ cams,
+                                                    uint32_t *__restrict__ vdepth_minmax) {
     __shared__ float L[24][16], G[24][16], Ci[24][16], s_rt[24 * 12];
+    __shared__ float s_zmin[4], s_zmax[4];
     const int t = threadIdx.x;
     {
         const size_t fr = blockIdx.y;
@@ -197,8 +201,24 @@ __global__ void __launch_bounds__(256) k_fk_lbs_fwd(int N, const float *__restri
         }
     }
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    lbs_blend(N, 24, n, xyz, w, s_rt, out);
+    float pos[3] = {0.f, 0.f, 0.f};
+    if (n < N) lbs_blend(N, 24, n, xyz, w, s_rt, out, pos);
+    if (vdepth_minmax) {
+        // view depth range of this block's posed vertices (bit patterns of floats >= 0.2: what is visible lies beyond the near cut, and a
+        // Gaussian's mean is the centroid of three of these vertices): the depth ranking's bucket map without a pass over the Gaussians
+        const float *v = cams ? cams[blockIdx.y].view : cam1.view;
+        const float z = v[2] * pos[0] + v[6] * pos[1] + v[10] * pos[2] + v[14];
+        float lo = n < N ? z : 3.0e38f, hi = n < N ? z : -3.0e38f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+        if ((t & 63) == 0) { s_zmin[t >> 6] = lo; s_zmax[t >> 6] = hi; }
+        __syncthreads();
+        if (t == 0) {
+            lo = fmaxf(fminf(fminf(s_zmin[0], s_zmin[1]), fminf(s_zmin[2], s_zmin[3])), 0.2f);
+            hi = fmaxf(fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3])), 0.2f);
+            reinterpret_cast<uint2 *>(vdepth_minmax)[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_uint2(__float_as_uint(lo), __float_as_uint(hi));
+        }
+    }
 }
 
 // ---- per-face Gaussian frame: geom_face.hpp ------------------------------------
@@ -436,10 +456,11 @@ extern "C" int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const f
 }
 
 int gom_fk_lbs_forward_batch(int B, int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights,
-                             float *RT, float *fk_save, float *out, void *stream) {
+                             float *RT, float *fk_save, float *out, void *stream, const GomCamera *cam1, const GomCamera *cams, uint32_t *vdepth_minmax) {
     if (!cnl_gtfms || !dst_Rs || !dst_Ts || !RT || !fk_save || !xyz || !weights || !out) { gom_set_error("gom_fk_lbs_forward: null pointer"); return -1; }
     if (N <= 0) return gom_fk_forward_batch(B, cnl_gtfms, dst_Rs, dst_Ts, RT, fk_save, stream);
-    hipLaunchKernelGGL(k_fk_lbs_fwd, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, cnl_gtfms, dst_Rs, dst_Ts, xyz, weights, RT, fk_save, out);
+    hipLaunchKernelGGL(k_fk_lbs_fwd, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, cnl_gtfms, dst_Rs, dst_Ts, xyz, weights, RT, fk_save, out,
+                       cam1 ? *cam1 : GomCamera{}, cams, cam1 ? vdepth_minmax : nullptr);
     GOM_LAUNCH_CHECK();
     return 0;
 }

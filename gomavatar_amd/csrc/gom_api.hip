@@ -52,7 +52,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count, s->vdepth_minmax};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -238,7 +238,12 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         if (s->rankSort && P > 393216) { gom_set_error("GOM_OPT_SORT_MODE 2 needs P <= 393216 per frame (the frame's rank bitmap lives in 64 KiB of LDS)"); return -1; }
         if (int rc = gom_launch_preprocess(s, *cam, P, means3D, cov6, opacity, radii, st, face)) return rc;
         if (s->rankSort) {
-            if (int rc = gom_launch_depth_hist(s, P, st)) return rc;
+            // the depth range behind the bucket map: per block of k_preprocess, or the frame step's vertex ranges (then k_preprocess has
+            // built the histogram as well)
+            const bool vranges = face && face->vdepth_minmax;
+            s->rank_minmax = vranges ? face->vdepth_minmax : s->depth_minmax;
+            s->rank_blocks = vranges ? face->vdepth_blocks : (P + 255) / 256;
+            if (!vranges) { if (int rc = gom_launch_depth_hist(s, P, st)) return rc; }
             if (int rc = gom_launch_scan_emit(s, P, st, true, out_color, C, cam->bg)) return rc;
             if (int rc = gom_launch_tile_rank(s, st)) return rc;
         } else {
@@ -372,6 +377,11 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
 
 // per-frame slices of the parameter gradients of a batched call: [so3 | scale | appearance : B x 3F each][vertices : B x 3N]
 static int ensure_batch_grads(GomState *s, int B, int N, int F) {
+    const size_t vneed = (size_t)B * ((N + 255) / 256) * 2;   // vertex depth ranges of the skinning blocks (frame step)
+    if (vneed > s->capVdepth) {
+        if (grow(&s->vdepth_minmax, vneed)) return -2;
+        s->capVdepth = vneed;
+    }
     const size_t need = B > 1 ? (size_t)B * (9 * (size_t)F + 3 * (size_t)N) : 0;
     if (need > s->capBatchGrads) {
         if (grow(&s->batch_grads, need)) return -2;
@@ -452,10 +462,13 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     fa.N = N; fa.verts = f->work_vobs; fa.faces = f->faces; fa.so3 = f->so3; fa.scale = f->scale; fa.sigma = f->sigma;
     fa.appearance = f->appearance; fa.feat4 = f->work_feat;
     fa.d_corner = f->work_dcorner; fa.d_so3 = b_so3; fa.d_scale = b_scale; fa.d_appearance = b_app;
+    fa.vdepth_minmax = s->vdepth_minmax; fa.vdepth_blocks = (N + 255) / 256;
     const GomFaceArgs *face = s->fuseFace ? &fa : nullptr;
     if (!(flags & GOM_FRAME_BACKWARD_ONLY)) {
         if (face) {   // (GOM_OPT_FUSE_FACE also fuses the kinematic chain into the skinning launch)
-            if ((rc = gom_fk_lbs_forward_batch(B, N, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->vertices, f->lbs_weights, f->work_RT, f->work_fk, f->work_vobs, stream))) return rc;
+            if ((rc = gom_fk_lbs_forward_batch(B, N, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->vertices, f->lbs_weights, f->work_RT, f->work_fk, f->work_vobs, stream,
+                                               &f->cam, cams, s->vdepth_minmax)))
+                return rc;
         } else {
             if ((rc = gom_fk_forward_batch(B, f->cnl_gtfms, f->dst_Rs, f->dst_Ts, f->work_RT, f->work_fk, stream))) return rc;
             if ((rc = gom_lbs_forward_batch(B, N, J, f->vertices, f->lbs_weights, f->work_RT, f->work_vobs, stream))) return rc;

@@ -107,6 +107,10 @@ struct GomState {
     uint32_t *seg_cost = nullptr;     // [capSegs][4 sub-ranges][4 quadrants] entries that survived the cull in the pieces k_seg_fwd found alive = cost estimate of the backward's tasks
     uint32_t *bwd_order = nullptr;    // the backward's tasks per queue shard, most expensive first (riders of the loss kernel): GOM_BWD_ORDER_* below
     bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
+    const uint32_t *rank_minmax = nullptr;   // where the depth ranking of the current forward takes its depth range from: depth_minmax (per
+    int rank_blocks = 0;                     //   block of k_preprocess) or the frame step's vertex ranges (GomFaceArgs::vdepth_minmax)
+    uint32_t *vdepth_minmax = nullptr;       // [frames][skinning blocks][2], frame step
+    size_t capVdepth = 0;
     uint32_t *big_list = nullptr;     // [frames][GOM_BIG_CAP] the Gaussians of each frame that touch more than GOM_BIG_NT tiles (k_preprocess_bwd gives each a whole wave)
     uint32_t *big_count = nullptr;    // [2][frames] their number per frame: [0] published by the scan kernel, [1] being counted by k_preprocess
     int capBigFrames = 0;
@@ -192,6 +196,8 @@ struct GomFaceArgs {
     float sigma;
     const float *appearance;     // (3, F)
     float *feat4;                // (B, F, 4) rasterizer features [r g b 1], written by the forward
+    const uint32_t *vdepth_minmax;   // (B, vdepth_blocks, 2) view-depth range of the posed vertices per skinning block (k_fk_lbs_fwd): the depth
+    int vdepth_blocks;               //   ranking's bucket map comes from it and k_preprocess builds the bucket histogram itself (null: k_depth_hist)
     float *d_corner;             // (B, F, 9)      written by the backward
     float *d_so3, *d_scale, *d_appearance;   // (B, 3, F) per-frame slices
 };
@@ -231,7 +237,8 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 int gom_fk_forward_batch(int B, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, float *RT, float *fk_save, void *stream);
 int gom_lbs_forward_batch(int B, int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream);
 int gom_fk_lbs_forward_batch(int B, int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights,
-                             float *RT, float *fk_save, float *out, void *stream);
+                             float *RT, float *fk_save, float *out, void *stream, const GomCamera *cam1 = nullptr, const GomCamera *cams = nullptr,
+                             uint32_t *vdepth_minmax = nullptr);
 int gom_face_forward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                            float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream);
 int gom_face_backward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,

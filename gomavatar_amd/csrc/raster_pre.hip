@@ -21,6 +21,7 @@
 //    (no float atomics anywhere -> bitwise reproducible, no searching).
 #include "gom_internal.h"
 #include "geom_face.hpp"
+#include "rank_map.hpp"
 
 namespace {
 
@@ -116,8 +117,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
                                                     int32_t *__restrict__ radii_user, uint32_t *__restrict__ tile_count,
                                                     uint32_t *__restrict__ pair_off, GomDevStatus *__restrict__ status,
                                                     int gx, int gy, uint32_t cap_pairs, uint32_t *__restrict__ depth_minmax,
-                                                    float4 *__restrict__ rec_g, uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, int big_frames) {
+                                                    float4 *__restrict__ rec_g, uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, int big_frames,
+                                                    uint32_t *__restrict__ bucket_count, uint32_t nb) {
     extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_dmin[4], s_dmax[4];
     __shared__ uint32_t s_blockbase;
@@ -140,6 +143,15 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < n_tiles; i += 256) s_hist[i] = 0;
         __syncthreads();
+    }
+    // Frame step with the depth ranking: the bucket histogram is built here (the depth range comes from the posed vertices, which the
+    // skinning kernel already had in registers) -- k_depth_hist was a launch and a pass over the Gaussians for nothing else.
+    const bool hist_here = FACE && face.vdepth_minmax && bucket_count;
+    uint32_t *s_bcnt = s_hist + (LDS_HIST ? n_tiles : 0);
+    gom_rank::BucketMap bm{};
+    if (hist_here) {
+        for (uint32_t b = threadIdx.x; b < nb; b += 256) s_bcnt[b] = 0;
+        bm = gom_rank::bucket_map(face.vdepth_minmax, fr, face.vdepth_blocks, nb, s_red);   // (ends with a barrier)
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
@@ -213,6 +225,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         xy[i] = make_float2(o_x, o_y);
         conic_opacity[i] = make_float4(o_cx, o_cy, o_cz, o_op);
         tiles_touched[i] = o_tiles;
+        if (hist_here && o_rad > 0) atomicAdd(&s_bcnt[bm(o_depth)], 1u);
         if (big_list && o_tiles > GOM_BIG_NT) {   // (a few hundred per frame at most: one counter per frame is enough)
             const uint32_t bi = atomicAdd(&big_count[big_frames + fr], 1u);   // ([0, big_frames): last forward's counts, published by the scan kernel)
             if (bi < GOM_BIG_CAP) big_list[(size_t)fr * GOM_BIG_CAP + bi] = (uint32_t)i;
@@ -287,6 +300,12 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
         for (int t = threadIdx.x; t < n_tiles; t += 256) {
             const uint32_t c = s_hist[t];
             if (c) atomicAdd(&tile_count[t], c);
+        }
+    }
+    if (hist_here) {   // (the barriers of the pair-range scan above lie between the LDS atomics and these reads)
+        for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+            const uint32_t c = s_bcnt[b];
+            if (c) atomicAdd(&bucket_count[(size_t)fr * nb + b], c);
         }
     }
 }
@@ -768,9 +787,12 @@ int gom_launch_preprocess(GomState *s, const GomCamera &cam, int P, const float 
     const GomFaceArgs fa = face ? *face : GomFaceArgs{};
     // (with `face` the two arrays are this kernel's outputs: the frame step owns them)
     float *m = const_cast<float *>(means3D), *c = const_cast<float *>(cov6);
-#define GOM_PP(LDSH, FACEV) hipLaunchKernelGGL((k_preprocess<LDSH, FACEV>), grid, dim3(256), LDSH ? n_tiles * sizeof(uint32_t) : 0, st, cam, s->cams, P, m, c, opacity, fa, \
+    const bool hist_here = face && face->vdepth_minmax && s->rankSort;
+    const uint32_t nb = 1u << s->nbShift;
+#define GOM_PP(LDSH, FACEV) hipLaunchKernelGGL((k_preprocess<LDSH, FACEV>), grid, dim3(256), ((LDSH ? n_tiles : 0) + (hist_here ? nb : 0)) * sizeof(uint32_t), st, cam, s->cams, P, m, c, opacity, fa, \
                                                s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, radii_out, s->tile_count, s->pair_off,  \
-                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr, s->big_list, s->big_count, s->capBigFrames)
+                                               s->status, s->gx, s->gy, cap, s->rankSort ? s->depth_minmax : nullptr, s->rankSort ? s->rec_g : nullptr, s->big_list, s->big_count, s->capBigFrames, \
+                                               hist_here ? s->bucket_count : nullptr, nb)
     if (lds) { if (face) GOM_PP(true, true); else GOM_PP(true, false); }
     else { if (face) GOM_PP(false, true); else GOM_PP(false, false); }
 #undef GOM_PP

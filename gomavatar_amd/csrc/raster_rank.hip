@@ -24,60 +24,23 @@
 // chunk + global-merge path of sort_util.hpp: slower, same result.
 #include "gom_internal.h"
 #include "sort_util.hpp"
+#include "rank_map.hpp"
 
 namespace {
 
 using namespace gom_sort;
 
-struct BucketMap {
-    float dmin, scale;
-    uint32_t nb;
-    __device__ __forceinline__ uint32_t operator()(float d) const {
-        const float v = (d - dmin) * scale;              // monotone in d (IEEE subtraction / multiplication by a constant >= 0)
-        const uint32_t b = v > 0.f ? (uint32_t)v : 0u;   // (truncation is monotone; NaN cannot occur: scale is finite)
-        return b < nb ? b : nb - 1u;
-    }
-};
-
-// The frame's depth range from the per-block (min, max) pairs k_preprocess left (float BIT PATTERNS: depths are > 0.2, unsigned
-// order = float order; a block without a visible Gaussian wrote min > max): every workgroup folds the ~200 pairs itself --
-// 1.7 KB from L2 -- instead of a reduction kernel or contended atomics.  Ends with a __syncthreads().
-__device__ __forceinline__ BucketMap bucket_map(const uint32_t *__restrict__ minmax, int fr, int nblk, uint32_t nb, uint32_t *s_red /* [8] */) {
-    const uint2 *mm = reinterpret_cast<const uint2 *>(minmax) + (size_t)fr * nblk;
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
-        const uint2 v = mm[k];
-        lo = min(lo, v.x);
-        hi = max(hi, v.y);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = lo; s_red[4 + (threadIdx.x >> 6)] = hi; }
-    __syncthreads();
-    lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-    BucketMap m;
-    m.nb = nb;
-    m.dmin = __uint_as_float(lo);
-    const float span = lo < hi ? __uint_as_float(hi) - __uint_as_float(lo) : 0.f;
-    float sc = span > 0.f ? (float)nb / span : 0.f;
-    if (!(sc < 1.0e30f)) sc = 0.f;   // a span of a few ulps: one bucket (still correct, the bucket sort orders it)
-    m.scale = sc;
-    return m;
-}
+using namespace gom_rank;   // BucketMap, bucket_map: rank_map.hpp
 
 // ---- counts per (frame, bucket) ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_depth_hist(int P, uint32_t nb, const float *__restrict__ depth, const int32_t *__restrict__ radii,
-                                                    const uint32_t *__restrict__ minmax, uint32_t *__restrict__ bucket_count,
+                                                    const uint32_t *__restrict__ minmax, int nblk, uint32_t *__restrict__ bucket_count,
                                                     const GomDevStatus *__restrict__ status) {
     extern __shared__ uint32_t s_cnt[];
     __shared__ uint32_t s_red[8];
     const int fr = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
-    const BucketMap bm = bucket_map(minmax, fr, gridDim.x, nb, s_red);
+    const BucketMap bm = bucket_map(minmax, fr, nblk, nb, s_red);
     const int il = blockIdx.x * 256 + threadIdx.x;
     const size_t i = (size_t)fr * P + il;
     if (il < P && radii[i] > 0) atomicAdd(&s_cnt[bm(depth[i])], 1u);
@@ -90,14 +53,14 @@ __global__ void __launch_bounds__(256) k_depth_hist(int P, uint32_t nb, const fl
 
 // ---- keys into the bucket ranges (order inside a bucket arbitrary: the bucket sort fixes it) -------------------------------
 __global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, const float *__restrict__ depth, const int32_t *__restrict__ radii,
-                                                        const uint32_t *__restrict__ minmax, uint32_t *__restrict__ bucket_cursor,
+                                                        const uint32_t *__restrict__ minmax, int nblk, uint32_t *__restrict__ bucket_cursor,
                                                         uint64_t *__restrict__ bkeys) {
     extern __shared__ uint32_t s_mem[];
     uint32_t *s_cnt = s_mem, *s_base = s_mem + nb;
     __shared__ uint32_t s_red[8];
     const int fr = blockIdx.y;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
-    const BucketMap bm = bucket_map(minmax, fr, gridDim.x, nb, s_red);
+    const BucketMap bm = bucket_map(minmax, fr, nblk, nb, s_red);
     const int il = blockIdx.x * 256 + threadIdx.x;
     const size_t i = (size_t)fr * P + il;
     const bool vis = il < P && radii[i] > 0;
@@ -291,7 +254,7 @@ int gom_launch_depth_rank(GomState *s, int P, hipStream_t st) {
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_DEPTH_RANK, st);
     const uint32_t nb = 1u << s->nbShift;
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->depth_minmax,
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->rank_minmax, s->rank_blocks,
                        s->bucket_cursor, s->bkeys);
     GOM_LAUNCH_CHECK();
     const int cap = 8 * GOM_BSORT_NT;
@@ -307,7 +270,7 @@ int gom_launch_depth_hist(GomState *s, int P, hipStream_t st) {
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_DEPTH_HIST, st);
     const uint32_t nb = 1u << s->nbShift;
-    hipLaunchKernelGGL(k_depth_hist, dim3(blocks, s->B), dim3(256), nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->depth_minmax, s->bucket_count,
+    hipLaunchKernelGGL(k_depth_hist, dim3(blocks, s->B), dim3(256), nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->rank_minmax, s->rank_blocks, s->bucket_count,
                        s->status);
     GOM_LAUNCH_CHECK();
     return 0;

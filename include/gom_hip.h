@@ -369,8 +369,8 @@ int gom_ssim(int H, int W, int C, const float *img0, const float *img1, int win,
  * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused
  * unpack + L1 losses (forward and backward) -> splat backward -> face backward -> vertex gather + LBS backward
  * (reference models/model.py:213-250, renderer/gaussian.py:22-100, train.py:53-55,101-111 and their autograd
- * backward).  15 kernel launches enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
- * per-face frame and its backward inside the rasterizer's per-Gaussian kernels: GOM_OPT_FUSE_FACE); every pointer is caller-owned device
+ * backward).  14 kernel launches enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
+ * per-face frame, the depth histogram and the frame's backward inside the rasterizer's per-Gaussian kernels: GOM_OPT_FUSE_FACE); every pointer is caller-owned device
  * memory, `work_*` are scratch tensors of the stated sizes. */
 typedef struct GomFrame {
     int32_t N, F, H, W;                 /* vertices, faces (= Gaussians), image size; 24 joints                  */
@@ -406,7 +406,7 @@ typedef struct GomFrame {
                                        hipGraph on first use and replay it afterwards: one submission instead of 17 */
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
 
-/* B frames in ONE launch sequence (the same 15 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
+/* B frames in ONE launch sequence (the same 14 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
  * kernels of a single 512x512 frame become B times larger launches, which is what fills 256 CUs.  The reference has
  * batch size 1 (train.py:309-349); a batch here is B frames whose gradients are SUMMED, i.e. one optimizer step on B
  * frames, the same semantics as the frame-parallel all-reduce across GPUs.

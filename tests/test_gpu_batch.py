@@ -1,4 +1,4 @@
-"""Batched launches (gom_batch_forward_backward): B frames through the same 15
+"""Batched launches (gom_batch_forward_backward): B frames through the same 14
 kernels must reproduce B single-frame calls BITWISE (images, losses, binning)
 and sum the gradients in frame order."""
 import numpy as np
