@@ -422,7 +422,7 @@ __device__ __forceinline__ void ld4(const float *base, size_t row, int pxi, floa
 
 
 // Dynamic distribution of the (segment, piece) tasks of the segment kernels.  A static grid-stride assignment left a
-// third of the chip idle behind the last workgroups to start (timeline: scripts/phase_prof.py); instead exactly as
+// third of the chip idle behind the last workgroups to start (timeline: scripts/wg_timeline_T.py); instead exactly as
 // many workgroups as the chip holds are launched and each draws tasks from a queue until they run out, so all of
 // them finish within one task of each other.
 //   * One device-scope counter saturates at ~88 dequeues/us (MI355X_MICROARCH.md "dequeue"): the queue is sharded 8
