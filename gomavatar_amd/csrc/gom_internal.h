@@ -123,6 +123,7 @@ struct GomState {
     float *seg_Tend = nullptr;        // [capSegs][256]     transmittance after the segment (combine pass)
     float *seg_Sbehind = nullptr;     // [capSegs][4][256]  colour still to come behind the segment
     // per 32-entry sub-range of a segment (4 per segment) x 256 pixels
+    unsigned long long *cull_masks = nullptr;   // [capSegs][4 sub-ranges][4 quadrants] the entries of a sub-range that can reach the quadrant at all (k_seg_T; read by the passes behind it)
     float *sub_T = nullptr;           // [capSegs][4][256]     product of (1-alpha) over the sub-range
     float *sub_C = nullptr;           // [capSegs][4][4][256]  colour the sub-range really added to the pixel
     float *sub_Tend = nullptr;        // [capSegs][4][256]     transmittance behind the sub-range

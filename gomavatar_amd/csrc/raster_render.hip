@@ -366,7 +366,8 @@ struct EntryRegs {
 // one entry each and test it against the wave's 8x8 rectangle.
 template <int C>
 __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_geo, const float *__restrict__ ent_col, uint32_t start,
-                                                 uint32_t cnt, int sub, int lane, float qx0, float qy0, float qx1, float qy1, uint32_t sub_sz) {
+                                                 uint32_t cnt, int sub, int lane, float qx0, float qy0, float qx1, float qy1, uint32_t sub_sz,
+                                                 const unsigned long long *__restrict__ known = nullptr) {
     EntryRegs<C> r;
     const uint32_t e = (uint32_t)sub * sub_sz + (uint32_t)lane;
     const bool valid = (uint32_t)lane < sub_sz && e < cnt;
@@ -385,7 +386,9 @@ __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_
             if (C > 3) r.col[3 % (C > 0 ? C : 1)] = cl.w;
         }
     }
-    r.keep = valid && !cull_entry(r.x, r.y, r.a, r.b, r.c, r.o, qx0, qy0, qx1, qy1);
+    // `known`: the survivors of this (sub-range, quadrant) as k_seg_T found them (cull_masks) -- the same test on the same numbers, so
+    // the compositing pass and the backward take its 64 bits instead of ~55 instructions per lane; null: test here.
+    r.keep = known ? valid && ((*known >> lane) & 1ull) != 0ull : valid && !cull_entry(r.x, r.y, r.a, r.b, r.c, r.o, qx0, qy0, qx1, qy1);
     return r;
 }
 
@@ -565,7 +568,7 @@ template <int C>
 __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                 const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
                                                 float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
-                                                const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr) {
+                                                const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, unsigned long long *__restrict__ cull_masks) {
     __shared__ float s_P[2][GOM_NSUB][64];
     __shared__ uint32_t s_task[2];
     // Survivors' attributes reach the lanes through a wave-private LDS slab (uniform addresses = broadcast reads) instead of six
@@ -605,6 +608,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             tq.request();
             unsigned long long mask = __ballot(r.keep);
+            if (lane == 0) cull_masks[((size_t)seg * GOM_NSUB + sub) * 4 + q] = mask;   // for the two passes that follow
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
             ph_lastsurv = __popcll(mask);
 #endif
@@ -648,7 +652,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
-                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, uint32_t *__restrict__ seg_cost) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, uint32_t *__restrict__ seg_cost, const unsigned long long *__restrict__ cull_masks) {
     __shared__ float s_c[GOM_NSUB][C][64];
     __shared__ float s_t[GOM_NSUB][64];
     __shared__ uint32_t s_l[GOM_NSUB][64];
@@ -681,7 +685,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
         // issued early: the entry loads overlap the transmittance prefix below
-        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
+        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz, cull_masks + ((size_t)seg * GOM_NSUB + sub) * 4 + q);
         // transmittance at the start of this sub-range; 0 = the pixel has certainly stopped earlier.
         // (In the 1e-5-wide borderline band the pixel stays alive; the fold below / the combine pass honour
         //  the exact stop flag of the earlier piece.)
@@ -1003,7 +1007,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
-                                                  uint32_t *__restrict__ task_ctr) {
+                                                  uint32_t *__restrict__ task_ctr, const unsigned long long *__restrict__ cull_masks) {
     constexpr int NV = 6 + C;  // values reduced per entry
     // [task parity][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote.
     // Double-buffered by task parity and never cleared: the flush reads only the rows s_done names, and the next task
@@ -1092,7 +1096,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             ld4<C>(seg_Sbehind, seg, pxi, S);
             if (sub < GOM_NSUB - 1) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + sub, pxi, cu);   // what the later pieces of the segment added (wave-uniform condition)
             const uint32_t lim = min(cnt, wmax - e0);  // entries at or beyond wmax are dead for this wave
-            const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
+            const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx1, qy1, sub_sz, cull_masks + ((size_t)seg * GOM_NSUB + sub) * 4 + q);
             tq.request();  // (behind every load of this task)
             requested = true;
             const float invT = T > 0.f ? 1.f / T : 0.f;
@@ -1237,7 +1241,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                                                   const float *__restrict__ dL_dpix, const float *__restrict__ sub_Tend,
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
-                                                  uint32_t *__restrict__ task_ctr, const uint32_t *__restrict__ task_order) {
+                                                  uint32_t *__restrict__ task_ctr, const uint32_t *__restrict__ task_order, const unsigned long long *__restrict__ cull_masks) {
     constexpr int NV = 6 + C;
     // [half of the pair][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote
     __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
@@ -1317,7 +1321,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                 ld4<C>(seg_Sbehind, seg, pxi, S);
                 if (sub < GOM_NSUB - 1) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + sub, pxi, cu);
                 const uint32_t lim = min(cnt, wmax - e0);
-                const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx0 + 7.f, qy0 + 7.f, sub_sz);
+                const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, lim, sub, lane, qx0, qy0, qx0 + 7.f, qy0 + 7.f, sub_sz, cull_masks + ((size_t)seg * GOM_NSUB + sub) * 4 + q);
                 if (!requested) { tq.request(); requested = true; }   // (behind the loads of this piece)
                 if (sub < GOM_NSUB - 1) {
 #pragma unroll
@@ -1501,10 +1505,10 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
             if (C == 3)
                 hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_RESIDENT(k_seg_T<3>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR);
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR, s->cull_masks);
             else
                 hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_RESIDENT(k_seg_T<4>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR);
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR, s->cull_masks);
         } else {  // only the colours changed: bring them into list order
             if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
             else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
@@ -1515,7 +1519,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_RESIDENT(k_seg_fwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
-                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr)
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
     }
@@ -1543,7 +1547,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 #define GOM_SBW(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_pair<CC>), dim3(GOM_RESIDENT(k_seg_bwd_pair<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, s->B > 1 && s->bwdOrderReady ? s->bwd_order : nullptr)
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, s->B > 1 && s->bwdOrderReady ? s->bwd_order : nullptr, s->cull_masks)
         if (C == 3) GOM_SBW(3); else GOM_SBW(4);
 #undef GOM_SBW
         GOM_LAUNCH_CHECK();
@@ -1552,7 +1556,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 #define GOM_SB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_bwd<CC>), dim3(GOM_RESIDENT(k_seg_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR)
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, s->cull_masks)
     if (C == 3) GOM_SB(3); else GOM_SB(4);
 #undef GOM_SB
     GOM_LAUNCH_CHECK();
