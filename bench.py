@@ -157,7 +157,7 @@ class Runner:
         with torch.cuda.stream(sl["stream"]):
             sl["step"].cam = bt["cam"]
             if self.B > 1:
-                sl["step"].cams_dev.copy_(bt["cams_dev"], non_blocking=True)   # this step's cameras (device array read by the kernels)
+                sl["step"].cams_dev = bt["cams_dev"]   # this batch's device camera array: resident like its targets and poses (one recorded graph per batch)
             sl["step"].forward_backward(self.wl.params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
             sl["fp"].all_reduce_grads()  # no-op at world size 1
 
@@ -492,7 +492,7 @@ def main():
         with torch.cuda.stream(main_run.slots[0]["stream"]):
             st0.cam = bt0["cam"]
             if B > 1:
-                st0.cams_dev.copy_(bt0["cams_dev"])
+                st0.cams_dev = bt0["cams_dev"]
             st0.forward_backward(wl.params, bt0, bt0["gt_rgb"], bt0["gt_mask"], bt0["bg"], graph=not args.no_graph)
         torch.cuda.synchronize()
         out["cpu_baseline"], psnr = cpu_baseline(torch, args, wl, st0, bt0)

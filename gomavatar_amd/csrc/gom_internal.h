@@ -220,6 +220,17 @@ struct GomEmptyFill {
     float *out_color, *final_T;
     uint32_t *n_contrib;
 };
+// The bucket sorts of the depth ranking as the FIRST blocks of the emit launch (one per (frame, bucket)): the emission writes Gaussian ids,
+// not ranks, so the two are independent, and the sorts' latency chains run beside the emission's atomics.
+struct GomSortRider {
+    int B;                      // frames of the launch (always set: the grid is frame-minor)
+    int blocks;                 // = buckets per frame; 0: no riders
+    int P;
+    uint32_t log_chunk;
+    const uint32_t *bucket_base;
+    uint64_t *bkeys, *scratch;
+    uint32_t *order, *rank_of;
+};
 // fill_out: the image this forward writes (C planes per frame) -- the emit kernel then also paints the empty tiles and the compositing
 // assembly skips them (GomState::emptyFilled).
 int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false, float *fill_out = nullptr, int fill_C = 0, const float *fill_bg = nullptr);

@@ -22,6 +22,7 @@
 #include "gom_internal.h"
 #include "geom_face.hpp"
 #include "rank_map.hpp"
+#include "rank_sort.hpp"
 
 namespace {
 
@@ -460,17 +461,29 @@ template <bool LDS_AGG, bool RANK>
 __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ depth, const int32_t *__restrict__ radii,
                                               const ushort4 *__restrict__ rect, uint32_t *__restrict__ tile_cursor,
                                               uint64_t *__restrict__ keys, int gx, int gy,
-                                              const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ rank_of,
-                                              uint32_t *__restrict__ keys32, GomEmptyFill fill) {
-    extern __shared__ uint32_t s_mem[];
+                                              const GomDevStatus *__restrict__ status, uint32_t *__restrict__ keys32, GomEmptyFill fill,
+                                              GomSortRider sorts) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     if (status->overflow) return;
     const int n_tiles = gx * gy;  // per frame
-    const int fr = blockIdx.y;
+    // frame-minor block order: the sort riders of EVERY frame are dispatched first (as the y index of a 2-D grid the last frame's would
+    // start behind everything else and the launch would end with their chains)
+    const int fr = (int)(blockIdx.x % (uint32_t)sorts.B), bi = (int)(blockIdx.x / (uint32_t)sorts.B);
+    // The first blocks sort the buckets of the depth ranking (one each): a latency chain of ~30 active lanes that runs beside the
+    // emission's atomics instead of in a launch of its own in front of it (18 us).
+    const bool is_sort = bi < sorts.blocks;
+    const int sort_b = bi;
+    if (is_sort) {
+        gom_rank::bucket_sort_block<256>(fr, sort_b, sorts.P, (uint32_t)sorts.blocks, sorts.bucket_base, sorts.bkeys, sorts.scratch, sorts.order,
+                                         sorts.rank_of, sorts.log_chunk, reinterpret_cast<uint64_t *>(s_mem));
+        return;
+    }
+    const int bx = bi - sorts.blocks;
     // Blocks beyond the Gaussians paint the tiles NOTHING touches (five in six on a body: background colour, T = 1, no contributor):
     // pure stores that run in the shadow of this kernel's atomics instead of holding 6 800 workgroup slots of the compositing
     // assembly (k_combine_fwd: 54 -> 36 us without them).
-    if ((int)blockIdx.x >= fill.first_block) {
-        const int t0 = ((int)blockIdx.x - fill.first_block) * GOM_FILL_TILES;
+    if (bx >= fill.first_block) {
+        const int t0 = (bx - fill.first_block) * GOM_FILL_TILES;
         const size_t HW = (size_t)fill.H * fill.W;
         float bg[4] = {fill.bg[0], fill.bg[1], fill.bg[2], fill.bg[3]};
         if (fill.cams) {
@@ -491,14 +504,14 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
     }
     uint32_t *s_cnt = s_mem;
     uint32_t *s_base = s_mem + n_tiles;
-    const int il = blockIdx.x * 256 + threadIdx.x;
+    const int il = bx * 256 + threadIdx.x;
     const size_t i = (size_t)fr * P + il;  // global Gaussian id: the low key bits stay unique across the batch
     const bool vis = (il < P) && (radii[i] > 0);
     ushort4 r = make_ushort4(0, 0, 0, 0);
     uint64_t key = 0;
     if (vis) {
         r = rect[i];
-        key = RANK ? (uint64_t)rank_of[i] : ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+        key = RANK ? (uint64_t)(uint32_t)i : ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;   // (RANK: the tile pass looks the rank up)
     }
     tile_cursor += (size_t)fr * n_tiles;  // rect rows are stacked: bring them back to this frame's tile block
     r.y -= (unsigned short)(vis ? fr * gy : 0);
@@ -825,13 +838,23 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
         fill.H = s->H; fill.W = s->W; fill.C = fill_C;
         for (int ch = 0; ch < 4; ch++) fill.bg[ch] = fill_bg[ch];
     }
-    const dim3 grid(blocks + (fill_out ? (n_tiles + GOM_FILL_TILES - 1) / GOM_FILL_TILES : 0), s->B);
-#define GOM_EMIT(AGG, RK, LDS) hipLaunchKernelGGL((k_emit<AGG, RK>), grid, dim3(256), LDS, st, P, s->depth, s->radii, s->rect, s->tile_cursor, s->keys, s->gx, s->gy, \
-                                                  s->status, s->rank_of, s->keys32, fill)
+    GomSortRider sorts{};
+    if (rank) {
+        const int cap = 8 * 256;
+        sorts.blocks = 1 << s->nbShift;
+        sorts.P = P;
+        sorts.log_chunk = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < cap ? s->sortCap : cap)));
+        sorts.bucket_base = s->bucket_base; sorts.bkeys = s->bkeys; sorts.scratch = s->bkeys_scratch; sorts.order = s->order; sorts.rank_of = s->rank_of;
+    }
+    sorts.B = s->B;
+    const dim3 grid((unsigned)((size_t)(sorts.blocks + blocks + (fill_out ? (n_tiles + GOM_FILL_TILES - 1) / GOM_FILL_TILES : 0)) * s->B));
+    const size_t sort_lds = rank ? 8 * 256 * sizeof(uint64_t) : 0;   // the riders' key slab shares the dynamic LDS
+#define GOM_EMIT(AGG, RK, LDS) hipLaunchKernelGGL((k_emit<AGG, RK>), grid, dim3(256), (LDS) > sort_lds ? (LDS) : sort_lds, st, P, s->depth, s->radii, s->rect, s->tile_cursor, s->keys, s->gx, s->gy, \
+                                                  s->status, s->keys32, fill, sorts)
     if (n_tiles <= GOM_LDS_TILE_LIMIT) {
         if (rank) GOM_EMIT(true, true, 2 * n_tiles * sizeof(uint32_t)); else GOM_EMIT(true, false, 2 * n_tiles * sizeof(uint32_t));
     } else {
-        if (rank) GOM_EMIT(false, true, 0); else GOM_EMIT(false, false, 0);
+        if (rank) GOM_EMIT(false, true, (size_t)0); else GOM_EMIT(false, false, (size_t)0);
     }
 #undef GOM_EMIT
     GOM_LAUNCH_CHECK();

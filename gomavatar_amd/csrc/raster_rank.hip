@@ -11,10 +11,11 @@
 //   k_depth_hist      per Gaussian: depth -> one of NB equal-width buckets between the frame's min / max depth (a monotone
 //   k_bucket_scatter  map: every key of bucket b precedes every key of bucket b + 1); counts, then (after the scan kernel)
 //                     (depth_bits << 32 | index) keys scattered into the bucket's range.
-//   k_bucket_sort     per bucket (~200 keys): merge sort in registers + LDS -> rank q of every visible Gaussian in the
-//                     packed (frame, depth, index) order: order[q] = Gaussian, rank_of[Gaussian] = q.
-//   k_emit<RANK>      (raster_pre.hip) writes q instead of a 64-bit key into the tile's range, in arbitrary order.
-//   k_tile_rank       per tile: the ranks of its entries set bits of a P-bit bitmap in LDS; a popcount scan turns the bitmap
+//   bucket sort       per bucket (~200 keys): merge sort in registers + LDS -> rank q of every visible Gaussian in the
+//                     packed (frame, depth, index) order: order[q] = Gaussian, rank_of[Gaussian] = q (rank_sort.hpp; the
+//                     first blocks of the emit launch, beside the emission).
+//   k_emit<RANK>      (raster_pre.hip) writes the Gaussian's 32-bit id instead of a 64-bit key into the tile's range, in arbitrary order.
+//   k_tile_rank       per tile: the ranks of its entries (rank_of[id]) set bits of a P-bit bitmap in LDS; a popcount scan turns the bitmap
 //                     into the sorted list; the entries' 32-byte records (rec_g, left by k_preprocess) are gathered through
 //                     order[] and written in LIST order (point_list, ent_geo, ent_slot, segment descriptors).  No comparison,
 //                     no log factor, no limit on the list length.
@@ -83,44 +84,6 @@ __global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, cons
     if (vis) bkeys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = ((uint64_t)dbits << 32) | (uint32_t)il;   // index INSIDE the frame: ties keep Gaussian order
 }
 
-// ---- per bucket: sort -> rank of every visible Gaussian ---------------------------------------------------------------
-// order[q] = global Gaussian id at packed rank q, rank_of[g] = q.  Nothing else moves here: the tile pass fetches a Gaussian's
-// 32-byte record (rec_g, written by k_preprocess in Gaussian order) through order[] -- the entries of one tile are neighbours on
-// the mesh, so their records are neighbours in memory, where a copy in rank order (first version: 113 MB of sector traffic to
-// build it, 30 us) scattered them by depth.  A bucket is ~200 keys: 2-wave workgroups, 8 keys per thread.
-#define GOM_BSORT_NT 128
-__global__ void __launch_bounds__(GOM_BSORT_NT) k_bucket_sort(int P, uint32_t nb, const uint32_t *__restrict__ bucket_base, uint64_t *__restrict__ bkeys,
-                                                              uint64_t *__restrict__ scratch, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
-                                                              uint32_t log_chunk, const GomDevStatus *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * GOM_BSORT_NT];
-    const int fr = blockIdx.y;
-    if (status->overflow) return;
-    const uint32_t base = bucket_base[(size_t)fr * nb + blockIdx.x];
-    const uint32_t n = bucket_base[(size_t)fr * nb + blockIdx.x + 1] - base;
-    if (n == 0) return;
-    const uint32_t go = (uint32_t)fr * (uint32_t)P;
-    uint64_t x[8];
-    bool in_regs;
-    const uint64_t *sorted = block_sort_any<GOM_BSORT_NT>(bkeys + base, scratch + base, n, s_x, log_chunk, x, in_regs);
-    if (in_regs) {   // blocked registers: thread t holds positions 8t .. 8t+7
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t i = 8 * threadIdx.x + r;
-            if (i < n) {
-                const uint32_t g = go + (uint32_t)x[r];
-                order[base + i] = g;
-                rank_of[g] = base + i;
-            }
-        }
-        return;
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += GOM_BSORT_NT) {
-        const uint32_t g = go + (uint32_t)sorted[i];
-        order[base + i] = g;
-        rank_of[g] = base + i;
-    }
-}
-
 // ---- per tile: bitmap of ranks -> sorted list -> records in list order -------------------------------------------------
 // Work item = (non-empty tile, window of GOM_RANK_WIN consecutive list positions), listed by the scan kernel: four fifths of a
 // body frame's tiles are empty (a workgroup per tile that only finds that out cost more than the work), and a 5 000-entry list
@@ -133,7 +96,7 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
                                                   const uint32_t *__restrict__ order, const float4 *__restrict__ rec_g,
                                                   uint32_t *__restrict__ point_list, uint4 *__restrict__ seg_desc,
                                                   uint32_t *__restrict__ ent_slot, float2 *__restrict__ ent_geo,
-                                                  const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words, uint32_t *__restrict__ seg_cost) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t seg_shift, uint32_t bm_words, uint32_t *__restrict__ seg_cost, const uint32_t *__restrict__ rank_of) {
     extern __shared__ uint32_t s_mem[];
     __shared__ uint32_t s_wsum[NT / 64];
     uint32_t *s_bm = s_mem, *s_stage = s_mem + bm_words;
@@ -168,7 +131,9 @@ __global__ void __launch_bounds__(NT) k_tile_rank(int gx, int gy, uint32_t nb, c
         for (uint32_t i0 = t; i0 < n; i0 += 8 * NT) {            // 8 independent loads in flight per thread
             uint32_t r[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) r[u] = i0 + u * NT < n ? keys32[base + i0 + u * NT] - fs : 0xffffffffu;
+            for (int u = 0; u < 8; u++) r[u] = i0 + u * NT < n ? keys32[base + i0 + u * NT] : 0xffffffffu;   // Gaussian ids (the emission ran beside the bucket sorts)
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = r[u] != 0xffffffffu ? rank_of[r[u]] - fs : 0xffffffffu;
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (r[u] != 0xffffffffu) atomicOr(&s_bm[r[u] >> 5], 1u << (r[u] & 31u));   // ranks of one frame are unique, a Gaussian is in a tile list once
@@ -249,18 +214,14 @@ __global__ void __launch_bounds__(256) k_rebuild_keys(const uint32_t *__restrict
 }  // namespace
 
 int gom_launch_depth_rank(GomState *s, int P, hipStream_t st) {
-    // (called between the scan kernel -- which turned bucket_count into bucket_base / bucket_cursor -- and the emission)
+    // the keys into their buckets (called between the scan kernel -- which turned bucket_count into bucket_base / bucket_cursor -- and the
+    // emission, whose first blocks sort the buckets)
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
     GomKernelTimer timer(s, GOM_K_DEPTH_RANK, st);
     const uint32_t nb = 1u << s->nbShift;
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->rank_minmax, s->rank_blocks,
                        s->bucket_cursor, s->bkeys);
-    GOM_LAUNCH_CHECK();
-    const int cap = 8 * GOM_BSORT_NT;
-    const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < cap ? s->sortCap : cap)));
-    hipLaunchKernelGGL(k_bucket_sort, dim3(nb, s->B), dim3(GOM_BSORT_NT), 0, st, P, nb, s->bucket_base, s->bkeys, s->bkeys_scratch, s->order, s->rank_of, lc,
-                       s->status);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -286,7 +247,7 @@ int gom_launch_tile_rank(GomState *s, hipStream_t st) {
     const int cap_items = n_tiles + (int)(s->capPairs / GOM_RANK_WIN < 0x7fffffff ? s->capPairs / GOM_RANK_WIN : 0x7fffffff);
     const int grid = cap_items < 2048 ? cap_items : 2048;   // a resident grid striding over the work items of the scan kernel
     hipLaunchKernelGGL((k_tile_rank<256>), dim3(grid), dim3(256), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, s->work_items, &s->status->n_work_items,
-                       s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words, s->seg_cost);
+                       s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words, s->seg_cost, s->rank_of);
     GOM_LAUNCH_CHECK();
     return 0;
 }

@@ -15,9 +15,10 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
 names = [short(r["Kernel_Name"]) for r in rows]
-# a step = from one k_fk* launch to the next; take the 10th step from the end
+# a step = from one k_fk* launch to the next; take the 50th: inside the timed loop of graph replays (20 warm-up + 60 timed steps; the
+# steps after those belong to bench.py's event-bracketed per-kernel pass, launched one by one)
 starts = [i for i, n in enumerate(names) if n.startswith("k_fk")]   # k_fk_fwd or k_fk_lbs_fwd: the first kernel of a step
-a, b = starts[-10], starts[-9]
+a, b = starts[50], starts[51]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
 out = []
 for r, n in zip(rows[a:b], names[a:b]):
