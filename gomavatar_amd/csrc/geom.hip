@@ -304,6 +304,13 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
     const bool ok = n < N;
+    // the skinning weights first (J <= 24: registers): their loads do not depend on the corner gather and used to follow it one by one
+    float wr[24];
+    const bool w_regs = J <= 24;
+    if (w_regs) {
+#pragma unroll
+        for (int j = 0; j < 24; j++) wr[j] = (ok && j < J) ? w[(size_t)j * N + n] : 0.f;
+    }
     float g[3] = {0.f, 0.f, 0.f};
     if (ok) {
         if (csr_off) {
@@ -337,13 +344,26 @@ __global__ void __launch_bounds__(256) k_vertex_bwd(int N, int J, const float *_
         }
     }
     float ox = 0.f, oy = 0.f, oz = 0.f;
-    for (int j = 0; j < J; j++) {
-        const float wj = ok ? w[(size_t)j * N + n] : 0.f;
-        if (wj != 0.f) {
-            const float *m = s_rt + 12 * j;
-            ox += (m[0] * g[0] + m[3] * g[1] + m[6] * g[2]) * wj;
-            oy += (m[1] * g[0] + m[4] * g[1] + m[7] * g[2]) * wj;
-            oz += (m[2] * g[0] + m[5] * g[1] + m[8] * g[2]) * wj;
+    if (w_regs) {
+#pragma unroll
+        for (int j = 0; j < 24; j++) {
+            const float wj = wr[j];
+            if (wj != 0.f) {
+                const float *m = s_rt + 12 * j;
+                ox += (m[0] * g[0] + m[3] * g[1] + m[6] * g[2]) * wj;
+                oy += (m[1] * g[0] + m[4] * g[1] + m[7] * g[2]) * wj;
+                oz += (m[2] * g[0] + m[5] * g[1] + m[8] * g[2]) * wj;
+            }
+        }
+    } else {
+        for (int j = 0; j < J; j++) {
+            const float wj = ok ? w[(size_t)j * N + n] : 0.f;
+            if (wj != 0.f) {
+                const float *m = s_rt + 12 * j;
+                ox += (m[0] * g[0] + m[3] * g[1] + m[6] * g[2]) * wj;
+                oy += (m[1] * g[0] + m[4] * g[1] + m[7] * g[2]) * wj;
+                oz += (m[2] * g[0] + m[5] * g[1] + m[8] * g[2]) * wj;
+            }
         }
     }
     if (ok) {
@@ -418,7 +438,14 @@ __global__ void __launch_bounds__(256) k_sum_frames(int B, SumFramesArgs a) {
         while (j >= a.n[k]) { j -= a.n[k]; k++; }
         const float *src = a.src[k];
         float acc = 0.f;
-        for (int b = 0; b < B; b++) acc += src[(size_t)b * a.n[k] + j];
+        for (int b0 = 0; b0 < B; b0 += 8) {   // eight frames' loads in flight, added in frame order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = b0 + u < B ? src[(size_t)(b0 + u) * a.n[k] + j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (b0 + u < B) acc += v[u];
+        }
         a.dst[k][j] = acc;
     }
 }
