@@ -18,15 +18,31 @@ struct FaceFwd {
     float B[3][3], M[3][3];
 };
 
-__device__ __forceinline__ void face_forward(const float *verts, int N, const int32_t *faces, const float *so3, const float *scale,
-                                             int F, int f, float sigma, FaceFwd &o, float *xyz3, float *s3) {
-#pragma clang fp contract(on)   // fused multiply-adds as the expressions spell them, whichever kernel this is inlined into: same bits in all of them
+// What face_forward reads from memory (15 floats behind one dependent index load): a kernel with a long gather of its own in front of
+// the face arithmetic (k_preprocess_bwd) issues these loads first and computes later.
+struct FaceIn {
+    float v0[3], v1[3], v2[3], w[3], s[3];
+};
+
+__device__ __forceinline__ void face_load(const float *verts, int N, const int32_t *faces, const float *so3, const float *scale, int F, int f, FaceIn &in) {
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        o.v0[k] = verts[(size_t)k * N + i0];
-        o.v1[k] = verts[(size_t)k * N + i1];
-        o.v2[k] = verts[(size_t)k * N + i2];
+        in.v0[k] = verts[(size_t)k * N + i0];
+        in.v1[k] = verts[(size_t)k * N + i1];
+        in.v2[k] = verts[(size_t)k * N + i2];
+        in.w[k] = so3[(size_t)k * F + f];
+        in.s[k] = scale[(size_t)k * F + f];
+    }
+}
+
+__device__ __forceinline__ void face_forward_in(const FaceIn &in, float sigma, FaceFwd &o, float *xyz3, float *s3) {
+#pragma clang fp contract(on)   // fused multiply-adds as the expressions spell them, whichever kernel this is inlined into: same bits in all of them
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.v0[k] = in.v0[k];
+        o.v1[k] = in.v1[k];
+        o.v2[k] = in.v2[k];
     }
     const float K2C = 0.28867513459481287f;  // 1 / (2 sqrt 3)
     float c[3];
@@ -58,7 +74,7 @@ __device__ __forceinline__ void face_forward(const float *verts, int N, const in
         o.A[k][2] = o.n[k] / o.nn * sigma;
     }
     // so3 exponential (PyTorch3D: theta^2 clamped at 1e-4)
-    const float wx = so3[f], wy = so3[(size_t)F + f], wz = so3[2 * (size_t)F + f];
+    const float wx = in.w[0], wy = in.w[1], wz = in.w[2];
     const float n2 = wx * wx + wy * wy + wz * wz;
     o.clamped = !(n2 > 1e-4f);
     o.th2 = o.clamped ? 1e-4f : n2;
@@ -76,7 +92,7 @@ __device__ __forceinline__ void face_forward(const float *verts, int N, const in
             o.K[i][j] = K[i][j];
             o.K2[i][j] = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
         }
-    s3[0] = scale[f]; s3[1] = scale[(size_t)F + f]; s3[2] = scale[2 * (size_t)F + f];
+    s3[0] = in.s[0]; s3[1] = in.s[1]; s3[2] = in.s[2];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -88,6 +104,13 @@ __device__ __forceinline__ void face_forward(const float *verts, int N, const in
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) o.M[i][j] = o.A[i][0] * o.B[0][j] + o.A[i][1] * o.B[1][j] + o.A[i][2] * o.B[2][j];
+}
+
+__device__ __forceinline__ void face_forward(const float *verts, int N, const int32_t *faces, const float *so3, const float *scale,
+                                             int F, int f, float sigma, FaceFwd &o, float *xyz3, float *s3) {
+    FaceIn in;
+    face_load(verts, N, faces, so3, scale, F, f, in);
+    face_forward_in(in, sigma, o, xyz3, s3);
 }
 
 

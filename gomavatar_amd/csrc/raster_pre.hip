@@ -588,6 +588,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         i = blockIdx.x * 256 + threadIdx.x;
         if (i >= P) return;
     }
+    // the inputs of the face arithmetic at the end (an index load and the gathers behind it): issued here, in front of the record gather
+    gom_face::FaceIn fin;
+    if (FACE) gom_face::face_load(face.verts + (size_t)fr * 3 * face.N, face.N, face.faces, face.so3, face.scale, P, i, fin);
     const GomCamera cam = pick_camera(cam1, cams, fr);
     {
         const size_t go = (size_t)fr * P;
@@ -615,6 +618,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         // (2) the LIVE records only, GOM_PB_W per trip, in ascending k (fixed summation order).
         const uint32_t nt = tiles_touched[i];
         if (!rider && use_big && nt > GOM_BIG_NT) return;   // a rider wave has it
+        // (what the arithmetic behind the gather reads: in flight while the records arrive)
+        const float4 co = conic_opacity[i];
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
         const uint32_t po = pair_off[i];
         const ushort4 rc = rect[i];
         const uint32_t rw = (uint32_t)(rc.z - rc.x);
@@ -683,7 +692,6 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         }
         // record layout: [0..3] colours, [4] sum Q, [5] sum Q dx, [6] sum Q dy, [7] sum Q dx dx, [8] sum Q dx dy, [9] sum Q dy dy
         // with Q = G * dL/dalpha and d = centre - pixel (App. A.4 regrouped).
-        const float4 co = conic_opacity[i];
         const float o = co.w;
         g2x = -(0.5f * (float)cam.W) * o * (co.x * acc[5] + co.y * acc[6]);
         g2y = -(0.5f * (float)cam.H) * o * (co.z * acc[6] + co.y * acc[5]);
@@ -695,12 +703,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
         const float fx = (float)cam.W / (2.0f * cam.tanfovx);
         const float fy = (float)cam.H / (2.0f * cam.tanfovy);
         const float *v = cam.view, *pr = cam.proj;
-        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
         ProjJac pj;
         proj_jacobian(cam, p, fx, fy, pj);
-        float c6[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) c6[k] = cov6[6 * i + k];
         float a, b, c, SM0[3], SM1[3];
         cov2d_from(c6, pj, a, b, c, SM0, SM1);
         const float denom = a * c - b * b;
@@ -755,7 +759,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
     if (FACE) {   // blockIdx.y = frame: the parameter gradients go to per-frame slices (summed by k_sum_frames)
         gom_face::FaceFwd o;
         float cdummy[3], s3[3], dcr[9], dw[3], dS[3];
-        gom_face::face_forward(face.verts + (size_t)fr * 3 * face.N, face.N, face.faces, face.so3, face.scale, P, i, face.sigma, o, cdummy, s3);
+        gom_face::face_forward_in(fin, face.sigma, o, cdummy, s3);
         gom_face::face_backward(o, s3, face.sigma, gm, gc, dcr, dw, dS);
         const size_t P3 = 3 * (size_t)P;
         float *dc = face.d_corner + (size_t)fr * 9 * P + 9 * (size_t)i;
