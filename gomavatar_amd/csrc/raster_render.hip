@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
 
 // ----------------------------------------------- forward, pass C (assembly) -
 template <int C>
-__global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+__device__ __forceinline__ void combine_tile(const int tile, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
                                                      const GomCamera *__restrict__ cams,
                                                      const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_C,
                                                      const uint32_t *__restrict__ seg_last, float *__restrict__ seg_Tend,
@@ -852,7 +852,6 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
                                                      uint32_t *__restrict__ tile_qlim, int skip_empty) {
     __shared__ uint32_t s_nmax[4], s_qmax[4];
-    const int tile = blockIdx.x;
     const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -989,6 +988,37 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
     }
     // the four quadrant maxima once per SEGMENT of the tile: the backward finds them with the segment index alone
     for (uint32_t i = threadIdx.x; i < nseg; i += 256) seg_qmax[sb + i] = make_uint4(s_nmax[0], s_nmax[1], s_nmax[2], s_nmax[3]);
+}
+
+// One workgroup per tile -- or, when this forward's k_emit has painted the empty tiles (five in six on a body) and the scan kernel has
+// listed the others (`work`: the items of the tile pass, one per tile and window of list positions), a grid that strides over the list:
+// 6 800 workgroups that start only to find their tile empty were most of this launch's dispatch.
+template <int C>
+__global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
+                                                     const GomCamera *__restrict__ cams,
+                                                     const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_C,
+                                                     const uint32_t *__restrict__ seg_last, float *__restrict__ seg_Tend,
+                                                     float *__restrict__ seg_Sbehind, float *__restrict__ out_color,
+                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                     uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
+                                                     const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
+                                                     const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
+                                                     uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles) {
+#define GOM_COMBINE_TILE(T) combine_tile<C>((T), H, W, gx, gy, bg0, bg1, bg2, bg3, cams, seg_base, seg_C, seg_last, seg_Tend, seg_Sbehind, out_color, final_T, \
+                                            n_contrib, tile_nmax, seg_qmax, status, tile_base, point_list, rank_of, tile_qlim, skip_empty)
+    if (!work) { GOM_COMBINE_TILE((int)blockIdx.x); return; }
+    if (status->overflow) {   // (no work items then: every tile is poisoned)
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) { GOM_COMBINE_TILE(tile); __syncthreads(); }
+        return;
+    }
+    const uint32_t n_work = status->n_work_items;
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t item = work[wi];
+        if (item >> 24) continue;   // (further windows of a long list: the tile has been taken with window 0)
+        GOM_COMBINE_TILE((int)(item & 0xffffffu));
+        __syncthreads();            // s_nmax / s_qmax of this tile have been read
+    }
+#undef GOM_COMBINE_TILE
 }
 
 // ---------------------------------------------------------------- backward -
@@ -1526,10 +1556,12 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     GOM_LAUNCH_CHECK();
     {
         GomKernelTimer timer(s, GOM_K_COMBINE, st);
+        const bool listed = s->emptyFilled && s->rankSort;   // the non-empty tiles are listed (work items of the tile pass) and the others painted
 #define GOM_CF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(listed ? (n_tiles < 2048 ? n_tiles : 2048) : n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
-                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim, s->emptyFilled ? 1 : 0)
+                       s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim, s->emptyFilled ? 1 : 0, \
+                       listed ? s->work_items : nullptr, n_tiles)
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }
