@@ -458,7 +458,7 @@ int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, con
     const size_t total = n0 + n1 + n2 + n3;
     if (total == 0) return 0;
     const size_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_sum_frames, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, B, a);
+    hipLaunchKernelGGL(k_sum_frames, dim3((unsigned)(blocks < 2048 ? blocks : 2048))   /* one resident round of workgroups; the kernel strides */, dim3(256), 0, (hipStream_t)stream, B, a);
     GOM_LAUNCH_CHECK();
     return 0;
 }
