@@ -142,6 +142,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         if (nbuck > s->capBuckets) {
             if (grow(&s->bucket_count, (size_t)nbuck) || grow(&s->bucket_base, (size_t)nbuck + 1) || grow(&s->bucket_cursor, (size_t)nbuck)) return -2;
             GOM_HIP_CHECK(hipMemset(s->bucket_count, 0, (size_t)nbuck * sizeof(uint32_t)));
+            GOM_HIP_CHECK(hipMemset(s->bucket_cursor, 0, (size_t)nbuck * sizeof(uint32_t)));
             s->capBuckets = nbuck;
         }
         const int64_t nmm = (int64_t)B * ((P_frame + 255) / 256);      // one (min, max) pair per preprocess block

@@ -230,12 +230,24 @@ struct GomSortRider {
     const uint32_t *bucket_base;
     uint64_t *bkeys, *scratch;
     uint32_t *order, *rank_of;
+    uint32_t *bucket_count, *bucket_cursor;   // zeroed here for the next frame's histogram and scatter
+};
+// The bucket scatter of the depth ranking as further workgroups of the scan launch (1 024 Gaussians each): it needs the bucket COUNTS, which
+// are complete when the scan starts, not the scan's result -- every scatter workgroup folds the counts in front of its frame and scans its
+// frame's itself (a few KB from L2) instead of waiting a launch for one workgroup to do it.
+struct GomScatterRider {
+    int P, B;                   // P = 0: no riders
+    uint32_t nb;
+    int nblk;                   // (min, max) pairs per frame behind `minmax`
+    const float *depth;
+    const int32_t *radii;
+    const uint32_t *minmax;
+    uint64_t *bkeys;
 };
 // fill_out: the image this forward writes (C planes per frame) -- the emit kernel then also paints the empty tiles and the compositing
 // assembly skips them (GomState::emptyFilled).
 int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank = false, float *fill_out = nullptr, int fill_C = 0, const float *fill_bg = nullptr);
 int gom_launch_depth_hist(GomState *s, int P, hipStream_t st);
-int gom_launch_depth_rank(GomState *s, int P, hipStream_t st);
 int gom_launch_tile_rank(GomState *s, hipStream_t st);
 int gom_launch_rebuild_keys(GomState *s, hipStream_t st);
 // lists of up to this many entries go to the 4-wave instantiations of the per-tile kernels (0: one instantiation takes all)

@@ -19,7 +19,7 @@ struct BucketMap {
 // The frame's depth range from the per-block (min, max) pairs k_preprocess left (float BIT PATTERNS: depths are > 0.2, unsigned
 // order = float order; a block without a visible Gaussian wrote min > max): every workgroup folds the ~200 pairs itself --
 // 1.7 KB from L2 -- instead of a reduction kernel or contended atomics.  Ends with a __syncthreads().
-__device__ __forceinline__ BucketMap bucket_map(const uint32_t *__restrict__ minmax, int fr, int nblk, uint32_t nb, uint32_t *s_red /* [8] */) {
+__device__ __forceinline__ BucketMap bucket_map(const uint32_t *__restrict__ minmax, int fr, int nblk, uint32_t nb, uint32_t *s_red /* [2 * waves of the workgroup] */) {
     const uint2 *mm = reinterpret_cast<const uint2 *>(minmax) + (size_t)fr * nblk;
     uint32_t lo = 0xffffffffu, hi = 0u;
     for (int k = threadIdx.x; k < nblk; k += blockDim.x) {
@@ -32,10 +32,11 @@ __device__ __forceinline__ BucketMap bucket_map(const uint32_t *__restrict__ min
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
         hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
     }
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = lo; s_red[4 + (threadIdx.x >> 6)] = hi; }
+    const uint32_t nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = lo; s_red[nw + (threadIdx.x >> 6)] = hi; }
     __syncthreads();
-    lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    lo = s_red[0]; hi = s_red[nw];
+    for (uint32_t w = 1; w < nw; w++) { lo = min(lo, s_red[w]); hi = max(hi, s_red[nw + w]); }
     BucketMap m;
     m.nb = nb;
     m.dmin = __uint_as_float(lo);

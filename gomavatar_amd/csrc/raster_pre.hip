@@ -336,18 +336,71 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
     return wave_off + (x - v);
 }
 
+// One scatter workgroup of the depth ranking (GomScatterRider): 1 024 Gaussians of frame `fr`.  s_mem: 3 * nb words.
+__device__ __forceinline__ void scatter_keys_block(const GomScatterRider &sr, int fr, int chunk, const uint32_t *__restrict__ bucket_count,
+                                                   uint32_t *__restrict__ bucket_cursor, uint32_t *s_mem, uint32_t *s_red, uint32_t *s_wave) {
+    const uint32_t nb = sr.nb, tid = threadIdx.x;
+    uint32_t *s_cnt = s_mem, *s_base = s_mem + nb, *s_gbase = s_mem + 2 * nb;
+    for (uint32_t b = tid; b < nb; b += 1024) s_cnt[b] = 0;
+    const gom_rank::BucketMap bm = gom_rank::bucket_map(sr.minmax, fr, sr.nblk, nb, s_red);   // (ends with a barrier)
+    const int il = chunk * 1024 + (int)tid;
+    const size_t i = (size_t)fr * sr.P + il;
+    const bool vis = il < sr.P && sr.radii[i] > 0;
+    uint32_t b = 0, dbits = 0;
+    if (vis) {
+        const float d = sr.depth[i];
+        dbits = __float_as_uint(d);
+        b = bm(d);
+        atomicAdd(&s_cnt[b], 1u);
+    }
+    // packed rank at which each bucket of this frame starts: the visible Gaussians of the frames in front + a scan of this frame's counts
+    uint32_t part = 0;
+    for (uint32_t k = tid; k < (uint32_t)fr * nb; k += 1024) part += bucket_count[k];
+    uint32_t before, tot;
+    (void)block_excl_scan_1024(part, s_wave, before);
+    const uint32_t per = (nb + 1023u) / 1024u;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t idx = tid * per + k;
+        if (idx < nb) mine += bucket_count[(size_t)fr * nb + idx];
+    }
+    uint32_t run = before + block_excl_scan_1024(mine, s_wave, tot);
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t idx = tid * per + k;
+        if (idx < nb) { s_gbase[idx] = run; run += bucket_count[(size_t)fr * nb + idx]; }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nb; k += 1024) {
+        const uint32_t c = s_cnt[k];
+        if (c) {
+            s_base[k] = s_gbase[k] + atomicAdd(&bucket_cursor[(size_t)fr * nb + k], c);   // (cursor: keys already in the bucket; zeroed by the emit launch)
+            s_cnt[k] = 0;
+        }
+    }
+    __syncthreads();
+    if (vis) sr.bkeys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = ((uint64_t)dbits << 32) | (uint32_t)il;   // index INSIDE the frame: ties keep Gaussian order
+}
+
 __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_base,
                                                      uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ seg_base,
                                                      uint32_t *__restrict__ tile_nmax, int n_tiles,
                                                      GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift,
                                                      uint32_t *__restrict__ bucket_count, uint32_t *__restrict__ bucket_base,
                                                      uint32_t *__restrict__ bucket_cursor, int n_buckets,
-                                                     uint32_t *__restrict__ work_items, uint32_t *__restrict__ big_count, int n_frames, int big_frames) {
+                                                     uint32_t *__restrict__ work_items, uint32_t *__restrict__ big_count, int n_frames, int big_frames,
+                                                     GomScatterRider sr) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
+    if (blockIdx.x >= 2) {   // the bucket scatter of the depth ranking: independent of the two scans, in their shadow
+        extern __shared__ uint32_t s_scatter[];
+        __shared__ uint32_t s_red[32];
+        const int r = (int)blockIdx.x - 2;
+        scatter_keys_block(sr, r % sr.B, r / sr.B, bucket_count, bucket_cursor, s_scatter, s_red, s_wave);
+        return;
+    }
     // two workgroups: block 0 scans the tiles (and lists the work items), block 1 -- launched with the depth ranking -- the buckets: the two
     // chains (load, block scans, stores) are independent and this kernel is nothing but their latency
-    const bool do_tiles = blockIdx.x == 0, do_buckets = bucket_count != nullptr && blockIdx.x == gridDim.x - 1;
+    const bool do_tiles = blockIdx.x == 0, do_buckets = bucket_count != nullptr && blockIdx.x == 1;
     uint32_t carry = 0, seg_carry = 0, wi_carry = 0;
     // 8 consecutive tiles per thread and trip: a batched launch (8 192 tiles at 8 x 512x512) is ONE trip = one load latency and
     // two block scans, where one tile per thread took eight dependent trips (20 us of a single workgroup's latency chain).
@@ -428,7 +481,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
             uint32_t excl = bcarry + block_excl_scan_1024(tsum, s_wave, tot);
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                if (i0 + k < n_buckets) { bucket_base[i0 + k] = excl; bucket_cursor[i0 + k] = excl; bucket_count[i0 + k] = 0u; }
+                if (i0 + k < n_buckets) bucket_base[i0 + k] = excl;   // (the counts are read by the scatter workgroups beside this one: the emit launch zeroes them)
                 excl += v[k];
             }
             bcarry += tot;
@@ -464,6 +517,11 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
                                               const GomDevStatus *__restrict__ status, uint32_t *__restrict__ keys32, GomEmptyFill fill,
                                               GomSortRider sorts) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    if ((int)(blockIdx.x / (uint32_t)sorts.B) < sorts.blocks && threadIdx.x == 0) {   // sort rider of (frame, bucket): its counters are spent (also when the frame overflowed)
+        const size_t cb = (size_t)(blockIdx.x % (uint32_t)sorts.B) * sorts.blocks + blockIdx.x / (uint32_t)sorts.B;
+        sorts.bucket_count[cb] = 0u;
+        sorts.bucket_cursor[cb] = 0u;
+    }
     if (status->overflow) return;
     const int n_tiles = gx * gy;  // per frame
     // frame-minor block order: the sort riders of EVERY frame are dispatched first (as the y index of a 2-D grid the last frame's would
@@ -824,16 +882,21 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
     const uint32_t cap = (uint32_t)(s->capPairs > 0xffffffffLL ? 0xffffffffLL : s->capPairs);
     {
         GomKernelTimer timer(s, GOM_K_SCAN, st);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(rank ? 2 : 1), dim3(1024), 0, st, s->tile_count, s->tile_base, s->tile_cursor, s->seg_base,
+        GomScatterRider sr{};
+        unsigned scatter_blocks = 0;
+        if (rank && P > 0) {
+            sr.P = P; sr.B = s->B; sr.nb = 1u << s->nbShift; sr.nblk = s->rank_blocks; sr.depth = s->depth; sr.radii = s->radii; sr.minmax = s->rank_minmax;
+            sr.bkeys = s->bkeys;
+            scatter_blocks = (unsigned)((P + 1023) / 1024) * (unsigned)s->B;
+        }
+        hipLaunchKernelGGL(k_scan_tiles, dim3((rank ? 2 : 1) + scatter_blocks), dim3(1024), scatter_blocks ? 3 * sr.nb * sizeof(uint32_t) : 0, st, s->tile_count,
+                           s->tile_base, s->tile_cursor, s->seg_base,
                            s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
-                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr, s->big_count, s->B, s->capBigFrames);
+                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr, s->big_count, s->B, s->capBigFrames, sr);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;
     if (blocks == 0) return 0;
-    if (rank) {
-        if (int rc = gom_launch_depth_rank(s, P, st)) return rc;
-    }
     GomKernelTimer timer(s, GOM_K_EMIT, st);
     GomEmptyFill fill{};
     fill.first_block = blocks;
@@ -849,6 +912,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
         sorts.P = P;
         sorts.log_chunk = (uint32_t)(31 - __builtin_clz((unsigned)(s->sortCap < cap ? s->sortCap : cap)));
         sorts.bucket_base = s->bucket_base; sorts.bkeys = s->bkeys; sorts.scratch = s->bkeys_scratch; sorts.order = s->order; sorts.rank_of = s->rank_of;
+        sorts.bucket_count = s->bucket_count; sorts.bucket_cursor = s->bucket_cursor;
     }
     sorts.B = s->B;
     const dim3 grid((unsigned)((size_t)(sorts.blocks + blocks + (fill_out ? (n_tiles + GOM_FILL_TILES - 1) / GOM_FILL_TILES : 0)) * s->B));

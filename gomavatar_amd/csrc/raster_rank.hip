@@ -9,8 +9,8 @@
 // length:
 //
 //   k_depth_hist      per Gaussian: depth -> one of NB equal-width buckets between the frame's min / max depth (a monotone
-//   k_bucket_scatter  map: every key of bucket b precedes every key of bucket b + 1); counts, then (after the scan kernel)
-//                     (depth_bits << 32 | index) keys scattered into the bucket's range.
+//   bucket scatter    map: every key of bucket b precedes every key of bucket b + 1); counts, then (depth_bits << 32 | index)
+//                     keys scattered into the bucket's range (raster_pre.hip: further workgroups of the scan launch).
 //   bucket sort       per bucket (~200 keys): merge sort in registers + LDS -> rank q of every visible Gaussian in the
 //                     packed (frame, depth, index) order: order[q] = Gaussian, rank_of[Gaussian] = q (rank_sort.hpp; the
 //                     first blocks of the emit launch, beside the emission).
@@ -50,38 +50,6 @@ __global__ void __launch_bounds__(256) k_depth_hist(int P, uint32_t nb, const fl
         const uint32_t c = s_cnt[b];
         if (c) atomicAdd(&bucket_count[(size_t)fr * nb + b], c);
     }
-}
-
-// ---- keys into the bucket ranges (order inside a bucket arbitrary: the bucket sort fixes it) -------------------------------
-__global__ void __launch_bounds__(256) k_bucket_scatter(int P, uint32_t nb, const float *__restrict__ depth, const int32_t *__restrict__ radii,
-                                                        const uint32_t *__restrict__ minmax, int nblk, uint32_t *__restrict__ bucket_cursor,
-                                                        uint64_t *__restrict__ bkeys) {
-    extern __shared__ uint32_t s_mem[];
-    uint32_t *s_cnt = s_mem, *s_base = s_mem + nb;
-    __shared__ uint32_t s_red[8];
-    const int fr = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
-    const BucketMap bm = bucket_map(minmax, fr, nblk, nb, s_red);
-    const int il = blockIdx.x * 256 + threadIdx.x;
-    const size_t i = (size_t)fr * P + il;
-    const bool vis = il < P && radii[i] > 0;
-    uint32_t b = 0, dbits = 0;
-    if (vis) {
-        const float d = depth[i];
-        dbits = __float_as_uint(d);
-        b = bm(d);
-        atomicAdd(&s_cnt[b], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < nb; k += 256) {
-        const uint32_t c = s_cnt[k];
-        if (c) {
-            s_base[k] = atomicAdd(&bucket_cursor[(size_t)fr * nb + k], c);
-            s_cnt[k] = 0;
-        }
-    }
-    __syncthreads();
-    if (vis) bkeys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = ((uint64_t)dbits << 32) | (uint32_t)il;   // index INSIDE the frame: ties keep Gaussian order
 }
 
 // ---- per tile: bitmap of ranks -> sorted list -> records in list order -------------------------------------------------
@@ -212,19 +180,6 @@ __global__ void __launch_bounds__(256) k_rebuild_keys(const uint32_t *__restrict
 }
 
 }  // namespace
-
-int gom_launch_depth_rank(GomState *s, int P, hipStream_t st) {
-    // the keys into their buckets (called between the scan kernel -- which turned bucket_count into bucket_base / bucket_cursor -- and the
-    // emission, whose first blocks sort the buckets)
-    const int blocks = (P + 255) / 256;
-    if (blocks == 0) return 0;
-    GomKernelTimer timer(s, GOM_K_DEPTH_RANK, st);
-    const uint32_t nb = 1u << s->nbShift;
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks, s->B), dim3(256), 2 * nb * sizeof(uint32_t), st, P, nb, s->depth, s->radii, s->rank_minmax, s->rank_blocks,
-                       s->bucket_cursor, s->bkeys);
-    GOM_LAUNCH_CHECK();
-    return 0;
-}
 
 int gom_launch_depth_hist(GomState *s, int P, hipStream_t st) {
     const int blocks = (P + 255) / 256;

@@ -120,7 +120,7 @@ class RenderStep:
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
                          target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False,
                          image_grad_hook=None) -> None:
-        """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 13 kernels (14 for a batch).
+        """One native call (`gom_frame_forward_backward` / `gom_batch_forward_backward`) that enqueues the 12 kernels (13 for a batch).
         params: vertices (3,N), so3 (3,F), scale (3,F), appearance (3,F) device tensors.
         frame: cnl_gtfms (24,4,4), dst_Rs (24,3,3), dst_Ts (24,3) device tensors (contiguous fp32).
         target_rgb (H,W,3), target_mask (H,W), bgcolor (3,) device tensors.

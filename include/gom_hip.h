@@ -403,10 +403,10 @@ typedef struct GomFrame {
                                        caller may ADD any other image-space gradient to work_dimage -- that is how LPIPS
                                        (gom_lpips_vgg_value_and_grad on the unpacked image, train.py:113-121) joins the native path. */
 #define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
-                                       hipGraph on first use and replay it afterwards: one submission instead of 13 */
+                                       hipGraph on first use and replay it afterwards: one submission instead of 12 */
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
 
-/* B frames in ONE launch sequence (the same 13 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
+/* B frames in ONE launch sequence (the same 12 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
  * kernels of a single 512x512 frame become B times larger launches, which is what fills 256 CUs.  The reference has
  * batch size 1 (train.py:309-349); a batch here is B frames whose gradients are SUMMED, i.e. one optimizer step on B
  * frames, the same semantics as the frame-parallel all-reduce across GPUs.
