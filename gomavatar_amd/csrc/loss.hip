@@ -95,9 +95,10 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
         const float m = pred[3 * (size_t)HW + p];
         const float s = shade ? shade[p] : 1.f;
         const float a0 = pred[p], a1 = pred[(size_t)HW + p], a2 = pred[2 * (size_t)HW + p];
-        const float r0 = a0 * s * m + b0 * (1.f - m) - gt_rgb[3 * (size_t)p];
-        const float r1 = a1 * s * m + b1 * (1.f - m) - gt_rgb[3 * (size_t)p + 1];
-        const float r2 = a2 * s * m + b2 * (1.f - m) - gt_rgb[3 * (size_t)p + 2];
+        const float3 g = *reinterpret_cast<const float3 *>(gt_rgb + 3 * (size_t)p);   // one 12-byte load per lane (three strided 4-byte loads cost the texture path three passes)
+        const float r0 = a0 * s * m + b0 * (1.f - m) - g.x;
+        const float r1 = a1 * s * m + b1 * (1.f - m) - g.y;
+        const float r2 = a2 * s * m + b2 * (1.f - m) - g.z;
         const float rm = m - gt_mask[p];
         sum_rgb += fabsf(r0) + fabsf(r1) + fabsf(r2);
         sum_mask += fabsf(rm);
