@@ -31,7 +31,8 @@ static int grow(T **p, size_t count) {
 
 extern "C" GomState *gom_state_create(void) {
     GomState *s = new GomState();
-    if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // development switch (A/B of the cost-ordered backward queue)
+    if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;
+    if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // development switch (A/B of the loss kernel skipping empty tiles)   // development switch (A/B of the cost-ordered backward queue)
     if (hipGetDevice(&s->device) != hipSuccess) {
         gom_set_error("hipGetDevice failed (no HIP device?)");
         delete s;
@@ -479,16 +480,18 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
                                              f->work_feat, stream)))
                 return rc;
         }
-        if ((rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image,
-                                      f->work_radii, 0, stream, face)))
-            return rc;
-        // batched launches: the loss kernel carries the rider that orders the backward's task queue by the cost the forward counted
-        GomBwdOrderRider rider{s->status, s->seg_cost, s->bwd_order};
-        const bool ride = B > 1 && s->bwdOrder && s->rankSort;   // (the tile pass of the depth ranking zeroes the cost words)
+        // batched launches: the assembly pass of the forward carries the riders that order the backward's task queue by the cost the forward counted
+        const bool ride = B > 1 && s->bwdOrder;   // (and the depth ranking, decided inside the forward: its tile pass zeroes the cost words)
+        s->rideBwdOrder = ride;
+        rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image, f->work_radii, 0, stream, face);
+        s->rideBwdOrder = false;
+        if (rc) return rc;
+
+        GomLossSkip skip{s->tile_base, cams, {f->cam.bg[0], f->cam.bg[1], f->cam.bg[2], f->cam.bg[3]}, s->gx, s->gy, W};
         if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
-                                    nullptr, f->loss_partials, stream, ride ? &rider : nullptr)))
+                                    nullptr, f->loss_partials, stream, s->lossSkip ? &skip : nullptr)))
             return rc;
-        s->bwdOrderReady = ride;
+        s->bwdOrderReady = ride && s->rankSort;
     }
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;
     if ((rc = raster_backward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->work_dimage,

@@ -60,6 +60,7 @@ struct GomState {
     int B = 1;
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
+    bool lossSkip = true;             // the frame step's loss kernel skips loads and stores of empty tiles (GomLossSkip)
     bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write
     bool bwdOrder = true;             // development switch: cost-ordered backward queue in the frame step
     bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
@@ -106,6 +107,7 @@ struct GomState {
     uint4 *seg_qmax = nullptr;        // [capSegs] max n_contrib over each 8x8 quadrant of the segment's tile (combine pass, for the backward)
     uint32_t *seg_cost = nullptr;     // [capSegs][4 sub-ranges][4 quadrants] entries that survived the cull in the pieces k_seg_fwd found alive = cost estimate of the backward's tasks
     uint32_t *bwd_order = nullptr;    // the backward's tasks per queue shard, most expensive first (riders of the loss kernel): GOM_BWD_ORDER_* below
+    bool rideBwdOrder = false;        // set by the frame step around its forward: k_combine_fwd carries the riders
     bool bwdOrderReady = false;       // bwd_order belongs to the forward that has just run (frame step, batched launches)
     const uint32_t *rank_minmax = nullptr;   // where the depth ranking of the current forward takes its depth range from: depth_minmax (per
     int rank_blocks = 0;                     //   block of k_preprocess) or the frame step's vertex ranges (GomFaceArgs::vdepth_minmax)
@@ -278,17 +280,25 @@ int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, cons
 #define GOM_BWD_SPLIT_COST 110u
 #endif
 #define GOM_BWD_ORDER_BASE 64u
-// Riders of the loss kernel in the frame step: eight extra workgroups, one per shard of the render backward's task queue, order its tasks
-// by the cost the forward counted (counting sort, 512 levels, most expensive first).  It runs in the shadow of the loss blocks -- between the forward and the backward there
-// is no other launch to hide them in.
+// Riders of the compositing assembly (k_combine_fwd) in the frame step: eight extra workgroups, one per shard of the render backward's task
+// queue, order its tasks by the cost k_seg_fwd counted (counting sort, 512 levels, most expensive first; bwd_order.hpp).  Their chain (~17 us)
+// runs beside the tiles' -- in the loss kernel, where they first lived, the launch lasted as long as they did.
 struct GomBwdOrderRider {
     const GomDevStatus *status;
     const uint32_t *seg_cost;
     uint32_t *bwd_order;
 };
+// The frame step's loss knows which tiles are EMPTY (five in six on a body): their prediction is the rasterizer's background, which is not
+// read, and their image gradient, which the backward never reads (no list entry there), is not written: 16 instead of 48 bytes per pixel.
+struct GomLossSkip {
+    const uint32_t *tile_base;   // [frames * tiles + 1]; null: every pixel is read and written
+    const GomCamera *cams;       // per-frame background, or null: bg
+    float bg[4];
+    int gx, gy, W;
+};
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream, const GomBwdOrderRider *rider = nullptr);
+                      float *loss_partials, void *stream, const GomLossSkip *skip = nullptr);
 int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
                     float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,

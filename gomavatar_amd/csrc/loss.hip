@@ -16,85 +16,33 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0
 __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict__ pred, const float *__restrict__ shade,
                                                  const float *__restrict__ gt_rgb, const float *__restrict__ gt_mask,
                                                  const float *__restrict__ bg, float k_rgb, float k_mask,
-                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials, GomBwdOrderRider rider) {
+                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials, GomLossSkip skip) {
     __shared__ float s_red[2][4];
-    if (blockIdx.x >= GOM_LOSS_BLOCKS) {   // the riders (eight workgroups, frame 0's row of the grid only): see GomBwdOrderRider
-        if (blockIdx.y != 0 || rider.status->overflow) return;
-        // Rider x orders the tasks of queue shard x (the segments with seg mod 8 = x): a counting sort over 512 cost levels, most
-        // expensive first; a pair of sub-ranges above GOM_BWD_SPLIT_COST becomes two single-sub-range tasks.
-        __shared__ uint32_t s_lvl[512];
-        const uint32_t x = blockIdx.x - GOM_LOSS_BLOCKS, nsegs = rider.status->num_segs;
-        const uint32_t npairs = nsegs > x ? 2u * ((nsegs - x + 7u) / 8u) : 0u;       // (segment, pair) units of this shard
-        const uint32_t region = 4u * ((nsegs + 7u) / 8u);
-        uint32_t *out = rider.bwd_order + GOM_BWD_ORDER_BASE + (size_t)x * region;
-        for (int k = threadIdx.x; k < 512; k += 256) s_lvl[k] = 0u;
-        __syncthreads();
-        auto level = [](uint32_t c) { return 511u - min(c, 511u); };                  // level 0 = the most expensive
-        for (int pass = 0; pass < 2; pass++) {
-            for (uint32_t j0 = threadIdx.x; j0 < npairs; j0 += 2 * 256) {            // 2 units = 4 independent 16-byte loads in flight per thread
-                uint2 c[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t j = j0 + u * 256, seg = (j >> 1) * 8u + x;
-                    c[u] = make_uint2(0xffffffffu, 0u);
-                    if (j < npairs && seg < nsegs) {
-                        // what the pair costs its workgroup: wave w takes quadrant w of the first sub-range, then quadrant 3 - w of the second
-                        // (k_seg_bwd_pair), and the task lasts as long as its busiest wave; a sub-range alone: its busiest quadrant
-                        const uint4 a = *reinterpret_cast<const uint4 *>(rider.seg_cost + 16 * (size_t)seg + 8 * (j & 1u));
-                        const uint4 b = *reinterpret_cast<const uint4 *>(rider.seg_cost + 16 * (size_t)seg + 8 * (j & 1u) + 4);
-                        const uint32_t both = max(max(a.x + b.w, a.y + b.z), max(a.z + b.y, a.w + b.x));
-                        c[u] = make_uint2(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w)));
-                        if (both <= GOM_BWD_SPLIT_COST) c[u] = make_uint2(both, 0xfffffffeu);   // (.y = marker: not split)
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    if (c[u].x == 0xffffffffu) continue;
-                    const uint32_t j = j0 + u * 256, seg = (j >> 1) * 8u + x, pair = j & 1u, tot = c[u].x;
-                    if (c[u].y != 0xfffffffeu) {
-                        if (pass == 0) { atomicAdd(&s_lvl[level(c[u].x)], 1u); atomicAdd(&s_lvl[level(c[u].y)], 1u); }
-                        else {
-                            out[atomicAdd(&s_lvl[level(c[u].x)], 1u)] = (seg << 3) | (4u + 2u * pair);
-                            out[atomicAdd(&s_lvl[level(c[u].y)], 1u)] = (seg << 3) | (5u + 2u * pair);
-                        }
-                    } else {
-                        if (pass == 0) atomicAdd(&s_lvl[level(tot)], 1u);
-                        else out[atomicAdd(&s_lvl[level(tot)], 1u)] = (seg << 3) | pair;    // (order inside a level: any)
-                    }
-                }
-            }
-            __syncthreads();
-            if (pass == 0) {
-                if (threadIdx.x < 64) {   // exclusive scan of the 512 level counts: 8 per lane + a wave scan
-                    uint32_t c8[8], tot = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { c8[k] = s_lvl[8 * threadIdx.x + k]; tot += c8[k]; }
-                    uint32_t y = tot;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t z = __shfl_up(y, d, 64); if ((int)threadIdx.x >= d) y += z; }
-                    uint32_t run = y - tot;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { s_lvl[8 * threadIdx.x + k] = run; run += c8[k]; }
-                    if (threadIdx.x == 63) rider.bwd_order[x] = run;   // tasks of this shard
-                }
-                __syncthreads();
-            }
-        }
-        return;
-    }
     {  // blockIdx.y = frame of a batched launch: [B][4][HW] images, [B][HW][3] targets, [B][3] backgrounds
         const size_t fr = blockIdx.y;
         pred += fr * 4 * HW; gt_rgb += fr * 3 * HW; gt_mask += fr * HW; bg += fr * 3; dpred += fr * 4 * HW;
-        partials += fr * 2 * GOM_LOSS_BLOCKS;   // (the grid's x extent may carry one rider block more)
+        partials += fr * 2 * GOM_LOSS_BLOCKS;
         if (shade) shade += fr * HW;
         if (dshade) dshade += fr * HW;
     }
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     float sum_rgb = 0.f, sum_mask = 0.f;
+    // (GomLossSkip) a pixel of an empty tile: the rasterizer wrote its background there -- the same value, not loaded
+    float e0 = skip.bg[0], e1 = skip.bg[1], e2 = skip.bg[2], e3 = skip.bg[3];
+    const uint32_t *tb = nullptr;
+    if (skip.tile_base) {
+        tb = skip.tile_base + (size_t)blockIdx.y * skip.gx * skip.gy;
+        if (skip.cams) { const float *cb = skip.cams[blockIdx.y].bg; e0 = cb[0]; e1 = cb[1]; e2 = cb[2]; e3 = cb[3]; }
+    }
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += GOM_LOSS_BLOCKS * 256) {
-        const float m = pred[3 * (size_t)HW + p];
+        bool empty = false;
+        if (tb) {
+            const int y = p / skip.W, x = p - y * skip.W, t = (y >> 4) * skip.gx + (x >> 4);
+            empty = tb[t + 1] == tb[t];
+        }
+        const float m = empty ? e3 : pred[3 * (size_t)HW + p];
         const float s = shade ? shade[p] : 1.f;
-        const float a0 = pred[p], a1 = pred[(size_t)HW + p], a2 = pred[2 * (size_t)HW + p];
+        const float a0 = empty ? e0 : pred[p], a1 = empty ? e1 : pred[(size_t)HW + p], a2 = empty ? e2 : pred[2 * (size_t)HW + p];
         const float3 g = *reinterpret_cast<const float3 *>(gt_rgb + 3 * (size_t)p);   // one 12-byte load per lane (three strided 4-byte loads cost the texture path three passes)
         const float r0 = a0 * s * m + b0 * (1.f - m) - g.x;
         const float r1 = a1 * s * m + b1 * (1.f - m) - g.y;
@@ -103,6 +51,7 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
         sum_rgb += fabsf(r0) + fabsf(r1) + fabsf(r2);
         sum_mask += fabsf(rm);
         const float s0 = sgn(r0) * k_rgb, s1 = sgn(r1) * k_rgb, s2 = sgn(r2) * k_rgb;
+        if (empty) continue;   // (no list entry touches the pixel: the backward does not read its gradient)
         dpred[p] = s0 * s * m;
         dpred[(size_t)HW + p] = s1 * s * m;
         dpred[2 * (size_t)HW + p] = s2 * s * m;
@@ -127,14 +76,14 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
 
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream, const GomBwdOrderRider *rider) {
+                      float *loss_partials, void *stream, const GomLossSkip *skip) {
     if (H <= 0 || W <= 0) { gom_set_error("gom_l1_loss: bad image size"); return -1; }
     if (!pred || !gt_rgb || !gt_mask || !bg || !dL_dpred || !loss_partials) { gom_set_error("gom_l1_loss: null pointer"); return -1; }
     const int HW = H * W;
     const float k_rgb = grad_scale * c_rgb / (3.0f * (float)HW);
     const float k_mask = grad_scale * c_mask / (float)HW;
-    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS + (rider ? 8 : 0), B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
-                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials, rider ? *rider : GomBwdOrderRider{});
+    hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
+                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials, skip ? *skip : GomLossSkip{});
     GOM_LAUNCH_CHECK();
     return 0;
 }

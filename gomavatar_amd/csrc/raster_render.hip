@@ -48,6 +48,7 @@
 // loop is branch-free and keeps its state in VGPRs (float masks) so that the
 // serial T chain never round-trips through SALU/VCC logic.
 #include "gom_internal.h"
+#include "bwd_order.hpp"
 #include "sort_util.hpp"
 #include <cstdlib>
 
@@ -1003,16 +1004,21 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
                                                      const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
-                                                     uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles) {
+                                                     uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles,
+                                                     GomBwdOrderRider rider) {
+    // (frame step, batched) the first eight workgroups order the backward's task queue: bwd_order.hpp
+    const uint32_t n_rid = rider.status ? 8u : 0u;
+    if (blockIdx.x < n_rid) { gom_bwd_order_rider(rider, blockIdx.x); return; }
+    const uint32_t bx = blockIdx.x - n_rid, nbx = gridDim.x - n_rid;
 #define GOM_COMBINE_TILE(T) combine_tile<C>((T), H, W, gx, gy, bg0, bg1, bg2, bg3, cams, seg_base, seg_C, seg_last, seg_Tend, seg_Sbehind, out_color, final_T, \
                                             n_contrib, tile_nmax, seg_qmax, status, tile_base, point_list, rank_of, tile_qlim, skip_empty)
-    if (!work) { GOM_COMBINE_TILE((int)blockIdx.x); return; }
+    if (!work) { GOM_COMBINE_TILE((int)bx); return; }
     if (status->overflow) {   // (no work items then: every tile is poisoned)
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) { GOM_COMBINE_TILE(tile); __syncthreads(); }
+        for (int tile = (int)bx; tile < n_tiles; tile += (int)nbx) { GOM_COMBINE_TILE(tile); __syncthreads(); }
         return;
     }
     const uint32_t n_work = status->n_work_items;
-    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    for (uint32_t wi = bx; wi < n_work; wi += nbx) {
         const uint32_t item = work[wi];
         if (item >> 24) continue;   // (further windows of a long list: the tile has been taken with window 0)
         GOM_COMBINE_TILE((int)(item & 0xffffffu));
@@ -1556,12 +1562,13 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
     GOM_LAUNCH_CHECK();
     {
         GomKernelTimer timer(s, GOM_K_COMBINE, st);
+        const bool ride = s->rideBwdOrder && s->rankSort && s->B > 1;
         const bool listed = s->emptyFilled && s->rankSort;   // the non-empty tiles are listed (work items of the tile pass) and the others painted
 #define GOM_CF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3(listed ? (n_tiles < 2048 ? n_tiles : 2048) : n_tiles), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3((listed ? (n_tiles < 2048 ? n_tiles : 2048) : n_tiles) + (ride ? 8 : 0)), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
                        s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim, s->emptyFilled ? 1 : 0, \
-                       listed ? s->work_items : nullptr, n_tiles)
+                       listed ? s->work_items : nullptr, n_tiles, ride ? GomBwdOrderRider{s->status, s->seg_cost, s->bwd_order} : GomBwdOrderRider{})
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }

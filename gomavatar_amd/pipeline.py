@@ -57,7 +57,7 @@ class RenderStep:
         self.radii = torch.empty(lead + (F,), dtype=torch.int32, device=dev)
         self.loss_partials = torch.zeros(lead + (_lib.GOM_LOSS_BLOCKS, 2), **f32)
         # backward intermediates
-        self.d_image = torch.empty(lead + (4, H, W), **f32)
+        self.d_image = torch.zeros(lead + (4, H, W), **f32)   # (the loss kernel leaves the pixels of empty tiles alone: finite from the start)
         self.d_xyz = torch.empty(lead + (F, 3), **f32)
         self.d_cov6 = torch.empty(lead + (F, 6), **f32)
         self.d_feat = torch.empty(lead + (F, 4), **f32)
