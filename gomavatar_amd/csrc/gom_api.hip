@@ -31,8 +31,9 @@ static int grow(T **p, size_t count) {
 
 extern "C" GomState *gom_state_create(void) {
     GomState *s = new GomState();
-    if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;
-    if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // development switch (A/B of the loss kernel skipping empty tiles)   // development switch (A/B of the cost-ordered backward queue)
+    // development switches (A / B measurements; both default on)
+    if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // the cost-ordered backward queue of the batched frame step
+    if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // the frame step's loss kernel leaving the pixels of empty tiles alone
     if (hipGetDevice(&s->device) != hipSuccess) {
         gom_set_error("hipGetDevice failed (no HIP device?)");
         delete s;
