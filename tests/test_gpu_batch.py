@@ -1,4 +1,4 @@
-"""Batched launches (gom_batch_forward_backward): B frames through the same 14
+"""Batched launches (gom_batch_forward_backward): B frames through the same 12
 kernels must reproduce B single-frame calls BITWISE (images, losses, binning)
 and sum the gradients in frame order."""
 import numpy as np
@@ -269,3 +269,38 @@ def test_face_frame_inside_the_per_gaussian_kernels_matches_the_separate_face_ke
         rel = float((ga - gb).abs().max() / ga.abs().max())
         print(f"[fused face kernels, B={B}] d{k}: max |difference| / max |g| = {rel:.2e}  bitwise: {torch.equal(ga, gb)}")
         assert float(ga.abs().max()) > 0 and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_development_switches_do_not_change_results(B, monkeypatch):
+    """GOM_LOSS_SKIP=0 (the loss kernel reads and writes the pixels of empty tiles too) and GOM_BWD_ORDER=0 (the backward's tasks in list
+    order) are A/B switches: image, loss sums and every gradient must be BITWISE those of the default path -- the skipped pixels hold
+    the background and no list entry reads their gradient; the order of the tasks is not the order of any sum."""
+    from gomavatar_amd.pipeline import RenderStep
+    img = 128
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    bg4 = (0.1, 0.2, 0.3, 0.0)
+
+    def run():
+        step = RenderStep(faces, N, (img, img), w25, batch=B)   # (the switches are read when the state is created)
+        if B > 1:
+            step.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames], bg4)
+            step.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b)
+        else:
+            step.set_camera(frames[0]["K"][0], frames[0]["E"][0], bg4)
+            step.forward_backward(params, {k: v[0].contiguous() for k, v in fr_b.items()}, gt_rgb[0].contiguous(), gt_mask[0].contiguous(), bg_b[0].contiguous())
+        torch.cuda.synchronize()
+        return step.image.clone(), step.loss_partials.clone(), {k: v.clone() for k, v in step.grads.items()}
+
+    ref_img, ref_loss, ref_grads = run()
+    assert float(ref_img[..., 3, :, :].max()) > 0.5 and all(float(g.abs().max()) > 0 for g in ref_grads.values())
+    for name in ("GOM_LOSS_SKIP", "GOM_BWD_ORDER"):
+        monkeypatch.setenv(name, "0")
+        im, lo, gr = run()
+        monkeypatch.delenv(name)
+        assert torch.equal(im, ref_img) and torch.equal(lo, ref_loss), name
+        for k in ref_grads:
+            assert torch.equal(gr[k], ref_grads[k]), (name, k)
