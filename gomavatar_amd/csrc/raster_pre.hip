@@ -580,12 +580,15 @@ __global__ void __launch_bounds__(256) k_emit(int P, const float *__restrict__ d
         for (int y = r.y; y < r.w; y++)
             for (int x = r.x; x < r.z; x++) atomicAdd(&s_cnt[y * gx + x], 1u);
         __syncthreads();
-        for (int t = threadIdx.x; t < n_tiles; t += 256) {
-            const uint32_t c = s_cnt[t];
-            if (c) {
-                s_base[t] = atomicAdd(&tile_cursor[t], c);
-                s_cnt[t] = 0;
-            }
+        for (int t0 = threadIdx.x; t0 < n_tiles; t0 += 4 * 256) {   // four returning atomics in flight per thread (a 512 x 512 frame: one trip), not four round trips in a row
+            uint32_t c[4], base[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) c[u] = t0 + u * 256 < n_tiles ? s_cnt[t0 + u * 256] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) base[u] = c[u] ? atomicAdd(&tile_cursor[t0 + u * 256], c[u]) : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (c[u]) { s_base[t0 + u * 256] = base[u]; s_cnt[t0 + u * 256] = 0; }
         }
         __syncthreads();
         for (int y = r.y; y < r.w; y++)
