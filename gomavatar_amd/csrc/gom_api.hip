@@ -29,6 +29,13 @@ static int grow(T **p, size_t count) {
     return 0;
 }
 
+// a buffer OF THE STATE: recorded launch sequences that hold its old address must not be replayed (GomState::allocGen)
+template <typename T>
+static int grow_s(GomState *s, T **p, size_t count) {
+    s->allocGen++;
+    return grow(p, count);
+}
+
 extern "C" GomState *gom_state_create(void) {
     GomState *s = new GomState();
     // development switches (A / B measurements; both default on)
@@ -129,9 +136,9 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int pix = H * W * B;
     if (P > s->capP) {
         const int cap = P + P / 8 + 256;
-        if (grow(&s->depth, cap) || grow(&s->xy, cap) || grow(&s->conic_opacity, cap) || grow(&s->tiles_touched, cap) ||
-            grow(&s->rect, cap) || grow(&s->radii, cap) || grow(&s->pair_off, cap) || grow(&s->bkeys, cap) || grow(&s->bkeys_scratch, cap) ||
-            grow(&s->rec_g, (size_t)cap * 2) || grow(&s->order, cap) || grow(&s->rank_of, cap))
+        if (grow_s(s, &s->depth, cap) || grow_s(s, &s->xy, cap) || grow_s(s, &s->conic_opacity, cap) || grow_s(s, &s->tiles_touched, cap) ||
+            grow_s(s, &s->rect, cap) || grow_s(s, &s->radii, cap) || grow_s(s, &s->pair_off, cap) || grow_s(s, &s->bkeys, cap) || grow_s(s, &s->bkeys_scratch, cap) ||
+            grow_s(s, &s->rec_g, (size_t)cap * 2) || grow_s(s, &s->order, cap) || grow_s(s, &s->rank_of, cap))
             return -2;
         s->capP = cap;
     }
@@ -142,32 +149,32 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         s->nbShift = sh;
         const int64_t nbuck = (int64_t)B << sh;
         if (nbuck > s->capBuckets) {
-            if (grow(&s->bucket_count, (size_t)nbuck) || grow(&s->bucket_base, (size_t)nbuck + 1) || grow(&s->bucket_cursor, (size_t)nbuck)) return -2;
+            if (grow_s(s, &s->bucket_count, (size_t)nbuck) || grow_s(s, &s->bucket_base, (size_t)nbuck + 1) || grow_s(s, &s->bucket_cursor, (size_t)nbuck)) return -2;
             GOM_HIP_CHECK(hipMemset(s->bucket_count, 0, (size_t)nbuck * sizeof(uint32_t)));
             GOM_HIP_CHECK(hipMemset(s->bucket_cursor, 0, (size_t)nbuck * sizeof(uint32_t)));
             s->capBuckets = nbuck;
         }
         const int64_t nmm = (int64_t)B * ((P_frame + 255) / 256);      // one (min, max) pair per preprocess block
         if (nmm > s->capFrames) {
-            if (grow(&s->depth_minmax, (size_t)nmm * 2)) return -2;
+            if (grow_s(s, &s->depth_minmax, (size_t)nmm * 2)) return -2;
             s->capFrames = (int)nmm;
         }
     }
     if (B > s->capBigFrames) {
-        if (grow(&s->big_list, (size_t)B * GOM_BIG_CAP) || grow(&s->big_count, (size_t)2 * B)) return -2;
+        if (grow_s(s, &s->big_list, (size_t)B * GOM_BIG_CAP) || grow_s(s, &s->big_count, (size_t)2 * B)) return -2;
         GOM_HIP_CHECK(hipMemset(s->big_count, 0, (size_t)2 * B * sizeof(uint32_t)));
         s->capBigFrames = B;
     }
     if (tiles > s->capTiles) {
-        if (grow(&s->tile_count, tiles) || grow(&s->tile_base, (size_t)tiles + 1) || grow(&s->tile_cursor, tiles) ||
-            grow(&s->tile_nmax, tiles) || grow(&s->seg_base, (size_t)tiles + 1) || grow(&s->tile_qlim, tiles))
+        if (grow_s(s, &s->tile_count, tiles) || grow_s(s, &s->tile_base, (size_t)tiles + 1) || grow_s(s, &s->tile_cursor, tiles) ||
+            grow_s(s, &s->tile_nmax, tiles) || grow_s(s, &s->seg_base, (size_t)tiles + 1) || grow_s(s, &s->tile_qlim, tiles))
             return -2;
         GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
         s->capTiles = tiles;
         s->capSegs = 0;  // segment buffers depend on the tile count too
     }
     if (pix > s->capPix) {
-        if (grow(&s->final_T, pix) || grow(&s->n_contrib, pix) || grow(&s->scratch_img, (size_t)pix * 4)) return -2;
+        if (grow_s(s, &s->final_T, pix) || grow_s(s, &s->n_contrib, pix) || grow_s(s, &s->scratch_img, (size_t)pix * 4)) return -2;
         s->capPix = pix;
     }
     // Pair buffers: sized for 288 GB of HBM, not for frugality.  Default 16 pairs
@@ -176,9 +183,9 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     if (s->wantPairs <= 0 && want < (4 << 20)) want = 4 << 20;
     if (want > 0xffffffffLL) want = 0xffffffffLL;
     if (want != s->capPairs && (want > s->capPairs || s->wantPairs > 0)) {
-        if (grow(&s->keys, (size_t)want) || grow(&s->point_list, (size_t)want) || grow(&s->pair_pos, (size_t)want) || grow(&s->ent_slot, (size_t)want) || grow(&s->keys32, (size_t)want) ||
-            grow(&s->ent_geo, (size_t)want * 3) || grow(&s->ent_col, (size_t)want * 4) ||
-            grow(&s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
+        if (grow_s(s, &s->keys, (size_t)want) || grow_s(s, &s->point_list, (size_t)want) || grow_s(s, &s->pair_pos, (size_t)want) || grow_s(s, &s->ent_slot, (size_t)want) || grow_s(s, &s->keys32, (size_t)want) ||
+            grow_s(s, &s->ent_geo, (size_t)want * 3) || grow_s(s, &s->ent_col, (size_t)want * 4) ||
+            grow_s(s, &s->partial, (size_t)want * GOM_PARTIAL_STRIDE))
             return -2;
         s->capPairs = want;
         s->capSegs = 0;
@@ -186,7 +193,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     {
         const int64_t wantItems = s->capTiles + s->capPairs / GOM_RANK_WIN + 1;
         if (wantItems > s->capItems) {
-            if (grow(&s->work_items, (size_t)wantItems)) return -2;
+            if (grow_s(s, &s->work_items, (size_t)wantItems)) return -2;
             s->capItems = wantItems;
         }
     }
@@ -194,9 +201,9 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow(&s->seg_desc, n) || grow(&s->seg_cost, 16 * n) || grow(&s->bwd_order, 4 * n + 64) || grow(&s->seg_qmax, n) || grow(&s->seg_T, n * GOM_TPX) || grow(&s->seg_C, n * 4 * GOM_TPX) || grow(&s->seg_last, n * GOM_TPX) ||
-            grow(&s->seg_Tend, n * GOM_TPX) || grow(&s->seg_Sbehind, n * 4 * GOM_TPX) || grow(&s->sub_T, n * 4 * GOM_TPX) || grow(&s->cull_masks, n * 16) ||
-            grow(&s->sub_C, n * 16 * GOM_TPX) || grow(&s->sub_Tend, n * 4 * GOM_TPX))
+        if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, 4 * n + 64) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
+            grow_s(s, &s->seg_Tend, n * GOM_TPX) || grow_s(s, &s->seg_Sbehind, n * 4 * GOM_TPX) || grow_s(s, &s->sub_T, n * 4 * GOM_TPX) || grow_s(s, &s->cull_masks, n * 16) ||
+            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX))
             return -2;
         s->capSegs = wantSegs;
     }
@@ -382,12 +389,12 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
 static int ensure_batch_grads(GomState *s, int B, int N, int F) {
     const size_t vneed = (size_t)B * ((N + 255) / 256) * 2;   // vertex depth ranges of the skinning blocks (frame step)
     if (vneed > s->capVdepth) {
-        if (grow(&s->vdepth_minmax, vneed)) return -2;
+        if (grow_s(s, &s->vdepth_minmax, vneed)) return -2;
         s->capVdepth = vneed;
     }
     const size_t need = B > 1 ? (size_t)B * (9 * (size_t)F + 3 * (size_t)N) : 0;
     if (need > s->capBatchGrads) {
-        if (grow(&s->batch_grads, need)) return -2;
+        if (grow_s(s, &s->batch_grads, need)) return -2;
         s->capBatchGrads = need;
     }
     return 0;
@@ -405,6 +412,16 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     hipStream_t st = (hipStream_t)stream;
     const uint32_t kflags = flags & ~GOM_FRAME_USE_GRAPH;
     s->graphClock++;
+    for (size_t i = 0; i < s->graphs.size();) {   // recordings made before a buffer of the state moved (another frame size on the same state)
+        if (s->graphs[i].alloc_gen != s->allocGen) {
+            (void)hipGraphExecDestroy(s->graphs[i].exec);
+            (void)hipGraphDestroy(s->graphs[i].graph);
+            s->graphs[i] = s->graphs.back();
+            s->graphs.pop_back();
+        } else {
+            i++;
+        }
+    }
     for (auto &g : s->graphs) {
         if (g.flags == kflags && g.B == B && g.cams == cams && memcmp(&g.key, f, sizeof(GomFrame)) == 0) {
             g.last_use = s->graphClock;
@@ -422,6 +439,7 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     e.B = B;
     e.cams = cams;
     e.last_use = s->graphClock;
+    e.alloc_gen = s->allocGen;   // (after the two ensure_* calls above: nothing is allocated inside the capture)
     GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = frame_enqueue(s, f, B, cams, kflags, stream);
     hipError_t ce = hipStreamEndCapture(st, &e.graph);

@@ -46,6 +46,7 @@ struct GomGraphEntry {
     hipGraph_t graph;
     hipGraphExec_t exec;
     uint64_t last_use;
+    uint64_t alloc_gen;   // GomState::allocGen at capture: a recorded launch sequence holds the addresses of the state's buffers
 };
 
 struct GomState {
@@ -155,6 +156,7 @@ struct GomState {
     // captured whole-frame launch sequences (GOM_FRAME_USE_GRAPH), keyed by the exact frame descriptor
     std::vector<GomGraphEntry> graphs;
     uint64_t graphClock = 0;
+    uint64_t allocGen = 0;            // bumped whenever a buffer of the state is re-allocated: older recordings are dropped, not replayed
 };
 
 struct GomKernelTimer {

@@ -304,3 +304,41 @@ def test_development_switches_do_not_change_results(B, monkeypatch):
         assert torch.equal(im, ref_img) and torch.equal(lo, ref_loss), name
         for k in ref_grads:
             assert torch.equal(gr[k], ref_grads[k]), (name, k)
+
+
+def test_recorded_step_survives_a_larger_frame_on_the_same_state():
+    """A recorded launch sequence (GOM_FRAME_USE_GRAPH) holds the addresses of the state's buffers.  A larger frame on the SAME state
+    re-allocates them: the old recording must be dropped and re-recorded, not replayed on freed memory."""
+    from gomavatar_amd.pipeline import RenderStep
+    B = 2
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(64, B)
+    stack = lambda fs, k: torch.from_numpy(np.stack([f[k][0] for f in fs])).contiguous().cuda()
+    fr_b = {k: stack(frames, k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack(frames, "bgcolor")
+    small = RenderStep(faces, N, (64, 64), w25, batch=B)
+    small.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames])
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+
+    def run_small():
+        with torch.cuda.stream(stream):
+            for _ in range(2):   # record, replay
+                small.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b, graph=True)
+        stream.synchronize()
+        return small.image.clone(), small.loss_partials.clone(), {k: v.clone() for k, v in small.grads.items()}
+
+    ref = run_small()
+    # a 4x larger image through the same state: every per-tile / per-pixel / pair buffer is re-allocated
+    _, _, _, _, frames2, gt_rgb2, gt_mask2 = _scene(256, B)
+    big = RenderStep(faces, N, (256, 256), w25, batch=B)
+    big.state = small.state
+    big.set_cameras([f["K"][0] for f in frames2], [f["E"][0] for f in frames2])
+    fr2 = {k: stack(frames2, k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    with torch.cuda.stream(stream):
+        big.forward_backward(params, fr2, gt_rgb2, gt_mask2, stack(frames2, "bgcolor"), graph=True)
+    stream.synchronize()
+    assert float(big.image[:, 3].max()) > 0.5
+    again = run_small()
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+    for k in ref[2]:
+        assert torch.equal(again[2][k], ref[2][k]), k
