@@ -79,34 +79,37 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
         case GOM_OPT_SORT_CAP:
             if (value < 64 || value > GOM_SORT_CAP_MAX) { gom_set_error("sort cap must be in [64, %d]", GOM_SORT_CAP_MAX); return -1; }
             s->sortCap = (int)value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_PAIR_CAPACITY:
             if (value < 0 || value > 0xffffffffLL) { gom_set_error("pair capacity out of range"); return -1; }
             s->wantPairs = value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_SEG_SHIFT:
             if (value != 0 && value != 7 && value != 8) { gom_set_error("segment shift must be 0 (auto), 7 or 8"); return -1; }
             s->wantSegShift = (int)value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_TASK_GRID_PCT:
             if (value < 10 || value > 100) { gom_set_error("task grid share must be in [10, 100] percent"); return -1; }
             s->taskGridPct = (int)value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_BWD_MODE:
             if (value < -1 || value > 1) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges) or 1 (one sub-range per barrier)"); return -1; }
             s->bwdMode = (int)value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_FUSE_FACE:
             if (value != 0 && value != 1) { gom_set_error("GOM_OPT_FUSE_FACE is 0 or 1"); return -1; }
-            if ((value != 0) != s->fuseFace) {   // recorded graphs hold the other launch sequence
-                for (auto &g : s->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-                s->graphs.clear();
-            }
+            if ((value != 0) != s->fuseFace) s->allocGen++;   // recorded graphs hold the other launch sequence
             s->fuseFace = value != 0;
             return 0;
         case GOM_OPT_SORT_MODE:
             if (value < 0 || value > 2) { gom_set_error("sort mode must be 0 (auto), 1 (per-tile merge sort) or 2 (depth ranking)"); return -1; }
             s->sortMode = (int)value;
+            s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_PROFILE:
             if (value && !s->ev[0]) {

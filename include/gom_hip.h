@@ -403,7 +403,9 @@ typedef struct GomFrame {
                                        caller may ADD any other image-space gradient to work_dimage -- that is how LPIPS
                                        (gom_lpips_vgg_value_and_grad on the unpacked image, train.py:113-121) joins the native path. */
 #define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
-                                       hipGraph on first use and replay it afterwards: one submission instead of 12 */
+                                       hipGraph on first use and replay it afterwards: one submission instead of 12.  A recording is
+                                       dropped (and made again at its next use) when a buffer of the state is re-allocated -- a larger
+                                       frame through the same state -- or one of its options changes */
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
 
 /* B frames in ONE launch sequence (the same 12 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
