@@ -88,3 +88,18 @@ def test_header_is_plain_c_and_links(tmp_path, lib_path):
     assert run.returncode == 0, (run.stdout, run.stderr)
     ver, size = run.stdout.split()
     assert int(ver) >= 2 and int(size) == 160
+
+
+def test_kinematic_level_table_matches_the_parent_table():
+    """csrc/geom.hip walks the kinematic tree level by level: c_level_start must be the first joint of every depth of c_parent's tree,
+    and the joints of a depth a contiguous range of the numbering."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gomavatar_amd", "csrc", "geom.hip")).read()
+    table = lambda name: [int(v) for v in re.search(name + r"\[\d+\] = \{([^}]*)\}", src).group(1).split(",")]
+    parent, start = table("c_parent"), table("c_level_start")
+    depth = [0] * len(parent)
+    for i in range(1, len(parent)):
+        assert 0 <= parent[i] < i
+        depth[i] = depth[parent[i]] + 1
+    assert depth == sorted(depth)
+    assert start == [depth.index(d) for d in range(1, max(depth) + 1)] + [len(parent)]
