@@ -401,7 +401,9 @@ typedef struct GomFrame {
 #define GOM_FRAME_BACKWARD_ONLY 4u  /* second half of a split call: the previous call on this state was the same frame with
                                        GOM_FRAME_FORWARD_ONLY (which also leaves d(L1 losses)/d(image) in work_dimage).  In between the
                                        caller may ADD any other image-space gradient to work_dimage -- that is how LPIPS
-                                       (gom_lpips_vgg_value_and_grad on the unpacked image, train.py:113-121) joins the native path. */
+                                       (gom_lpips_vgg_value_and_grad on the unpacked image, train.py:113-121) joins the native path.
+                                       work_dimage is a gradient for the BACKWARD: the pixels of tiles no Gaussian touches are never read
+                                       by it and the loss kernel leaves them as they are (allocate the buffer zeroed; adding to it is fine) */
 #define GOM_FRAME_USE_GRAPH 2u      /* capture the launch sequence of this exact GomFrame (all pointers/sizes equal) into a
                                        hipGraph on first use and replay it afterwards: one submission instead of 12.  A recording is
                                        dropped (and made again at its next use) when a buffer of the state is re-allocated -- a larger
