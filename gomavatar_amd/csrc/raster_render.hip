@@ -52,7 +52,7 @@
 #include "sort_util.hpp"
 #include <cstdlib>
 
-#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2) or k_seg_fwd (3), scripts/wg_timeline_T.py
+#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3 | 4): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2), k_seg_fwd (3): scripts/wg_timeline_T.py; of k_combine_fwd (4): scripts/combine_timeline.py
 __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_wg_busy[GOM_SEG_GRID * 4];
 extern "C" int gom_debug_phase_counters(unsigned long long *out, unsigned long long *wg, int reset) {
@@ -1006,6 +1006,12 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
                                                      uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles,
                                                      GomBwdOrderRider rider) {
+#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 4   // (development: lifetime of every workgroup of this launch, riders first; scripts/combine_timeline.py)
+    struct PhRec {
+        unsigned long long w0;
+        __device__ ~PhRec() { if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) { g_wg_t0[blockIdx.x] = w0; g_wg_t1[blockIdx.x] = wall_clock64(); } }
+    } ph_rec{(unsigned long long)wall_clock64()};
+#endif
     // (frame step, batched) the first eight workgroups order the backward's task queue: bwd_order.hpp
     const uint32_t n_rid = rider.status ? 8u : 0u;
     if (blockIdx.x < n_rid) { gom_bwd_order_rider(rider, blockIdx.x); return; }
