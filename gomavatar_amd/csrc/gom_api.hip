@@ -242,6 +242,7 @@ static int raster_forward_impl(GomState *s, const GomCamera *cam, const GomCamer
         }
     } else {
         if (int rc = ensure_capacity(s, P, cam->H, cam->W, B)) return rc;
+        s->bwdOrderReady = false;   // a new binning: the cost-ordered task table of an earlier forward (frame step, forward-only call) is stale
         s->P = P; s->H = cam->H; s->W = cam->W; s->cams = cams;
         // Tile-list order: rank the frame's Gaussians by depth once + a linear bitmap pass per tile (raster_rank.hip), unless
         // the frame's bitmap would not fit in LDS (P > 2^19) or the caller asked for the per-tile merge sort.
@@ -430,6 +431,8 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
             g.last_use = s->graphClock;
             GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
             s->P = f->F; s->H = f->H; s->W = f->W; s->C = 4; s->B = B; s->cams = cams; s->haveForward = true;
+            s->gx = g.gx; s->gy = g.gy; s->segShift = g.segShift; s->rankSort = g.rankSort; s->bwdOrderReady = g.bwdOrderReady;
+            s->emptyFilled = false;
             return 0;
         }
     }
@@ -448,6 +451,7 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     hipError_t ce = hipStreamEndCapture(st, &e.graph);
     if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return rc; }
     if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return -2; }
+    e.gx = s->gx; e.gy = s->gy; e.segShift = s->segShift; e.rankSort = s->rankSort; e.bwdOrderReady = s->bwdOrderReady;
     GOM_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
     if (s->graphs.size() >= 64) {  // evict the least recently used capture
         size_t victim = 0;
@@ -509,7 +513,7 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
         s->rideBwdOrder = false;
         if (rc) return rc;
 
-        GomLossSkip skip{s->tile_base, cams, {f->cam.bg[0], f->cam.bg[1], f->cam.bg[2], f->cam.bg[3]}, s->gx, s->gy, W};
+        GomLossSkip skip{s->tile_base, cams, {f->cam.bg[0], f->cam.bg[1], f->cam.bg[2], f->cam.bg[3]}, s->gx, s->gy, W, (flags & GOM_FRAME_FORWARD_ONLY) ? 1 : 0};
         if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
                                     nullptr, f->loss_partials, stream, s->lossSkip ? &skip : nullptr)))
             return rc;

@@ -47,6 +47,10 @@ struct GomGraphEntry {
     hipGraphExec_t exec;
     uint64_t last_use;
     uint64_t alloc_gen;   // GomState::allocGen at capture: a recorded launch sequence holds the addresses of the state's buffers
+    // host-side state the recorded sequence left behind (a replay skips the host code that derives it; a later stand-alone call on
+    // the state -- gom_raster_backward, REUSE_BINNING -- must see what the replayed forward really did)
+    int gx, gy, segShift;
+    bool rankSort, bwdOrderReady;
 };
 
 struct GomState {
@@ -297,6 +301,8 @@ struct GomLossSkip {
     const GomCamera *cams;       // per-frame background, or null: bg
     float bg[4];
     int gx, gy, W;
+    int zero_empty;              // split frame call (GOM_FRAME_FORWARD_ONLY: a caller's hook reads / adds to the gradient image between the halves):
+                                 // the pixels of empty tiles get an explicit 0 instead of being left as they were
 };
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,

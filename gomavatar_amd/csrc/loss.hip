@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
         sum_rgb += fabsf(r0) + fabsf(r1) + fabsf(r2);
         sum_mask += fabsf(rm);
         const float s0 = sgn(r0) * k_rgb, s1 = sgn(r1) * k_rgb, s2 = sgn(r2) * k_rgb;
-        if (empty) continue;   // (no list entry touches the pixel: the backward does not read its gradient)
+        if (empty) {           // (no list entry touches the pixel: the backward does not read its gradient)
+            if (skip.zero_empty) { dpred[p] = 0.f; dpred[(size_t)HW + p] = 0.f; dpred[2 * (size_t)HW + p] = 0.f; dpred[3 * (size_t)HW + p] = 0.f; }
+            continue;
+        }
         dpred[p] = s0 * s * m;
         dpred[(size_t)HW + p] = s1 * s * m;
         dpred[2 * (size_t)HW + p] = s2 * s * m;

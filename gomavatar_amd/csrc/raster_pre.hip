@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
                                                      GomDevStatus *__restrict__ status, uint32_t cap_pairs, uint32_t seg_shift,
                                                      uint32_t *__restrict__ bucket_count, uint32_t *__restrict__ bucket_base,
                                                      uint32_t *__restrict__ bucket_cursor, int n_buckets,
-                                                     uint32_t *__restrict__ work_items, uint32_t *__restrict__ big_count, int n_frames, int big_frames,
+                                                     uint32_t *__restrict__ work_items, uint32_t cap_items, uint32_t *__restrict__ big_count, int n_frames, int big_frames,
                                                      GomScatterRider sr) {
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x;
@@ -465,7 +465,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
             uint32_t pi = wi_carry + block_excl_scan_1024(ci, s_wave, ti);
 #pragma unroll
             for (int k = 0; k < kPer; k++)
-                for (uint32_t w = 0; w * GOM_RANK_WIN < v[k]; w++) work_items[pi++] = (uint32_t)(i0 + k) | (w << 24);
+                for (uint32_t w = 0; w * GOM_RANK_WIN < v[k]; w++, pi++)
+                    if (pi < cap_items) work_items[pi] = (uint32_t)(i0 + k) | (w << 24);   // (tile_count keeps counting after the pair buffer has overflowed: the list is then longer than its buffer, and unused)
             wi_carry += ti;
         }
     }
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ tile
         status->num_segs = over ? 0u : seg_carry;
         status->pair_cursor = 0;
         status->shard_overflow = 0;
-        status->n_work_items = over ? 0u : wi_carry;
+        status->n_work_items = (over || wi_carry > cap_items) ? 0u : wi_carry;
         for (int x = 0; x < 8; x++) status->shard_cursor[x][0] = 0;
     }
 }
@@ -895,7 +896,7 @@ int gom_launch_scan_emit(GomState *s, int P, hipStream_t st, bool rank, float *f
         hipLaunchKernelGGL(k_scan_tiles, dim3((rank ? 2 : 1) + scatter_blocks), dim3(1024), scatter_blocks ? 3 * sr.nb * sizeof(uint32_t) : 0, st, s->tile_count,
                            s->tile_base, s->tile_cursor, s->seg_base,
                            s->tile_nmax, n_tiles * s->B, s->status, cap, (uint32_t)s->segShift, rank ? s->bucket_count : nullptr, s->bucket_base,
-                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr, s->big_count, s->B, s->capBigFrames, sr);
+                           s->bucket_cursor, rank ? (s->B << s->nbShift) : 0, rank ? s->work_items : nullptr, (uint32_t)s->capItems, s->big_count, s->B, s->capBigFrames, sr);
     }
     GOM_LAUNCH_CHECK();
     const int blocks = (P + 255) / 256;

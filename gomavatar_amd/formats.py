@@ -80,7 +80,10 @@ def load_reference_state_dict(model, sd: Dict[str, torch.Tensor], strict: bool =
 
 def _adopt_topology(model, sd: Dict[str, torch.Tensor]) -> None:
     """Resize the model to the mesh of a checkpoint: faces from the checkpoint, per-vertex / per-face parameters re-created with
-    the checkpoint's shapes (their values are copied by the caller), adjacency rebuilt."""
+    the checkpoint's shapes (the vertices with the checkpoint's values, so that the edge lengths `_rebuild_topology` derives are real
+    even when the caller loads non-strictly; the rest is copied by the caller), adjacency rebuilt.  The model's nn.Parameters are
+    REPLACED: an optimizer built before the load still points at the old ones and must be rebuilt (as train.py:341-346 does after a
+    subdivision)."""
     import torch.nn as nn
     dev = model.vertices.device
     faces = sd["faces"].to(dev, model.faces.dtype).contiguous()
@@ -88,7 +91,7 @@ def _adopt_topology(model, sd: Dict[str, torch.Tensor]) -> None:
     if int(faces.max()) >= N or int(faces.min()) < 0:
         raise ValueError("checkpoint faces index vertices the checkpoint does not have")
     model.faces = faces
-    model.vertices = nn.Parameter(torch.zeros(3, N, device=dev))
+    model.vertices = nn.Parameter(sd["vertices"].to(dev, torch.float32).contiguous().clone())
     for name in ("so3", "scale", "appearance"):
         old = getattr(model, name)
         setattr(model, name, nn.Parameter(torch.zeros(3, F, device=dev), requires_grad=old.requires_grad))
@@ -158,6 +161,9 @@ class ReferenceDataset:
             self.framelist = sorted(self.mesh_infos.keys())
         self.bgcolor = bgcolor
         self.load_images = load_images and os.path.isdir(img_dir)
+        if not self.load_images and (self.target_size is not None or self.crop_size != (-1, -1)):
+            # dataset/train.py:158-163,255-256 derive both from the loaded image's size: without images the intrinsics cannot follow
+            raise ValueError("target_size / crop_size need the images (their scale and offset come from the image size)")
 
     def get_canonical_info(self):
         return {"canonical_joints": self.canonical_joints, "canonical_vertex": self.canonical_vertex,
@@ -178,6 +184,10 @@ class ReferenceDataset:
                "global_tfms": gt, "dst_poses": poses, "dst_Rs": dst_Rs, "dst_Ts": dst_Ts,
                "cnl_gtfms": _syn.canonical_global_tfms(self.canonical_joints), "dst_posevec": poses.reshape(-1)[3:] + 1e-2,
                "dst_tpose_joints": tpose}
+        if not self.load_images and self.resize_img_scale != (1.0, 1.0):   # dataset/train.py:239-244: K follows the resize whether or not the pixels are read
+            K[:1] *= self.resize_img_scale[0]
+            K[1:2] *= self.resize_img_scale[1]
+            out["K"] = K.astype(np.float32)
         if self.load_images:
             from PIL import Image
             from . import imageops as iop

@@ -7,8 +7,8 @@ frame-parallel trainer and by smoke().
        -> splat backward -> face backward -> vertex gather + LBS backward
 
 i.e. reference models/model.py:213-250 + models/modules/renderer/gaussian.py:22-100
-+ train.py:53-55,101-111 and the autograd backward of all of it, as 18 kernel
-launches on one stream.  Gradients land in `self.grads` (vertices (3,N), so3
++ train.py:53-55,101-111 and the autograd backward of all of it, as 12 kernel
+launches on one stream (13 for a batch: + the frame sum).  Gradients land in `self.grads` (vertices (3,N), so3
 (3,F), scale (3,F), appearance (3,F)) and are bitwise reproducible.
 
 `batch=B > 1` runs B frames through the SAME launches (every kernel covers

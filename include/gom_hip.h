@@ -369,7 +369,7 @@ int gom_ssim(int H, int W, int C, const float *img0, const float *img1, int win,
  * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused
  * unpack + L1 losses (forward and backward) -> splat backward -> face backward -> vertex gather + LBS backward
  * (reference models/model.py:213-250, renderer/gaussian.py:22-100, train.py:53-55,101-111 and their autograd
- * backward).  14 kernel launches enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
+ * backward).  12 kernel launches (13 for a batch: + the frame sum; 16 / 17 with GOM_OPT_FUSE_FACE 0) enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
  * per-face frame, the depth histogram and the frame's backward inside the rasterizer's per-Gaussian kernels: GOM_OPT_FUSE_FACE); every pointer is caller-owned device
  * memory, `work_*` are scratch tensors of the stated sizes. */
 typedef struct GomFrame {

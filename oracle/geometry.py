@@ -165,4 +165,4 @@ def render_path(params: dict, frame: dict, faces: torch.Tensor, lbs_weights: tor
     opacity = torch.ones(F, dtype=xyz.dtype)
     img = rasterize(cam, xyz, cov6, feat, opacity)  # (4,H,W)
     pred = img.permute(1, 2, 0)[None]
-    return pred[..., :3], pred[..., 3], dict(v_obs=v_obs, xyz=xyz, cov6=cov6, cam=cam)
+    return pred[..., :3], pred[..., 3], dict(v_obs=v_obs, xyz=xyz, cov6=cov6, cam=cam, img=img, feat=feat)

@@ -63,14 +63,16 @@ def _seg_dist2(px, py, ax, ay, bx, by):
     return torch.where(l2 > K_EPS, d, (px - bx) ** 2 + (py - by) ** 2)
 
 
-def rasterize(verts_ndc, faces, H, W, blur_radius, rows=None):
+def rasterize(verts_ndc, faces, H, W, blur_radius, rows=None, cols=None):
     """Per pixel and face: qualifies (bool), signed squared distance, interpolated depth.  Returns dense (HW, F); `rows` = (r0, r1)
-    restricts the pixels to image rows r0 .. r1-1 (pixels are independent: large meshes are rendered in row bands)."""
+    restricts the pixels to image rows r0 .. r1-1, `cols` = (c0, c1) to columns c0 .. c1-1 (pixels are independent: large meshes are
+    rendered in row bands or tiles)."""
     dt = verts_ndc.dtype
     xf, yf = pixel_centers(H, W, dt)
     r0, r1 = rows if rows is not None else (0, H)
-    px = xf[None, :].expand(r1 - r0, W).reshape(-1, 1)
-    py = yf[r0:r1, None].expand(r1 - r0, W).reshape(-1, 1)
+    c0, c1 = cols if cols is not None else (0, W)
+    px = xf[None, c0:c1].expand(r1 - r0, c1 - c0).reshape(-1, 1)
+    py = yf[r0:r1, None].expand(r1 - r0, c1 - c0).reshape(-1, 1)
     v = verts_ndc[faces]                                  # (F,3,3)
     x0, y0, z0 = v[:, 0, 0][None], v[:, 0, 1][None], v[:, 0, 2][None]
     x1, y1, z1 = v[:, 1, 0][None], v[:, 1, 1][None], v[:, 1, 2][None]
@@ -96,12 +98,15 @@ def rasterize(verts_ndc, faces, H, W, blur_radius, rows=None):
     return qual, torch.where(inside, -d, d), pz
 
 
-def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50, training=True, rows=None):
-    """mesh.py:114-128.  Returns (normal (H,W,3), mask (H,W) or None, pix_to_face (H,W)) -- of the row band `rows` when given."""
-    Hfull = H
-    qual, _, pz = rasterize(verts_ndc, faces, H, W, 0.0, rows)
+def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50, training=True, rows=None, cols=None):
+    """mesh.py:114-128.  Returns (normal (H,W,3), mask (H,W) or None, pix_to_face (H,W)) -- of the row band `rows` (and the columns
+    `cols`) when given."""
+    Hfull, Wfull = H, W
+    qual, _, pz = rasterize(verts_ndc, faces, H, W, 0.0, rows, cols)
     if rows is not None:
         H = rows[1] - rows[0]
+    if cols is not None:
+        W = cols[1] - cols[0]
     zsel = torch.where(qual, pz, torch.full_like(pz, float("inf")))
     zmin, top = zsel.min(1)
     hit = torch.isfinite(zmin)
@@ -111,7 +116,7 @@ def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50,
     if not training:
         return normal.reshape(H, W, 3), None, pix_to_face.reshape(H, W)
     blur_radius = math.log(1.0 / 1e-4 - 1.0) * sigma_cfg
-    qual, sd, pz = rasterize(verts_ndc, faces, Hfull, W, blur_radius, rows)
+    qual, sd, pz = rasterize(verts_ndc, faces, Hfull, Wfull, blur_radius, rows, cols)
     zsel = torch.where(qual, pz, torch.full_like(pz, float("inf")))
     k = min(faces_per_pixel, zsel.shape[1])
     zk, idx = torch.topk(zsel, k, dim=1, largest=False)
@@ -119,3 +124,52 @@ def render(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50,
     prob = torch.sigmoid(-torch.gather(sd, 1, idx) / BLEND_SIGMA) * valid
     alpha = 1.0 - torch.prod(1.0 - prob, 1)
     return normal.reshape(H, W, 3), alpha.reshape(H, W), pix_to_face.reshape(H, W)
+
+
+def render_tiled(verts_ndc, faces, vnormals, H, W, sigma_cfg=1e-5, faces_per_pixel=50, training=True, tile=16, use_checkpoint=True):
+    """`render` tile by tile, each tile over only the faces whose blur-expanded bounding box reaches it.  EXACT, not an approximation:
+    `rasterize` requires `in_box` of every qualifying (pixel, face) pair, a face outside every pixel's box of a tile qualifies nowhere
+    in it, and a non-qualifying face contributes nothing to the top-1 / product and receives no gradient -- so the result and its
+    gradients are those of the dense O(pixels x faces) evaluation (tests/test_oracle_mesh_tiled.py checks bitwise equality).  It
+    is what makes a 512 x 512 / 55 104-face training loop affordable for the float64 oracle (scripts/make_train_loop_goldens.py).
+    Tiles are re-computed in the backward (torch checkpoint) so that only one tile's dense tensors are alive at a time."""
+    from torch.utils.checkpoint import checkpoint
+    dt = verts_ndc.dtype
+    xf, yf = pixel_centers(H, W, dt)
+    blur = math.sqrt(math.log(1.0 / 1e-4 - 1.0) * sigma_cfg) if training else 0.0
+    with torch.no_grad():
+        v = verts_ndc[faces]
+        xmin, xmax = v[:, :, 0].min(1).values - blur, v[:, :, 0].max(1).values + blur
+        ymin, ymax = v[:, :, 1].min(1).values - blur, v[:, :, 1].max(1).values + blur
+    normal = torch.zeros(H, W, 3, dtype=dt)
+    alpha = torch.zeros(H, W, dtype=dt) if training else None
+    p2f = torch.full((H, W), -1, dtype=torch.long)
+    n_rows, a_rows = [], []
+    for r0 in range(0, H, tile):
+        r1 = min(H, r0 + tile)
+        ylo, yhi = min(float(yf[r0]), float(yf[r1 - 1])), max(float(yf[r0]), float(yf[r1 - 1]))
+        row_sel = (ymin <= yhi) & (ymax >= ylo)
+        n_cols, a_cols = [], []
+        for c0 in range(0, W, tile):
+            c1 = min(W, c0 + tile)
+            xlo, xhi = min(float(xf[c0]), float(xf[c1 - 1])), max(float(xf[c0]), float(xf[c1 - 1]))
+            idx = torch.nonzero(row_sel & (xmin <= xhi) & (xmax >= xlo)).squeeze(1)
+            if idx.numel() == 0:
+                n_cols.append(torch.zeros(r1 - r0, c1 - c0, 3, dtype=dt))
+                a_cols.append(torch.zeros(r1 - r0, c1 - c0, dtype=dt))
+                continue
+            sub = faces[idx]
+
+            def fn(ndc_, vn_, sub=sub, r0=r0, r1=r1, c0=c0, c1=c1):
+                n, a, t = render(ndc_, sub, vn_, H, W, sigma_cfg, faces_per_pixel, training, rows=(r0, r1), cols=(c0, c1))
+                return n, (a if a is not None else torch.zeros(r1 - r0, c1 - c0, dtype=dt)), t
+            if use_checkpoint and torch.is_grad_enabled() and (verts_ndc.requires_grad or vnormals.requires_grad):
+                n, a, t = checkpoint(fn, verts_ndc, vnormals, use_reentrant=False)
+            else:
+                n, a, t = fn(verts_ndc, vnormals)
+            n_cols.append(n); a_cols.append(a)
+            p2f[r0:r1, c0:c1] = torch.where(t >= 0, idx[t.clamp_min(0)], t)
+        n_rows.append(torch.cat(n_cols, 1)); a_rows.append(torch.cat(a_cols, 1))
+    normal = torch.cat(n_rows, 0)
+    alpha = torch.cat(a_rows, 0) if training else None
+    return normal, alpha, p2f

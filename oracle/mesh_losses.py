@@ -41,10 +41,19 @@ def uniform_laplacian(edges: torch.Tensor, n_verts: int, dtype=torch.float64) ->
 
 
 def laplacian_smoothing(verts: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
-    """network_util.py:782,789,792."""
-    with torch.no_grad():
-        L = uniform_laplacian(edges, verts.shape[0], verts.dtype)
-    return ((L @ verts).norm(dim=1) ** 2).mean()
+    """network_util.py:782,789,792.  Small meshes multiply by the dense L; from 4 096 vertices on (a dense float64 L of the
+    27 554-vertex body is 6 GB) the same rows are applied edge by edge: (L v)_i = (sum of the neighbours of i) / deg_i - v_i."""
+    N = verts.shape[0]
+    if N <= 4096:
+        with torch.no_grad():
+            L = uniform_laplacian(edges, N, verts.dtype)
+        return ((L @ verts).norm(dim=1) ** 2).mean()
+    e0, e1 = edges[:, 0], edges[:, 1]
+    one = torch.ones(e0.shape[0], dtype=verts.dtype)
+    deg = torch.zeros(N, dtype=verts.dtype).index_add_(0, e0, one).index_add_(0, e1, one)
+    nb = torch.zeros_like(verts).index_add(0, e0, verts[e1]).index_add(0, e1, verts[e0])
+    Lv = torch.where(deg[:, None] > 0, nb / deg.clamp_min(1)[:, None], torch.zeros_like(nb)) - verts
+    return (Lv.norm(dim=1) ** 2).mean()
 
 
 def edge_face_pairs(faces: torch.Tensor, n_verts: int):
@@ -55,13 +64,18 @@ def edge_face_pairs(faces: torch.Tensor, n_verts: int):
     eid, fid = flat[order], order // 3
     starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
     ends = np.r_[starts[1:], len(eid)]
-    pf, pe = [], []
-    for s, e in zip(starts, ends):
+    n = ends - starts
+    two = n == 2                                     # a manifold edge: one pair (all of them on a closed mesh), taken without a Python loop
+    pf = [np.stack([fid[starts[two]], fid[starts[two] + 1]], 1)]
+    pe = [eid[starts[two]]]
+    for s, e in zip(starts[n > 2], ends[n > 2]):     # more than two faces on an edge: all pairs
         for i in range(s, e):
             for j in range(i + 1, e):
-                pf.append((fid[i], fid[j])); pe.append(eid[s])
-    pf = np.asarray(pf, np.int64).reshape(-1, 2)
-    return torch.from_numpy(pf), edges[torch.from_numpy(np.asarray(pe, np.int64))]
+                pf.append(np.asarray([[fid[i], fid[j]]])); pe.append(np.asarray([eid[s]]))
+    pf = np.concatenate(pf, 0).astype(np.int64).reshape(-1, 2)
+    pe = np.concatenate(pe, 0).astype(np.int64)
+    order2 = np.argsort(pe, kind="stable")           # pairs in edge order, as the loop over edges produced them
+    return torch.from_numpy(pf[order2]), edges[torch.from_numpy(pe[order2])]
 
 
 def normal_consistency(verts: torch.Tensor, faces: torch.Tensor) -> torch.Tensor:
@@ -83,12 +97,20 @@ def face_connectivity(faces: torch.Tensor, n_verts: int) -> torch.Tensor:
     """models/model.py:115-125: for edge id i in range(max_edge_id) with exactly two faces, the (sorted) face pair."""
     _, f2e = edges_of(faces, n_verts)
     f2e_np = f2e.numpy()
-    out = []
-    for i in range(int(f2e_np.max())):
-        fs = np.nonzero((f2e_np == i).any(1))[0]
-        if len(fs) == 2:
-            out.append(fs)
-    return torch.from_numpy(np.asarray(out, np.int64).reshape(-1, 2))
+    if f2e_np.shape[0] <= 4096:                      # the reference's loop, literally
+        out = []
+        for i in range(int(f2e_np.max())):
+            fs = np.nonzero((f2e_np == i).any(1))[0]
+            if len(fs) == 2:
+                out.append(fs)
+        return torch.from_numpy(np.asarray(out, np.int64).reshape(-1, 2))
+    # the same list without the O(edges x faces) scan: (edge, face) incidences grouped by edge id (a face counts once per edge)
+    inc = np.unique(np.stack([f2e_np.reshape(-1), np.repeat(np.arange(f2e_np.shape[0]), 3)], 1), axis=0)     # sorted by (edge, face)
+    eid, fid = inc[:, 0], inc[:, 1]
+    starts = np.flatnonzero(np.r_[True, eid[1:] != eid[:-1]])
+    n = np.r_[starts[1:], len(eid)] - starts
+    sel = starts[(n == 2) & (eid[starts] < int(f2e_np.max()))]
+    return torch.from_numpy(np.stack([fid[sel], fid[sel + 1]], 1).astype(np.int64))
 
 
 def color_consistency(colors_F3: torch.Tensor, pairs: torch.Tensor) -> torch.Tensor:

@@ -45,6 +45,24 @@ def shadow_mlp(normals: torch.Tensor, wb: List[torch.Tensor], multires: int = 6)
     return torch.sigmoid(F.linear(h, wb[6], wb[7]))
 
 
+def subdivide_midpoint(verts: np.ndarray, faces: np.ndarray, attrs: Dict[str, np.ndarray]):
+    """utils/pc_util.py:49-150 (`_subdivide`, adapted there from trimesh; called by models/model.py:145): one midpoint per unique
+    edge appended behind the old vertices, every face replaced IN PLACE by its four children [v0 m0 m2] [m0 v1 m1] [m2 m1 v2]
+    [m0 m1 m2] (m_k = midpoint of the face's k-th edge (v_k, v_k+1)) -> children of face f are rows 4f .. 4f+3; generic vertex
+    attributes are averaged onto the midpoints.  Midpoints are numbered in the lexicographic order of their sorted (lo, hi) vertex
+    pair (trimesh numbers them by first occurrence of a row hash instead: a relabelling of the new vertices, results identical up
+    to that permutation -- gomavatar_amd.formats adopts a checkpoint's own numbering when it loads one)."""
+    e = np.sort(np.stack([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 1).reshape(-1, 2), 1)
+    key = e[:, 0].astype(np.int64) * (int(faces.max()) + 1) + e[:, 1]
+    uk, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    pairs = e[first]
+    m = inv.reshape(-1, 3) + len(verts)
+    f = np.stack([faces[:, 0], m[:, 0], m[:, 2], m[:, 0], faces[:, 1], m[:, 1], m[:, 2], m[:, 1], faces[:, 2], m[:, 0], m[:, 1], m[:, 2]], 1).reshape(-1, 3)
+    new_v = np.concatenate([verts, 0.5 * (verts[pairs[:, 0]] + verts[pairs[:, 1]])], 0)
+    new_a = {k: np.concatenate([a, 0.5 * (a[pairs[:, 0]] + a[pairs[:, 1]])], 0) for k, a in attrs.items()}
+    return new_v, f.astype(np.int64), new_a
+
+
 def render_mesh_banded(ndc, faces, vn, H, W, band: int = 16):
     """oracle/mesh.render in row bands, each band re-computed in the backward (dense pixels x faces tensors: 13 776 faces x 128^2
     pixels would otherwise keep tens of GB alive for autograd)."""
@@ -68,9 +86,25 @@ class OracleAvatar:
         self.w25 = torch.cat([w, torch.zeros(1, w.shape[1])], 0).to(dtype)
         self.p = {k: v.detach().clone().to(dtype).requires_grad_() for k, v in params.items()}
         self.shadow = [t.detach().clone().to(dtype).requires_grad_() for t in shadow_wb]
+        self.tiled_mesh = False      # oracle/mesh.py::render_tiled (exact; what a 512 x 512 loop needs)
+        self._topology()
+
+    def _topology(self):
         N = self.p["vertices"].shape[1]
         self.edges, _ = oml.edges_of(self.faces, N)
         self.face_connectivity = oml.face_connectivity(self.faces, N)
+
+    def subdivide(self):
+        """models/model.py:136-179: midpoint subdivision of the canonical mesh; skinning weights averaged onto the midpoints; so3 /
+        scale / appearance of a face inherited by its four children (`x[..., None].repeat(1, 1, 4).reshape(3, -1)`: child 4f + c).
+        The caller rebuilds its optimizer (train.py:341-346)."""
+        v, f, a = subdivide_midpoint(self.p["vertices"].detach().T.numpy(), self.faces.numpy(), {"w": self.w25.T.numpy()})
+        rep = lambda t: t.detach()[..., None].repeat(1, 1, 4).reshape(t.shape[0], -1).clone()
+        self.p = dict(vertices=torch.from_numpy(v).to(self.dtype).T.contiguous().requires_grad_(), so3=rep(self.p["so3"]).requires_grad_(),
+                      scale=rep(self.p["scale"]).requires_grad_(), appearance=rep(self.p["appearance"]).requires_grad_())
+        self.faces = torch.from_numpy(f).long()
+        self.w25 = torch.from_numpy(a["w"]).to(self.dtype).T.contiguous()
+        self._topology()
 
     def param_groups(self):
         """models/model.py:305-324 (lbs_weights is a buffer: its group holds no trainable tensor)."""
@@ -89,7 +123,13 @@ class OracleAvatar:
         vn = om.vertex_normals(v_obs.T, self.faces)                                 # model.py:271
         vn = (fr["E"][0, :3, :3] @ vn.T).T                                          # model.py:272
         ndc = om.ndc_T_world(v_obs[None], fr["K"], fr["E"], img, img)[0]
-        if training:
+        if self.tiled_mesh:
+            if training:
+                normal, alpha, _ = om.render_tiled(ndc, self.faces, vn, img, img, sigma_cfg=1e-5)
+            else:
+                with torch.no_grad():
+                    normal, alpha, _ = om.render_tiled(ndc, self.faces, vn, img, img, training=False)
+        elif training:
             normal, alpha = render_mesh_banded(ndc, self.faces, vn, img, img)
         else:
             with torch.no_grad():

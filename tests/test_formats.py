@@ -125,6 +125,13 @@ def test_dataset_reader_undistorts_resizes_and_crops_like_the_reference(tmp_path
         np.testing.assert_allclose(half["K"][:2], plain["K"][:2] * 0.5, rtol=1e-6)
         assert half["target_masks"].min() >= 0.0 and half["target_masks"].max() <= 1.0 and half["target_masks"][16, 16] == 1.0
         np.testing.assert_allclose(half["target_rgbs"][0, 0], [0.0, 1.0, 0.0], atol=1e-5)
+    # without the pixels the intrinsics still follow resize_img_scale (dataset/train.py:239-244); a size that needs the image is refused
+    noimg = formats.ReferenceDataset(str(tmp_path), bgcolor=[0.0, 255.0, 0.0], load_images=False, resize_img_scale=(0.5, 0.5))[0]
+    np.testing.assert_allclose(noimg["K"][:2], plain["K"][:2] * 0.5, rtol=1e-6)
+    assert "target_rgbs" not in noimg
+    for kw in (dict(target_size=(32, 32)), dict(crop_size=(40, 32))):
+        with pytest.raises(ValueError):
+            formats.ReferenceDataset(str(tmp_path), load_images=False, **kw)
     # a real distortion moves pixels; the crop keeps at least 20 mask units and moves the principal point by the crop offset
     for c in cams.values():
         c["distortions"] = np.array([0.3, 0.0, 0.0, 0.0, 0.0])

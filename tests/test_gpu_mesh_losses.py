@@ -90,17 +90,30 @@ def test_laplacian_matches_reference_golden(golden_dir):
 
 
 def test_metric_size_mesh_against_oracle_sparse():
-    """55 104 faces: the kernels against the fp64 restatement with the same pair lists (vectorised host formulas)."""
+    """55 104 faces: the kernels (values and vertex gradient) against oracle/mesh_losses.py in float64 -- the oracle's OWN edge and
+    face-pair lists built from the faces, not the product's (round 1 compared the product with itself here and an un-squared
+    Laplacian went through)."""
     from gomavatar_amd import train_util as tu
     body = syn.make_body(1)
     g = torch.Generator().manual_seed(3)
     v = torch.from_numpy(body["canonical_vertex"]).float() + 0.002 * torch.randn(body["canonical_vertex"].shape, generator=g)
     faces = torch.from_numpy(body["faces"]).long()
     mesh_g, vg, lt, conn, allp = _hip_mesh(v, faces)
-    (tu.mesh_laplacian_smoothing(mesh_g) + 0.1 * tu.mesh_normal_consistency(mesh_g)).backward()
-    from gomavatar_amd.model import SimpleMesh, mesh_edges
-    edges, _ = mesh_edges(faces, v.shape[0])
-    vh = v.double().requires_grad_()
-    mesh_h = SimpleMesh(vh, faces, edges, None, None, allp)
-    (tu.mesh_laplacian_smoothing(mesh_h) + 0.1 * tu.mesh_normal_consistency(mesh_h)).backward()
-    assert float((vg.grad.cpu().double() - vh.grad).abs().max()) <= 5e-5 * float(vh.grad.abs().max())
+    l_lap, l_nc = tu.mesh_laplacian_smoothing(mesh_g), tu.mesh_normal_consistency(mesh_g)
+    (l_lap + 0.1 * l_nc).backward()
+    vo = v.double().requires_grad_()
+    edges_o, _ = oml.edges_of(faces, v.shape[0])
+    o_lap, o_nc = oml.laplacian_smoothing(vo, edges_o), oml.normal_consistency(vo, faces)
+    (o_lap + 0.1 * o_nc).backward()
+    assert abs(float(l_lap) - float(o_lap)) <= 2e-5 * float(o_lap) and abs(float(l_nc) - float(o_nc)) <= 2e-5 * float(o_nc)
+    assert float((vg.grad.cpu().double() - vo.grad).abs().max()) <= 5e-5 * float(vo.grad.abs().max())
+    # colour consistency at the same size: the oracle's face pairs (model.py:115-125, last edge id skipped)
+    colors = torch.rand(faces.shape[0], 3, generator=g)
+    cg = colors.cuda().requires_grad_()
+    l_cc = tu.mesh_color_consistency(cg, conn.cuda(), lt)
+    l_cc.backward()
+    co = colors.double().requires_grad_()
+    o_cc = oml.color_consistency(co, oml.face_connectivity(faces, v.shape[0]))
+    o_cc.backward()
+    assert abs(float(l_cc) - float(o_cc)) <= 2e-6 * float(o_cc)
+    assert float((cg.grad.cpu().double() - co.grad).abs().max()) <= 2e-5 * float(co.grad.abs().max())

@@ -142,6 +142,30 @@ def test_pair_buffer_overflow_is_loud():
     assert torch.isnan(out).all()
 
 
+def test_overflow_with_long_lists_in_rank_mode_stays_inside_its_buffers():
+    """The scan kernel lists one k_tile_rank work item per 2 048 list positions of a tile from counts that keep growing AFTER the pair
+    buffer has overflowed: 5 000 Gaussians over all 16 tiles are 48 items for a 19-item buffer (capacity 4 096 pairs).  The store is
+    guarded by the buffer's capacity; the overflow is reported, the image poisoned, and the state is intact afterwards (a normal
+    frame on the same state is bit-identical to one on a fresh state)."""
+    from gpu_util import hip_forward
+    from gomavatar_amd import _lib, rasterizer as R
+    cam, means, cov6, colors, op = small_scene(seed=5, P=5000, H=64, W=64, spread=0.2, scale=0.6, opacity=0.05)
+    st = R.RasterState()
+    st.set_option(_lib.OPT_SORT_MODE, 2)
+    st.set_option(_lib.OPT_PAIR_CAPACITY, 4096)
+    out, radii, st, _ = hip_forward(cam, means, cov6, colors, op, state=st)
+    D, overflow = st.poll()
+    assert overflow and D > 16 * 2048 * 2, D           # every tile's list is longer than two windows
+    assert torch.isnan(out).all()
+    st.set_option(_lib.OPT_PAIR_CAPACITY, 0)
+    small = small_scene(seed=24, P=2000, H=64, W=64)
+    a, ra, st, _ = hip_forward(*small, state=st)
+    fresh = R.RasterState()
+    fresh.set_option(_lib.OPT_SORT_MODE, 2)
+    b, rb, _, _ = hip_forward(*small, state=fresh)
+    assert not st.poll()[1] and torch.equal(a, b) and torch.equal(ra, rb)
+
+
 @pytest.mark.parametrize("sort_mode", [1, 2])
 @pytest.mark.parametrize("C", [3, 4])
 def test_backward_matches_oracle(C, sort_mode):

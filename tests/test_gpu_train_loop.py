@@ -1,0 +1,102 @@
+"""BASELINE configs[1] in miniature, against an ORACLE-TRAINED run ("PSNR-vs-iteration of HIP vs oracle-trained
+avatars"): the reference's training loop (train.py:309-349) at 512 x 512 -- 20 iterations on the S body (13 776 Gaussians),
+`subdivide()` with the optimizer rebuilt (train.py:341-346; children 4f .. 4f+3 inherit so3 / scale / appearance, Adam moments
+reset), 10 iterations on the M body (55 104 Gaussians: the metric workload's size) -- recorded from the float64 CPU oracle by
+scripts/make_train_loop_goldens.py (tests/golden/train_loop.npz; LPIPS coefficient 0, every other term of exps/zju-mocap_377.yaml)
+and replayed here through gomavatar_amd.model.Model + train_util.train_iteration.  Held per iteration: every loss term, the total,
+the 8-bit PSNR of the prediction against the target frame, image checksums, gradient and parameter norms per group."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from gomavatar_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("rgb", "mask", "laplacian_observation", "normal_mask", "normal_consist", "color_consist")
+
+
+def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, capsys):
+    from gomavatar_amd.model import Model
+    from gomavatar_amd import train_util as tu
+    from gomavatar_amd.metrics import from_8b, psnr, to_8b
+    g = np.load(os.path.join(golden_dir, "train_loop.npz"))
+    img, n1, n2 = int(g["img"]), int(g["n1"]), int(g["n2"])
+    assert img == 512 and n1 >= 10 and n2 >= 5
+    cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
+             normal_renderer=NS(sigma=1e-5, soft_mask=True), shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)),
+             lbs_weights=NS(refine=False))
+    train_cfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, canonical_geometry_xyz=0.0005, shadow=0.0005), lr_decay_steps=100000,
+                   losses=NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                             normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05)))      # exps/zju-mocap_377.yaml, LPIPS off
+    body = syn.make_body(0)
+
+    def make(seed):
+        m = Model(cfg, body).train()
+        gp = syn.make_gaussian_params(m.faces.shape[0], seed)
+        with torch.no_grad():
+            m.so3.copy_(torch.from_numpy(gp["so3"])); m.scale.copy_(torch.from_numpy(gp["scale"])); m.appearance.copy_(torch.from_numpy(gp["appearance"]))
+            lin = [l for l in m.shadow_module.block_mlps if isinstance(l, torch.nn.Linear)]
+            for i, l in enumerate(lin):
+                l.weight.copy_(torch.from_numpy(g[f"shadow_wb{2 * i}"])); l.bias.copy_(torch.from_numpy(g[f"shadow_wb{2 * i + 1}"]))
+        return m
+    teacher, student = make(2), make(1)
+    teacher.eval()
+    opt = torch.optim.Adam(student.get_param_groups(train_cfg), betas=(0.9, 0.999))
+    rows, worst = [], {}
+
+    def hold(name, it, got, ref, rel, absol=0.0):
+        err = abs(got - ref)
+        worst[name] = max(worst.get(name, 0.0), err / max(abs(ref), 1e-30))
+        assert err <= rel * abs(ref) + absol, (name, it, got, ref)
+
+    for it in range(n1 + n2):
+        fr = {k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(it, img).items()}
+        with torch.no_grad():
+            rgbs, masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            fr["target_rgbs"], fr["target_masks"] = tu.unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
+        assert student.faces.shape[0] == int(g["n_faces"][it]) if it < n1 else True
+        loss, items, rgb, mask = tu.train_iteration(student, opt, fr, train_cfg, it, lpips_func=None)
+        # ---- per-iteration quantities against the oracle-trained run.  The two runs are two trajectories of the same optimisation
+        # (fp32 kernels / float64 oracle; Adam's first steps are +-lr whatever the gradient's size, so near-zero components whose sign
+        # differs in the last bits part by 2 lr): the bounds are those of trajectories that stay together, not of bitwise replay.
+        for k in KEYS:
+            # mask: ~3e-4 = a few hundred pixels' worth of |difference| at 512^2 (one pixel: 4e-6)
+            hold(k, it, float(items[k]["unscaled"].detach()), float(g[k][it]), 2e-3 if k != "mask" else 2e-2, 1e-7 if k != "mask" else 2e-5)
+        hold("total", it, float(loss.detach()), float(g["total"][it]), 1e-3)
+        p8 = float(psnr(from_8b(to_8b(rgb.detach()[0])), from_8b(to_8b(fr["target_rgbs"][0]))))
+        assert abs(p8 - float(g["psnr8"][it])) <= 0.02, (it, p8, float(g["psnr8"][it]))
+        worst["psnr8_db"] = max(worst.get("psnr8_db", 0.0), abs(p8 - float(g["psnr8"][it])))
+        assert abs(float(rgb.detach().mean()) - float(g["rgb_mean"][it])) <= 2e-5 and abs(float(mask.detach().mean()) - float(g["mask_mean"][it])) <= 2e-5
+        hold("rgb_l2", it, float(rgb.detach().norm()), float(g["rgb_l2"][it]), 1e-4)
+        # gradient norms (recorded before the step; p.grad still holds them) -- on the parameters the iteration differentiated, i.e.
+        # before a subdivision replaces them
+        groups = opt.param_groups[1:]              # the product keeps the reference's leading lbs_weights group (a buffer)
+        for gi, pg in enumerate(groups):
+            gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in pg["params"])))
+            hold(f"gradnorm_{gi}_{pg['name']}", it, gn, float(g["gradnorm"][it, gi]), 3e-2)
+        if it == n1 - 1:                           # train.py:341-346
+            student.subdivide()
+            opt = torch.optim.Adam(student.get_param_groups(train_cfg), betas=(0.9, 0.999))
+            tu.update_lr(opt, it, train_cfg)       # (train_iteration updated the old optimizer; the reference updates the NEW one: train.py:348)
+            assert student.faces.shape[0] == 4 * int(g["n_faces"][0]) and len(opt.state) == 0
+        for gi, pg in enumerate(opt.param_groups[1:]):
+            pn = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in pg["params"])))
+            hold(f"paramnorm_{gi}", it, pn, float(g["paramnorm"][it, gi]), 1e-5)
+        rows.append((it, float(loss.detach()), float(g["total"][it]), p8, float(g["psnr8"][it])))
+    # the closing eval frame (eval.py:336-361) on the subdivided student
+    student.eval()
+    fr = {k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(n1 + n2, img).items()}
+    with torch.no_grad():
+        t_rgbs, t_masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+        fr["target_rgbs"] = tu.unpack(t_rgbs, t_masks, torch.ones(1, 3, device="cuda"))
+    _, value = tu.eval_frame(student, fr)
+    assert abs(value - float(g["eval_psnr"])) <= 0.02, (value, float(g["eval_psnr"]))
+    with capsys.disabled():
+        print("\n[train loop S -> subdivide -> M @ 512^2] iteration: total (HIP / oracle), PSNR8 (HIP / oracle)")
+        for it, a, b, c, d in rows[::3] + rows[-1:]:
+            print(f"  it {it:2d}: {a:.6f} / {b:.6f}   {c:.3f} / {d:.3f} dB")
+        print("  worst relative deviations: " + "  ".join(f"{k} {v:.1e}" for k, v in sorted(worst.items())) + f"   eval PSNR {value:.3f} vs {float(g['eval_psnr']):.3f}")
