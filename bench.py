@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- rendered frames/sec (fwd+bwd) of the GoMAvatar hot path on MI355X.
 
-One "step" = one batch of B frames (--batch, default 8) per GPU through the whole hot path, forward AND backward, in ONE
-sequence of kernel launches: FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused unpack + L1(rgb) +
+One "step" = one batch of B frames per GPU (--batch; default 8 at N = 1 = BASELINE configs[1], 1 at N > 1 = configs[3]'s literal
+"one frame per GPU") through the whole hot path, forward AND backward, in ONE sequence of kernel launches: FK -> LBS -> per-face Gaussians -> splat forward (4-channel) -> fused unpack + L1(rgb) +
 L1(mask) loss fwd/bwd -> splat backward -> face backward -> vertex gather + LBS backward -> sum of the per-frame gradients,
-producing the batch gradient for vertices / so3 / scale / appearance.  Workload (BASELINE.json metric; built by
+producing the batch gradient for vertices / so3 / scale / appearance -> (N > 1: ONE all-reduce of the flat gradient buffer) -> Adam on the
+flat parameter buffer (the reference's optimizer, one native launch), so that step k + 1 renders with the parameters step k produced.  Workload (BASELINE.json metric; built by
 gomavatar_amd.workload, the same object the -m gpu parity tests check): 512x512, 55 104 Gaussians (SMPL-topology body, one
 midpoint subdivision), synthetic poses / cameras / targets already resident in HBM when the timed region starts.
 `value` counts FRAMES per second, with ONE step in flight per GPU by default (what an optimizer loop can do: step k + 1
@@ -12,9 +13,10 @@ needs step k's update).  The other operating points are measured in the same run
 
 `python bench.py --gpus N` launches itself: with WORLD_SIZE unset and N > 1 it re-executes under torch.distributed.run
 (one rank per GPU, RCCL); with fewer devices than ranks (the 1-GPU development lease) the ranks share device 0 over gloo --
-a functional proof of the N > 1 path, labelled as such.  N > 1: frame-parallel data parallelism, B frames per GPU per
-step, plus ONE all-reduce of the flat fp32 gradient buffer (951 023 floats = the reference model's parameter count)
-per step inside the timed region.  Weak scaling: per-GPU work is fixed.
+a functional proof of the N > 1 path, labelled as such.  N > 1: frame-parallel data parallelism, ONE frame per GPU per
+step by default (BASELINE configs[3]; `modes.b8_*` repeats it with 8), plus ONE all-reduce of the flat fp32 gradient buffer
+(951 023 floats = the reference model's parameter count) and the Adam step per step inside the timed region.  Weak scaling:
+per-GPU work is fixed; `config.local_only_fps` is the same loop without the collective (what N x one GPU would do).
 
 Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.  When such a
 region is shorter than 0.25 s (the driver's K = 20 is 17 ms) it is REPEATED -- each repetition again exactly K steps between
@@ -43,7 +45,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
 MIN_TIMED_S = 0.25
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
+ADAM_LR = 1e-9   # the reference's Adam arithmetic and traffic at a rate that leaves the synthetic workload the parity tests check unchanged over 10^4 timed steps
 
 
 def parse():
@@ -54,7 +57,7 @@ def parse():
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
     ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames cycled through")
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU, rendered by one batched launch sequence")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU, rendered by one batched launch sequence (0 = 8 at N = 1, 1 at N > 1)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
                          "1 (default) = strictly one step after the other, as an optimizer loop runs")
@@ -62,7 +65,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step one by one instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the other operating points (modes) and the raster-only / full-step figures")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames per CPU-baseline row at all cores (1 at one thread)")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="timed frames per CPU-baseline row (median; after 3 warm-up frames at M, 1 at S)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (cfg 3 at 1024^2 / 540^2, cfg 5) of the `configs` block")
+    ap.add_argument("--no-adam", action="store_true", help="leave the optimizer step out of the timed loop (round-2 behaviour)")
     ap.add_argument("--task-grid-pct", type=int, default=0, help="GOM_OPT_TASK_GRID_PCT, 10..100 (0 = library default, 100)")
     ap.add_argument("--bwd-mode", type=int, default=-1, help="GOM_OPT_BWD_MODE (-1 = library default)")
     ap.add_argument("--sort-mode", type=int, default=-1, help="GOM_OPT_SORT_MODE (-1 = library default)")
@@ -132,11 +137,15 @@ class Runner:
         n_own = 3 * wl.N + 9 * wl.F
         pad = MODEL_PARAMS_M if wl.subdiv == 1 else n_own   # padded to the reference model's full parameter count: the collective moves what a real step moves
         self.slots = []
+        self.adam = not args.no_adam
+        from gomavatar_amd.parallel import FlatAdam
         for k in range(S):
             st = wl.step(B)
             fp = FrameParallel(shapes_for_model(wl.N, wl.F), wl.device, pad_to=pad)
             for name in ("vertices", "so3", "scale", "appearance"):
                 st.grads[name] = fp.grads[name]
+                fp.params[name].copy_(wl.params[name])   # every slot trains its own replica of the parameters (S > 1: independent steps)
+            opt = FlatAdam(fp, {"default": ADAM_LR}) if self.adam else None
             if args.seg_shift:
                 st.state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
             if args.task_grid_pct:
@@ -145,12 +154,12 @@ class Runner:
                 st.state.set_option(_lib.OPT_BWD_MODE, args.bwd_mode)
             if args.sort_mode >= 0:
                 st.state.set_option(_lib.OPT_SORT_MODE, args.sort_mode)
-            self.slots.append(dict(step=st, fp=fp, stream=torch.cuda.Stream(device=wl.device)))   # (the legacy NULL stream cannot be graph-captured)
+            self.slots.append(dict(step=st, fp=fp, opt=opt, params=dict(fp.params.items()), stream=torch.cuda.Stream(device=wl.device)))   # (the legacy NULL stream cannot be graph-captured)
         self.batches = wl.batches(self.slots[0]["step"])
         assert self.batches, "not enough frames for one batch"
         self.payload = int(self.slots[0]["fp"].grads.flat.numel())
 
-    def run_step(self, i):
+    def run_step(self, i, collective=True):
         torch = self.torch
         bt = self.batches[i % len(self.batches)]
         sl = self.slots[i % self.S]
@@ -158,21 +167,24 @@ class Runner:
             sl["step"].cam = bt["cam"]
             if self.B > 1:
                 sl["step"].cams_dev = bt["cams_dev"]   # this batch's device camera array: resident like its targets and poses (one recorded graph per batch)
-            sl["step"].forward_backward(self.wl.params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
-            sl["fp"].all_reduce_grads()  # no-op at world size 1
+            sl["step"].forward_backward(sl["params"], bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
+            if collective:
+                sl["fp"].all_reduce_grads()  # no-op at world size 1
+            if sl["opt"] is not None:
+                sl["opt"].step(1.0 / self.B)  # mean over the frames of the batch (the collective has averaged over the ranks)
 
-    def region(self, steps, warmup, first=0):
+    def region(self, steps, warmup, first=0, collective=True):
         """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
         torch = self.torch
         for i in range(warmup):
-            self.run_step(first + i)
+            self.run_step(first + i, collective)
         torch.cuda.synchronize()
         if self.world > 1:
             import torch.distributed as dist
             dist.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            self.run_step(first + warmup + i)
+            self.run_step(first + warmup + i, collective)
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
@@ -183,14 +195,14 @@ class Runner:
             el = float(t.item())
         return el
 
-    def measure(self, steps, warmup):
+    def measure(self, steps, warmup, collective=True):
         """-> (total seconds, total steps, regions).  Regions shorter than MIN_TIMED_S are repeated (same brackets, no new warm-up)."""
-        el = self.region(steps, warmup)
+        el = self.region(steps, warmup, collective=collective)
         total, n = el, 1
         if el < MIN_TIMED_S:
             reps = min(200, int(math.ceil(MIN_TIMED_S * 1.2 / max(el, 1e-6))) - 1)   # el is the MAX over ranks: every rank repeats equally often
             for r in range(reps):
-                total += self.region(steps, 0, first=(r + 1) * steps)
+                total += self.region(steps, 0, first=(r + 1) * steps, collective=collective)
                 n += 1
         return total, steps * n, n
 
@@ -306,35 +318,45 @@ def extra_figures(torch, wl):
 
 
 def cpu_baseline(torch, args, wl_M, batched_step, batched_batch):
-    """The oracle (`kind: port`) on this box's host cores: fwd+bwd of the render path (geometry + raster + L1 losses), 1 thread
-    and all physical cores, at S (BASELINE configs[0]: 13 776 Gaussians) and M (the metric workload).  Bounded sample."""
+    """The oracle (`kind: port`) on this box's host cores, SURVEY.md 8(d)'s protocol: the render path (geometry + raster + L1 losses)
+    forward alone and forward + backward, 1 thread and all physical cores, at S (BASELINE configs[0]: 13 776 Gaussians) and M (the
+    metric workload); warm-up frames first, then the MEDIAN of `--cpu-frames` timed frames.  Bounded sample (about 20-30 s)."""
     from oracle import geometry as og, raster as orast
     from gomavatar_amd.workload import MetricWorkload
+    import statistics
     phys, logical = physical_cores(), os.cpu_count() or 1
     rows, keep = {}, {}
-    wl_S = MetricWorkload(wl_M.device, subdiv=0, img=wl_M.img, n_frames=max(2, args.cpu_frames + 1))
+    n_timed = max(1, args.cpu_frames)
+    wl_S = MetricWorkload(wl_M.device, subdiv=0, img=wl_M.img, n_frames=8)
     for tag, wl in (("S", wl_S), ("M", wl_M)):
+        n_warm = 3 if tag == "M" else 1
         for k in (1, phys):
             torch.set_num_threads(k)
             orast.set_threads(k)
-            n = 1 if k == 1 else args.cpu_frames
-            times = []
-            for i in range(n + (0 if k == 1 else 1)):
+            t_fwd, t_all = [], []
+            for j in range(n_warm + n_timed):
+                i = j % len(wl.frames)
                 fr = wl.oracle_frame(i)
-                po = {kk: v.clone().requires_grad_() for kk, v in wl.params_cpu.items()}
                 gt = wl.frames[i]
                 gt_rgb, gt_mask = gt["gt_rgb"].cpu()[None], gt["gt_mask"].cpu()[None]
-                t1 = time.perf_counter()
+                with torch.no_grad():                                          # forward alone
+                    t1 = time.perf_counter()
+                    o_rgb, o_mask, _ = og.render_path(wl.params_cpu, fr, wl.faces, wl.w25, wl.img)
+                    og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt_rgb, gt_mask)
+                    tf = time.perf_counter() - t1
+                po = {kk: v.clone().requires_grad_() for kk, v in wl.params_cpu.items()}
+                t1 = time.perf_counter()                                       # forward + backward
                 o_rgb, o_mask, _ = og.render_path(po, fr, wl.faces, wl.w25, wl.img)
                 l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, gt_rgb, gt_mask)
                 (l1 + 5.0 * l2).backward()
-                times.append(time.perf_counter() - t1)
+                ta = time.perf_counter() - t1
+                if j >= n_warm:
+                    t_fwd.append(tf); t_all.append(ta)
                 if tag == "M" and k == phys:
                     keep[i] = (o_rgb[0].detach(), o_mask[0].detach())
-            if k != 1:
-                times = times[1:]   # the first multi-threaded frame warms the thread pool / page-faults
-            rows[f"{tag}_threads{k}"] = {"frames_per_s": round(len(times) / sum(times), 3), "frames": len(times), "threads": k,
-                                         "gaussians": wl.F}
+            rows[f"{tag}_threads{k}"] = {"frames_per_s": round(1.0 / statistics.median(t_all), 3), "fwd_only_frames_per_s": round(1.0 / statistics.median(t_fwd), 3),
+                                         "median_ms_fwd_bwd": round(1e3 * statistics.median(t_all), 2), "median_ms_fwd": round(1e3 * statistics.median(t_fwd), 2),
+                                         "frames": len(t_all), "warmup_frames": n_warm, "threads": k, "gaussians": wl.F}
     # "PSNR vs ref": the BATCHED step's own image (what the timed loop renders) against the oracle's render of the same frames
     mse, n = 0.0, 0
     img = batched_step.image.reshape(batched_step.B, 4, wl_M.img, wl_M.img)
@@ -346,19 +368,55 @@ def cpu_baseline(torch, args, wl_M, batched_step, batched_batch):
             mse += float((dd ** 2).mean()); n += 1
     head = max((rows["M_threads1"], rows[f"M_threads{phys}"]), key=lambda r: r["frames_per_s"])   # (OpenMP over ~170 busy tiles + torch's pools: more threads are not faster here)
     cb = {"value": head["frames_per_s"], "unit": "frames/s", "cores": head["threads"], "kind": "port",
-          "sample": f"{head['frames']} frame(s) of the metric workload (fwd+bwd: geometry + raster + L1 losses) through the CPU oracle at {head['threads']} thread(s) "
-                    f"(torch + OpenMP), the faster of 1 thread / all {phys} physical cores; host has {logical} logical CPUs.  `rows`: both thread counts, "
-                    "at M (the metric workload) and S (BASELINE configs[0])",
+          "sample": f"median of {head['frames']} frames (after {head['warmup_frames']} warm-up frames) of the metric workload, fwd+bwd: geometry + raster + L1 losses, through the CPU oracle at "
+                    f"{head['threads']} thread(s) (torch + OpenMP), the faster of 1 thread / all {phys} physical cores; host has {logical} logical CPUs.  `rows`: both thread counts, "
+                    "forward alone and forward + backward, at M (the metric workload) and S (BASELINE configs[0])",
           "rows": rows, "physical_cores": phys, "logical_cpus": logical}
     return cb, (round(-10.0 * math.log10(max(mse / n, 1e-30)), 2) if n else None)
 
 
+def other_configs(torch, dev, args):
+    """The BASELINE configs the headline is not quoted on, each on its own synthetic workload: cfg 3 (55 104 Gaussians at 1024^2, and at
+    540^2 -- the size exps/snapshot_f3c.yaml really uses) and cfg 5 (220 416 Gaussians at 1024^2, "HBM-bound stress").  Frames/s one frame
+    at a time and 8 per launch sequence (one step in flight, Adam inside), and the roofline fraction of the kernel that dominates there."""
+    from gomavatar_amd.workload import MetricWorkload
+    out = {}
+    for name, subdiv, img in (("cfg3_M_1024", 1, 1024), ("cfg3_M_540", 1, 540), ("cfg5_L_1024", 2, 1024)):
+        try:
+            wl = MetricWorkload(dev, subdiv=subdiv, img=img, n_frames=8)
+            row = {"gaussians": wl.F, "image": [img, img]}
+            for b in (1, 8):
+                r = Runner(wl, b, 1, not args.no_graph, 1, args)
+                el, ns, _ = r.measure(40 if b > 1 else 150, 8)
+                r.check()
+                iso, D = r.kernel_profile(6)
+                ab = algorithmic_bytes(wl.F * b, D, img * img * b, 4)
+                dom = max(iso, key=iso.get)
+
+                def frac(k):
+                    return round(ab[k] / (iso[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get(k, 0) > 0 and ab[k] else 0.0
+                row[f"b{b}"] = {"fps": round(b * ns / el, 1), "ms_per_step": round(1e3 * el / ns, 4), "pairs_D": int(D),
+                                "dominant": {"kernel": "k_" + dom, "avg_us": round(iso[dom] * 1e3, 2), "algorithmic_bytes": int(ab[dom]), "frac": frac(dom)},
+                                "raster_backward": {"kernel": "k_seg_bwd", "avg_us": round(iso["seg_bwd"] * 1e3, 2), "algorithmic_bytes": int(ab["seg_bwd"]), "frac": frac("seg_bwd")}}
+                del r
+            out[name] = row
+            del wl
+            torch.cuda.empty_cache()
+        except Exception as e:   # report, do not hide
+            out[name] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
 def read_profile_json(name):
-    p = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
+    """A PMC summary committed under profiles/ (collected by scripts/collect_profiles.sh in its OWN rocprofv3 passes, not in this run):
+    -> (dict, stamp) with the file's path and sha256 so that the bench line says where `traffic` / `valu` come from."""
+    import hashlib
+    rel = os.path.join("profiles", f"{PROFILE_TAG}_{name}.json")
     try:
-        return json.load(open(p))
+        raw = open(os.path.join(ROOT, rel), "rb").read()
+        return json.loads(raw), {"file": rel, "sha256_16": hashlib.sha256(raw).hexdigest()[:16], "measured_in_this_run": False}
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -393,6 +451,8 @@ def main():
     from gomavatar_amd import _lib
     from gomavatar_amd.workload import MetricWorkload
 
+    if args.batch <= 0:
+        args.batch = 8 if world == 1 else 1      # N = 1: BASELINE configs[1] (the metric); N > 1: configs[3], one frame per GPU per step
     img, B, S = args.img, max(1, args.batch), max(1, args.inflight)
     wl = MetricWorkload(dev, subdiv=args.subdiv, img=img, n_frames=max(args.frames, B), rank=rank)
     F, N = wl.F, wl.N
@@ -403,9 +463,12 @@ def main():
     main_run.check()
     value = world * B * n_steps / elapsed
 
-    # ---------------- the collective alone (N > 1) ----------------
+    # ---------------- the collective alone, and the same loop without it (N > 1) ----------------
     allreduce_us = None
+    local_only_fps = None
     if world > 1:
+        el_l, ns_l, _ = main_run.measure(args.steps, min(args.warmup, 10), collective=False)   # (MAX over ranks, like `value`)
+        local_only_fps = round(world * B * ns_l / el_l, 1)
         fp = main_run.slots[0]["fp"]
         for _ in range(5):
             fp.all_reduce_grads()
@@ -421,8 +484,13 @@ def main():
     iso, D_avg = alone_run.kernel_profile(12)
     abytes = algorithmic_bytes(F * B, D_avg, img * img * B, 4)   # per launch: B frames (D_avg already counts all B)
     dom = max(iso, key=iso.get)                                   # dominant kernel = the one that costs most when it owns the chip
-    traffic_j = read_profile_json("traffic") if (args.subdiv == 1 and img == 512) else None
-    valu_j = read_profile_json("valu") if (args.subdiv == 1 and img == 512) else None
+    traffic_j, traffic_src = read_profile_json("traffic") if (args.subdiv == 1 and img == 512) else (None, None)
+    valu_j, valu_src = read_profile_json("valu") if (args.subdiv == 1 and img == 512) else (None, None)
+    # a summary collected for another batch size, or before a kernel of today's step existed, says nothing about this run: dropped
+    if traffic_j and (traffic_j.get("batch") != B or ("k_" + dom) not in traffic_j or "k_seg_bwd" not in traffic_j):
+        traffic_j, traffic_src = None, None
+    if valu_j and (valu_j.get("batch", B) != B or ("k_" + dom) not in valu_j):
+        valu_j, valu_src = None, None
 
     def kernel_row(name, us):
         gbs = abytes[name] / (us * 1e-6) / 1e9 if us > 0 and abytes[name] else 0.0
@@ -439,7 +507,7 @@ def main():
                     (abytes["seg_bwd"] + abytes["preprocess_bwd"]) / ((iso["seg_bwd"] + iso["preprocess_bwd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 # These kernels are VALU-issue bound, not bandwidth bound: the second axis, from the SQ counters
                 # of the PMC pass (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES and useful lanes), when profiles/ holds it
-                "valu": (valu_j or {}).get("k_" + dom)}
+                "valu": (valu_j or {}).get("k_" + dom), "traffic_source": traffic_src, "valu_source": valu_src}
 
     out = {
         "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians; PSNR vs ref",
@@ -457,14 +525,26 @@ def main():
         "timed_regions": regions,
         "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, {B} frames per GPU per step "
                                f"(one batched launch sequence), {S} step(s) in flight per GPU"
-                               + (", + all-reduce of the flat grad buffer" if world > 1 else ""),
+                               + (", + all-reduce of the flat grad buffer" if world > 1 else "") + ("" if args.no_adam else ", + Adam"),
                    "gaussians": F, "image": [img, img], "frames_per_step": world * B, "frames_per_gpu_per_step": B,
                    "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S,
-                   "allreduce_floats": main_run.payload if world > 1 else 0, "allreduce_us": allreduce_us,
+                   "optimizer": (f"Adam on the flat parameter buffer inside the timed loop (gom_adam_flat, lr {ADAM_LR:g}: the reference's arithmetic, a rate that "
+                                 "keeps the synthetic workload fixed)" if not args.no_adam else None),
+                   "allreduce_floats": main_run.payload if world > 1 else 0, "allreduce_us": allreduce_us, "allreduce_impl": "torch.distributed all_reduce (RCCL ReduceOp.AVG)" if world > 1 else None,
+                   "local_only_fps": local_only_fps,
                    "backend": (("rccl" if backend == "nccl" else backend) + (f" ({world} ranks share {n_dev} device(s): functional proof, not a scaling number)" if shared else ""))
                    if world > 1 else None},
         "roofline": roofline,
     }
+
+    # ---------------- N > 1: the same job with 8 frames per GPU per step (the batched launch of the N = 1 metric) ----------------
+    if world > 1 and not args.no_modes and B != 8:
+        r8 = Runner(wl, 8, 1, not args.no_graph, world, args)
+        el8, ns8, _ = r8.measure(max(20, args.steps // 4), 10)
+        el8l, ns8l, _ = r8.measure(max(20, args.steps // 4), 5, collective=False)
+        out["modes"] = {"unit": "frames/s", "what": "whole job, b = frames per GPU per step; local_only = the same loop without the collective",
+                        f"b{B}_per_gpu": round(value, 1), "b8_per_gpu": round(world * 8 * ns8 / el8, 1), "b8_per_gpu_local_only": round(world * 8 * ns8l / el8l, 1)}
+        del r8
 
     # ---------------- the other operating points (N = 1) ----------------
     if world == 1 and not args.no_modes:
@@ -484,6 +564,11 @@ def main():
             del r_
         out["modes"] = {"unit": "frames/s", "what": "render path fwd+bwd (b = frames per launch sequence, inflight = independent steps on separate streams)", **modes}
         out["modes"].update(extra_figures(torch, wl))
+
+    # ---------------- the other BASELINE configs (N = 1) ----------------
+    if world == 1 and not args.no_configs and not args.no_modes:
+        out["configs"] = {"unit": "frames/s", "what": "render path fwd+bwd + Adam, one step in flight; frac = SURVEY 8(d) bytes / HIP-event duration / 8 TB/s",
+                          **other_configs(torch, dev, args)}
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only) ----------------
     if world == 1 and not args.no_cpu_baseline:

@@ -111,6 +111,40 @@ class FrameParallel:
         return torch.optim.Adam(groups, betas=betas, eps=eps)
 
 
+class FlatAdam:
+    """torch.optim.Adam(param_groups, betas, eps) -- the reference's optimizer, train.py:263-267 -- as ONE native launch over the flat
+    parameter buffer (`gom_adam_flat`, csrc/frame_parallel.hip): per-tensor learning rates (`lrs[name]`, or `lrs['default']`), moments
+    in two more flat buffers, the step count on the host.  Device buffers only: there is no CPU path (the gloo tests use `make_adam`)."""
+
+    def __init__(self, fp: "FrameParallel", lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8):
+        import ctypes
+        from . import _lib
+        if not fp.params.flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the GPU only (libgom_hip.so); use FrameParallel.make_adam on the host")
+        self.fp, self._lib, self._ct = fp, _lib, ctypes
+        self.betas, self.eps, self.t = (float(betas[0]), float(betas[1])), float(eps), 0
+        n = fp.params.numel
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=fp.params.flat.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.names = [name for name, _, _, _ in fp.params.layout]
+        bounds = [off for _, _, off, _ in fp.params.layout] + [fp.params.layout[-1][2] + fp.params.layout[-1][3]]
+        self._begin = (ctypes.c_int64 * len(bounds))(*bounds)
+        self.base_lr = [float(lrs.get(name, lrs.get("default", 1e-3))) for name in self.names]
+        self.lr = list(self.base_lr)
+
+    def decay(self, iter_step: int, lr_decay_steps: float) -> None:
+        """update_lr (train.py:166-175)."""
+        self.lr = [b * 0.1 ** (iter_step / lr_decay_steps) for b in self.base_lr]
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        """One Adam step on the current stream, reading `fp.grads.flat` (as the all-reduce left it)."""
+        self.t += 1
+        lr = (self._ct.c_float * len(self.lr))(*self.lr)
+        fp, P = self.fp, self._lib.ptr
+        self._lib.check(self._lib.load().gom_adam_flat(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq), len(self.lr),
+                                                       self._begin, lr, self.t, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+
+
 def shapes_for_model(n_verts: int, n_faces: int, extra: Iterable[Tuple[str, Tuple[int, ...]]] = ()):
     """The hot path's trainables in the reference's layouts (models/model.py:74-85,
     appearance_module.py:14) followed by any extra tensors (MLP weights...)."""

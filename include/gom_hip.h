@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 4
+#define GOM_ABI_VERSION 5
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -421,6 +421,17 @@ int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, v
  *     hipGraph picks up new cameras without re-capture.  f->cam only provides H and W.
  *   - results are bit-identical to B separate gom_frame_forward_backward calls. */
 int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_t B, const GomCamera *cams_device, uint32_t flags, void *stream);
+
+/* ---- frame-parallel step, behind the gradient -----------------------------------------------------------------
+ * Adam on the FLAT parameter buffer: the reference's torch.optim.Adam(param_groups, betas=(0.9, 0.999)) (train.py:263-267,
+ * per-group learning rates models/model.py:305-327, decayed by update_lr train.py:166-175) as one launch over the buffer the
+ * gradient all-reduce leaves behind.  Segment i = elements [seg_begin[i], seg_begin[i + 1]) with learning rate seg_lr[i] (host
+ * arrays, n_segments + 1 bounds); elements outside every segment (padding) are left alone.  `step` counts from 1 (bias correction);
+ * the gradient is multiplied by grad_scale first (1 / world size when the collective summed).  No weight decay, no amsgrad. */
+#define GOM_ADAM_MAX_SEGMENTS 12
+int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                  const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
+                  void *stream);
 
 #ifdef __cplusplus
 }

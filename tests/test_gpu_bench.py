@@ -35,8 +35,11 @@ def test_bench_line_contract_single_gpu():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
     assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["traffic_source"] is None or (r["traffic_source"]["measured_in_this_run"] is False and len(r["traffic_source"]["sha256_16"]) == 16)
+    assert d["config"]["optimizer"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and set(c["rows"]) >= {"S_threads1", "M_threads1"}
+    assert c["rows"]["M_threads1"]["fwd_only_frames_per_s"] > c["rows"]["M_threads1"]["frames_per_s"] > 0
     assert d["psnr_vs_oracle_db"] > 80.0
 
 
@@ -50,6 +53,37 @@ def test_bench_launches_itself_for_two_ranks():
         if "Connection closed by peer" not in str(e) and "connection closed" not in str(e).lower():
             raise
         d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 16 and d["config"]["allreduce_floats"] == 951023
+    # N > 1 defaults to BASELINE configs[3]'s literal operating point: ONE frame per GPU per step, all-reduce + Adam inside the timed loop
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["frames_per_gpu_per_step"] == 1 and d["config"]["allreduce_floats"] == 951023
     assert d["config"]["allreduce_us"] > 0 and d["config"]["parallelism"] == "frame-dp2" and d["value"] > 0
+    assert d["config"]["optimizer"] and d["config"]["local_only_fps"] >= d["value"] * 0.5 and d["modes"]["b8_per_gpu"] > 0
     assert "cpu_baseline" not in d     # rank 0 at N = 1 only
+
+
+def test_flat_adam_is_torch_adam():
+    """gom_adam_flat (one launch over the flat parameter buffer, per-tensor learning rates, update_lr's decay) against
+    torch.optim.Adam with the same groups -- the reference's optimizer (train.py:263-267) -- over several steps."""
+    import torch
+    from gomavatar_amd.parallel import FlatAdam, FrameParallel, shapes_for_model
+    shapes = shapes_for_model(1001, 2003, extra=[("mlp.w", (7, 13)), ("mlp.b", (5,))])
+    fp = FrameParallel(shapes, "cuda", pad_to=3 * 1001 + 9 * 2003 + 96 + 33)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    fp.params.flat.copy_(torch.randn(fp.params.numel, device="cuda", generator=g))
+    lrs = {"vertices": 5e-4, "so3": 1e-3, "default": 2e-3}
+    ref_p = {k: v.detach().clone().requires_grad_() for k, v in fp.params.items()}
+    ref = torch.optim.Adam([{"params": [ref_p[k]], "lr": lrs.get(k, lrs["default"]), "name": k} for k in ref_p], betas=(0.9, 0.999))
+    opt = FlatAdam(fp, lrs)
+    pad0 = fp.grads.flat[fp.params.numel:].clone()
+    for it in range(6):
+        fp.grads.flat.copy_(torch.randn(fp.grads.numel, device="cuda", generator=g) * (10.0 ** (it - 3)))
+        for k in ref_p:
+            ref_p[k].grad = fp.grads[k].clone() * 0.5
+        for pg in ref.param_groups:
+            pg["lr"] = lrs.get(pg["name"], lrs["default"]) * 0.1 ** (it / 100.0)
+        opt.decay(it, 100.0)
+        opt.step(grad_scale=0.5)
+        ref.step()
+        for k in ref_p:
+            a, b = fp.params[k], ref_p[k].detach()
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (it, k, float((a - b).abs().max()))
+    assert opt.t == 6 and torch.isfinite(fp.params.flat).all()

@@ -145,7 +145,7 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
     # the sum over the frames.  Two comparisons:
     #   (c1) the rasterizer + geometry backward GIVEN THE SAME IMAGE GRADIENT (the oracle is driven with the HIP path's own
     #        dL/d(image)): what remains is fp32 arithmetic and the rasterizer's threshold flips -- and the flips are ATTRIBUTED: the
-    #        Gaussians whose footprint covers a pixel where the two forwards took different branches (|d image| > 1e-4 or another
+    #        Gaussians that reach (alpha >= 1/255) a pixel where the two forwards took different branches (|d image| > 1e-4 or another
     #        n_contrib) are set aside, the rest must agree to 2e-4 of the largest gradient; the ones set aside are bounded separately;
     #   (c2) the whole step including the loss: L1's sign() adds its own discontinuity (inside the body both masks sit within 1e-4 of
     #        1, so sign(mask - target) is decided in the last bits, fp32 against float64) -- bounded at 3x what was measured.
@@ -177,11 +177,17 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
         flip = (np.abs(image[b].cpu().numpy().astype(np.float64) - f64["color"]).max(axis=0) > IMG_TOL) | (e["n_contrib"][b] != f64["n_contrib"])
         ys, xs = np.nonzero(flip)
         n_flip_px += len(ys)
-        # Gaussians (= faces) whose tile rect reaches a tile with such a pixel, and the vertices of those faces
+        # the Gaussians (= faces) that reach such a pixel with alpha >= 1/255 -- the entries of its tile list whose blend weight or
+        # whose transmittance behind the flip the pixel's gradient carries -- and the vertices of those faces
         bad_face = np.zeros(P, bool)
-        rect = f64["rect"]
-        for ty, tx in set(zip((ys // 16).tolist(), (xs // 16).tolist())):
-            bad_face |= (f64["radii"] > 0) & (rect[:, 0] <= tx) & (tx < rect[:, 2]) & (rect[:, 1] <= ty) & (ty < rect[:, 3])
+        T_ = (img // 16)
+        for y_, x_ in zip(ys.tolist(), xs.tolist()):
+            t_ = (y_ // 16) * T_ + (x_ // 16)
+            lst = f64["point_list"][f64["ranges"][t_, 0]:f64["ranges"][t_, 1]].astype(np.int64)
+            dx, dy = f64["xy"][lst, 0] - x_, f64["xy"][lst, 1] - y_
+            co = f64["conic_opacity"][lst]
+            power = -0.5 * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy
+            bad_face[lst[(power <= 0) & (co[:, 3] * np.exp(power) >= 0.5 / 255.0)]] = True      # (half the threshold: the entries AT the threshold are the flips)
         bad_vert = np.zeros(wl.params_cpu["vertices"].shape[1], bool)
         bad_vert[faces_np[bad_face].reshape(-1)] = True
         n_set_aside += int(bad_face.sum())

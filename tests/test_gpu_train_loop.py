@@ -48,10 +48,13 @@ def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, 
     opt = torch.optim.Adam(student.get_param_groups(train_cfg), betas=(0.9, 0.999))
     rows, worst = [], {}
 
+    failures = []
+
     def hold(name, it, got, ref, rel, absol=0.0):
         err = abs(got - ref)
-        worst[name] = max(worst.get(name, 0.0), err / max(abs(ref), 1e-30))
-        assert err <= rel * abs(ref) + absol, (name, it, got, ref)
+        worst[name] = max(worst.get(name, 0.0), max(err - absol, 0.0) / max(abs(ref), 1e-30))
+        if err > rel * abs(ref) + absol:
+            failures.append((name, it, got, ref))                # (all deviations are printed before the first one fails the test)
 
     for it in range(n1 + n2):
         fr = {k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(it, img).items()}
@@ -68,7 +71,8 @@ def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, 
             hold(k, it, float(items[k]["unscaled"].detach()), float(g[k][it]), 2e-3 if k != "mask" else 2e-2, 1e-7 if k != "mask" else 2e-5)
         hold("total", it, float(loss.detach()), float(g["total"][it]), 1e-3)
         p8 = float(psnr(from_8b(to_8b(rgb.detach()[0])), from_8b(to_8b(fr["target_rgbs"][0]))))
-        assert abs(p8 - float(g["psnr8"][it])) <= 0.02, (it, p8, float(g["psnr8"][it]))
+        if abs(p8 - float(g["psnr8"][it])) > 0.02:
+            failures.append(("psnr8", it, p8, float(g["psnr8"][it])))
         worst["psnr8_db"] = max(worst.get("psnr8_db", 0.0), abs(p8 - float(g["psnr8"][it])))
         assert abs(float(rgb.detach().mean()) - float(g["rgb_mean"][it])) <= 2e-5 and abs(float(mask.detach().mean()) - float(g["mask_mean"][it])) <= 2e-5
         hold("rgb_l2", it, float(rgb.detach().norm()), float(g["rgb_l2"][it]), 1e-4)
@@ -94,9 +98,11 @@ def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, 
         t_rgbs, t_masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
         fr["target_rgbs"] = tu.unpack(t_rgbs, t_masks, torch.ones(1, 3, device="cuda"))
     _, value = tu.eval_frame(student, fr)
-    assert abs(value - float(g["eval_psnr"])) <= 0.02, (value, float(g["eval_psnr"]))
+    if abs(value - float(g["eval_psnr"])) > 0.02:
+        failures.append(("eval_psnr", n1 + n2, value, float(g["eval_psnr"])))
     with capsys.disabled():
         print("\n[train loop S -> subdivide -> M @ 512^2] iteration: total (HIP / oracle), PSNR8 (HIP / oracle)")
         for it, a, b, c, d in rows[::3] + rows[-1:]:
             print(f"  it {it:2d}: {a:.6f} / {b:.6f}   {c:.3f} / {d:.3f} dB")
         print("  worst relative deviations: " + "  ".join(f"{k} {v:.1e}" for k, v in sorted(worst.items())) + f"   eval PSNR {value:.3f} vs {float(g['eval_psnr']):.3f}")
+    assert not failures, failures[:8]
