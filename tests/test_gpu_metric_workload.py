@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 
 IMG_TOL, FLIP_RATE, MEAN_TOL = 1e-4, 2e-4, 2e-6     # as tests/test_gpu_raster.py
 # |err| / max|g| bounds (median, q99, q99.9, max), <= 3x the values measured on MI355X (printed with -s), per parameter:
-#   BOUND_CLEAN      same image gradient, Gaussians under a flipped pixel set aside: max
-#   BOUND_SAME_DIMG  same image gradient, all Gaussians
-#   BOUND_STEP       whole step including the L1 loss's sign()
-BOUND_CLEAN = dict(vertices=2e-4, so3=2e-4, scale=2e-4, appearance=2e-4)
-BOUND_SAME_DIMG = dict(vertices=(1e-5, 2e-3, 5e-2, 0.25), so3=(1e-5, 2e-3, 5e-2, 0.25), scale=(1e-5, 2e-3, 5e-2, 0.25), appearance=(1e-5, 2e-3, 5e-2, 0.25))
-BOUND_STEP = dict(vertices=(1e-5, 2e-3, 5e-2, 0.25), so3=(1e-5, 2e-3, 5e-2, 0.25), scale=(1e-5, 2e-3, 5e-2, 0.25), appearance=(1e-5, 2e-3, 5e-2, 0.25))
+#   MAX_SAME_DIMG    HIP against the float64 oracle driven with the HIP path's own image gradient: the single worst element
+#   BOUND_VS_FP32    HIP against the fp32 build of the oracle, same image gradient
+#   BOUND_STEP       whole step including the L1 loss's sign(), against the float64 oracle (round 2's bounds here were 1e-5 / 2e-3 / 5e-2 / 0.25)
+MAX_SAME_DIMG = dict(vertices=1e-2, so3=6.5e-2, scale=0.18, appearance=2e-2)                      # measured 3.1e-3 / 2.1e-2 / 5.8e-2 / 6.7e-3 (worst of 8 frames)
+BOUND_VS_FP32 = dict(vertices=(5e-8, 6e-6, 7e-4, 1e-2), so3=(3e-9, 1.2e-6, 9e-5, 8e-2), scale=(1.2e-9, 4e-7, 9e-5, 0.15), appearance=(4e-8, 5e-6, 2e-5, 2e-2))
+BOUND_STEP = dict(vertices=(7e-8, 1e-4, 2.2e-3, 7.5e-2), so3=(4e-9, 1e-5, 2.6e-4, 6.5e-2), scale=(2e-9, 9e-6, 2.5e-4, 0.18), appearance=(7e-8, 6e-6, 1e-4, 2e-2))
 
 
 @pytest.fixture(scope="module")
@@ -162,6 +162,7 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
     ref2 = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in wl.params_cpu.items()}
     worst1 = {k: (0.0, 0.0, 0.0, 0.0) for k in names}; worst1_clean = {k: 0.0 for k in names}; worst2 = {k: (0.0, 0.0, 0.0, 0.0) for k in names}
     n_flip_px = n_set_aside = 0
+    worst32 = {k: (0.0, 0.0, 0.0, 0.0) for k in names}; worst_h32 = {k: (0.0, 0.0, 0.0, 0.0) for k in names}; worst_ratio = {k: 0.0 for k in names}; diag = []
     faces_np = wl.faces.numpy()
     for b in range(B):
         got_b = frame_grads[b] if frame_grads is not None else grads
@@ -173,6 +174,11 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
         g1 = {k: po[k].grad.clone() for k in names}
         for k in names:
             po[k].grad = None
+        # the yardstick: the fp32 build of the ORACLE, same inputs, same image gradient -- what fp32 arithmetic alone does to these gradients
+        p32 = {k: v.clone().requires_grad_() for k, v in wl.params_cpu.items()}
+        _, _, aux32 = og.render_path(p32, wl.oracle_frame(b), wl.faces, wl.w25, img)
+        aux32["img"].backward(gradient=dimg[b].cpu())
+        g32 = {k: p32[k].grad.double() for k in names}
         f64 = orast.forward(aux["cam"], aux["xyz"].detach().numpy(), aux["cov6"].detach().numpy(), aux["feat"].detach().numpy(), np.ones(P), dtype=np.float64)
         flip = (np.abs(image[b].cpu().numpy().astype(np.float64) - f64["color"]).max(axis=0) > IMG_TOL) | (e["n_contrib"][b] != f64["n_contrib"])
         ys, xs = np.nonzero(flip)
@@ -198,6 +204,17 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
             worst1[k] = tuple(max(a, c) for a, c in zip(worst1[k], st))
             clean = float((got - g1[k]).abs()[:, keep].max()) / float(g1[k].abs().max())
             worst1_clean[k] = max(worst1_clean[k], clean)
+            st32 = grad_stats(g32[k], g1[k])
+            worst32[k] = tuple(max(a, c) for a, c in zip(worst32[k], st32))
+            sth = grad_stats(got, g32[k])
+            worst_h32[k] = tuple(max(a, c) for a, c in zip(worst_h32[k], sth))
+            # where the HIP gradient is furthest from float64: what the fp32 oracle does at that very element
+            e_h, e_o = (got - g1[k]).abs(), (g32[k] - g1[k]).abs()
+            j = int(e_h.argmax()); ch, idx = divmod(j, e_h.shape[1])
+            diag.append(f"    frame {b} d{k}[{ch},{idx}]: fp64 {float(g1[k].flatten()[j]):+.4e}  HIP {float(got.flatten()[j]):+.4e}  fp32 oracle {float(g32[k].flatten()[j]):+.4e}"
+                        f"   (max|g| {float(g1[k].abs().max()):.3e}; set aside: {bool(~keep[idx])})")
+            ratio = float((e_h.flatten().topk(min(2000, e_h.numel())).values.sum()) / max(float(e_o.flatten().topk(min(2000, e_o.numel())).values.sum()), 1e-300))
+            worst_ratio[k] = max(worst_ratio[k], ratio)
         # (c2) the whole step with the oracle's own loss
         d = wl.frames[b]
         l1, l2 = og.l1_losses(og.unpack(o_rgb, o_mask, fr["bgcolor"]), o_mask, d["gt_rgb"].cpu().double()[None], d["gt_mask"].cpu().double()[None])
@@ -214,10 +231,28 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
             print(f"[metric workload, B={B}] d{k}: |err|/max|g|  same image gradient, worst frame: median {worst1[k][0]:.1e} q99 {worst1[k][1]:.1e} q99.9 {worst1[k][2]:.1e} max {worst1[k][3]:.1e}"
                   f"  max WITHOUT the set-aside Gaussians {worst1_clean[k]:.1e}   |  whole step incl. L1 sign(), worst frame: median {worst2[k][0]:.1e} q99 {worst2[k][1]:.1e} q99.9 {worst2[k][2]:.1e} max {worst2[k][3]:.1e}"
                   f"  sum of frames: q99.9 {st[2]:.1e} max {st[3]:.1e}")
+            print(f"[metric workload, B={B}] d{k}: the fp32 ORACLE against the float64 one, same image gradient, worst frame: median {worst32[k][0]:.1e} q99 {worst32[k][1]:.1e} q99.9 {worst32[k][2]:.1e} max {worst32[k][3]:.1e}"
+                  f"   sum of the 2000 largest errors, HIP / fp32 oracle: {worst_ratio[k]:.2f}"
+                  f"   |  HIP against the fp32 ORACLE: median {worst_h32[k][0]:.1e} q99 {worst_h32[k][1]:.1e} q99.9 {worst_h32[k][2]:.1e} max {worst_h32[k][3]:.1e}")
+        print("\n".join(diag[:16]))
     for k in names:
-        # (c1): everything that is not under a flipped pixel agrees to 2e-4 of the largest gradient; with them, the tail is bounded
-        assert worst1_clean[k] <= BOUND_CLEAN[k], (k, worst1_clean[k])
-        assert all(a <= c for a, c in zip(worst1[k], BOUND_SAME_DIMG[k])), (k, worst1[k])
+        # (c1) against the float64 oracle with the same image gradient.  The yardstick is the fp32 build of the oracle itself: HIP, the
+        # fp32 oracle and the float64 oracle are three realisations whose tails are mutually alike (measured: same quantiles, and at most
+        # of the worst elements HIP and the fp32 oracle agree with EACH OTHER to four digits) -- elements whose value hangs on a
+        # threshold deep in a tile list or on a near-singular 2D covariance.  Bulk quantiles <= 3x the yardstick's, the 2 000 largest
+        # errors together <= 5x the yardstick's (measured <= 2.6x), the single worst element <= 3x the measured one.
+        for q in range(3):
+            assert worst1[k][q] <= 3.0 * worst32[k][q] + 1e-9, (k, q, worst1[k], worst32[k])
+        assert worst_ratio[k] <= 5.0, (k, worst_ratio[k])
+        assert worst1[k][3] <= MAX_SAME_DIMG[k], (k, worst1[k])
+        # like for like (fp32 against fp32), same image gradient
+        assert all(a <= c for a, c in zip(worst_h32[k], BOUND_VS_FP32[k])), (k, worst_h32[k])
         # (c2): <= 3x the measured quantiles of the whole step
         assert all(a <= c for a, c in zip(worst2[k], BOUND_STEP[k])), (k, worst2[k])
         assert all(a <= c for a, c in zip(grad_stats(grads[k].cpu().double(), ref2[k]), BOUND_STEP[k])), k
+    # Attribution of the tail to threshold flips, tested rather than asserted in a comment: it holds for the COLOUR gradient (a Gaussian's
+    # colour gradient is a plain sum of alpha T dL/dC over its pixels: setting aside the Gaussians that reach a flipped pixel takes the
+    # largest error from 1.5e-3 / 5.9e-3 to 8e-6 / 3e-5 of the largest gradient), and it does NOT hold for vertices / so3 / scale: their
+    # worst elements are not under any pixel whose image or n_contrib differs, the fp32 oracle misses the float64 value there by the same
+    # amount (yardstick above) -- conditioning of the projected covariance, not a branch.
+    assert worst1_clean["appearance"] <= 1e-4, worst1_clean
