@@ -41,6 +41,7 @@ extern "C" GomState *gom_state_create(void) {
     // development switches (A / B measurements; both default on)
     if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // the cost-ordered backward queue of the batched frame step
     if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // the frame step's loss kernel leaving the pixels of empty tiles alone
+    if (const char *e = getenv("GOM_BWD_MODE")) s->bwdMode = atoi(e);          // initial GOM_OPT_BWD_MODE (A / B runs of the whole test suite)
     if (hipGetDevice(&s->device) != hipSuccess) {
         gom_set_error("hipGetDevice failed (no HIP device?)");
         delete s;
@@ -97,7 +98,7 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_BWD_MODE:
-            if (value < -1 || value > 1) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges) or 1 (one sub-range per barrier)"); return -1; }
+            if (value < -1 || value > 2) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges), 1 (one sub-range per barrier) or 2 (4x4-block items per DPP row)"); return -1; }
             s->bwdMode = (int)value;
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;

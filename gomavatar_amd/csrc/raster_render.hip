@@ -1498,7 +1498,17 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     tq.finish();
 }
 
+#include "seg_bwd_blk.hpp"
+
 }  // namespace
+
+#ifdef GOM_BLK_STATS
+extern "C" int gom_debug_blk_stats(unsigned long long *out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_stats), sizeof(unsigned long long) * 8);
+    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 int gom_launch_sort(GomState *s, hipStream_t st) {
     const int n_tiles = s->gx * s->gy * s->B;
@@ -1588,6 +1598,16 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
+    if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (seg_bwd_blk.hpp)
+#define GOM_SBB(CC)                                                                                                       \
+    hipLaunchKernelGGL((k_seg_bwd_blk<CC>), dim3(GOM_RESIDENT(k_seg_bwd_blk<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+                       s->sub_Tend, s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, s->B > 1 && s->bwdOrderReady ? s->bwd_order : nullptr, s->cull_masks)
+        if (C == 3) GOM_SBB(3); else GOM_SBB(4);
+#undef GOM_SBB
+        GOM_LAUNCH_CHECK();
+        return 0;
+    }
     if (s->bwdMode == 0 || (s->bwdMode < 0 && s->B > 1)) {   // two sub-ranges between barriers, opposite quadrants per wave (GOM_OPT_BWD_MODE 1: one sub-range per barrier, round 1)
 #define GOM_SBW(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_pair<CC>), dim3(GOM_RESIDENT(k_seg_bwd_pair<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \

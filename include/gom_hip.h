@@ -96,7 +96,9 @@ enum {
                                   slot until it ends).  Results do not depend on it. */
     GOM_OPT_BWD_MODE = 6,      /* render backward: 0 = a workgroup replays two consecutive sub-ranges between barriers, every wave taking
                                   diagonally opposite 8x8 quadrants in the two (evens out the quadrant imbalance of a tile); 1 = one
-                                  sub-range per barrier (round 1); -1 (default) = 0 for a batched launch, 1 for a single frame.  Same gradients, bitwise. */
+                                  sub-range per barrier (round 1); 2 (round 3) = (sub-range, 4x4 pixel block) items, one per 16-lane row of a wave, the 16
+                                  blocks of a tile dealt to the waves by survivor count; -1 (default) = auto.  0 and 1 give bitwise the same
+                                  gradients; 2 sums in another order (fp32 round-off apart), reproducible run to run and batch = single frames. */
     GOM_OPT_SORT_MODE = 5,     /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
                                   frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
                                   bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */
