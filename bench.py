@@ -314,6 +314,41 @@ def extra_figures(torch, wl):
         out["full_step_lpips_fp32_adam_b1_fps"] = round(timeit(torch, full, warm=3, chunk=5), 1)
     except Exception as e:  # report, do not hide
         out["full_step_lpips_fp32_adam_b1_fps"] = f"failed: {type(e).__name__}: {e}"
+    del lp, opt, P
+    # (iii) again, through the NATIVE path: forward half of the frame step -> LPIPS value + image gradient on the hand-written trunk
+    # (RenderStep.lpips_hook -> gom_lpips_vgg_value_and_grad) chained through `unpack` into the image gradient -> backward half ->
+    # gom_adam_flat.  bf16x3 = hi + lo bf16 planes, three MFMA passes: the reference's fp32 precision (tests/test_gpu_vgg_bf16.py:
+    # <= 1e-5 on the value against the fp32 library convolutions); bf16 = one pass, 3 % on the value.
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    from gomavatar_amd.parallel import FlatAdam, FrameParallel, shapes_for_model
+    for prec in ("bf16x3", "bf16"):
+        for b_ in (1, 8):
+            key = f"full_step_lpips_{prec}_native_adam_b{b_}_fps"
+            try:
+                st = wl.step(b_)
+                bt = wl.batches(st)[0]
+                fp = FrameParallel(shapes_for_model(N, F), dev)
+                for name in ("vertices", "so3", "scale", "appearance"):
+                    st.grads[name] = fp.grads[name]
+                    fp.params[name].copy_(wl.params[name])
+                optn = FlatAdam(fp, {"default": ADAM_LR})
+                mc = LPIPSMatrixCore(trunk_seed=0, device=dev, precision=prec)
+                hook = st.lpips_hook(mc, bt["gt_rgb"], bt["bg"], coeff=1.0)
+                pv = dict(fp.params.items())
+                stream = torch.cuda.Stream(device=dev)
+
+                def native():
+                    with torch.cuda.stream(stream):
+                        st.cam = bt["cam"]
+                        if b_ > 1:
+                            st.cams_dev = bt["cams_dev"]
+                        st.forward_backward(pv, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=True, image_grad_hook=hook)
+                        optn.step(1.0 / b_)
+                out[key] = round(b_ * timeit(torch, native, warm=3, chunk=5), 1)
+                assert torch.isfinite(fp.grads.flat).all() and torch.isfinite(st.lpips_value)
+                del st, mc, fp, optn
+            except Exception as e:  # report, do not hide
+                out[key] = f"failed: {type(e).__name__}: {e}"
     return out
 
 

@@ -312,3 +312,14 @@ int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, con
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,
                                    const float *cov6, float *dL_dmeans3D, float *dL_dcov6, float *dL_dcolors,
                                    float *dL_dopacity, float *dL_dmeans2D, hipStream_t st, const GomFaceArgs *face = nullptr);
+
+// ---- LPIPS trunk with one or two bf16 planes per tensor (vgg_bf16.hip; `*_lo` = element offset of the lo plane, 0 = plain bf16) ----
+int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *stream);
+int gom_maxpool2x2_planes(int B, int H, int W, int C, const void *x, void *y, size_t x_lo, size_t y_lo, void *stream);
+int gom_maxpool2x2_backward_planes(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo, void *stream);
+int gom_lpips_prepare_planes(int B, int H, int W, const float *rgb, void *out32, size_t out_lo, void *stream);
+int gom_lpips_unprepare_planes(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, size_t in_lo, void *stream);
+int gom_lpips_layer_forward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, size_t f_lo, void *stream);
+int gom_lpips_layer_backward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, size_t f_lo, size_t d_lo,
+                                    void *stream);

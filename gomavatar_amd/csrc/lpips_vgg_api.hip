@@ -16,6 +16,8 @@ struct GomLpipsVgg {
     const void *w_fwd[13], *w_bwd[13];
     const float *bias[13], *lin[5];
     int cin[13], cout[13];
+    int x3 = 0;                                  // GOM_LPIPS_PRECISION_BF16X3: two bf16 planes per tensor, three MFMA passes (vgg_bf16.hip)
+    size_t lo_x = 0, lo_act[13] = {}, lo_pooled[13] = {}, lo_g = 0;   // element offsets of the lo planes (0 in the plain mode)
     // workspace for (B, H, W)
     int B = 0, H = 0, W = 0;
     void *x[2] = {nullptr, nullptr};            // trunk inputs (B,H,W,32)
@@ -63,6 +65,13 @@ extern "C" GomLpipsVgg *gom_lpips_vgg_create(const void *const *w_fwd, const voi
     return h;
 }
 
+extern "C" int gom_lpips_vgg_set_precision(GomLpipsVgg *h, int32_t precision) {
+    if (!h || (precision != GOM_LPIPS_PRECISION_BF16 && precision != GOM_LPIPS_PRECISION_BF16X3)) { gom_set_error("gom_lpips_vgg_set_precision: bad argument"); return -1; }
+    if (h->x3 != (precision == GOM_LPIPS_PRECISION_BF16X3)) lp_free(h);   // other buffer sizes; the weights the handle points at must match
+    h->x3 = precision == GOM_LPIPS_PRECISION_BF16X3;
+    return 0;
+}
+
 extern "C" void gom_lpips_vgg_destroy(GomLpipsVgg *h) {
     if (!h) return;
     lp_free(h);
@@ -76,19 +85,24 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
     int hh = H, ww = W;
     // prediction and target walk the trunk as ONE batch of 2B images (twice the workgroups per launch, half the launches):
     // every forward buffer is [2][B][...], its second half is image set 1
-    auto alloc2 = [](void **p0, void **p1, size_t bytes) -> hipError_t {
-        const hipError_t e = hipMalloc(p0, 2 * bytes);
+    // (bf16x3: [hi of set 0][hi of set 1][lo of set 0][lo of set 1] -- the lo plane 2n elements behind the hi plane for both sets)
+    const size_t planes = h->x3 ? 2 : 1;
+    auto alloc2 = [planes](void **p0, void **p1, size_t bytes) -> hipError_t {
+        const hipError_t e = hipMalloc(p0, 2 * bytes * planes);
         *p1 = e == hipSuccess ? (void *)((char *)*p0 + bytes) : nullptr;
         return e;
     };
     GOM_HIP_CHECK(alloc2(&h->x[0], &h->x[1], (size_t)B * H * W * 32 * 2));
+    h->lo_x = h->x3 ? 2 * (size_t)B * H * W * 32 : 0;
     for (int i = 0; i < 13; i++) {
         if (kPoolBefore[i]) {
             hh /= 2; ww /= 2;
             GOM_HIP_CHECK(alloc2(&h->pooled[0][i], &h->pooled[1][i], (size_t)B * hh * ww * h->cin[i] * 2));
+            h->lo_pooled[i] = h->x3 ? 2 * (size_t)B * hh * ww * h->cin[i] : 0;
         }
         const size_t n = (size_t)B * hh * ww * h->cout[i];
         GOM_HIP_CHECK(alloc2(&h->act[0][i], &h->act[1][i], n * 2));
+        h->lo_act[i] = h->x3 ? 2 * n : 0;
         maxact = n > maxact ? n : maxact;
         const size_t nin = (size_t)B * hh * ww * (h->cin[i] < 64 ? 64 : h->cin[i]);
         maxact = nin > maxact ? nin : maxact;
@@ -97,8 +111,9 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
         maxsplit = sf > maxsplit ? sf : maxsplit;
         maxsplit = sb > maxsplit ? sb : maxsplit;
     }
-    for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->grad[k], maxact * 2));
-    GOM_HIP_CHECK(hipMalloc(&h->gtap, maxact * 2));
+    for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->grad[k], maxact * 2 * planes));
+    GOM_HIP_CHECK(hipMalloc(&h->gtap, maxact * 2 * planes));
+    h->lo_g = h->x3 ? maxact : 0;
     GOM_HIP_CHECK(hipMalloc((void **)&h->splitk, maxsplit * sizeof(float)));
     GOM_HIP_CHECK(hipMalloc((void **)&h->go, (size_t)B * sizeof(float)));
     h->splitk_elems = maxsplit;
@@ -107,9 +122,9 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
 }
 
 static int lp_conv(GomLpipsVgg *h, int B, int hh, int ww, int cin, int cout, const void *in, const void *wt, const float *bias, const void *mask,
-                   void *out, uint32_t flags, void *stream) {
+                   void *out, uint32_t flags, size_t in_lo, size_t out_lo, void *stream) {
     const int s = gom_conv3x3_splits(B, hh, ww, cin, cout);
-    return gom_conv3x3_bf16_splitk(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? h->splitk : nullptr, stream);
+    return gom_conv3x3_planes(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? h->splitk : nullptr, in_lo, out_lo, stream);
 }
 
 __global__ void k_fill(float *p, int n, float v) {
@@ -150,18 +165,19 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
     int rc;
     const float *img[2] = {pred, gt};
     for (int k = 0; k < 2; k++)
-        if ((rc = gom_lpips_prepare_bf16(B, H, W, img[k], h->x[k], stream))) return rc;
+        if ((rc = gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
     {
         int hh = H, ww = W;
         const void *cur = h->x[0];
+        size_t cur_lo = h->lo_x;
         for (int i = 0; i < 13; i++) {
             if (kPoolBefore[i]) {
-                if ((rc = gom_maxpool2x2_bf16(2 * B, hh, ww, h->cin[i], cur, h->pooled[0][i], stream))) return rc;
+                if ((rc = gom_maxpool2x2_planes(2 * B, hh, ww, h->cin[i], cur, h->pooled[0][i], cur_lo, h->lo_pooled[i], stream))) return rc;
                 hh /= 2; ww /= 2;
-                cur = h->pooled[0][i];
+                cur = h->pooled[0][i]; cur_lo = h->lo_pooled[i];
             }
-            if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, stream))) return rc;
-            cur = h->act[0][i];
+            if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
+            cur = h->act[0][i]; cur_lo = h->lo_act[i];
         }
     }
     {   // heads
@@ -170,8 +186,8 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
             if (kPoolBefore[i]) { hh /= 2; ww /= 2; }
             const int t = kTapIndex[i];
             if (t < 0) continue;
-            if ((rc = gom_lpips_layer_forward_nhwc_bf16(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t],
-                                                        value_partials + (size_t)t * B * GOM_LOSS_BLOCKS, stream)))
+            if ((rc = gom_lpips_layer_forward_planes(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t],
+                                                     value_partials + (size_t)t * B * GOM_LOSS_BLOCKS, h->lo_act[i], stream)))
                 return rc;
         }
     }
@@ -190,9 +206,9 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         const int hh = hs[i], ww = wsz[i], t = kTapIndex[i];
         if (t >= 0) {
             void *gh = h->gtap;
-            if ((rc = gom_lpips_layer_backward_nhwc_bf16(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh, stream))) return rc;
+            if ((rc = gom_lpips_layer_backward_planes(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh, h->lo_act[i], h->lo_g, stream))) return rc;
             if (g) {  // g = gradient w.r.t. the pooled activation feeding conv i+1
-                if ((rc = gom_maxpool2x2_backward_bf16(B, hh, ww, h->cout[i], h->act[0][i], g, gh, 1, stream))) return rc;
+                if ((rc = gom_maxpool2x2_backward_planes(B, hh, ww, h->cout[i], h->act[0][i], g, gh, 1, h->lo_act[i], h->lo_g, h->lo_g, stream))) return rc;
             }
             g = gh;
         }
@@ -200,8 +216,8 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         const void *mask = (i > 0 && !kPoolBefore[i]) ? h->act[0][i - 1] : nullptr;
         void *dst = h->grad[pp];
         pp ^= 1;
-        if ((rc = lp_conv(h, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, stream))) return rc;
+        if ((rc = lp_conv(h, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
         g = dst;
     }
-    return gom_lpips_unprepare_bf16(B, H, W, 64, g, d_pred, stream);
+    return gom_lpips_unprepare_planes(B, H, W, 64, g, d_pred, h->lo_g, stream);
 }

@@ -31,6 +31,28 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
+// ---- "bf16x3": fp32-accurate trunk on the bf16 matrix cores ---------------------------------------------------------------------
+// Every activation, gradient and weight is kept as TWO bf16 planes, hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits together:
+// 7.6e-6 relative), the lo plane `lo` elements behind the hi plane.  A convolution then runs over 3 x Cin/32 VIRTUAL input-channel
+// chunks -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) -- through the unchanged MFMA loop (fp32 accumulation; the dropped x_lo w_lo
+// term is 2^-16 of a product), i.e. three v_mfma_f32_16x16x32_bf16 where the plain mode issues one: ~830 TFLOP/s of fp32-grade peak
+// instead of the 157 TFLOP/s of v_mfma_f32_32x32x2_f32.  lo == 0 everywhere means the plain bf16 mode.
+__device__ __forceinline__ void split_bf(float v, bf16_t &hi, bf16_t &lo) { hi = f2bf(v); lo = f2bf(v - bf2f(hi)); }
+__device__ __forceinline__ void store4(bf16_t *p, size_t lo, const float (&v)[4]) {   // 4 consecutive channels: one 8-byte store per plane
+    if (lo == 0) {
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2 *>(p) = o;
+        return;
+    }
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) split_bf(v[r], h[r], l[r]);
+    *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    *reinterpret_cast<uint2 *>(p + lo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
 constexpr int kTileW = 16, kBN = 64, kKC = 32;
 constexpr int kPatchW = kTileW + 2;  // 18
 // TH = pixel rows per workgroup (2 per wave): 8 rows / 4 waves for the small deep layers, 16 rows / 8 waves for the large
@@ -54,7 +76,7 @@ template <bool RELU, bool SPLITK, int TH>
 __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
                                                       const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                       const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
-                                                      float *__restrict__ partial) {
+                                                      float *__restrict__ partial, size_t in_lo, size_t out_lo) {
     constexpr int kTileH = TH, kPatchPx = (TH + 2) * kPatchW, NT = TH * 32;
     __shared__ __attribute__((aligned(16))) bf16_t s_in[kPatchPx * kKC];   // 11 520 B (TH = 8) / 20 736 B (TH = 16)
     __shared__ __attribute__((aligned(16))) bf16_t s_w[9 * kBN * kKC];      // 36 864 B
@@ -71,18 +93,20 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunk = Cin / kKC;
+    const int nchunk = in_lo ? 3 * (Cin / kKC) : Cin / kKC;   // bf16x3: three virtual chunks per 32 input channels
     const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
     // (A register-prefetch software pipeline -- next chunk's global loads in flight during the MFMA loop -- was measured
     //  25 % SLOWER: +50 VGPRs, spills and one wave less per SIMD; latency is hidden by the 2-3 co-resident workgroups instead.)
     for (int cc = cc_lo; cc < cc_hi; cc++) {
         __syncthreads();  // the previous chunk's MFMA reads are done
+        const int sc = in_lo ? cc / 3 : cc;                                   // source chunk; the x_lo plane for the middle one of a triple
+        const bf16_t *src_plane = in + ((in_lo && cc % 3 == 1) ? in_lo : 0);
         for (int idx = tid; idx < kPatchPx * 4; idx += NT) {
             const int px = idx >> 2, part = idx & 3;
             const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const uint4 *>(in + (img + (size_t)gy * W + gx) * Cin + cc * kKC + part * 8);
+                v = *reinterpret_cast<const uint4 *>(src_plane + (img + (size_t)gy * W + gx) * Cin + sc * kKC + part * 8);
             *reinterpret_cast<uint4 *>(s_in + px * kKC + swz_part(part, px) * 8) = v;
         }
         {
@@ -142,10 +166,7 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
             }
-            uint2 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2 *>(out + pix + co) = o;
+            store4(out + pix + co, out_lo, v);
         }
     }
 }
@@ -179,7 +200,7 @@ template <bool RELU, bool SPLITK, int RPW>
 __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
                                                                 const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                                 const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
-                                                                float *__restrict__ partial) {
+                                                                float *__restrict__ partial, size_t in_lo, size_t out_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 16, NW = TH / RPW;                                  // RPW pixel rows per wave, NW waves
     constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: patch (162 / 324), weights (96 / 192)
@@ -193,7 +214,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    const int nchunk = Cin / kKC;
+    const int nchunk = in_lo ? 3 * (Cin / kKC) : Cin / kKC;   // bf16x3: three virtual chunks per 32 input channels
     const int cc_lo = SPLITK ? zs * nchunk / splits : 0, cc_hi = SPLITK ? (zs + 1) * nchunk / splits : nchunk;
     const int NS = 3 * (cc_hi - cc_lo);   // stages
 
@@ -228,7 +249,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
             if (64 * j + lane < WU) glds16(wsrc + woff[j], wb + 64 * j * 16);
         if (ky == 0) {
             unsigned char *pb = smem + ((s / 3) & 1) * kV2PatchBytes + (PU * wave) * 16;
-            const size_t coff = (size_t)cc * kKC * 2;
+            const size_t coff = in_lo ? (size_t)(cc / 3) * kKC * 2 + (cc % 3 == 1 ? in_lo * 2 : 0) : (size_t)cc * kKC * 2;   // (virtual chunk -> source chunk and plane)
 #pragma unroll
             for (int j = 0; j < PI; j++)
                 if (64 * j + lane < PU) glds16(pin[j] ? psrc[j] + coff : psrc[j], pb + 64 * j * 16);
@@ -301,18 +322,40 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
             }
-            uint2 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2 *>(out + pix + co) = o;
+            store4(out + pix + co, out_lo, v);
         }
     }
+}
+
+__device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) { f[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); f[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
+}
+// 8 consecutive channels of a tensor kept as one or two bf16 planes
+__device__ __forceinline__ void load8(const bf16_t *p, size_t lo, float (&f)[8]) {
+    unpack8(*reinterpret_cast<const uint4 *>(p), f);
+    if (lo) {
+        float l[8];
+        unpack8(*reinterpret_cast<const uint4 *>(p + lo), l);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] += l[k];
+    }
+}
+__device__ __forceinline__ float load1(const bf16_t *p, size_t lo) { return lo ? bf2f(p[0]) + bf2f(p[lo]) : bf2f(p[0]); }
+__device__ __forceinline__ void store1(bf16_t *p, size_t lo, float v) {
+    if (lo) { bf16_t h, l; split_bf(v, h, l); p[0] = h; p[lo] = l; } else p[0] = f2bf(v);
+}
+__device__ __forceinline__ void store8(bf16_t *p, size_t lo, const float (&v)[8]) {
+    const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+    store4(p, lo, a);
+    store4(p + 4, lo, b);
 }
 
 // sum of the split-K partials + bias, ReLU, mask -> bf16; 4 channels per thread
 __global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n4, int Cout, int splits, const float *__restrict__ partial,
                                                          const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out,
-                                                         int relu) {
+                                                         int relu, size_t out_lo) {
     const size_t stride = n4 * 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 a = *reinterpret_cast<const f32x4 *>(partial + 4 * i);
@@ -336,15 +379,12 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n4, int Cout, in
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
         }
-        uint2 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2 *>(out + 4 * i) = o;
+        store4(out + 4 * i, out_lo, v);
     }
 }
 
 // ---- 2x2 max-pool (NHWC bf16), 8 channels per thread ------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, bf16_t *__restrict__ y) {
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, bf16_t *__restrict__ y, size_t x_lo, size_t y_lo) {
     const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
     const size_t total = (size_t)B * Ho * Wo * C8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -352,18 +392,25 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C
         const size_t p = i / C8;
         const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
         const bf16_t *src = x + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c8 * 8;
-        uint4 q[4] = {*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + C),
-                      *reinterpret_cast<const uint4 *>(src + (size_t)W * C), *reinterpret_cast<const uint4 *>(src + (size_t)W * C + C)};
-        uint32_t o[4];
+        const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        float m[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]) + k, *w1 = reinterpret_cast<const uint32_t *>(&q[1]) + k;
-            const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]) + k, *w3 = reinterpret_cast<const uint32_t *>(&q[3]) + k;
-            const float lo = fmaxf(fmaxf(bf2f((bf16_t)(*w0 & 0xffff)), bf2f((bf16_t)(*w1 & 0xffff))), fmaxf(bf2f((bf16_t)(*w2 & 0xffff)), bf2f((bf16_t)(*w3 & 0xffff))));
-            const float hi = fmaxf(fmaxf(bf2f((bf16_t)(*w0 >> 16)), bf2f((bf16_t)(*w1 >> 16))), fmaxf(bf2f((bf16_t)(*w2 >> 16)), bf2f((bf16_t)(*w3 >> 16))));
-            o[k] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        for (int w4 = 0; w4 < 4; w4++) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4 *>(src + off[w4]), f);
+            if (x_lo) {   // bf16x3: the value is hi + lo (exact in fp32)
+                float l[8];
+                unpack8(*reinterpret_cast<const uint4 *>(src + x_lo + off[w4]), l);
+#pragma unroll
+                for (int k = 0; k < 8; k++) f[k] += l[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) m[k] = w4 == 0 ? f[k] : fmaxf(m[k], f[k]);
         }
-        *reinterpret_cast<uint4 *>(y + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        bf16_t *dst = y + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8;
+        const float lo4[4] = {m[0], m[1], m[2], m[3]}, hi4[4] = {m[4], m[5], m[6], m[7]};
+        store4(dst, y_lo, lo4);   // (a maximum is one of the inputs: hi + lo represents it exactly again)
+        store4(dst + 4, y_lo, hi4);
     }
 }
 
@@ -371,7 +418,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C
 // ReLU derivative [x > 0] of the layer that produced x (x = the pool's input = a post-ReLU activation);
 // accumulate: dx already holds another gradient (the LPIPS head's) for this activation
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
-                                                      bf16_t *__restrict__ dx, int accumulate) {
+                                                      bf16_t *__restrict__ dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo) {
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)B * Ho * Wo * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -382,43 +429,45 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(int B, int H, int W, int C
         const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = bf2f(x[base + off[k]]);
+        for (int k = 0; k < 4; k++) v[k] = load1(x + base + off[k], x_lo);
         int am = 0;
 #pragma unroll
         for (int k = 1; k < 4; k++)
             if (v[k] > v[am]) am = k;
-        const float g = bf2f(dy[i]);
+        const float g = load1(dy + i, dy_lo);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float add = (k == am && v[am] > 0.f) ? g : 0.f;
-            dx[base + off[k]] = f2bf(accumulate ? bf2f(dx[base + off[k]]) + add : add);
+            store1(dx + base + off[k], dx_lo, accumulate ? load1(dx + base + off[k], dx_lo) + add : add);
         }
     }
 }
 
 // ---- image -> trunk input: ((2x - 1) - shift) / scale, NHWC bf16 padded to 32 channels ------------------------------
-__global__ void __launch_bounds__(256) k_lpips_prepare(size_t npix, const float *__restrict__ rgb, bf16_t *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_lpips_prepare(size_t npix, const float *__restrict__ rgb, bf16_t *__restrict__ out, size_t out_lo) {
     const float shift[3] = {-0.030f, -0.088f, -0.188f}, scale[3] = {0.458f, 0.448f, 0.450f};
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
-        uint32_t w[16];
+        bf16_t c[3], cl[3] = {0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 16; k++) w[k] = 0u;
-        bf16_t c[3];
+        for (int k = 0; k < 3; k++) {
+            const float v = ((2.f * rgb[3 * p + k] - 1.f) - shift[k]) / scale[k];
+            if (out_lo) split_bf(v, c[k], cl[k]); else c[k] = f2bf(v);
+        }
+        for (int plane = 0; plane < (out_lo ? 2 : 1); plane++) {
+            const bf16_t *q = plane ? cl : c;
+            uint4 *dst = reinterpret_cast<uint4 *>(out + (plane ? out_lo : 0) + p * 32);
+            dst[0] = make_uint4((uint32_t)q[0] | ((uint32_t)q[1] << 16), (uint32_t)q[2], 0u, 0u);
 #pragma unroll
-        for (int k = 0; k < 3; k++) c[k] = f2bf(((2.f * rgb[3 * p + k] - 1.f) - shift[k]) / scale[k]);
-        w[0] = (uint32_t)c[0] | ((uint32_t)c[1] << 16);
-        w[1] = (uint32_t)c[2];
-        uint4 *dst = reinterpret_cast<uint4 *>(out + p * 32);
-#pragma unroll
-        for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+            for (int k = 1; k < 4; k++) dst[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }
 // gradient wrt the (B,H,W,3) image in [0,1] from the gradient wrt the trunk input (first 3 of Cpad channels)
-__global__ void __launch_bounds__(256) k_lpips_unprepare(size_t npix, int Cpad, const bf16_t *__restrict__ d_in, float *__restrict__ d_rgb) {
+__global__ void __launch_bounds__(256) k_lpips_unprepare(size_t npix, int Cpad, const bf16_t *__restrict__ d_in, float *__restrict__ d_rgb, size_t in_lo) {
     const float scale[3] = {0.458f, 0.448f, 0.450f};
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) d_rgb[3 * p + k] = bf2f(d_in[p * Cpad + k]) * (2.f / scale[k]);
+        for (int k = 0; k < 3; k++) d_rgb[3 * p + k] = load1(d_in + p * Cpad + k, in_lo) * (2.f / scale[k]);
     }
 }
 
@@ -428,12 +477,6 @@ __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a DPP
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;
 }
-__device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) { f[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); f[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
-}
-
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
                                                          const float *__restrict__ w, const float *__restrict__ grad_out,
@@ -506,7 +549,7 @@ __global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const
 template <bool BWD, int LPP>
 __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
                                                                         const float *__restrict__ w, const float *__restrict__ grad_out,
-                                                                        float *__restrict__ partials, bf16_t *__restrict__ d_f0) {
+                                                                        float *__restrict__ partials, bf16_t *__restrict__ d_f0, size_t f_lo, size_t d_lo) {
     constexpr int C = 8 * LPP;
     __shared__ float s_red[16];
     const size_t b = blockIdx.y;
@@ -521,8 +564,8 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
     float acc = 0.f;
     for (size_t p = grp; p < HW; p += ngrp) {
         float x[8], y[8];
-        unpack8(*reinterpret_cast<const uint4 *>(f0 + p * C + sub * 8), x);
-        unpack8(*reinterpret_cast<const uint4 *>(f1 + p * C + sub * 8), y);
+        load8(f0 + p * C + sub * 8, f_lo, x);
+        load8(f1 + p * C + sub * 8, f_lo, y);
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; k++) { s0 += x[k] * x[k]; s1 += y[k] * y[k]; }
@@ -542,15 +585,11 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
             acc += (sub == 0) ? v : 0.f;
         } else {
             const float kk = v * i0 * i0 / n0;
-            uint32_t o[4];
+            float gq[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // times the ReLU derivative of the tap's own layer (x = 0 <=> the pre-activation was clipped)
-                const float g0 = x[2 * k] > 0.f ? go * (wl[2 * k] * (x[2 * k] * i0 - y[2 * k] * i1) * i0 - x[2 * k] * kk) : 0.f;
-                const float g1 = x[2 * k + 1] > 0.f ? go * (wl[2 * k + 1] * (x[2 * k + 1] * i0 - y[2 * k + 1] * i1) * i0 - x[2 * k + 1] * kk) : 0.f;
-                o[k] = (uint32_t)f2bf(g0) | ((uint32_t)f2bf(g1) << 16);
-            }
-            *reinterpret_cast<uint4 *>(d_f0 + p * C + sub * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            for (int k = 0; k < 8; k++)   // times the ReLU derivative of the tap's own layer (x = 0 <=> the pre-activation was clipped)
+                gq[k] = x[k] > 0.f ? go * (wl[k] * (x[k] * i0 - y[k] * i1) * i0 - x[k] * kk) : 0.f;
+            store8(d_f0 + p * C + sub * 8, d_lo, gq);
         }
     }
     if (!BWD) {
@@ -573,6 +612,11 @@ extern "C" int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const vo
     return gom_conv3x3_bf16_splitk(B, H, W, Cin, Cout, in, wt, bias, mask, out, flags, 1, nullptr, stream);
 }
 
+extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                                       void *out, uint32_t flags, int splits, float *workspace, void *stream) {
+    return gom_conv3x3_planes(B, H, W, Cin, Cout, in, wt, bias, mask, out, flags, splits, workspace, 0, 0, stream);
+}
+
 extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
     const long blocks = (long)((W + kTileW - 1) / kTileW) * ((H + 7) / 8) * (Cout / kBN) * B;
     int s = 1;
@@ -581,8 +625,10 @@ extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
     return s;
 }
 
-extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
-                                       void *out, uint32_t flags, int splits, float *workspace, void *stream) {
+// in_lo / out_lo: element offsets of the lo planes of input and output (0: plain bf16); bf16x3 takes `wt` with 3 x Cin/32 chunks
+// (w_hi, w_hi, w_lo per 32 input channels: lpips.pack_conv_weight_x3)
+int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
+                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kKC || Cout % kBN) { gom_set_error("gom_conv3x3_bf16: Cin %% 32 / Cout %% 64 / sizes"); return -1; }
     if (!in || !wt || !out) { gom_set_error("gom_conv3x3_bf16: null pointer"); return -1; }
     if (splits < 1 || (splits > 1 && (!workspace || (Cin / kKC) % splits))) { gom_set_error("gom_conv3x3_bf16: bad split-K arguments"); return -1; }
@@ -608,65 +654,75 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
         else hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                            \
     } while (0)
     if (splits > 1) {
-        GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace);
+        GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace, in_lo, out_lo);
         GOM_LAUNCH_CHECK();
         const size_t n4 = (size_t)B * H * W * Cout / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, n4, Cout, splits, workspace,
-                           bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0);
+                           bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0, out_lo);
     } else if (flags & GOM_CONV_RELU) {
-        GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+        GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo);
     } else {
-        GOM_CONV_LAUNCH(false, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr);
+        GOM_CONV_LAUNCH(false, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo);
     }
 #undef GOM_CONV_LAUNCH
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gom_maxpool2x2_bf16(int B, int H, int W, int C, const void *x, void *y, void *stream) {
+extern "C" int gom_maxpool2x2_bf16(int B, int H, int W, int C, const void *x, void *y, void *stream) { return gom_maxpool2x2_planes(B, H, W, C, x, y, 0, 0, stream); }
+int gom_maxpool2x2_planes(int B, int H, int W, int C, const void *x, void *y, size_t x_lo, size_t y_lo, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % 8) { gom_set_error("gom_maxpool2x2_bf16: bad sizes"); return -1; }
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(k_maxpool2_fwd, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, B, H, W, C,
-                       (const bf16_t *)x, (bf16_t *)y);
+                       (const bf16_t *)x, (bf16_t *)y, x_lo, y_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gom_maxpool2x2_backward_bf16(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, void *stream) {
+    return gom_maxpool2x2_backward_planes(B, H, W, C, x, dy, dx, accumulate, 0, 0, 0, stream);
+}
+int gom_maxpool2x2_backward_planes(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) { gom_set_error("gom_maxpool2x2_backward_bf16: bad sizes"); return -1; }
     const size_t total = (size_t)B * (H / 2) * (W / 2) * C;
     hipLaunchKernelGGL(k_maxpool2_bwd, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0, (hipStream_t)stream, B, H, W, C,
-                       (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, accumulate);
+                       (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, accumulate, x_lo, dy_lo, dx_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gom_lpips_prepare_bf16(int B, int H, int W, const float *rgb, void *out32, void *stream) {
+extern "C" int gom_lpips_prepare_bf16(int B, int H, int W, const float *rgb, void *out32, void *stream) { return gom_lpips_prepare_planes(B, H, W, rgb, out32, 0, stream); }
+int gom_lpips_prepare_planes(int B, int H, int W, const float *rgb, void *out32, size_t out_lo, void *stream) {
     const size_t npix = (size_t)B * H * W;
     if (!rgb || !out32 || npix == 0) { gom_set_error("gom_lpips_prepare_bf16: bad arguments"); return -1; }
     hipLaunchKernelGGL(k_lpips_prepare, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, npix, rgb,
-                       (bf16_t *)out32);
+                       (bf16_t *)out32, out_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gom_lpips_unprepare_bf16(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, void *stream) {
+extern "C" int gom_lpips_unprepare_bf16(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, void *stream) { return gom_lpips_unprepare_planes(B, H, W, Cpad, d_in, d_rgb, 0, stream); }
+int gom_lpips_unprepare_planes(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, size_t in_lo, void *stream) {
     const size_t npix = (size_t)B * H * W;
     if (!d_in || !d_rgb || npix == 0 || Cpad < 3) { gom_set_error("gom_lpips_unprepare_bf16: bad arguments"); return -1; }
     hipLaunchKernelGGL(k_lpips_unprepare, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, npix, Cpad,
-                       (const bf16_t *)d_in, d_rgb);
+                       (const bf16_t *)d_in, d_rgb, in_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gom_lpips_layer_forward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, void *stream) {
+    return gom_lpips_layer_forward_planes(B, C, HW, f0, f1, w, partials, 0, stream);
+}
+int gom_lpips_layer_forward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, size_t f_lo, void *stream) {
+    if (f_lo && C != 64 && C != 128 && C != 256 && C != 512) { gom_set_error("bf16x3 LPIPS head: C must be 64, 128, 256 or 512"); return -1; }
     if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_forward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
 #define GOM_HEAD1P(BWD_, LPP_, GRID_, NT_, ...) hipLaunchKernelGGL((k_lpips_head_nhwc_1p<BWD_, LPP_>), GRID_, dim3(NT_), 0, (hipStream_t)stream, __VA_ARGS__)
     const dim3 grid(GOM_LOSS_BLOCKS, B);
-    if (C == 64) GOM_HEAD1P(false, 8, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
-    else if (C == 128) GOM_HEAD1P(false, 16, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
-    else if (C == 256) GOM_HEAD1P(false, 32, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
-    else if (C == 512) GOM_HEAD1P(false, 64, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr);
+    if (C == 64) GOM_HEAD1P(false, 8, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr, f_lo, (size_t)0);
+    else if (C == 128) GOM_HEAD1P(false, 16, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr, f_lo, (size_t)0);
+    else if (C == 256) GOM_HEAD1P(false, 32, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr, f_lo, (size_t)0);
+    else if (C == 512) GOM_HEAD1P(false, 64, grid, 1024, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, nullptr, partials, nullptr, f_lo, (size_t)0);
     else
     hipLaunchKernelGGL(k_lpips_head_nhwc<false>, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w,
                        nullptr, partials, nullptr);
@@ -676,13 +732,18 @@ extern "C" int gom_lpips_layer_forward_nhwc_bf16(int B, int C, int HW, const voi
 
 extern "C" int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0,
                                                   void *stream) {
+    return gom_lpips_layer_backward_planes(B, C, HW, f0, f1, w, grad_out, d_f0, 0, 0, stream);
+}
+int gom_lpips_layer_backward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, size_t f_lo, size_t d_lo,
+                                    void *stream) {
+    if (f_lo && C != 64 && C != 128 && C != 256 && C != 512) { gom_set_error("bf16x3 LPIPS head: C must be 64, 128, 256 or 512"); return -1; }
     if (B <= 0 || C <= 0 || (C % 128 && C != 64) || HW <= 0) { gom_set_error("gom_lpips_layer_backward_nhwc_bf16: C must be 64 or a multiple of 128"); return -1; }
     const size_t groups = ((size_t)HW + 15) / 16;
     const dim3 gridb((unsigned)(groups < 4096 ? groups : 4096), B);
-    if (C == 64) GOM_HEAD1P(true, 8, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
-    else if (C == 128) GOM_HEAD1P(true, 16, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
-    else if (C == 256) GOM_HEAD1P(true, 32, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
-    else if (C == 512) GOM_HEAD1P(true, 64, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);
+    if (C == 64) GOM_HEAD1P(true, 8, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0, f_lo, d_lo);
+    else if (C == 128) GOM_HEAD1P(true, 16, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0, f_lo, d_lo);
+    else if (C == 256) GOM_HEAD1P(true, 32, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0, f_lo, d_lo);
+    else if (C == 512) GOM_HEAD1P(true, 64, gridb, 256, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0, f_lo, d_lo);
     else
     hipLaunchKernelGGL(k_lpips_head_nhwc<true>, dim3((unsigned)(groups < 4096 ? groups : 4096), B), dim3(256), 0, (hipStream_t)stream, C, (size_t)HW, (const bf16_t *)f0,
                        (const bf16_t *)f1, w, grad_out, nullptr, (bf16_t *)d_f0);

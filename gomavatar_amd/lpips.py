@@ -153,6 +153,19 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return wp.permute(2, 3, 0, 1).reshape(9, cop, cip // 32, 32).permute(2, 0, 1, 3).contiguous().to(torch.bfloat16)
 
 
+def pack_conv_weight_x3(w: torch.Tensor) -> torch.Tensor:
+    """bf16x3 (csrc/vgg_bf16.hip): w = w_hi + w_lo as two bf16 tensors, laid out as THREE chunks per 32 input channels --
+    (w_hi, w_hi, w_lo), the partners of the activation chunks (x_hi, x_lo, x_hi) -> [3 Cin_p/32][9][Cout_p][32] bf16."""
+    co, ci = w.shape[0], w.shape[1]
+    cop, cip = _pad_to(co, 64), _pad_to(ci, 32)
+    wp = torch.zeros(cop, cip, 3, 3, dtype=torch.float32, device=w.device)
+    wp[:co, :ci] = w
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    chunk = lambda t: t.permute(2, 3, 0, 1).reshape(9, cop, cip // 32, 32).permute(2, 0, 1, 3)      # [Cin_p/32][9][Cout_p][32]
+    return torch.stack([chunk(hi), chunk(hi), chunk(lo)], 1).reshape(3 * (cip // 32), 9, cop, 32).contiguous()
+
+
 def pack_conv_weight_backward(w: torch.Tensor) -> torch.Tensor:
     """Weights of the backward-data convolution: dX = conv3x3(dY, rot180(W) with in/out channels swapped)."""
     return pack_conv_weight(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
@@ -166,7 +179,11 @@ class LPIPSMatrixCore:
 
     H and W must be multiples of 16 (four 2x2 pools)."""
 
-    def __init__(self, trunk_seed: int = 0, device=None):
+    def __init__(self, trunk_seed: int = 0, device=None, precision: str = "bf16"):
+        """precision: "bf16" (bf16 activations, 3 % on the value) or "bf16x3" (two bf16 planes per tensor, three MFMA passes:
+        the reference's fp32 precision on the matrix cores)."""
+        assert precision in ("bf16", "bf16x3")
+        self.precision = precision
         self.lib = _lib.load()
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = dev
@@ -179,8 +196,12 @@ class LPIPSMatrixCore:
         if getattr(self, "_h", None):
             self.lib.gom_lpips_vgg_destroy(self._h)
             self._h = None
-        self.w_fwd = [pack_conv_weight(wb[2 * i]) for i in range(13)]
-        self.w_bwd = [pack_conv_weight_backward(wb[2 * i]) for i in range(13)]
+        if self.precision == "bf16x3":
+            self.w_fwd = [pack_conv_weight_x3(wb[2 * i]) for i in range(13)]
+            self.w_bwd = [pack_conv_weight_x3(wb[2 * i].flip(2, 3).permute(1, 0, 2, 3).contiguous()) for i in range(13)]
+        else:
+            self.w_fwd = [pack_conv_weight(wb[2 * i]) for i in range(13)]
+            self.w_bwd = [pack_conv_weight_backward(wb[2 * i]) for i in range(13)]
         self.bias = [torch.cat([wb[2 * i + 1].float(), torch.zeros(_pad_to(wb[2 * i + 1].numel(), 64) - wb[2 * i + 1].numel(), device=self.device)]).contiguous()
                      for i in range(13)]
         self.cin = [_pad_to(wb[2 * i].shape[1], 32) for i in range(13)]
@@ -203,6 +224,7 @@ class LPIPSMatrixCore:
             self._h = self.lib.gom_lpips_vgg_create(*self._keep)
             if not self._h:
                 _lib.check(-1)
+            _lib.check(self.lib.gom_lpips_vgg_set_precision(self._h, 1 if self.precision == "bf16x3" else 0))
         return self._h
 
     def __del__(self):

@@ -306,6 +306,14 @@ typedef struct GomLpipsVgg GomLpipsVgg;
 GomLpipsVgg *gom_lpips_vgg_create(const void *const *w_fwd, const void *const *w_bwd, const float *const *bias, const float *const *lin,
                                   const int32_t *cin, const int32_t *cout);
 void gom_lpips_vgg_destroy(GomLpipsVgg *h);
+/* Arithmetic of the trunk.  BF16 (default): bf16 activations, fp32 accumulation -- 3 % on the LPIPS value, narrower than the
+ * reference's fp32 convolutions (utils/lpips/pretrained_networks.py:96-134 through cuDNN).  BF16X3: every activation, gradient and
+ * weight as two bf16 planes (hi + lo = 16 mantissa bits), three MFMA passes per product (hi hi + lo hi + hi lo, fp32 accumulation):
+ * the reference's precision (<= 1e-5 relative on the value against fp32 library convolutions) at matrix-core speed.  The handle's
+ * weight tensors must then carry 3 x Cin/32 chunks per layer (w_hi, w_hi, w_lo per 32 input channels).  Set before the first call. */
+#define GOM_LPIPS_PRECISION_BF16 0
+#define GOM_LPIPS_PRECISION_BF16X3 1
+int gom_lpips_vgg_set_precision(GomLpipsVgg *h, int32_t precision);
 #define GOM_LPIPS_USE_GRAPH 1u   /* capture the ~75 launches once per (sizes, pointers) and replay them as one hipGraph */
 int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
                                  float grad_scale, float *d_pred, uint32_t flags, void *stream);

@@ -99,6 +99,64 @@ def test_lpips_matrix_core_matches_fp32_path():
     assert none is None and float(v2) == float(val)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 256)])
+def test_lpips_bf16x3_trunk_has_the_precision_of_the_fp32_path(shape):
+    """GOM_LPIPS_PRECISION_BF16X3: activations, gradients and weights as hi + lo bf16 planes, three MFMA passes per product.  Against the
+    fp32 library convolutions (the reference's precision, utils/lpips/pretrained_networks.py:96-134): value <= 1e-5 relative (the plain
+    bf16 trunk: 3 %).  The image gradient passes thirteen ReLU masks and four max-pool argmaxes, each a branch on an activation: two fp32
+    implementations differ at isolated pixels by whole gradient contributions.  Measured against the FLOAT64 trunk (printed, with the
+    fp32 library's own distance beside it): bf16x3 3e-3 .. 6e-3 relative L2 where the plain bf16 trunk is 0.2 and the fp32 library
+    2e-6 .. 4e-4 -- exactly what storing the activations with 16-17 mantissa bits costs when everything else is exact
+    (scripts/lpips_storage_precision.py, CPU float64: 1.3e-3 at 17 bits, 3.0e-3 at 16).  Bounds: 3x the measured values."""
+    from gomavatar_amd.lpips import LPIPS, LPIPSMatrixCore, lpips_loss
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    pred = torch.rand(B, H, W, 3, generator=g).cuda()
+    gt = (pred.cpu() + 0.2 * torch.randn(B, H, W, 3, generator=g)).clamp(0, 1).cuda()
+
+    def library(dtype):
+        m = LPIPS(trunk_seed=5, trunk_dtype=dtype)
+        m.lins = [l.to(dtype) for l in m.lins] if dtype == torch.float64 else m.lins
+        p = pred.to(dtype).clone().requires_grad_()
+        if dtype == torch.float64:   # the fp32 head kernels are not the subject here: plain torch head in float64
+            m.shift, m.scale = m.shift.double(), m.scale.double()
+            f0 = m.features(2 * p.permute(0, 3, 1, 2) - 1)
+            with torch.no_grad():
+                f1 = m.features(2 * gt.double().permute(0, 3, 1, 2) - 1)
+            val = 0
+            for k in range(5):
+                n0 = f0[k] / (f0[k].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+                n1 = f1[k] / (f1[k].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+                val = val + ((n0 - n1) ** 2 * m.lins[k].view(1, -1, 1, 1)).sum(1).mean((1, 2))
+            val = val.mean()
+        else:
+            val = lpips_loss(m, p, gt)
+        val.backward()
+        return float(val.detach()), p.grad.double()
+    v64, g64 = library(torch.float64)
+    v32, g32 = library(torch.float32)
+    mc = LPIPSMatrixCore(trunk_seed=5, precision="bf16x3")
+    val, grad = mc.value_and_grad(pred, gt)
+    torch.cuda.synchronize()
+
+    def stats(a):
+        e = (a.double() - g64).abs().flatten()
+        return float(e.norm() / g64.norm()), float(torch.quantile(e[:1_000_000], 0.999)) / float(g64.abs().max()), float(e.max()) / float(g64.abs().max())
+    sx, s32 = stats(grad), stats(g32)
+    rel, rel32 = abs(float(val) - v64) / v64, abs(v32 - v64) / v64
+    print(f"\n[bf16x3 {shape}] LPIPS value vs float64: bf16x3 {rel:.2e}, fp32 library {rel32:.2e};  image gradient vs float64 (rel L2, q99.9 / max, max / max): "
+          f"bf16x3 {sx[0]:.2e} {sx[1]:.2e} {sx[2]:.2e}   fp32 library {s32[0]:.2e} {s32[1]:.2e} {s32[2]:.2e}")
+    assert abs(float(val) - v32) <= 1e-5 * v32 and rel <= 1e-5, (float(val), v32, v64)
+    assert sx[0] <= 1.8e-2 and sx[1] <= 4e-2 and sx[2] <= 0.2, (sx, s32)
+    plain = LPIPSMatrixCore(trunk_seed=5)                                  # the one-pass bf16 trunk on the same inputs
+    vp, gp = plain.value_and_grad(pred, gt)
+    sp = stats(gp)
+    print(f"[bf16   {shape}] value vs float64 {abs(float(vp) - v64) / v64:.2e}; gradient rel L2 {sp[0]:.2e}")
+    assert sx[0] <= sp[0] / 20.0 and rel <= abs(float(vp) - v64) / v64 / 100.0
+    val2, grad2 = mc.value_and_grad(pred, gt)
+    assert float(val2) == float(val) and torch.equal(grad, grad2)          # reproducible
+
+
 def test_pipelined_conv_is_race_free_over_many_launches():
     """The 16-row kernel orders its LDS-DMA staging by counted vmcnt waits and one barrier per stage: a misplaced wait would show
     up as rare, timing-dependent wrong tiles.  300 back-to-back launches (other launches in between to perturb timing) must
