@@ -1271,6 +1271,12 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 //   (Measured and dropped on the way here: one task per SEGMENT with the next piece's entries prefetched -- 276 us instead of 205:
 //    a quarter of the tasks, and these kernels live on many short independent chains; one WAVE per task walking its four quadrants
 //    without any barrier -- 218-259 us: it needs ~100 VGPRs, and at five waves per SIMD with spills the gain is gone.)
+#ifdef GOM_BLK_STATS
+__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] lanes with alpha >= 1/255 before the my_last test
+#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
+#else
+#define GOM_PAIR_STAT(I, V) do { } while (0)
+#endif
 #ifndef GOM_BWDP_WAVES
 #define GOM_BWDP_WAVES 5   // (at 6 waves per SIMD = 80 registers, 7 of them spill: same speed, +40 MB of scratch traffic per launch)
 #endif
@@ -1377,6 +1383,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                     R_acc = sd * (T > 0.f ? 1.f / T : 0.f);   // (same operations as k_seg_bwd: the two kernels agree bitwise)
                 }
                 unsigned long long mask = __ballot(r.keep);
+                GOM_PAIR_STAT(0, 1); GOM_PAIR_STAT(1, __popcll(mask));
                 s_e0[wv][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
                 s_e1[wv][lane] = make_float2(r.c, r.o);
                 {
@@ -1419,6 +1426,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 #pragma unroll
                     for (int u = 0; u < GOM_BWD_EPT; u++) {
                         if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;
+                        { const unsigned long long am_ = __ballot(al[u] > 0.f); GOM_PAIR_STAT(2, 1); GOM_PAIR_STAT(3, __popcll(am_)); }
                         const float a = al[u];
                         const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);
                         T = T * inv1ma;
@@ -1504,8 +1512,8 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 
 #ifdef GOM_BLK_STATS
 extern "C" int gom_debug_blk_stats(unsigned long long *out, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_stats), sizeof(unsigned long long) * 8);
-    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stats), z, sizeof(z)); }
+    if (out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_stats), sizeof(unsigned long long) * 8); (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_pair_stats), sizeof(unsigned long long) * 8); }
+    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stats), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), z, sizeof(z)); }
     return 0;
 }
 #endif
