@@ -22,6 +22,7 @@ IMG_TOL, FLIP_RATE, MEAN_TOL = 1e-4, 2e-4, 2e-6     # as tests/test_gpu_raster.p
 #   BOUND_STEP       whole step including the L1 loss's sign(), against the float64 oracle (round 2's bounds here were 1e-5 / 2e-3 / 5e-2 / 0.25)
 MAX_SAME_DIMG = dict(vertices=1e-2, so3=6.5e-2, scale=0.18, appearance=2e-2)                      # measured 3.1e-3 / 2.1e-2 / 5.8e-2 / 6.7e-3 (worst of 8 frames)
 BOUND_VS_FP32 = dict(vertices=(5e-8, 6e-6, 7e-4, 1e-2), so3=(3e-9, 1.2e-6, 9e-5, 8e-2), scale=(1.2e-9, 4e-7, 9e-5, 0.15), appearance=(4e-8, 5e-6, 2e-5, 2e-2))
+BOUND_SUM = dict(vertices=(6e-7, 3e-4, 2.4e-3, 7.5e-2), so3=(3e-8, 2.4e-5, 3e-4, 6.5e-2), scale=(2.1e-8, 2.1e-5, 3e-4, 0.18), appearance=(2.1e-7, 6e-6, 1e-4, 2e-2))   # the sum over the 8 frames of the batch
 BOUND_STEP = dict(vertices=(7e-8, 1e-4, 2.2e-3, 7.5e-2), so3=(4e-9, 1e-5, 2.6e-4, 6.5e-2), scale=(2e-9, 9e-6, 2.5e-4, 0.18), appearance=(7e-8, 6e-6, 1e-4, 2e-2))
 
 
@@ -249,7 +250,7 @@ def test_metric_workload_matches_oracle_and_batch_matches_singles(wl, B, capsys)
         assert all(a <= c for a, c in zip(worst_h32[k], BOUND_VS_FP32[k])), (k, worst_h32[k])
         # (c2): <= 3x the measured quantiles of the whole step
         assert all(a <= c for a, c in zip(worst2[k], BOUND_STEP[k])), (k, worst2[k])
-        assert all(a <= c for a, c in zip(grad_stats(grads[k].cpu().double(), ref2[k]), BOUND_STEP[k])), k
+        assert all(a <= c for a, c in zip(grad_stats(grads[k].cpu().double(), ref2[k]), BOUND_STEP[k] if B == 1 else BOUND_SUM[k])), (k, grad_stats(grads[k].cpu().double(), ref2[k]))
     # Attribution of the tail to threshold flips, tested rather than asserted in a comment: it holds for the COLOUR gradient (a Gaussian's
     # colour gradient is a plain sum of alpha T dL/dC over its pixels: setting aside the Gaussians that reach a flipped pixel takes the
     # largest error from 1.5e-3 / 5.9e-3 to 8e-6 / 3e-5 of the largest gradient), and it does NOT hold for vertices / so3 / scale: their
