@@ -129,7 +129,7 @@ class Runner:
     """S steps in flight of B frames each on one GPU: slot k owns a stream, a RenderStep (scratch + intermediates) and a flat
     gradient buffer (the all-reduce payload; the hot path's gradients are views into it)."""
 
-    def __init__(self, wl, B, S, graph, world, args):
+    def __init__(self, wl, B, S, graph, world, args, impl="collective"):
         import torch
         from gomavatar_amd import _lib
         from gomavatar_amd.parallel import FrameParallel, shapes_for_model
@@ -141,7 +141,7 @@ class Runner:
         from gomavatar_amd.parallel import FlatAdam
         for k in range(S):
             st = wl.step(B)
-            fp = FrameParallel(shapes_for_model(wl.N, wl.F), wl.device, pad_to=pad)
+            fp = FrameParallel(shapes_for_model(wl.N, wl.F), wl.device, pad_to=pad, impl=impl)
             for name in ("vertices", "so3", "scale", "appearance"):
                 st.grads[name] = fp.grads[name]
                 fp.params[name].copy_(wl.params[name])   # every slot trains its own replica of the parameters (S > 1: independent steps)
@@ -514,6 +514,36 @@ def main():
         torch.cuda.synchronize()
         allreduce_us = round((time.perf_counter() - t0) / 50 * 1e6, 1)
 
+    # ---------------- N > 1: the same job over the direct peer-pointer all-reduce (csrc/frame_parallel.hip), when it comes up ----------------
+    peer_info = None
+    if world > 1:
+        peer_info = {"impl": "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum (gom_peer_reduce_*)"}
+        ok_t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        peer_run, err = None, None
+        try:
+            peer_run = Runner(wl, B, 1, not args.no_graph, world, args, impl="peer")
+        except Exception as e:   # report, do not hide (e.g. IPC not permitted between these devices)
+            err = f"{type(e).__name__}: {e}"
+            ok_t.zero_()
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)   # every rank takes the same branch
+        if int(ok_t.item()) == 1:
+            try:
+                el_p, ns_p, _ = peer_run.measure(max(20, args.steps // 2), 10)
+                fp_p = peer_run.slots[0]["fp"]
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    fp_p.all_reduce_grads()
+                torch.cuda.synchronize()
+                peer_info.update(us=round((time.perf_counter() - t0) / 50 * 1e6, 1), fps=round(world * B * ns_p / el_p, 1), frames_per_gpu_per_step=B)
+                fp_p.peer.check()
+                peer_info["status"] = "ok"
+            except Exception as e:
+                peer_info["status"] = f"failed: {type(e).__name__}: {e}"
+        else:
+            peer_info["status"] = f"not available on some rank ({err})" if err else "not available on some rank"
+        dist.barrier()
+
     # ---------------- per-kernel times, one step in flight (the kernels own the chip) ----------------
     alone_run = main_run if S == 1 else Runner(wl, B, 1, not args.no_graph, world, args)
     iso, D_avg = alone_run.kernel_profile(12)
@@ -566,7 +596,7 @@ def main():
                    "optimizer": (f"Adam on the flat parameter buffer inside the timed loop (gom_adam_flat, lr {ADAM_LR:g}: the reference's arithmetic, a rate that "
                                  "keeps the synthetic workload fixed)" if not args.no_adam else None),
                    "allreduce_floats": main_run.payload if world > 1 else 0, "allreduce_us": allreduce_us, "allreduce_impl": "torch.distributed all_reduce (RCCL ReduceOp.AVG)" if world > 1 else None,
-                   "local_only_fps": local_only_fps,
+                   "local_only_fps": local_only_fps, "allreduce_peer": peer_info,
                    "backend": (("rccl" if backend == "nccl" else backend) + (f" ({world} ranks share {n_dev} device(s): functional proof, not a scaling number)" if shared else ""))
                    if world > 1 else None},
         "roofline": roofline,

@@ -8,6 +8,7 @@
 // 16 bytes read and 12 written per parameter, HBM-bound (951 023 parameters: 26.6 MB, ~6 us).
 #include "gom_internal.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -87,4 +88,191 @@ extern "C" int gom_adam_flat(int64_t n, float *params, const float *grads, float
                        beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
     GOM_LAUNCH_CHECK();
     return 0;
+}
+
+// =====================================================================================================================================
+// Direct all-reduce of the flat gradient buffer over PEER POINTERS: every rank's buffer lives in a region the other
+// ranks have mapped (hipIpc handles exchanged once over the process group), and the sum is formed by two kernels per rank, no library
+// collective:
+//   k_peer_reduce_scatter   rank r raises "my gradient is ready" in every peer's flag row, waits for the peers' flags, sums ITS slice
+//                           (n / world elements) of all buffers in RANK ORDER, scales it and leaves it in its own region; its last
+//                           workgroup raises "slice r is reduced" at every peer;
+//   k_peer_all_gather       waits for those flags and copies every rank's reduced slice.
+// Every element is summed by exactly one rank in a fixed order, so all ranks end with the same bits -- bitwise equal to
+// ((g_0 + g_1) + g_2) + ... scaled.  The payload (3.8 MB at 55 104 Gaussians) is latency-bound on xGMI: a two-shot exchange moves
+// 2 x (world - 1) / world of it per rank over 7 point-to-point links in parallel, where a ring serialises 2 (world - 1) steps.
+// Flags are epoch counters (no reset, no ABA) written with system-scope release stores and polled with system-scope acquire loads; the
+// region is fine-grained memory (coherent across devices -- and across the XCDs of one device, which is what the 1-GPU test exercises
+// with several processes on one MI355X).  A wait gives up after ~1 s, sets the status word and lets the kernel finish: never a hang.
+// Reuse: a rank overwrites its gradient only after its own all-gather kernel, which has seen every peer's "reduced" flag (= the peer is
+// done reading it); it overwrites its reduced slice only in the next scatter kernel, behind the peers' next "ready" flags (= their
+// previous all-gather has completed).
+struct GomPeerReduce {
+    int rank = 0, world = 1;
+    int64_t n = 0;
+    size_t bytes = 0;
+    unsigned char *local = nullptr;                 // [grad n][reduced n][flags]
+    unsigned char *peer[GOM_PEER_MAX_RANKS] = {};    // mapped regions, own entry = local
+    bool opened[GOM_PEER_MAX_RANKS] = {};
+    uint32_t epoch = 0;
+    uint32_t *status = nullptr;                      // device word: 1 = a wait timed out
+    uint32_t *done_ctr = nullptr;                    // workgroups of the scatter kernel that have finished
+    int finegrained = 0;
+};
+
+namespace {
+constexpr int kPeerFlagStride = 16;   // uint32 per flag slot (64 bytes: one line per writer)
+struct PeerPtrs { unsigned char *p[GOM_PEER_MAX_RANKS]; };
+
+__device__ __forceinline__ uint32_t *peer_flags(unsigned char *region, int64_t n, int which) {   // which: 0 = ready, 1 = reduced
+    return reinterpret_cast<uint32_t *>(region + 2 * (size_t)n * sizeof(float)) + (size_t)which * GOM_PEER_MAX_RANKS * kPeerFlagStride;
+}
+// true when the flag reached `epoch`; gives up (status = 1) after ~1 s so that a missing peer can never hang the GPU
+__device__ __forceinline__ bool peer_wait(const uint32_t *flag, uint32_t epoch, uint32_t *status) {
+    for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) >= 0) return true;
+        __builtin_amdgcn_s_sleep(32);
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+__global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, float scale, uint32_t *status,
+                                                             uint32_t *done_ctr) {
+    __shared__ int s_ok;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)world)   // "my gradient of this epoch is complete" (the kernels that wrote it precede this one on the stream)
+        __hip_atomic_store(peer_flags(pp.p[threadIdx.x], n, 0) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int p = 0; p < world && ok; p++) ok = peer_wait(peer_flags(pp.p[rank], n, 0) + p * kPeerFlagStride, epoch, status);
+        s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (the waits were thread 0's: the other threads' loads must not be older than the flags)
+    if (s_ok) {
+        const int64_t n4 = n / 4, per = (n4 + world - 1) / world, lo = per * rank, hi = lo + per < n4 ? lo + per : n4;   // float4 units of my slice
+        float4 *dst = reinterpret_cast<float4 *>(pp.p[rank] + (size_t)n * sizeof(float));
+        for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
+            float4 a = reinterpret_cast<const float4 *>(pp.p[0])[i];
+            for (int p = 1; p < world; p++) {
+                const float4 b = reinterpret_cast<const float4 *>(pp.p[p])[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            dst[i] = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+        }
+        if (rank == world - 1) {   // the ragged end (n not a multiple of 4) belongs to the last rank
+            for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+                float a = reinterpret_cast<const float *>(pp.p[0])[i];
+                for (int p = 1; p < world; p++) a += reinterpret_cast<const float *>(pp.p[p])[i];
+                reinterpret_cast<float *>(pp.p[rank] + (size_t)n * sizeof(float))[i] = a * scale;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        if (atomicAdd(done_ctr, 1u) == gridDim.x - 1) {   // the last workgroup: my slice is complete everywhere -> tell the peers
+            *done_ctr = 0;
+            for (int p = 0; p < world; p++)
+                __hip_atomic_store(peer_flags(pp.p[p], n, 1) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_peer_all_gather(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, float *__restrict__ out, uint32_t *status) {
+    __shared__ int s_ok;
+    const int64_t n4 = n / 4, per = (n4 + world - 1) / world;
+    for (int src = 0; src < world; src++) {   // start with my own slice (ready first), then the others in ring order
+        const int p = (rank + src) % world;
+        if (threadIdx.x == 0) s_ok = peer_wait(peer_flags(pp.p[rank], n, 1) + p * kPeerFlagStride, epoch, status) ? 1 : 0;
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (s_ok) {
+            const int64_t lo = per * p, hi = lo + per < n4 ? lo + per : n4;
+            const float4 *srcp = reinterpret_cast<const float4 *>(pp.p[p] + (size_t)n * sizeof(float));
+            for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4 *>(out)[i] = srcp[i];
+            if (p == world - 1)
+                for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+                    out[i] = reinterpret_cast<const float *>(pp.p[p] + (size_t)n * sizeof(float))[i];
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" GomPeerReduce *gom_peer_reduce_create(int32_t rank, int32_t world, int64_t n_floats) {
+    if (world < 1 || world > GOM_PEER_MAX_RANKS || rank < 0 || rank >= world || n_floats <= 0) { gom_set_error("gom_peer_reduce_create: bad arguments"); return nullptr; }
+    GomPeerReduce *h = new GomPeerReduce();
+    h->rank = rank; h->world = world; h->n = n_floats;
+    h->bytes = 2 * (size_t)n_floats * sizeof(float) + 2 * GOM_PEER_MAX_RANKS * kPeerFlagStride * sizeof(uint32_t);
+    h->bytes = (h->bytes + 4095) & ~(size_t)4095;
+    // fine-grained: coherent across devices without a kernel boundary (the flags are polled INSIDE a kernel)
+    if (hipExtMallocWithFlags((void **)&h->local, h->bytes, hipDeviceMallocFinegrained) == hipSuccess) h->finegrained = 1;
+    else { (void)hipGetLastError(); if (hipMalloc((void **)&h->local, h->bytes) != hipSuccess) { gom_set_error("gom_peer_reduce_create: allocation failed"); delete h; return nullptr; } }
+    if (hipMemset(h->local, 0, h->bytes) != hipSuccess || hipMalloc((void **)&h->status, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(h->status, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        gom_set_error("gom_peer_reduce_create: initialisation failed");
+        if (h->local) (void)hipFree(h->local);
+        delete h;
+        return nullptr;
+    }
+    h->done_ctr = h->status + 1;
+    h->peer[rank] = h->local;
+    return h;
+}
+
+extern "C" int gom_peer_reduce_handle(GomPeerReduce *h, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (!h || !handle64) { gom_set_error("gom_peer_reduce_handle: null argument"); return -1; }
+    GOM_HIP_CHECK(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), h->local));
+    return 0;
+}
+
+extern "C" int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles) {
+    if (!h || !handles) { gom_set_error("gom_peer_reduce_connect: null argument"); return -1; }
+    for (int p = 0; p < h->world; p++) {
+        if (p == h->rank || h->opened[p]) continue;
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, (const unsigned char *)handles + 64 * (size_t)p, 64);
+        GOM_HIP_CHECK(hipIpcOpenMemHandle((void **)&h->peer[p], hd, hipIpcMemLazyEnablePeerAccess));
+        h->opened[p] = true;
+    }
+    return 0;
+}
+
+extern "C" float *gom_peer_reduce_buffer(GomPeerReduce *h) { return h ? reinterpret_cast<float *>(h->local) : nullptr; }
+
+extern "C" int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream) {
+    if (!h || !out) { gom_set_error("gom_peer_reduce_run: null argument"); return -1; }
+    for (int p = 0; p < h->world; p++)
+        if (!h->peer[p]) { gom_set_error("gom_peer_reduce_run: rank %d is not connected", p); return -1; }
+    h->epoch++;
+    PeerPtrs pp{};
+    for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];
+    // small resident grids: every workgroup polls flags, so all of them must fit on the chip next to whatever else runs
+    const int grid = 64;
+    hipLaunchKernelGGL(k_peer_reduce_scatter, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, scale, h->status, h->done_ctr);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_peer_all_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, out, h->status);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gom_peer_reduce_status(GomPeerReduce *h) {   // host-side check (synchronises the device): 0 = every wait was answered
+    if (!h) return -1;
+    uint32_t s = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&s, h->status, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) { gom_set_error("gom_peer_reduce_status: device error"); return -2; }
+    if (s) gom_set_error("gom_peer_reduce: a peer did not answer within the wait limit");
+    return (int)s;
+}
+
+extern "C" void gom_peer_reduce_destroy(GomPeerReduce *h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (int p = 0; p < h->world; p++)
+        if (h->opened[p] && h->peer[p]) (void)hipIpcCloseMemHandle(h->peer[p]);
+    if (h->local) (void)hipFree(h->local);
+    if (h->status) (void)hipFree(h->status);
+    delete h;
 }

@@ -1426,7 +1426,9 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 #pragma unroll
                     for (int u = 0; u < GOM_BWD_EPT; u++) {
                         if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;
+#ifdef GOM_BLK_STATS
                         { const unsigned long long am_ = __ballot(al[u] > 0.f); GOM_PAIR_STAT(2, 1); GOM_PAIR_STAT(3, __popcll(am_)); }
+#endif
                         const float a = al[u];
                         const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);
                         T = T * inv1ma;

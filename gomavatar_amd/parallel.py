@@ -39,6 +39,55 @@ class FlatBuffer:
         return self.views.items()
 
 
+class _DevicePtr:
+    """A raw device allocation as a torch tensor (through __cuda_array_interface__): the peer-mapped gradient region of PeerAllReduce."""
+
+    def __init__(self, ptr: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
+
+
+class PeerAllReduce:
+    """The direct two-shot all-reduce of csrc/frame_parallel.hip (`gom_peer_reduce_*`): every rank's gradient buffer lives in a region
+    the other ranks map through IPC handles (exchanged once over the process group); `run()` enqueues two kernels -- reduce-scatter in
+    rank order, all-gather -- on the current stream.  One process per GPU; several processes on ONE device work too (the 1-GPU test)."""
+
+    def __init__(self, numel: int, device, group: Optional[dist.ProcessGroup] = None):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.lib = _lib.load()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.numel = int(numel)
+        torch.cuda.set_device(device)
+        self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
+        if not self._h:
+            _lib.check(-1)
+        mine = (ctypes.c_ubyte * 64)()
+        _lib.check(self.lib.gom_peer_reduce_handle(self._h, mine))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(mine), group=group)
+        blob = (ctypes.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
+        _lib.check(self.lib.gom_peer_reduce_connect(self._h, blob))
+        self.buffer = torch.as_tensor(_DevicePtr(self.lib.gom_peer_reduce_buffer(self._h), self.numel), device=torch.device(device))
+        dist.barrier(group=group)   # every rank has mapped every region before anyone raises a flag in it
+
+    def run(self, out: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+        out = self.buffer if out is None else out
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self.numel
+        self._lib.check(self.lib.gom_peer_reduce_run(self._h, out.data_ptr(), float(scale), self._lib.stream_ptr()))
+        return out
+
+    def check(self) -> None:
+        """Synchronises; raises if a peer never answered (the kernels give up after ~1 s instead of hanging)."""
+        self._lib.check(-self.lib.gom_peer_reduce_status(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.buffer = None
+            self.lib.gom_peer_reduce_destroy(self._h)
+            self._h = None
+
+
 class FrameParallel:
     """Replicated parameters + flat gradient buffer + one all-reduce per step.
 
@@ -50,7 +99,9 @@ class FrameParallel:
     """
 
     def __init__(self, shapes: Sequence[Tuple[str, Tuple[int, ...]]], device, group: Optional[dist.ProcessGroup] = None,
-                 average: bool = True, pad_to: int = 0):
+                 average: bool = True, pad_to: int = 0, impl: str = "collective"):
+        """impl: "collective" = torch.distributed all_reduce (RCCL on GPUs, gloo on the host); "peer" = the direct two-shot all-reduce
+        over IPC-mapped peer buffers (`PeerAllReduce`; the gradient buffer then lives in the peer-mapped region)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -60,6 +111,11 @@ class FrameParallel:
         self._host = None
         self.params = FlatBuffer(shapes, device)
         self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
+        self.impl, self.peer = impl, None
+        if impl == "peer" and self.world > 1:
+            self.peer = PeerAllReduce(self.grads.numel, device, group)
+            self.grads.flat = self.peer.buffer          # gradients are written straight into the peer-mapped region
+            self.grads.views = {name: self.grads.flat[o:o + n].view(shape) for name, shape, o, n in self.grads.layout}
 
     def frame_index(self, step: int) -> int:
         """Global index of the frame this rank renders at `step`."""
@@ -75,6 +131,9 @@ class FrameParallel:
         if self.world <= 1:
             return
         flat = self.grads.flat
+        if self.peer is not None:
+            self.peer.run(flat, 1.0 / self.world if self.average else 1.0)
+            return
         if self._nccl:
             if self.average and self._native_avg:
                 try:

@@ -443,6 +443,21 @@ int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, 
                   const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
                   void *stream);
 
+/* Direct all-reduce of the flat gradient buffer over peer pointers ("for this latency-bound size use a direct one-/two-shot
+ * algorithm, not a ring"): one process per GPU; every rank creates a region, the 64-byte IPC handles are exchanged once (any transport:
+ * the process group), and `run` enqueues two kernels that leave scale x (sum over the ranks, in RANK ORDER) in `out` -- the same bits on
+ * every rank.  `buffer` is this rank's input (n_floats, device memory inside the region): the backward writes the gradient there.
+ * `out` may be that same buffer.  A peer that never answers makes the waits give up after ~1 s (status 1), never a hang. */
+#define GOM_PEER_MAX_RANKS 16
+typedef struct GomPeerReduce GomPeerReduce;
+GomPeerReduce *gom_peer_reduce_create(int32_t rank, int32_t world, int64_t n_floats);
+int gom_peer_reduce_handle(GomPeerReduce *h, void *handle64);
+int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles /* world x 64 bytes, rank order */);
+float *gom_peer_reduce_buffer(GomPeerReduce *h);
+int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream);
+int gom_peer_reduce_status(GomPeerReduce *h);
+void gom_peer_reduce_destroy(GomPeerReduce *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + stats of the default bench command, then two separate PMC passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950), everything under gpurun_out/prof_$TAG.
-TAG=${1:-r02}
+TAG=${1:-r03}
 BENCH_ARGS=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py $BENCH_ARGS > $OUT/bench_trace.log 2>&1
 grep "^{" $OUT/bench_trace.log > $OUT/bench_line.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py $BENCH_ARGS --steps 20 --warmup 4 --inflight 1 --no-graph --no-cpu-baseline --no-modes > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py $BENCH_ARGS --steps 20 --warmup 4 --inflight 1 --no-graph --no-cpu-baseline --no-modes > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py $BENCH_ARGS --steps 20 --warmup 4 --inflight 1 --no-graph --no-cpu-baseline --no-modes --no-configs > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py $BENCH_ARGS --steps 20 --warmup 4 --inflight 1 --no-graph --no-cpu-baseline --no-modes --no-configs > $OUT/pmc_write.log 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, collections, json, sys
 out = sys.argv[1]

@@ -4,7 +4,7 @@ TAG=$1; CTRS=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o pmc -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-graph --no-cpu-baseline "$@" > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o pmc -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-graph --no-cpu-baseline --no-configs "$@" > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

@@ -3,11 +3,12 @@
 # copy them into profiles/ afterwards):   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
 # Runs TWICE the PMC-derived pieces feed bench.py: the bench line of the second pass carries roofline.traffic / roofline.valu read
 # from the json files the first pass produced (copy them to profiles/ in between, or simply run this script twice).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1                       # default bench: one step in flight
 bash scripts/collect_profiles.sh ${TAG}_inflight3 "--inflight 3" > gpurun_out/collect_${TAG}_inflight3.log 2>&1
 bash scripts/pmc_pass.sh ${TAG}_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" --no-modes > gpurun_out/pmc_${TAG}_insts.log 2>&1
+bash scripts/pmc_pass.sh ${TAG}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" --no-modes > gpurun_out/pmc_${TAG}_lds.log 2>&1
 bash scripts/pmc_pass.sh ${TAG}_busy "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" --no-modes > gpurun_out/pmc_${TAG}_busy.log 2>&1
 OUT=gpurun_out/profiles_$TAG; mkdir -p $OUT
 cp gpurun_out/prof_$TAG/bench_line.json $OUT/${TAG}_bench_line.json
@@ -19,6 +20,7 @@ python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_fetch -name "*co
 python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_write_per_kernel.csv
 python scripts/summarize_pmc.py $(find gpurun_out/pmc_${TAG}_insts -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq_insts_per_kernel.csv
 python scripts/summarize_pmc.py $(find gpurun_out/pmc_${TAG}_busy -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq_busy_per_kernel.csv
+python scripts/summarize_pmc.py $(find gpurun_out/pmc_${TAG}_lds -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_sq_lds_per_kernel.csv
 # the VALU axis of bench.py's roofline block: per kernel, from the SQ pass (quad-cycle counters summed over the waves of a launch)
 python - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
@@ -44,4 +46,4 @@ PY
 ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-600
 # gpurun merges at most 64 MiB back: drop the raw traces / counter dumps, the summaries above are what is kept
 rm -rf gpurun_out/prof_${TAG}/trace gpurun_out/prof_${TAG}/pmc_fetch gpurun_out/prof_${TAG}/pmc_write gpurun_out/prof_${TAG}_inflight3/trace \
-       gpurun_out/prof_${TAG}_inflight3/pmc_fetch gpurun_out/prof_${TAG}_inflight3/pmc_write gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_busy
+       gpurun_out/prof_${TAG}_inflight3/pmc_fetch gpurun_out/prof_${TAG}_inflight3/pmc_write gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_busy gpurun_out/pmc_${TAG}_lds

@@ -57,6 +57,9 @@ def test_bench_launches_itself_for_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["frames_per_gpu_per_step"] == 1 and d["config"]["allreduce_floats"] == 951023
     assert d["config"]["allreduce_us"] > 0 and d["config"]["parallelism"] == "frame-dp2" and d["value"] > 0
     assert d["config"]["optimizer"] and d["config"]["local_only_fps"] >= d["value"] * 0.5 and d["modes"]["b8_per_gpu"] > 0
+    # the direct peer-pointer all-reduce comes up between two processes on the one device and carries the same loop
+    pr = d["config"]["allreduce_peer"]
+    assert pr["status"] == "ok" and pr["us"] > 0 and pr["fps"] > 0, pr
     assert "cpu_baseline" not in d     # rank 0 at N = 1 only
 
 
