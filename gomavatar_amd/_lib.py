@@ -117,6 +117,8 @@ SIGNATURES = {
     "gom_batch_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_int32, c_void_p, c_uint32, c_void_p]),
     "gom_adam_flat": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
                               c_float, c_float, c_void_p]),
+    "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_void_p, c_float,
+                                        c_float, c_float, c_float, c_float, c_void_p]),
     "gom_peer_reduce_create": (c_void_p, [c_int32, c_int32, c_int64]),
     "gom_peer_reduce_handle": (c_int, [c_void_p, c_void_p]),
     "gom_peer_reduce_connect": (c_int, [c_void_p, c_void_p]),

@@ -14,7 +14,7 @@ namespace {
 
 struct AdamSegs {
     uint32_t begin[GOM_ADAM_MAX_SEGMENTS + 1];   // segment i = [begin[i], begin[i + 1]) of the flat buffer
-    float step_size[GOM_ADAM_MAX_SEGMENTS];      // lr_i / (1 - beta1^t)
+    float step_size[GOM_ADAM_MAX_SEGMENTS];      // lr_i / (1 - beta1^t); with a device step counter: lr_i, corrected in the kernel
     int n;
 };
 
@@ -22,7 +22,20 @@ struct AdamSegs {
 //   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g g;  p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
 __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps, float inv_sqrt_bc2,
-                                                   float grad_scale) {
+                                                   float grad_scale, long long *__restrict__ step_dev, float lr_decay_steps) {
+    // Device-resident step count (step_dev[0] = steps taken so far, step_dev[1] = workgroups of this launch that are done): nothing of
+    // the step number is baked into the launch, so the optimizer can sit inside a captured graph.  Every workgroup reads the count
+    // before it works; the last one to finish advances it.
+    if (step_dev) {
+        const double t = (double)(step_dev[0] + 1);
+        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+        // update_lr (train.py:166-175) runs after the step of iteration n_iters (which counts from 1, train.py:268) with n_iters as its
+        // argument: step t uses base * 0.1^((t - 1) / D)
+        const double decay = lr_decay_steps > 0.f ? pow(0.1, (t - 1.0) / (double)lr_decay_steps) : 1.0;
+#pragma unroll
+        for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) segs.step_size[s2] = (float)((double)segs.step_size[s2] * decay / bc1);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
     // 4 consecutive parameters per thread and trip (the buffers come from hipMalloc / torch: 16-byte aligned); the ragged end one by one
     const uint32_t n4 = n >> 2;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n4 + (n & 3u); i += gridDim.x * 256) {
@@ -62,6 +75,13 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
             p[e0] = pp[0]; m[e0] = mm[0]; v[e0] = vv[0];
         }
     }
+    if (step_dev) {
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(reinterpret_cast<unsigned long long *>(step_dev + 1), 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            step_dev[1] = 0;
+            step_dev[0] = step_dev[0] + 1;
+        }
+    }
 }
 
 }  // namespace
@@ -69,9 +89,16 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
 extern "C" int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
                              const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
                              void *stream) {
+    return gom_adam_flat_graphable(n, params, grads, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, nullptr, 0.f, beta1, beta2, eps, grad_scale, stream);
+}
+
+extern "C" int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                                       const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
+                                       float beta2, float eps, float grad_scale, void *stream) {
     if (n < 0 || n > 0xffffffffLL) { gom_set_error("gom_adam_flat: bad size"); return -1; }
     if (n_segments < 1 || n_segments > GOM_ADAM_MAX_SEGMENTS || !seg_begin || !seg_lr) { gom_set_error("gom_adam_flat: 1..%d segments", GOM_ADAM_MAX_SEGMENTS); return -1; }
-    if (step < 1) { gom_set_error("gom_adam_flat: step counts from 1"); return -1; }
+    if (!step_device && step < 1) { gom_set_error("gom_adam_flat: step counts from 1"); return -1; }
+    if (step_device) step = 1;   // (host-side corrections unused: the kernel derives them from the device count)
     if (n == 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq) { gom_set_error("gom_adam_flat: null pointer"); return -1; }
     AdamSegs segs{};
@@ -81,11 +108,11 @@ extern "C" int gom_adam_flat(int64_t n, float *params, const float *grads, float
         if (seg_begin[i] < 0 || seg_begin[i] > n || (i > 0 && seg_begin[i] < seg_begin[i - 1])) { gom_set_error("gom_adam_flat: segment bounds must ascend inside [0, n]"); return -1; }
         segs.begin[i] = (uint32_t)seg_begin[i];
     }
-    for (int i = 0; i < n_segments; i++) segs.step_size[i] = (float)((double)seg_lr[i] / bc1);
+    for (int i = 0; i < n_segments; i++) segs.step_size[i] = step_device ? seg_lr[i] : (float)((double)seg_lr[i] / bc1);
     const uint32_t work = (uint32_t)(n >> 2) + (uint32_t)(n & 3);
     const unsigned blocks = (unsigned)((work + 255) / 256);
     hipLaunchKernelGGL(k_adam_flat, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, params, grads, exp_avg, exp_avg_sq, segs,
-                       beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+                       beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, reinterpret_cast<long long *>(step_device), lr_decay_steps);
     GOM_LAUNCH_CHECK();
     return 0;
 }

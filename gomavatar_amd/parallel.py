@@ -175,7 +175,10 @@ class FlatAdam:
     parameter buffer (`gom_adam_flat`, csrc/frame_parallel.hip): per-tensor learning rates (`lrs[name]`, or `lrs['default']`), moments
     in two more flat buffers, the step count on the host.  Device buffers only: there is no CPU path (the gloo tests use `make_adam`)."""
 
-    def __init__(self, fp: "FrameParallel", lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, fp: "FrameParallel", lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8, graphable: bool = False,
+                 lr_decay_steps: float = 0.0):
+        """graphable: the step count lives in device memory and the learning-rate decay (update_lr) is derived from it in the kernel
+        (`gom_adam_flat_graphable`), so `step()` can be captured into a graph behind the frame step and replayed."""
         import ctypes
         from . import _lib
         if not fp.params.flat.is_cuda:
@@ -190,6 +193,8 @@ class FlatAdam:
         self._begin = (ctypes.c_int64 * len(bounds))(*bounds)
         self.base_lr = [float(lrs.get(name, lrs.get("default", 1e-3))) for name in self.names]
         self.lr = list(self.base_lr)
+        self.graphable, self.lr_decay_steps = bool(graphable), float(lr_decay_steps)
+        self.step_dev = torch.zeros(2, dtype=torch.int64, device=fp.params.flat.device) if graphable else None
 
     def decay(self, iter_step: int, lr_decay_steps: float) -> None:
         """update_lr (train.py:166-175)."""
@@ -198,8 +203,14 @@ class FlatAdam:
     def step(self, grad_scale: float = 1.0) -> None:
         """One Adam step on the current stream, reading `fp.grads.flat` (as the all-reduce left it)."""
         self.t += 1
-        lr = (self._ct.c_float * len(self.lr))(*self.lr)
         fp, P = self.fp, self._lib.ptr
+        if self.graphable:
+            lr = (self._ct.c_float * len(self.base_lr))(*self.base_lr)
+            self._lib.check(self._lib.load().gom_adam_flat_graphable(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq),
+                                                                     len(self.base_lr), self._begin, lr, 1, P(self.step_dev), self.lr_decay_steps, self.betas[0],
+                                                                     self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+            return
+        lr = (self._ct.c_float * len(self.lr))(*self.lr)
         self._lib.check(self._lib.load().gom_adam_flat(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq), len(self.lr),
                                                        self._begin, lr, self.t, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
 

@@ -443,6 +443,14 @@ int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, 
                   const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
                   void *stream);
 
+/* The same step with the step COUNT in device memory -- step_device[0] = steps taken so far, step_device[1] = 0 (scratch), advanced by the
+ * kernel -- and the reference's learning-rate schedule (update_lr: base * 0.1^(iteration / lr_decay_steps); 0 = constant) derived from it
+ * on the device: no argument changes from step to step, so the launch can be captured into a hipGraph with the frame step in front of it.
+ * step_device == NULL: exactly gom_adam_flat. */
+int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                            const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
+                            float beta2, float eps, float grad_scale, void *stream);
+
 /* Direct all-reduce of the flat gradient buffer over peer pointers ("for this latency-bound size use a direct one-/two-shot
  * algorithm, not a ring"): one process per GPU; every rank creates a region, the 64-byte IPC handles are exchanged once (any transport:
  * the process group), and `run` enqueues two kernels that leave scale x (sum over the ranks, in RANK ORDER) in `out` -- the same bits on

@@ -90,3 +90,25 @@ def test_flat_adam_is_torch_adam():
             a, b = fp.params[k], ref_p[k].detach()
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (it, k, float((a - b).abs().max()))
     assert opt.t == 6 and torch.isfinite(fp.params.flat).all()
+    # the graphable variant (step count + learning-rate schedule on the device), captured ONCE and replayed, takes the same six steps
+    fp2 = FrameParallel(shapes, "cuda", pad_to=3 * 1001 + 9 * 2003 + 96 + 33)
+    g2 = torch.Generator(device="cuda").manual_seed(0)
+    fp2.params.flat.copy_(torch.randn(fp2.params.numel, device="cuda", generator=g2))
+    opt2 = FlatAdam(fp2, lrs, graphable=True, lr_decay_steps=100.0)
+    gs = [torch.randn(fp2.grads.numel, device="cuda", generator=g2) * (10.0 ** (it - 3)) for it in range(6)]
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        fp2.grads.flat.copy_(gs[0])
+        with torch.cuda.graph(graph, stream=stream):
+            opt2.step(grad_scale=0.5)
+        # (capture does not execute: the replays below are the six steps)
+        for it in range(6):
+            fp2.grads.flat.copy_(gs[it])
+            graph.replay()
+    stream.synchronize()
+    assert int(opt2.step_dev[0]) == 6 and int(opt2.step_dev[1]) == 0
+    for k in ref_p:
+        a, b = fp2.params[k], ref_p[k].detach()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (k, float((a - b).abs().max()))
