@@ -357,6 +357,9 @@ struct EntryRegs {
 // most independent waves; a batched launch has parallelism to spare and halves the per-task fixed cost (checkpoint loads,
 // cull, LDS fold, stores -- measured at 40-60 % of these kernels) with 256 / 64.
 #define GOM_NSUB 4
+#ifndef GOM_FWD_SKIP_DEAD_ROWS
+#define GOM_FWD_SKIP_DEAD_ROWS 1
+#endif
 #ifndef GOM_FWD_EPT
 #define GOM_FWD_EPT 4   // entries evaluated per trip of the forward loops
 #endif
@@ -793,11 +796,16 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
             uint32_t lastc = 0;
             float cadd[GOM_NSUB][C];
             bool going = true, stopped = false, any = false;
+            // Pieces every pixel of the quadrant has stopped in front of: no pixel's last contributor lies in or behind them, so the
+            // backward (which starts a (sub-range, quadrant) only when the quadrant's largest n_contrib reaches into it) never reads
+            // their checkpoint rows -- they are not written (GOM_FWD_SKIP_DEAD_ROWS; ~40 of this kernel's 158 MB per 8-frame launch).
+            int n_live = GOM_NSUB;
 #pragma unroll
             for (int u = 0; u < GOM_NSUB; u++) {
                 const float te = s_t[u][lane];
                 const bool counts = going && te != 0.f;
                 if (going && te == 0.f) going = false;  // had stopped before this piece
+                if (GOM_FWD_SKIP_DEAD_ROWS && n_live == GOM_NSUB && __ballot(counts) == 0ull) n_live = u;   // (wave-uniform; dead once = dead behind)
                 if (counts) {
                     any = true;
 #pragma unroll
@@ -807,7 +815,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
                     if (te < 0.f) { going = false; stopped = true; }
                 }
                 // checkpoints for the backward: T behind this piece, and (below) the colour the LATER pieces of the segment really added
-                sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
+                if (u < n_live) sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) cadd[u][ch] = counts ? s_c[u][ch][lane] : 0.f;
             }
@@ -818,7 +826,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
                 for (int ch = 0; ch < C; ch++) run[ch] = 0.f;
 #pragma unroll
                 for (int u = GOM_NSUB - 1; u >= 0; u--) {
-                    if (u < GOM_NSUB - 1) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);
+                    if (u < GOM_NSUB - 1 && u < n_live) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) run[ch] += cadd[u][ch];
                 }
