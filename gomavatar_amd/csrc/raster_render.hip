@@ -83,11 +83,14 @@ __device__ __forceinline__ float rl(float v, int lane) {
 }
 
 // Sum of 10 registers over the 64 lanes, transposed tree: v_permlane32_swap / v_permlane16_swap exchange halves (rows) of two registers, so
-// one swap + one add folds a level of the tree for TWO values and halves the number of live registers
-// (10 -> 5 -> 3); only the four in-row steps remain as DPP adds on 3 registers.  34 wave instructions instead of
-// 60 (scripts/ubench: ~130 issue cycles instead of ~265).  Totals land in lane 15 of each 16-lane row:
-//   s0: rows 0..3 = values 0, 2, 1, 3     s1: rows 0..3 = values 4, 6, 5, 7     s2: row 1 = value 8, row 3 = value 9
-// (layout checked on the hardware by scripts/ubench/permlane_probe.hip).
+// one swap + one add folds a level of the tree for TWO values and halves the number of live registers (10 -> 5 -> 3: every ROW then holds
+// partials of its own value).  Round 3: the four in-row steps are transposed too -- DPP bank_mask (one bit per quad of lanes) lets two source
+// registers fold into one destination, csrc/row_reduce.hpp -- lane ^ 8 (3 adds: 3 -> 2 registers), lane ^ 7 (2 adds: -> 1), two quad
+// butterflies (2 adds), one row_bcast for the value that was split over two rows: 8 cross-lane adds where four row_shr steps on three
+// registers took 13 (29 instead of 34 per entry).  Where the totals land in the ONE result register n, all four lanes of the quad alike:
+//   bank 0 (lanes 0-3 of the row):  rows 0..3 = values 0, 2, 1, 3        bank 2 (lanes 8-11):  rows 0..3 = values 4, 6, 5, 7
+//   bank 3 (lanes 12-15):  row 1 = value 8, row 3 = value 9              (bank 1 and bank 3 of rows 0, 2: partial sums, unused)
+// (layout of the swap levels checked by scripts/ubench/permlane_probe.hip, of the bank-masked steps by scripts/ubench/row_reduce_probe.hip).
 __device__ __forceinline__ float swap_add32(float a, float b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -96,17 +99,36 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ void wave_sum10_rows(const float (&w)[10], float &s0, float &s1, float &s2) {
+__device__ __forceinline__ float wave_sum10_banks(const float (&w)[10]) {
     const float p0 = swap_add32(w[0], w[1]), p1 = swap_add32(w[2], w[3]), p2 = swap_add32(w[4], w[5]), p3 = swap_add32(w[6], w[7]);
-    s2 = swap_add32(w[8], w[9]);
-    s0 = swap_add16(p0, p1);
-    s1 = swap_add16(p2, p3);
-#define GOM_ROW_STEP(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL "\n v_add_f32_dpp %1, %1, %1 " CTRL "\n v_add_f32_dpp %2, %2, %2 " CTRL "\n"
-    asm volatile("s_nop 1\n" GOM_ROW_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") GOM_ROW_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 GOM_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") GOM_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 "s_nop 1\n v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-                 : "+v"(s0), "+v"(s1), "+v"(s2));
-#undef GOM_ROW_STEP
+    const float s2 = swap_add32(w[8], w[9]);
+    const float s0 = swap_add16(p0, p1);
+    const float s1 = swap_add16(p2, p3);
+    float m, t, n;
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n"          // m: banks 0,1 <- s0 (lane ^ 8)
+                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"          // t: s2 (lane ^ 8)
+                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n"          // m: banks 2,3 <- s1
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n"    // n: banks 0,2 <- m (lane ^ 7)
+                 "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n"    // n: banks 1,3 <- t
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0x8\n"        // rows 1, 3, bank 3: + lane 15 of the row in front (the other half of values 8, 9)
+                 : "=&v"(m), "=&v"(t), "=&v"(n)
+                 : "v"(s0), "v"(s1), "v"(s2));
+    return n;
+}
+// the float index inside an entry's 10-value LDS record that this lane's share of wave_sum10_banks goes to, or -1
+__device__ __forceinline__ int wave_sum10_slot(int lane) {
+    const int l = lane & 15, row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);   // rows 0..3 -> 0, 2, 1, 3
+    if (l == 0) return row_slot;
+    if (l == 8) return 4 + row_slot;
+    if (l == 15 && (lane & 16)) return 8 + (lane >> 5);
+    return -1;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -1074,7 +1096,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 quadrants of one (segment, sub-range)
     const int pxi = q * 64 + lane;
-    const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);  // which value the row's total of s0 / s1 is: rows 0..3 -> 0, 2, 1, 3
+    const int sum_slot = wave_sum10_slot(lane);   // where this lane's share of a reduced entry goes (or -1)
     const size_t HW = (size_t)H * W;
 #ifdef GOM_PHASE_PROF
     const unsigned long long ph_k0 = __builtin_readcyclecounter(), ph_w0 = wall_clock64();
@@ -1221,19 +1243,14 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                     v[C + 3] = Q * dx * dx;
                     v[C + 4] = Q * dx * dy;
                     v[C + 5] = Q * dy * dy;
-                    float w10[10], r0, r1, r2;  // record layout: colour gradients in 0..3 (3 stays 0 for C = 3), geometry in 4..9
+                    float w10[10];  // record layout: colour gradients in 0..3 (3 stays 0 for C = 3), geometry in 4..9
 #pragma unroll
                     for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
 #pragma unroll
                     for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
-                    wave_sum10_rows(w10, r0, r1, r2);
+                    const float tot = wave_sum10_banks(w10);
                     done |= 1ull << kk[u];
-                    if ((lane & 15) == 15) {  // lane 15 of every row holds totals (see wave_sum10_rows)
-                        float *dst = &s_acc[buf][q][kk[u]][0];
-                        dst[row_slot] = r0;
-                        dst[4 + row_slot] = r1;
-                        if (lane & 16) dst[8 + (lane >> 5)] = r2;
-                    }
+                    if (sum_slot >= 0) s_acc[buf][q][kk[u]][sum_slot] = tot;   // three lanes per row hold a total each (see wave_sum10_banks)
                 }
             }
         }
@@ -1311,7 +1328,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);
+    const int sum_slot = wave_sum10_slot(lane);
     const size_t HW = (size_t)H * W;
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2   // (scripts/wg_timeline_T.py)
     const unsigned long long ph_w0 = wall_clock64();
@@ -1460,19 +1477,14 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                         v[C + 3] = Q * dx * dx;
                         v[C + 4] = Q * dx * dy;
                         v[C + 5] = Q * dy * dy;
-                        float w10[10], r0, r1, r2;
+                        float w10[10];
 #pragma unroll
                         for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
 #pragma unroll
                         for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
-                        wave_sum10_rows(w10, r0, r1, r2);
+                        const float tot = wave_sum10_banks(w10);
                         done |= 1ull << kk[u];
-                        if ((lane & 15) == 15) {
-                            float *dst = &s_acc[half][q][kk[u]][0];
-                            dst[row_slot] = r0;
-                            dst[4 + row_slot] = r1;
-                            if (lane & 16) dst[8 + (lane >> 5)] = r2;
-                        }
+                        if (sum_slot >= 0) s_acc[half][q][kk[u]][sum_slot] = tot;
                     }
                 }
             }
