@@ -59,17 +59,36 @@ class PeerAllReduce:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.numel = int(numel)
         torch.cuda.set_device(device)
-        self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
-        if not self._h:
-            _lib.check(-1)
-        mine = (ctypes.c_ubyte * 64)()
-        _lib.check(self.lib.gom_peer_reduce_handle(self._h, mine))
-        handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(mine), group=group)
-        blob = (ctypes.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
-        _lib.check(self.lib.gom_peer_reduce_connect(self._h, blob))
-        self.buffer = torch.as_tensor(_DevicePtr(self.lib.gom_peer_reduce_buffer(self._h), self.numel), device=torch.device(device))
-        dist.barrier(group=group)   # every rank has mapped every region before anyone raises a flag in it
+        # Every step that can fail (allocation, IPC export, IPC mapping) is followed by an exchange of its outcome, so that ALL ranks
+        # raise together instead of one leaving the others inside a collective.
+        self._h, mine, err = None, None, None
+        try:
+            self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
+            if not self._h:
+                _lib.check(-1)
+            buf = (ctypes.c_ubyte * 64)()
+            _lib.check(self.lib.gom_peer_reduce_handle(self._h, buf))
+            mine = bytes(buf)
+        except Exception as e:
+            err = f"rank {self.rank}: {type(e).__name__}: {e}"
+        got = [None] * self.world
+        dist.all_gather_object(got, (err, mine), group=group)
+        self._raise_together([g[0] for g in got])
+        try:
+            blob = (ctypes.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(g[1] for g in got))
+            _lib.check(self.lib.gom_peer_reduce_connect(self._h, blob))
+            self.buffer = torch.as_tensor(_DevicePtr(self.lib.gom_peer_reduce_buffer(self._h), self.numel), device=torch.device(device))
+        except Exception as e:
+            err = f"rank {self.rank}: {type(e).__name__}: {e}"
+        got = [None] * self.world
+        dist.all_gather_object(got, err, group=group)   # (also the barrier: every rank has mapped every region before anyone raises a flag in it)
+        self._raise_together(got)
+
+    def _raise_together(self, errs) -> None:
+        bad = [e for e in errs if e]
+        if bad:
+            self.close()
+            raise RuntimeError("peer all-reduce unavailable (" + bad[0] + ")")
 
     def run(self, out: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
         out = self.buffer if out is None else out
