@@ -382,6 +382,9 @@ struct EntryRegs {
 #ifndef GOM_FWD_SKIP_DEAD_ROWS
 #define GOM_FWD_SKIP_DEAD_ROWS 1
 #endif
+#ifndef GOM_FWD_SKIP_IDLE
+#define GOM_FWD_SKIP_IDLE 0   // (round 3, measured: 1 = skip the chain of an entry no compositing lane blends -- k_seg_fwd 110 -> 124 us: the branch between the four
+#endif                       //  unrolled chain steps costs more than the ~14 instructions it saves on a quarter of the entries)
 #ifndef GOM_FWD_EPT
 #define GOM_FWD_EPT 4   // entries evaluated per trip of the forward loops
 #endif
@@ -792,6 +795,9 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
 #pragma unroll
                 for (int u = 0; u < GOM_FWD_EPT; u++) {  // the serial chain: T -> test_T -> select
                     const float a = al[u] * wl;
+                    // no lane blends this entry (it misses every pixel that is still compositing: a quarter of the survivors of the
+                    // conservative cull): the chain below would leave T, wl, acc and last exactly as they are (wave-uniform skip)
+                    if (GOM_FWD_SKIP_IDLE && __ballot(a > 0.f) == 0ull) continue;
                     const float test_T = T * (1.f - a);
                     const bool cont = test_T >= kStopT;  // reference: `test_T < 0.0001f -> done`
                     const float w = cont ? a * T : 0.f;
