@@ -7,6 +7,9 @@ TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1                       # default bench: one step in flight
 bash scripts/collect_profiles.sh ${TAG}_inflight3 "--inflight 3" > gpurun_out/collect_${TAG}_inflight3.log 2>&1
+# the metric workload ALONE (no modes, no other configs): every launch of a kernel in this trace is a launch of the timed loop or of the
+# event-bracketed per-kernel pass on it, so the per-kernel averages are the ones roofline.avg_us must agree with
+( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/prof_${TAG}_pure && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_pure/trace -o bench -- python bench.py --no-modes --no-configs --no-cpu-baseline > gpurun_out/prof_${TAG}_pure/bench_trace.log 2>&1; grep "^{" gpurun_out/prof_${TAG}_pure/bench_trace.log > gpurun_out/prof_${TAG}_pure/bench_line.json )
 bash scripts/pmc_pass.sh ${TAG}_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" --no-modes > gpurun_out/pmc_${TAG}_insts.log 2>&1
 bash scripts/pmc_pass.sh ${TAG}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" --no-modes > gpurun_out/pmc_${TAG}_lds.log 2>&1
 bash scripts/pmc_pass.sh ${TAG}_busy "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" --no-modes > gpurun_out/pmc_${TAG}_busy.log 2>&1
@@ -15,6 +18,8 @@ cp gpurun_out/prof_$TAG/bench_line.json $OUT/${TAG}_bench_line.json
 cp gpurun_out/prof_$TAG/trace/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp $(find gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 cp gpurun_out/prof_$TAG/traffic.json $OUT/${TAG}_traffic.json
 cp gpurun_out/prof_${TAG}_inflight3/bench_line.json $OUT/${TAG}_inflight3_bench_line.json
+cp gpurun_out/prof_${TAG}_pure/bench_line.json $OUT/${TAG}_metric_only_bench_line.json
+cp $(find gpurun_out/prof_${TAG}_pure/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_metric_only_kernel_stats.csv
 cp $(find gpurun_out/prof_${TAG}_inflight3/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_inflight3_kernel_stats.csv
 python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_fetch -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_fetch_per_kernel.csv
 python scripts/summarize_pmc.py $(find gpurun_out/prof_$TAG/pmc_write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_write_per_kernel.csv
@@ -45,5 +50,5 @@ print(json.dumps(res.get("k_seg_bwd"), indent=1))
 PY
 ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-600
 # gpurun merges at most 64 MiB back: drop the raw traces / counter dumps, the summaries above are what is kept
-rm -rf gpurun_out/prof_${TAG}/trace gpurun_out/prof_${TAG}/pmc_fetch gpurun_out/prof_${TAG}/pmc_write gpurun_out/prof_${TAG}_inflight3/trace \
+rm -rf gpurun_out/prof_${TAG}_pure/trace gpurun_out/prof_${TAG}/trace gpurun_out/prof_${TAG}/pmc_fetch gpurun_out/prof_${TAG}/pmc_write gpurun_out/prof_${TAG}_inflight3/trace \
        gpurun_out/prof_${TAG}_inflight3/pmc_fetch gpurun_out/prof_${TAG}_inflight3/pmc_write gpurun_out/pmc_${TAG}_insts gpurun_out/pmc_${TAG}_busy gpurun_out/pmc_${TAG}_lds
