@@ -172,6 +172,10 @@ class Runner:
             if self.B > 1:
                 sl["step"].cams_dev = bt["cams_dev"]   # this batch's device camera array: resident like its targets and poses (one recorded graph per batch)
             sl["step"].forward_backward(sl["params"], bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
+            if collective and sl["fp"].peer is not None and sl["opt"] is not None:
+                # the peer exchange carries the optimizer in its all-gather kernel (1 / B: mean over the frames of the batch as well)
+                sl["fp"].peer.run_adam(sl["opt"], 1.0 / (self.world * self.B))
+                return
             if collective:
                 sl["fp"].all_reduce_grads()  # no-op at world size 1
             if sl["opt"] is not None:
@@ -532,7 +536,7 @@ def main():
     # ---------------- N > 1: the same job over the direct peer-pointer all-reduce (csrc/frame_parallel.hip), when it comes up ----------------
     peer_info, use_peer, collective_fps = None, False, None
     if world > 1:
-        peer_info = {"impl": "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum (gom_peer_reduce_*)"}
+        peer_info = {"impl": "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum, Adam inside the all-gather kernel (gom_peer_reduce_run_adam)"}
         ok_t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         peer_run, err = None, None
         try:

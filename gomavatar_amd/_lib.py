@@ -124,6 +124,8 @@ SIGNATURES = {
     "gom_peer_reduce_connect": (c_int, [c_void_p, c_void_p]),
     "gom_peer_reduce_buffer": (c_void_p, [c_void_p]),
     "gom_peer_reduce_run": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "gom_peer_reduce_run_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
+                                         c_float, c_void_p]),
     "gom_peer_reduce_status": (c_int, [c_void_p]),
     "gom_peer_reduce_destroy": (None, [c_void_p]),
     "gom_l1_loss": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,

@@ -96,6 +96,15 @@ class PeerAllReduce:
         self._lib.check(self.lib.gom_peer_reduce_run(self._h, out.data_ptr(), float(scale), self._lib.stream_ptr()))
         return out
 
+    def run_adam(self, opt: "FlatAdam", scale: float = 1.0, out: Optional[torch.Tensor] = None) -> None:
+        """The exchange with `opt`'s Adam step inside its second kernel (`gom_peer_reduce_run_adam`): every rank updates its parameter
+        replica straight from the reduced slices; `out` (optional) receives the reduced gradient."""
+        opt.t += 1
+        lr = (self._ct.c_float * len(opt.lr))(*opt.lr)
+        P = self._lib.ptr
+        self._lib.check(self.lib.gom_peer_reduce_run_adam(self._h, float(scale), P(out), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
+                                                          opt._begin, lr, opt.t, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+
     def check(self) -> None:
         """Synchronises; raises if a peer never answered (the kernels give up after ~1 s instead of hanging)."""
         self._lib.check(-self.lib.gom_peer_reduce_status(self._h))
@@ -177,6 +186,15 @@ class FrameParallel:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 flat.mul_(1.0 / self.world)
+
+    def all_reduce_and_step(self, opt: "FlatAdam") -> None:
+        """Mean of the gradients over the ranks + `opt`'s Adam step.  Over the peer exchange that is two launches (the optimizer rides in
+        the all-gather); otherwise the collective followed by `opt.step()`."""
+        if self.peer is not None and not opt.graphable:
+            self.peer.run_adam(opt, 1.0 / self.world if self.average else 1.0)
+        else:
+            self.all_reduce_grads()
+            opt.step()
 
     def make_adam(self, lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8) -> torch.optim.Adam:
         """Adam with one param group per tensor (the reference uses per-group

@@ -463,6 +463,10 @@ int gom_peer_reduce_handle(GomPeerReduce *h, void *handle64);
 int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles /* world x 64 bytes, rank order */);
 float *gom_peer_reduce_buffer(GomPeerReduce *h);
 int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream);
+/* The same exchange with the optimizer inside its second kernel: every rank applies gom_adam_flat's step of ITS parameter replica straight from
+ * the reduced slices as it reads them (n_floats = the flat parameter count; out may be NULL: the reduced gradient is then not materialised). */
+int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *out, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                             const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream);
 int gom_peer_reduce_status(GomPeerReduce *h);
 void gom_peer_reduce_destroy(GomPeerReduce *h);
 

@@ -45,6 +45,25 @@ for epoch in range(6):
         ref = ref + grad(r, epoch)
     ref = ref * (1.0 / world)
     ok = ok and bool(torch.equal(out, ref))
+# the optimizer inside the all-gather (gom_peer_reduce_run_adam) == the exchange followed by gom_adam_flat, bit for bit, padding untouched
+from gomavatar_amd.parallel import FrameParallel, FlatAdam, shapes_for_model
+if n > 5000:
+    shapes = shapes_for_model(1001, 2003)
+    fps = [FrameParallel(shapes, "cuda:0", pad_to=3 * 1001 + 9 * 2003 + 37, impl="peer") for _ in range(2)]
+    opts = [FlatAdam(f, {"vertices": 5e-4, "default": 1e-3}) for f in fps]
+    for f in fps:
+        f.params.flat.copy_(torch.randn(f.params.numel, generator=torch.Generator().manual_seed(7)).cuda())
+    for epoch in range(3):
+        gsrc = torch.randn(fps[0].grads.numel, generator=torch.Generator().manual_seed(50 * epoch + rank)).cuda()
+        for f in fps:
+            f.grads.flat.copy_(gsrc)
+        fps[0].all_reduce_grads(); opts[0].step()             # two kernels + Adam
+        fps[1].all_reduce_and_step(opts[1])                   # two kernels, Adam inside the second
+        torch.cuda.synchronize()
+        fps[0].peer.check(); fps[1].peer.check()
+        ok = ok and bool(torch.equal(fps[0].params.flat, fps[1].params.flat)) and bool(torch.equal(opts[0].exp_avg, opts[1].exp_avg)) and bool(torch.equal(opts[0].exp_avg_sq, opts[1].exp_avg_sq))
+    for f in fps:
+        f.peer.close()
 # timing (one device shared by all ranks: a functional number)
 t = grad(rank, 99); host = torch.empty(n).pin_memory()
 torch.cuda.synchronize(); dist.barrier()
