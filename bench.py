@@ -623,6 +623,10 @@ def main():
                                       "torch.distributed all_reduce (" + ("RCCL, ReduceOp.AVG" if backend == "nccl" else backend + " through pinned host memory") + ")"),
                    "allreduce_collective_fps": round(collective_fps, 1) if collective_fps is not None else None,
                    "local_only_fps": local_only_fps, "allreduce_peer": peer_info,
+                   "note": (None if world == 1 else
+                            f"per-GPU work at N > 1 is {B} frame(s) per step (BASELINE configs[3]: one frame per GPU), at N = 1 the default is 8 (configs[1], the metric): "
+                            "compare this line with `local_only_fps` (the same loop without the exchange = N independent GPUs at this batch) or with "
+                            "`python bench.py --batch 1` at N = 1, not with the N = 1 default; `modes.b8_per_gpu` is the job at 8 frames per GPU"),
                    "backend": (("rccl" if backend == "nccl" else backend) + (f" ({world} ranks share {n_dev} device(s): functional proof, not a scaling number)" if shared else ""))
                    if world > 1 else None},
         "roofline": roofline,
