@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int ra
     if (threadIdx.x == 0) {
         __atomic_thread_fence(__ATOMIC_RELEASE);
         if (atomicAdd(done_ctr, 1u) == gridDim.x - 1) {   // the last workgroup: my slice is complete everywhere -> tell the peers
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);      // (pairs with the other workgroups' release fences in front of their increments)
             *done_ctr = 0;
             for (int p = 0; p < world; p++)
                 __hip_atomic_store(peer_flags(pp.p[p], n, 1) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
