@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-modes", action="store_true", help="skip the other operating points (modes) and the raster-only / full-step figures")
     ap.add_argument("--cpu-frames", type=int, default=5, help="timed frames per CPU-baseline row (median; after 3 warm-up frames at M, 1 at S)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (cfg 3 at 1024^2 / 540^2, cfg 5) of the `configs` block")
+    ap.add_argument("--attach-adam", action="store_true", help="the optimizer as the last launch of the frame step's recorded graph (measured slower: off)")
     ap.add_argument("--no-adam", action="store_true", help="leave the optimizer step out of the timed loop (round-2 behaviour)")
     ap.add_argument("--task-grid-pct", type=int, default=0, help="GOM_OPT_TASK_GRID_PCT, 10..100 (0 = library default, 100)")
     ap.add_argument("--bwd-mode", type=int, default=-1, help="GOM_OPT_BWD_MODE (-1 = library default)")
@@ -145,7 +146,13 @@ class Runner:
             for name in ("vertices", "so3", "scale", "appearance"):
                 st.grads[name] = fp.grads[name]
                 fp.params[name].copy_(wl.params[name])   # every slot trains its own replica of the parameters (S > 1: independent steps)
-            opt = FlatAdam(fp, {"default": ADAM_LR}) if self.adam else None
+            # (Measured: the Adam launch as the LAST launch of the frame step's own recorded graph -- gom_state_set_frame_optimizer, --attach-adam --
+            #  is slower than a plain launch behind the graph: 13.96 k instead of 14.09 k frames/s, 4.65 k instead of 4.84 k at B = 1.  The ~9 us
+            #  between two graph replays are there either way, and the plain launch runs inside them.)
+            self.attached = self.adam and world == 1 and graph and args.attach_adam
+            opt = FlatAdam(fp, {"default": ADAM_LR}, graphable=self.attached) if self.adam else None
+            if self.attached:
+                opt.attach(st.state, 1.0 / B)
             if args.seg_shift:
                 st.state.set_option(_lib.OPT_SEG_SHIFT, args.seg_shift)
             if args.task_grid_pct:
@@ -178,7 +185,7 @@ class Runner:
                 return
             if collective:
                 sl["fp"].all_reduce_grads()  # no-op at world size 1
-            if sl["opt"] is not None:
+            if sl["opt"] is not None and not self.attached:
                 sl["opt"].step(1.0 / self.B)  # mean over the frames of the batch (the collective has averaged over the ranks)
 
     def region(self, steps, warmup, first=0, collective=True):
@@ -618,7 +625,8 @@ def main():
                    "gaussians": F, "image": [img, img], "frames_per_step": world * B, "frames_per_gpu_per_step": B,
                    "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S,
                    "optimizer": (f"Adam on the flat parameter buffer inside the timed loop (gom_adam_flat, lr {ADAM_LR:g}: the reference's arithmetic, a rate that "
-                                 "keeps the synthetic workload fixed)" if not args.no_adam else None),
+                                 "keeps the synthetic workload fixed)" + ("; the last launch of the frame step's recorded graph" if main_run.attached else "")
+                                 if not args.no_adam else None),
                    "allreduce_floats": main_run.payload if world > 1 else 0, "allreduce_us": allreduce_us, "allreduce_impl": (None if world == 1 else peer_info["impl"] if use_peer else
                                       "torch.distributed all_reduce (" + ("RCCL, ReduceOp.AVG" if backend == "nccl" else backend + " through pinned host memory") + ")"),
                    "allreduce_collective_fps": round(collective_fps, 1) if collective_fps is not None else None,

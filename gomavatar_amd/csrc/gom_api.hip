@@ -468,6 +468,24 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     return 0;
 }
 
+extern "C" int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                                             const int64_t *seg_begin, const float *seg_lr, int64_t *step_device, float lr_decay_steps, float beta1, float beta2,
+                                             float eps, float grad_scale) {
+    if (!s) { gom_set_error("null state"); return -1; }
+    s->allocGen++;   // recordings made with another (or no) optimizer behind them are dropped at their next use
+    if (n == 0 || !params) { s->adam.on = false; return 0; }
+    if (!grads || !exp_avg || !exp_avg_sq || !step_device || !seg_begin || !seg_lr || n_segments < 1 || n_segments > GOM_ADAM_MAX_SEGMENTS) {
+        gom_set_error("gom_state_set_frame_optimizer: null pointer / 1..%d segments / a device step counter is required", GOM_ADAM_MAX_SEGMENTS);
+        return -1;
+    }
+    s->adam.on = true; s->adam.n = n; s->adam.params = params; s->adam.grads = grads; s->adam.exp_avg = exp_avg; s->adam.exp_avg_sq = exp_avg_sq;
+    s->adam.n_segments = n_segments;
+    for (int i = 0; i <= n_segments; i++) s->adam.seg_begin[i] = seg_begin[i];
+    for (int i = 0; i < n_segments; i++) s->adam.seg_lr[i] = seg_lr[i];
+    s->adam.step_device = step_device; s->adam.lr_decay_steps = lr_decay_steps; s->adam.beta1 = beta1; s->adam.beta2 = beta2; s->adam.eps = eps; s->adam.grad_scale = grad_scale;
+    return 0;
+}
+
 extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
     return frame_call(s, f, 1, nullptr, flags, stream);
 }
@@ -535,6 +553,12 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     if (B > 1) {
         if ((rc = gom_sum_frames4(B, F3, b_so3, f->g_so3, F3, b_scale, f->g_scale, F3, b_app, f->g_appearance, N3, b_vert, f->g_vertices,
                                   stream)))
+            return rc;
+    }
+    if (s->adam.on) {   // the optimizer step behind the gradients, inside the same (recordable) launch sequence
+        if ((rc = gom_adam_flat_graphable(s->adam.n, s->adam.params, s->adam.grads, s->adam.exp_avg, s->adam.exp_avg_sq, s->adam.n_segments, s->adam.seg_begin,
+                                          s->adam.seg_lr, 1, s->adam.step_device, s->adam.lr_decay_steps, s->adam.beta1, s->adam.beta2, s->adam.eps, s->adam.grad_scale,
+                                          stream)))
             return rc;
     }
     return 0;

@@ -157,6 +157,19 @@ struct GomState {
     bool profile = false;
     hipEvent_t ev[2 * GOM_NUM_KERNELS] = {};
     bool evValid[GOM_NUM_KERNELS] = {};
+    // optimizer step appended to the frame step's launch sequence (gom_state_set_frame_optimizer): Adam on a flat parameter buffer with the
+    // step count in device memory, so that it is part of the recorded graph
+    struct {
+        bool on = false;
+        int64_t n = 0;
+        float *params = nullptr, *exp_avg = nullptr, *exp_avg_sq = nullptr;
+        const float *grads = nullptr;
+        int32_t n_segments = 0;
+        int64_t seg_begin[GOM_ADAM_MAX_SEGMENTS + 1] = {};
+        float seg_lr[GOM_ADAM_MAX_SEGMENTS] = {};
+        int64_t *step_device = nullptr;
+        float lr_decay_steps = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, grad_scale = 1.f;
+    } adam;
     // captured whole-frame launch sequences (GOM_FRAME_USE_GRAPH), keyed by the exact frame descriptor
     std::vector<GomGraphEntry> graphs;
     uint64_t graphClock = 0;

@@ -233,6 +233,16 @@ class FlatAdam:
         self.graphable, self.lr_decay_steps = bool(graphable), float(lr_decay_steps)
         self.step_dev = torch.zeros(2, dtype=torch.int64, device=fp.params.flat.device) if graphable else None
 
+    def attach(self, state, grad_scale: float = 1.0) -> None:
+        """Make this optimizer's step the LAST launch of `state`'s frame step (`gom_state_set_frame_optimizer`): forward, backward and Adam
+        are then one recorded graph.  Needs `graphable=True` (the step count lives on the device); do not call `step()` as well."""
+        assert self.graphable, "attach() needs FlatAdam(graphable=True)"
+        fp, P = self.fp, self._lib.ptr
+        lr = (self._ct.c_float * len(self.base_lr))(*self.base_lr)
+        self._lib.check(self._lib.load().gom_state_set_frame_optimizer(state.handle, fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq),
+                                                                       len(self.base_lr), self._begin, lr, P(self.step_dev), self.lr_decay_steps, self.betas[0], self.betas[1],
+                                                                       self.eps, float(grad_scale)))
+
     def decay(self, iter_step: int, lr_decay_steps: float) -> None:
         """update_lr (train.py:166-175)."""
         self.lr = [b * 0.1 ** (iter_step / lr_decay_steps) for b in self.base_lr]

@@ -451,6 +451,14 @@ int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float 
                             const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
                             float beta2, float eps, float grad_scale, void *stream);
 
+/* Attach that step to a state's frame step: gom_frame_forward_backward / gom_batch_forward_backward then end with the Adam launch
+ * (`grads` = the flat buffer the frame's g_* pointers are views of; the device step counter is required), so that forward, backward AND the
+ * optimizer are one recorded graph (a plain launch behind a graph launch starts ~9 us late).  Not applied by GOM_FRAME_FORWARD_ONLY calls.
+ * n == 0 or params == NULL detaches it. */
+int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                                  const int64_t *seg_begin, const float *seg_lr, int64_t *step_device, float lr_decay_steps, float beta1, float beta2,
+                                  float eps, float grad_scale);
+
 /* Direct all-reduce of the flat gradient buffer over peer pointers ("for this latency-bound size use a direct one-/two-shot
  * algorithm, not a ring"): one process per GPU; every rank creates a region, the 64-byte IPC handles are exchanged once (any transport:
  * the process group), and `run` enqueues two kernels that leave scale x (sum over the ranks, in RANK ORDER) in `out` -- the same bits on

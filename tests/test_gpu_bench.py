@@ -112,3 +112,47 @@ def test_flat_adam_is_torch_adam():
     for k in ref_p:
         a, b = fp2.params[k], ref_p[k].detach()
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (k, float((a - b).abs().max()))
+
+
+def test_optimizer_attached_to_the_frame_graph_takes_the_same_steps():
+    """gom_state_set_frame_optimizer: the Adam launch as the last launch of the frame step's recorded graph (forward + backward + optimizer =
+    one graph replay) against the frame step followed by a separate gom_adam_flat: same parameters and moments, bit for bit, over three steps
+    in which step k + 1 renders with what step k wrote."""
+    import torch
+    from gomavatar_amd.parallel import FlatAdam, FrameParallel, shapes_for_model
+    from gomavatar_amd.workload import MetricWorkload
+    wl = MetricWorkload("cuda", subdiv=0, img=128, n_frames=4)
+    runs = []
+    for attached in (False, True):
+        st = wl.step(2)
+        bt = wl.batches(st)[0]
+        fp = FrameParallel(shapes_for_model(wl.N, wl.F), "cuda")
+        for k in ("vertices", "so3", "scale", "appearance"):
+            st.grads[k] = fp.grads[k]
+            fp.params[k].copy_(wl.params[k])
+        opt = FlatAdam(fp, {"default": 1e-3}, graphable=attached, lr_decay_steps=50.0)
+        if attached:
+            opt.attach(st.state, 0.5)
+        pv = dict(fp.params.items())
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            st.cam = bt["cam"]; st.cams_dev = bt["cams_dev"]
+            for it in range(3):
+                st.forward_backward(pv, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=True)
+                if not attached:
+                    opt.decay(it + 1, 50.0)          # update_lr's schedule as the device variant derives it: step t uses base * 0.1^((t - 1) / D)
+                    opt.lr = [b * 0.1 ** (it / 50.0) for b in opt.base_lr]
+                    opt.step(0.5)
+        stream.synchronize()
+        runs.append((fp.params.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), int(opt.step_dev[0]) if attached else opt.t))
+    (p0, m0, v0, t0), (p1, m1, v1, t1) = runs
+    assert t0 == t1 == 3
+    assert float((p0 - wl_flat(wl, p0)).abs().max()) > 0          # the parameters really moved
+    # (host-side float(lr / bc1) against the device's double arithmetic: the last bit of step_size may differ -> a few ulp on the parameters)
+    assert float((p0 - p1).abs().max()) <= 2e-6 * float(p0.abs().max()) and torch.allclose(m0, m1, rtol=1e-6, atol=0) and torch.allclose(v0, v1, rtol=1e-6, atol=0)
+
+
+def wl_flat(wl, like):
+    import torch
+    return torch.cat([wl.params[k].reshape(-1) for k in ("vertices", "so3", "scale", "appearance")])[: like.numel()]
