@@ -366,6 +366,37 @@ def extra_figures(torch, wl):
                 del st, mc, fp, optn
             except Exception as e:  # report, do not hide
                 out[key] = f"failed: {type(e).__name__}: {e}"
+    # BASELINE configs[1] as the reference runs it: ONE iteration of train.py:309-349 through the drop-in `Model` (forward incl. the mesh normal /
+    # silhouette branch and the shadow MLP, unpack, every loss term of exps/zju-mocap_377.yaml incl. LPIPS, backward, torch Adam over the
+    # reference's parameter groups, update_lr), one frame per iteration, launched from Python like the reference's loop.
+    try:
+        from types import SimpleNamespace as NS
+        from gomavatar_amd.model import Model
+        from gomavatar_amd import train_util as tu
+        cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
+                 normal_renderer=NS(sigma=1e-5, soft_mask=True), shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)),
+                 lbs_weights=NS(refine=False))
+        tcfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, canonical_geometry_xyz=0.0005, shadow=0.0005), lr_decay_steps=100000,
+                  losses=NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=1.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                            normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05)))
+        for prec in ("bf16x3", "bf16"):
+            model = Model(cfg, wl.body).train()
+            mcl = LPIPSMatrixCore(trunk_seed=0, device=dev, precision=prec)
+            optm = torch.optim.Adam(model.get_param_groups(tcfg), betas=(0.9, 0.999))
+            frames = []
+            for i in range(4):
+                fr = {k_: torch.from_numpy(v_).to(dev) for k_, v_ in wl.frames_np[i].items()}
+                fr["target_rgbs"], fr["target_masks"] = wl.frames[i]["gt_rgb"][None], wl.frames[i]["gt_mask"][None]
+                frames.append(fr)
+            it_ = [0]
+
+            def train_it():
+                tu.train_iteration(model, optm, frames[it_[0] % 4], tcfg, it_[0] + 1, lpips_func=mcl)
+                it_[0] += 1
+            out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=5, chunk=5), 1)
+            del model, mcl, optm
+    except Exception as e:  # report, do not hide
+        out["model_train_iteration_b1_ips"] = f"failed: {type(e).__name__}: {e}"
     return out
 
 
