@@ -1070,6 +1070,13 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 }
 
 // ---------------------------------------------------------------- backward -
+#ifdef GOM_BLK_STATS
+__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] lanes with alpha >= 1/255 before the my_last test
+#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
+#else
+#define GOM_PAIR_STAT(I, V) do { } while (0)
+#endif
+#include "seg_bwd_replay.hpp"
 #ifndef GOM_BWD_EPT
 #define GOM_BWD_EPT 2   // entries evaluated per trip of the backward loop (4: 8 VGPRs spilled at 6 waves per SIMD, 215 us; 3: 205; 2: 203)
 #endif
@@ -1086,23 +1093,20 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
                                                   uint32_t *__restrict__ task_ctr, const unsigned long long *__restrict__ cull_masks) {
-    constexpr int NV = 6 + C;  // values reduced per entry
     // [task parity][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote.
     // Double-buffered by task parity and never cleared: the flush reads only the rows s_done names, and the next task
     // writes the other half, so one barrier per task (before the flush) is all the synchronisation there is.
-    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
-    __shared__ unsigned long long s_done[2][4];
+    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];   // rows by COMPACTED survivor position (seg_bwd_replay.hpp)
+    __shared__ unsigned long long s_done[2][4], s_mask[2][4];   // pairs of rows written; the survivors (list order) they belong to
     __shared__ uint32_t s_task[2];
-    // geometry of the survivors through wave-private LDS broadcast slabs (as in the forward kernels); the colours stay on
-    // v_readlane: with them the workgroup would no longer fit six times into a CU's LDS
-    __shared__ float4 s_e0[4][64];
-    __shared__ float2 s_e1[4][64];
+    __shared__ float4 s_slab[4][GOM_BPAIR_F4];       // wave-private pair records of the survivors, geometry and colours
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 quadrants of one (segment, sub-range)
     const int pxi = q * 64 + lane;
-    const int sum_slot = wave_sum10_slot(lane);   // where this lane's share of a reduced entry goes (or -1)
+    bool from_n1;
+    const int slot20 = wave_sum20_slot(lane, from_n1);   // where this lane's share of a reduced pair goes (or -1)
     const size_t HW = (size_t)H * W;
 #ifdef GOM_PHASE_PROF
     const unsigned long long ph_k0 = __builtin_readcyclecounter(), ph_w0 = wall_clock64();
@@ -1135,7 +1139,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
         const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));  // max n_contrib over this wave's 8x8 pixels
         // record slot of "my" entry (Gaussian-major: the per-Gaussian backward reads a Gaussian's records as one contiguous run)
         const uint32_t my_slot = threadIdx.x < scnt ? ent_slot[start + (uint32_t)sub * sub_sz + threadIdx.x] : 0u;
-        unsigned long long done = 0ull;
+        unsigned long long done = 0ull, smask = 0ull;
         bool requested = false;
         if (wmax > s0) {
             const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
@@ -1169,7 +1173,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             // App. A.4 keeps accum_rec[ch] / last_color[ch] per channel, but they only ever meet the gradient through their dot product
             // with this pixel's dL/dpix: the recurrence is linear, so it is carried as two scalars R = accum_rec . dpix and
             // U_last = last_color . dpix (half the instructions of the serial chain, six registers fewer).
-            float R_acc, U_last = 0.f, last_alpha = 0.f;
+            float R_acc;
             float S[C], cu[C];
             ld4<C>(seg_Sbehind, seg, pxi, S);
             if (sub < GOM_NSUB - 1) ld4<C>(sub_C, (size_t)seg * GOM_NSUB + sub, pxi, cu);   // what the later pieces of the segment added (wave-uniform condition)
@@ -1188,79 +1192,17 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
                 for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
                 R_acc = sd * invT;
             }
-            unsigned long long mask = __ballot(r.keep);
-            s_e0[q][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
-            s_e1[q][lane] = make_float2(r.c, r.o);
-            // Back to front, 4 entries per trip: independent alpha evaluations, then the short serial
-            // T / accum_rec recurrences, then the transposed reductions.
-            while (mask) {
-                int kk[GOM_BWD_EPT];
-                bool kv[GOM_BWD_EPT];
-                float al[GOM_BWD_EPT], G0[GOM_BWD_EPT], dxs[GOM_BWD_EPT], dys[GOM_BWD_EPT], ecol[GOM_BWD_EPT][C];
-#pragma unroll
-                for (int u = 0; u < GOM_BWD_EPT; u++) {
-                    kv[u] = mask != 0ull;
-                    const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
-                    mask &= ~(1ull << k);  // k = 0 when the mask is already empty: clearing bit 0 of 0 is a no-op
-                    kk[u] = k;
-                    const float4 g0 = s_e0[q][k];
-                    const float2 g1 = s_e1[q][k];
-                    const float eo = kv[u] ? g1.y : 0.f;
-                    const float dx = g0.x - pfx, dy = g0.y - pfy;
-                    const float ea = g0.z, eb = g0.w, ec = g1.x;
-#pragma unroll
-                    for (int ch = 0; ch < C; ch++) ecol[u][ch] = rl(r.col[ch], k);
-                    const float power = gauss_power(ea, eb, ec, dx, dy);
-                    const float g = __expf(power);
-                    float a = fminf(kMaxAlpha, eo * g);
-                    a = (power <= 0.f) ? a : 0.f;
-                    a = (a >= kMinAlpha) ? a : 0.f;
-                    a = (s0 + (uint32_t)k < my_last) ? a : 0.f;  // beyond this pixel's last contributor
-                    al[u] = a;
-                    G0[u] = (a > 0.f) ? g : 0.f;
-                    dxs[u] = dx;
-                    dys[u] = dy;
-                }
-#pragma unroll
-                for (int u = 0; u < GOM_BWD_EPT; u++) {
-                    if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;  // wave-uniform
-                    // An entry with a == 0 is replayed as a zero-alpha layer: the recurrences below then
-                    // leave T / accum_rec exactly as skipping would (App. A.4), without divergent branches.
-                    const float a = al[u];
-                    const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);  // v_rcp_f32 (1 ulp), shared by both divisions
-                    T = T * inv1ma;
-                    const float w = a * T;
-                    float v[NV], U = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < C; ch++) {
-                        U += ecol[u][ch] * dpix[ch];
-                        v[ch] = w * dpix[ch];
-                    }
-                    R_acc = last_alpha * U_last + (1.f - last_alpha) * R_acc;
-                    U_last = U;
-                    float dL_dalpha = (U - R_acc) * T;
-                    last_alpha = a;
-                    dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                    const float Q = G0[u] * dL_dalpha;
-                    const float dx = dxs[u], dy = dys[u];
-                    v[C + 0] = Q;
-                    v[C + 1] = Q * dx;
-                    v[C + 2] = Q * dy;
-                    v[C + 3] = Q * dx * dx;
-                    v[C + 4] = Q * dx * dy;
-                    v[C + 5] = Q * dy * dy;
-                    float w10[10];  // record layout: colour gradients in 0..3 (3 stays 0 for C = 3), geometry in 4..9
-#pragma unroll
-                    for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
-#pragma unroll
-                    for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
-                    const float tot = wave_sum10_banks(w10);
-                    done |= 1ull << kk[u];
-                    if (sum_slot >= 0) s_acc[buf][q][kk[u]][sum_slot] = tot;   // three lanes per row hold a total each (see wave_sum10_banks)
-                }
-            }
+            const unsigned long long mask = __ballot(r.keep);
+            const uint32_t npairs = stage_bwd_pairs<C>(s_slab[q], r, mask, lane);
+            const uint32_t pos_limit = survivors_before(mask, my_last > s0 ? my_last - s0 : 0u);
+            done = bwd_replay<C>(s_slab[q], npairs, &s_acc[buf][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1
+#ifdef GOM_BLK_STATS
+                                 , lane
+#endif
+            );
+            smask = mask;
         }
-        if (lane == 0) s_done[buf][q] = done;
+        if (lane == 0) { s_done[buf][q] = done; s_mask[buf][q] = smask; }
         if (!requested) tq.request();
         tq.publish(s_task);
         __syncthreads();
@@ -1270,9 +1212,11 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             for (int qq = 0; qq < 10; qq++) rr[qq] = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; w4++) {
-                const bool have = (s_done[buf][w4] >> threadIdx.x) & 1ull;
+                const unsigned long long sm = s_mask[buf][w4];
+                const uint32_t pos = (uint32_t)__popcll(sm & ((1ull << threadIdx.x) - 1ull));   // the entry's row in quadrant w4, if it survived there
+                const bool have = ((sm >> threadIdx.x) & 1ull) && ((s_done[buf][w4] >> (pos >> 1)) & 1ull);
 #pragma unroll
-                for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][threadIdx.x][qq] : 0.f;
+                for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[buf][w4][pos][qq] : 0.f;
             }
             float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)my_slot * GOM_PARTIAL_STRIDE);
             rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
@@ -1302,14 +1246,8 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 //   (Measured and dropped on the way here: one task per SEGMENT with the next piece's entries prefetched -- 276 us instead of 205:
 //    a quarter of the tasks, and these kernels live on many short independent chains; one WAVE per task walking its four quadrants
 //    without any barrier -- 218-259 us: it needs ~100 VGPRs, and at five waves per SIMD with spills the gain is gone.)
-#ifdef GOM_BLK_STATS
-__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] lanes with alpha >= 1/255 before the my_last test
-#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
-#else
-#define GOM_PAIR_STAT(I, V) do { } while (0)
-#endif
 #ifndef GOM_BWDP_WAVES
-#define GOM_BWDP_WAVES 5   // (at 6 waves per SIMD = 80 registers, 7 of them spill: same speed, +40 MB of scratch traffic per launch)
+#define GOM_BWDP_WAVES 5   // (at 6 waves per SIMD = 80 registers, 7 of them spill: same speed, +40 MB of scratch traffic per launch; both pieces' loads issued ahead of the first replay at 4 waves / 128 registers: 177 us instead of 153)
 #endif
 template <int C>
 __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,
@@ -1321,20 +1259,21 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                                                   const float *__restrict__ sub_C, const float *__restrict__ seg_Sbehind,
                                                   const uint32_t *__restrict__ ent_slot, float *__restrict__ partial, const GomDevStatus *__restrict__ status,
                                                   uint32_t *__restrict__ task_ctr, const uint32_t *__restrict__ task_order, const unsigned long long *__restrict__ cull_masks) {
-    constexpr int NV = 6 + C;
     // [half of the pair][quadrant][entry of the sub-range][value]; s_done = which entries the quadrant's wave really wrote
-    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];
-    __shared__ unsigned long long s_done[2][4];
+    __shared__ float s_acc[2][4][GOM_SUB_MAX][10];   // rows by COMPACTED survivor position (seg_bwd_replay.hpp)
+    __shared__ unsigned long long s_done[2][4], s_mask[2][4];   // pairs of rows written; the survivors (list order) they belong to
     __shared__ uint32_t s_task[2];
-    // survivors' attributes through wave-private LDS broadcast slabs, the colours included (four v_readlane at ~6.7 issue cycles each in
-    // k_seg_bwd, which has no LDS to spare at six workgroups per CU; this kernel runs five)
-    __shared__ float4 s_e0[4][64], s_e2[4][64];
-    __shared__ float2 s_e1[4][64];
+    __shared__ float4 s_slab[4][GOM_BPAIR_F4];       // wave-private pair records of the survivors, geometry and colours
+#ifdef GOM_KO_PAD_LDS   // development: occupancy sensitivity (extra LDS per workgroup, bytes)
+    __shared__ float s_pad[GOM_KO_PAD_LDS / 4];
+    if (seg_shift == 99u) { s_pad[threadIdx.x] = (float)H; __syncthreads(); partial[threadIdx.x] = s_pad[(threadIdx.x * 7) % (GOM_KO_PAD_LDS / 4)]; }
+#endif
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sum_slot = wave_sum10_slot(lane);
+    bool from_n1;
+    const int slot20 = wave_sum20_slot(lane, from_n1);
     const size_t HW = (size_t)H * W;
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2   // (scripts/wg_timeline_T.py)
     const unsigned long long ph_w0 = wall_clock64();
@@ -1353,7 +1292,11 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         const uint32_t e0 = d.w << seg_shift;
         const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
         const uint32_t s0a = e0 + (uint32_t)sub_a * sub_sz;
-        if ((uint32_t)sub_a * sub_sz >= cnt || s0a >= tmax) {   // no entries, or every pixel of the tile stopped before the pair: nothing is written
+#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 4
+        if (true) {
+#else
+        if ((uint32_t)sub_a * sub_sz >= cnt || s0a >= tmax) {
+#endif   // no entries, or every pixel of the tile stopped before the pair: nothing is written
             tq.request();
             tq.publish(s_task);
             __syncthreads();
@@ -1367,17 +1310,23 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         }
         bool live_h[2];
         uint32_t scnt_h[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int sub = sub_a + half;
+            const bool empty = half >= nhalf || (uint32_t)sub * sub_sz >= cnt;
+            scnt_h[half] = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
+            live_h[half] = !empty && e0 + (uint32_t)sub * sub_sz < tmax;
+        }
+        const bool my_rec = (threadIdx.x >> 6) < 2 && live_h[(threadIdx.x >> 6) & 1] && (uint32_t)(threadIdx.x & 63) < scnt_h[(threadIdx.x >> 6) & 1];
+
         bool requested = false;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int sub = sub_a + half;
             const uint32_t s0 = e0 + (uint32_t)sub * sub_sz;
-            const bool empty = half >= nhalf || (uint32_t)sub * sub_sz >= cnt;
-            scnt_h[half] = empty ? 0u : min(sub_sz, cnt - (uint32_t)sub * sub_sz);
-            live_h[half] = !empty && s0 < tmax;
             const int q = half == 0 ? wv : 3 - wv;   // the diagonally opposite quadrant in the second sub-range
             const uint32_t wmax = q == 0 ? qm4.x : (q == 1 ? qm4.y : (q == 2 ? qm4.z : qm4.w));
-            unsigned long long done = 0ull;
+            unsigned long long done = 0ull, smask = 0ull;
             if (live_h[half] && wmax > s0) {
                 const int pxi = q * 64 + lane;
                 const int px = tx * 16 + (q & 1) * 8 + (lane & 7);
@@ -1406,113 +1355,52 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) S[ch] += cu[ch];
                 }
-                float R_acc, U_last = 0.f, last_alpha = 0.f;
+                float R_acc;
                 {
                     float sd = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) sd += S[ch] * dpix[ch];
                     R_acc = sd * (T > 0.f ? 1.f / T : 0.f);   // (same operations as k_seg_bwd: the two kernels agree bitwise)
                 }
-                unsigned long long mask = __ballot(r.keep);
+                const unsigned long long mask = __ballot(r.keep);
                 GOM_PAIR_STAT(0, 1); GOM_PAIR_STAT(1, __popcll(mask));
-                s_e0[wv][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
-                s_e1[wv][lane] = make_float2(r.c, r.o);
-                {
-                    float4 cl = make_float4(r.col[0], 0.f, 0.f, 0.f);
-                    if (C > 1) cl.y = r.col[1 % C];
-                    if (C > 2) cl.z = r.col[2 % C];
-                    if (C > 3) cl.w = r.col[3 % C];
-                    s_e2[wv][lane] = cl;
-                }
-                while (mask) {
-                    int kk[GOM_BWD_EPT];
-                    bool kv[GOM_BWD_EPT];
-                    float al[GOM_BWD_EPT], G0[GOM_BWD_EPT], dxs[GOM_BWD_EPT], dys[GOM_BWD_EPT], ecol[GOM_BWD_EPT][C];
-#pragma unroll
-                    for (int u = 0; u < GOM_BWD_EPT; u++) {
-                        kv[u] = mask != 0ull;
-                        const int k = kv[u] ? 63 - __builtin_clzll(mask) : 0;
-                        mask &= ~(1ull << k);
-                        kk[u] = k;
-                        const float4 g0 = s_e0[wv][k], c4 = s_e2[wv][k];
-                        const float2 g1 = s_e1[wv][k];
-                        const float o_ = kv[u] ? g1.y : 0.f;
-                        const float dx = g0.x - pfx, dy = g0.y - pfy;
-                        {
-                            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-                            for (int ch = 0; ch < C; ch++) ecol[u][ch] = cv[ch];
-                        }
-                        const float power = gauss_power(g0.z, g0.w, g1.x, dx, dy);
-                        const float g = __expf(power);
-                        float a = fminf(kMaxAlpha, o_ * g);
-                        a = (power <= 0.f) ? a : 0.f;
-                        a = (a >= kMinAlpha) ? a : 0.f;
-                        a = (s0 + (uint32_t)k < my_last) ? a : 0.f;
-                        al[u] = a;
-                        G0[u] = (a > 0.f) ? g : 0.f;
-                        dxs[u] = dx;
-                        dys[u] = dy;
-                    }
-#pragma unroll
-                    for (int u = 0; u < GOM_BWD_EPT; u++) {
-                        if (!kv[u] || __ballot(al[u] > 0.f) == 0ull) continue;
-#ifdef GOM_BLK_STATS
-                        { const unsigned long long am_ = __ballot(al[u] > 0.f); GOM_PAIR_STAT(2, 1); GOM_PAIR_STAT(3, __popcll(am_)); }
+#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 6
+                const uint32_t npairs = 0;
+#else
+                const uint32_t npairs = stage_bwd_pairs<C>(s_slab[wv], r, mask, lane);
 #endif
-                        const float a = al[u];
-                        const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);
-                        T = T * inv1ma;
-                        const float w = a * T;
-                        float v[NV], U = 0.f;
-#pragma unroll
-                        for (int ch = 0; ch < C; ch++) {
-                            U += ecol[u][ch] * dpix[ch];
-                            v[ch] = w * dpix[ch];
-                        }
-                        R_acc = last_alpha * U_last + (1.f - last_alpha) * R_acc;
-                        U_last = U;
-                        float dL_dalpha = (U - R_acc) * T;
-                        last_alpha = a;
-                        dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                        const float Q = G0[u] * dL_dalpha;
-                        const float dx = dxs[u], dy = dys[u];
-                        v[C + 0] = Q;
-                        v[C + 1] = Q * dx;
-                        v[C + 2] = Q * dy;
-                        v[C + 3] = Q * dx * dx;
-                        v[C + 4] = Q * dx * dy;
-                        v[C + 5] = Q * dy * dy;
-                        float w10[10];
-#pragma unroll
-                        for (int ch = 0; ch < 4; ch++) w10[ch] = ch < C ? v[ch < C ? ch : 0] : 0.f;
-#pragma unroll
-                        for (int qq = 0; qq < 6; qq++) w10[4 + qq] = v[C + qq];
-                        const float tot = wave_sum10_banks(w10);
-                        done |= 1ull << kk[u];
-                        if (sum_slot >= 0) s_acc[half][q][kk[u]][sum_slot] = tot;
-                    }
-                }
+                const uint32_t pos_limit = survivors_before(mask, my_last > s0 ? my_last - s0 : 0u);
+                done = bwd_replay<C>(s_slab[wv], npairs, &s_acc[half][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1
+#ifdef GOM_BLK_STATS
+                                     , lane
+#endif
+                );
+                smask = mask;
             }
-            if (lane == 0) s_done[half][q] = done;
+            if (lane == 0) { s_done[half][q] = done; s_mask[half][q] = smask; }
             if (half == 0 && requested) tq.look_ahead();   // (the dequeue went out with the first half's loads: it is back)
         }
         if (!requested) tq.request();
         tq.publish(s_task);
         __syncthreads();
         {   // one 48-byte record per entry of the two sub-ranges (threads 0..127), quadrants summed in a fixed order
-            const int half = threadIdx.x >> 6, e = threadIdx.x & 63;
-            if (half < 2 && live_h[half] && (uint32_t)e < scnt_h[half]) {
-                const uint32_t li = start + (uint32_t)(sub_a + half) * sub_sz + (uint32_t)e;
-                const uint32_t slot = ent_slot[li];
+            const int half = (threadIdx.x >> 6) & 1, e = threadIdx.x & 63;
+#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 5
+            if (my_rec && cnt == 0xffffffffu) {
+#else
+            if (my_rec) {
+#endif
+                const uint32_t slot = ent_slot[start + (uint32_t)(sub_a + half) * sub_sz + (uint32_t)e];
                 float rr[10];
 #pragma unroll
                 for (int qq = 0; qq < 10; qq++) rr[qq] = 0.f;
 #pragma unroll
                 for (int w4 = 0; w4 < 4; w4++) {
-                    const bool have = (s_done[half][w4] >> e) & 1ull;
+                    const unsigned long long sm = s_mask[half][w4];
+                    const uint32_t pos = (uint32_t)__popcll(sm & ((1ull << e) - 1ull));   // the entry's row in quadrant w4, if it survived there
+                    const bool have = ((sm >> e) & 1ull) && ((s_done[half][w4] >> (pos >> 1)) & 1ull);
 #pragma unroll
-                    for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[half][w4][e][qq] : 0.f;
+                    for (int qq = 0; qq < 10; qq++) rr[qq] += have ? s_acc[half][w4][pos][qq] : 0.f;
                 }
                 float4 *rec = reinterpret_cast<float4 *>(partial + (size_t)slot * GOM_PARTIAL_STRIDE);
                 rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);

