@@ -122,7 +122,7 @@ struct GomState {
     uint32_t *big_count = nullptr;    // [2][frames] their number per frame: [0] published by the scan kernel, [1] being counted by k_preprocess
     int capBigFrames = 0;
     uint4 *seg_desc = nullptr;        // [capSegs] {tile, first list position, entries, index of the segment inside its tile}
-    float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (conic a,b) (conic c, opacity)
+    float2 *ent_geo = nullptr;        // [capPairs][3] list-ordered geometry of the entries: (x,y) (A,B) (Cq,lo) = the conic and the opacity pre-scaled for alpha_eval (entry_record.hpp)
     float *ent_col = nullptr;         // [capPairs][4] list-ordered colours
     float *seg_T = nullptr;           // [capSegs][256]     product of (1-alpha) over the segment
     float *seg_C = nullptr;           // [capSegs][4][256]  colour the segment adds to the pixel

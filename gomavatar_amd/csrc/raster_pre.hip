@@ -21,6 +21,7 @@
 //    (no float atomics anywhere -> bitwise reproducible, no searching).
 #include "gom_internal.h"
 #include "geom_face.hpp"
+#include "entry_record.hpp"
 #include "rank_map.hpp"
 #include "rank_sort.hpp"
 
@@ -289,11 +290,12 @@ __global__ void __launch_bounds__(256) k_preprocess(GomCamera cam1, const GomCam
             const uint32_t po = s_blockbase + woff + (x - my_tiles);
             pair_off[i] = po;
             if (rec_g) {   // everything the tile pass of the depth ranking needs of this Gaussian, in one 32-byte record (one sector per gather):
-                // (x, y, conic a, b) (conic c, opacity, first slot, rect: x0 | width << 10 | y0 << 20 in tiles, y0 in the stacked grid)
+                // (x, y, A, B) (Cq, lo, first slot, rect: x0 | width << 10 | y0 << 20 in tiles, y0 in the stacked grid)
                 float4 *d = rec_g + 2 * (size_t)i;
                 const uint32_t rx0 = my_rlo & 0xffffu, ry0 = my_rlo >> 16, rw = (my_rhi & 0xffffu) - rx0;
-                d[0] = my_r0;
-                d[1] = make_float4(my_r1.x, my_r1.y, __uint_as_float(po), __uint_as_float(rx0 | (rw << 10) | (ry0 << 20)));
+                const float4 er = gom_entry::entry_record(my_r0.z, my_r0.w, my_r1.x, my_r1.y);   // the list record's (A, B, Cq, lo): entry_record.hpp
+                d[0] = make_float4(my_r0.x, my_r0.y, er.x, er.y);
+                d[1] = make_float4(er.z, er.w, __uint_as_float(po), __uint_as_float(rx0 | (rw << 10) | (ry0 << 20)));
             }
         }
     }
@@ -753,14 +755,15 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GomCamera cam1, const Go
             }
         }
         // record layout: [0..3] colours, [4] sum Q, [5] sum Q dx, [6] sum Q dy, [7] sum Q dx dx, [8] sum Q dx dy, [9] sum Q dy dy
-        // with Q = G * dL/dalpha and d = centre - pixel (App. A.4 regrouped).
+        // with Q = opacity * G * dL/dalpha and d = centre - pixel (App. A.4 regrouped; the render backward's exp2 delivers opacity * G, so
+        // the opacity that multiplied the five geometry sums here now divides the opacity gradient instead).
         const float o = co.w;
-        g2x = -(0.5f * (float)cam.W) * o * (co.x * acc[5] + co.y * acc[6]);
-        g2y = -(0.5f * (float)cam.H) * o * (co.z * acc[6] + co.y * acc[5]);
-        const float gxx = -0.5f * o * acc[7];
-        const float gxy = -0.5f * o * acc[8];
-        const float gyy = -0.5f * o * acc[9];
-        gop = acc[4];
+        g2x = -(0.5f * (float)cam.W) * (co.x * acc[5] + co.y * acc[6]);
+        g2y = -(0.5f * (float)cam.H) * (co.z * acc[6] + co.y * acc[5]);
+        const float gxx = -0.5f * acc[7];
+        const float gxy = -0.5f * acc[8];
+        const float gyy = -0.5f * acc[9];
+        gop = o > 0.f ? acc[4] / o : 0.f;
 
         const float fx = (float)cam.W / (2.0f * cam.tanfovx);
         const float fy = (float)cam.H / (2.0f * cam.tanfovy);

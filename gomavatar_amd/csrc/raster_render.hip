@@ -50,6 +50,7 @@
 #include "gom_internal.h"
 #include "bwd_order.hpp"
 #include "sort_util.hpp"
+#include "entry_record.hpp"
 #include <cstdlib>
 
 #ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3 | 4): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2), k_seg_fwd (3): scripts/wg_timeline_T.py; of k_combine_fwd (4): scripts/combine_timeline.py
@@ -169,53 +170,100 @@ __device__ __forceinline__ bool cull_entry(float cx, float cy, float a, float b,
     return (-0.5f * q + (1e-5f * mag + 1e-2f)) < lthr;
 }
 
-// alpha of one entry at one pixel with the reference's skip rules folded in:
-// returns 0 when the reference would `continue` (power > 0 or alpha < 1/255).
-// power = -0.5 (a dx^2 + c dy^2) - b dx dy, written out operation by operation (no contraction left to the compiler): the
-// transmittance pre-pass, the compositing pass and the backward must see bit-identical alphas whether their operands arrive in
-// SGPRs (v_readlane) or VGPRs (LDS broadcast) -- sum_i alpha_i T_i + T_final = 1 only holds to 3e-6 if they do.
-__device__ __forceinline__ float gauss_power(float ea, float eb, float ec, float dx, float dy) {
-    const float q = __fmaf_rn(dx, __fmul_rn(ea, dx), __fmul_rn(dy, __fmul_rn(ec, dy)));
-    return __fsub_rn(__fmul_rn(-0.5f, q), __fmul_rn(dx, __fmul_rn(eb, dy)));
-}
-
-__device__ __forceinline__ float entry_alpha(float ex, float ey, float ea, float eb, float ec, float eo, float pfx, float pfy) {
-    const float dx = ex - pfx, dy = ey - pfy;
-    const float power = gauss_power(ea, eb, ec, dx, dy);
-    float a = fminf(kMaxAlpha, eo * __expf(power));
-    a = (power <= 0.f) ? a : 0.f;
-    a = (a >= kMinAlpha) ? a : 0.f;
-    return a;
-}
-
-// Two entries at one pixel, the same operations in the same order as entry_alpha, on register PAIRS: the products and sums become
-// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (one issue slot for both entries; the body of the segment kernels is bound by VALU
-// issue -- profiles/r02_valu.json, scripts/wg_timeline_T.py -- and a wave64 instruction occupies its SIMD for four cycles).
-// Bit-identical to two entry_alpha calls: packed fp32 operations round like the scalar ones, and nothing is left to contraction.
+// alpha of an entry at a pixel with the reference's skip rules folded in (0 where the reference would `continue`: power > 0 or
+// alpha < 1/255), from the entry's LIST record (x, y, A, B, Cq, lo) -- the tile pass stores the conic and the opacity pre-scaled,
+//     A = -0.5 log2(e) a,  B = -log2(e) b,  Cq = -0.5 log2(e) c,  lo = log2(opacity)        (entry_record.hpp)
+// so that, with d = centre - pixel,
+//     pw = dx (A dx + B dy) + Cq dy dy = log2(e) * power,      og = opacity * G = exp2(pw + lo),      alpha = min(0.99, og)
+// in five multiply-adds, one add and the v_exp_f32 (the reference's expression -- forward.cu:330-340, three products per term, the
+// -0.5, the log2(e) of __expf and the opacity as separate factors -- took eleven).  The two skip rules are 0 / 1 factors made by
+// clamped multiply-adds instead of compare + select pairs:  m1 = clamp(2^64 (og - pred(1/255))) is 1 exactly when og >= 1/255 (the
+// difference is then at least an ulp of 1/255 = 2^-31), m2 = clamp(1 - 2^126 pw) is 1 exactly when pw <= 0 (and 0 for pw >= 2^-126).
+// Why: the three segment kernels are bound by VALU issue, the alpha evaluation is half of what they issue, and on gfx950 a compare or a
+// select costs 4.2 issue cycles where a multiply-add costs 2.25 (scripts/ubench/valu_rate.hip).  Every operation is written out, nothing
+// is left to contraction, and the float and the register-pair version below are the same sequence: the transmittance pre-pass, the
+// compositing pass and the backward see bit-identical alphas -- sum_i alpha_i T_i + T_final = 1 only holds to 3e-6 if they do.
+// Against the reference's expression the exponent moves by a few ulp (re-association); tests/ hold the result to the float64 oracle.
+using gom_entry::entry_record;
+using gom_entry::entry_unrecord;
+constexpr float kMinAlphaPred = 0.003921568393707275f;   // the float below 1/255 (0x3b808080)
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct PairGeo { v2f x, y, a, b, c, o; };
-__device__ __forceinline__ v2f pair_alpha(const PairGeo &e, float pfx, float pfy) {
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// The 0 / 1 skip factors: m1 = clamp(2^64 og - 2^64 pred(1/255)), m2 = clamp(1 - 2^126 pw) and, for the backward, m3 = clamp(lim - pos)
+// (1 for list positions in front of this pixel's last contributor).  Scalar form: the compiler folds the clamp into v_fma_f32.  Pair form:
+// one inline-assembly block (the compiler does not fold a clamp into v_pk_fma_f32), m1 LAST -- `og` comes out of v_exp_f32, and a VALU
+// instruction that reads the result of a transcendental one needs two wait states the hazard recognizer does not insert in front of
+// inline assembly (without them the multiply-add read the register before the exponential had landed: 43 parity tests).
+__device__ __forceinline__ void skip_factors(float og, float pw, float &m1, float &m2) {
+    m1 = fminf(fmaxf(__fmaf_rn(og, 0x1p64f, -kMinAlphaPred * 0x1p64f), 0.f), 1.f);
+    m2 = fminf(fmaxf(__fmaf_rn(pw, -0x1p126f, 1.f), 0.f), 1.f);
+}
+__device__ __forceinline__ void skip_factors(v2f og, v2f pw, v2f &m1, v2f &m2) {
+    const v2f k1 = {0x1p64f, 0x1p64f}, k2 = {-kMinAlphaPred * 0x1p64f, -kMinAlphaPred * 0x1p64f}, k3 = {-0x1p126f, -0x1p126f}, one = {1.f, 1.f};
+    asm("v_pk_fma_f32 %1, %3, %6, %7 clamp\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %4, %5 clamp"
+        : "=&v"(m1), "=&v"(m2) : "v"(og), "v"(pw), "v"(k1), "v"(k2), "v"(k3), "v"(one));
+}
+__device__ __forceinline__ void skip_factors(v2f og, v2f pw, v2f lim, v2f pos, v2f &m1, v2f &m2, v2f &m3) {
+    const v2f k1 = {0x1p64f, 0x1p64f}, k2 = {-kMinAlphaPred * 0x1p64f, -kMinAlphaPred * 0x1p64f}, k3 = {-0x1p126f, -0x1p126f}, one = {1.f, 1.f};
+    asm("v_pk_fma_f32 %1, %4, %7, %8 clamp\n\tv_pk_add_f32 %2, %9, %10 neg_lo:[0,1] neg_hi:[0,1] clamp\n\tv_pk_fma_f32 %0, %3, %5, %6 clamp"
+        : "=&v"(m1), "=&v"(m2), "=&v"(m3) : "v"(og), "v"(pw), "v"(k1), "v"(k2), "v"(k3), "v"(one), "v"(lim), "v"(pos));
+}
+__device__ __forceinline__ float vexp2(float t) { return __builtin_amdgcn_exp2f(t); }
+__device__ __forceinline__ v2f vexp2(v2f t) { return v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
+__device__ __forceinline__ float vmin_alpha(float og) { return fminf(kMaxAlpha, og); }
+__device__ __forceinline__ v2f vmin_alpha(v2f og) { return v2f{fminf(kMaxAlpha, og.x), fminf(kMaxAlpha, og.y)}; }
+template <typename F> __device__ __forceinline__ F vsplat(float x);
+template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; }
+template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
+
+// F = float: one entry; F = v2f: two entries on register pairs (v_pk_mul / v_pk_fma / v_pk_add_f32).
+template <typename F>
+struct AlphaEval {
+    F al, og, mm, dx, dy;   // alpha (skips folded in), opacity * G unclamped, the 0 / 1 skip factor, centre - pixel
+};
+template <typename F>
+__device__ __forceinline__ AlphaEval<F> alpha_eval(F ex, F ey, F A, F B, F Cq, F lo, F px, F py) {
 #pragma clang fp contract(off)
-    const v2f px = {pfx, pfx}, py = {pfy, pfy};
-    const v2f dx = e.x - px, dy = e.y - py;
-    const v2f q = __builtin_elementwise_fma(dx, e.a * dx, dy * (e.c * dy));
-    const v2f mh = {-0.5f, -0.5f};
-    const v2f power = mh * q - dx * (e.b * dy);
-    const v2f l2e = {1.44269504088896340736f, 1.44269504088896340736f};   // __expf(x) = v_exp_f32(x * log2 e)
-    const v2f t = power * l2e;
-    const v2f g = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-    const v2f og = e.o * g;
-    v2f al;
-    al.x = (power.x <= 0.f) ? fminf(kMaxAlpha, og.x) : 0.f;
-    al.y = (power.y <= 0.f) ? fminf(kMaxAlpha, og.y) : 0.f;
-    al.x = (al.x >= kMinAlpha) ? al.x : 0.f;
-    al.y = (al.y >= kMinAlpha) ? al.y : 0.f;
-    return al;
+    AlphaEval<F> r;
+    r.dx = ex - px;
+    r.dy = ey - py;
+    const F t1 = vfma(A, r.dx, B * r.dy);
+    const F pw = vfma(r.dx, t1, (Cq * r.dy) * r.dy);
+    r.og = vexp2(pw + lo);
+    F m1, m2;
+    skip_factors(r.og, pw, m1, m2);
+    r.mm = m1 * m2;
+    r.al = vmin_alpha(r.og) * r.mm;
+    return r;
+}
+// the backward's: + the position limit (mm and al carry all three factors)
+__device__ __forceinline__ AlphaEval<v2f> alpha_eval_lim(v2f ex, v2f ey, v2f A, v2f B, v2f Cq, v2f lo, v2f px, v2f py, v2f lim, v2f pos) {
+#pragma clang fp contract(off)
+    AlphaEval<v2f> r;
+    r.dx = ex - px;
+    r.dy = ey - py;
+    const v2f t1 = vfma(A, r.dx, B * r.dy);
+    const v2f pw = vfma(r.dx, t1, (Cq * r.dy) * r.dy);
+    r.og = vexp2(pw + lo);
+    v2f m1, m2, m3;
+    skip_factors(r.og, pw, lim, pos, m1, m2, m3);
+    r.mm = (m1 * m2) * m3;
+    r.al = (vmin_alpha(r.og) * (m1 * m2)) * m3;   // (= alpha_eval's alpha times m3, bit for bit)
+    return r;
+}
+__device__ __forceinline__ float entry_alpha(float ex, float ey, float A, float B, float Cq, float lo, float pfx, float pfy) {
+    return alpha_eval<float>(ex, ey, A, B, Cq, lo, pfx, pfy).al;
+}
+struct PairGeo { v2f x, y, a, b, c, o; };   // (a, b, c, o hold A, B, Cq, lo)
+__device__ __forceinline__ v2f pair_alpha(const PairGeo &e, float pfx, float pfy) {
+    return alpha_eval<v2f>(e.x, e.y, e.a, e.b, e.c, e.o, v2f{pfx, pfx}, v2f{pfy, pfy}).al;
 }
 
 // Survivors of a sub-range, compacted in list order into PAIR records in a wave-private LDS slab: pair j = survivors 2j and
 // 2j + 1 as (x0 x1 y0 y1)(a0 a1 b0 b1)(c0 c1 o0 o1), so that three broadcast ds_read_b128 deliver both entries already laid
-// out as register pairs.  The slab is padded with null entries (opacity 0 -> alpha 0) up to a multiple of four survivors.
+// out as register pairs.  The slab is padded with null entries (opacity 0, lo = -inf -> alpha 0) up to a multiple of four survivors.
 #define GOM_PAIR_F4 (3 * (GOM_SUB_MAX / 2 + 2))   // float4 per wave slab
 __device__ __forceinline__ uint32_t stage_pairs(float4 *slab, bool keep, unsigned long long mask, int lane, float x, float y, float a, float b, float c,
                                                 float o) {
@@ -229,7 +277,7 @@ __device__ __forceinline__ uint32_t stage_pairs(float4 *slab, bool keep, unsigne
     if (lane < 3 && n + (uint32_t)lane < n4) {
         const uint32_t pp = n + (uint32_t)lane;
         float *d = f + 12u * (pp >> 1) + (pp & 1u);
-        d[0] = 0.f; d[2] = 0.f; d[4] = 0.f; d[6] = 0.f; d[8] = 0.f; d[10] = 0.f;
+        d[0] = 0.f; d[2] = 0.f; d[4] = 0.f; d[6] = 0.f; d[8] = 0.f; d[10] = -INFINITY;   // (lo = log2 of opacity 0)
     }
     return n4;
 }
@@ -312,7 +360,8 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
                     ent_slot[base + i] = po[u] + k;
                     // geometry of the entry in LIST order: the compositing kernels read it contiguously
                     float2 *dst = ent_geo + 3 * (size_t)(base + i);
-                    dst[0] = cxy[u]; dst[1] = make_float2(cco[u].x, cco[u].y); dst[2] = make_float2(cco[u].z, cco[u].w);
+                    const float4 er = entry_record(cco[u].x, cco[u].y, cco[u].z, cco[u].w);   // (A, B, Cq, lo: see alpha_eval)
+                    dst[0] = cxy[u]; dst[1] = make_float2(er.x, er.y); dst[2] = make_float2(er.z, er.w);
                 }
             }
         }
@@ -357,7 +406,8 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
         const float2 c = xy[g];
         const float4 co = conic_opacity[g];
         float2 *d2 = ent_geo + 3 * (size_t)(base + i);
-        d2[0] = c; d2[1] = make_float2(co.x, co.y); d2[2] = make_float2(co.z, co.w);
+        const float4 er = entry_record(co.x, co.y, co.z, co.w);
+        d2[0] = c; d2[1] = make_float2(er.x, er.y); d2[2] = make_float2(er.z, er.w);
     }
 }
 
@@ -365,7 +415,7 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
 // One lane's view of "its" entry of the wave's 32-entry sub-range.
 template <int C>
 struct EntryRegs {
-    float x, y, a, b, c, o, col[C > 0 ? C : 1];
+    float x, y, a, b, c, o, col[C > 0 ? C : 1];   // a, b, c, o: the record's A, B, Cq, lo (alpha_eval)
     bool keep;
 };
 
@@ -400,7 +450,8 @@ __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_
     EntryRegs<C> r;
     const uint32_t e = (uint32_t)sub * sub_sz + (uint32_t)lane;
     const bool valid = (uint32_t)lane < sub_sz && e < cnt;
-    r.x = r.y = r.a = r.b = r.c = r.o = 0.f;
+    r.x = r.y = r.a = r.b = r.c = 0.f;
+    r.o = -INFINITY;
 #pragma unroll
     for (int ch = 0; ch < (C > 0 ? C : 1); ch++) r.col[ch] = 0.f;
     if (valid) {
@@ -417,7 +468,12 @@ __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_
     }
     // `known`: the survivors of this (sub-range, quadrant) as k_seg_T found them (cull_masks) -- the same test on the same numbers, so
     // the compositing pass and the backward take its 64 bits instead of ~55 instructions per lane; null: test here.
-    r.keep = known ? valid && ((*known >> lane) & 1ull) != 0ull : valid && !cull_entry(r.x, r.y, r.a, r.b, r.c, r.o, qx0, qy0, qx1, qy1);
+    if (known) {
+        r.keep = valid && ((*known >> lane) & 1ull) != 0ull;
+    } else {
+        const float4 u = entry_unrecord(r.a, r.b, r.c, r.o);
+        r.keep = valid && !cull_entry(r.x, r.y, u.x, u.y, u.z, u.w, qx0, qy0, qx1, qy1);
+    }
     return r;
 }
 
@@ -786,7 +842,7 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
                     kk[u] = k;
                     const float4 e0 = s_e0[sub][k], e2 = s_e2[sub][k];
                     const float2 e1 = s_e1[sub][k];
-                    const float eo = kv ? e1.y : 0.f;  // opacity 0 -> alpha 0 -> "skip"
+                    const float eo = kv ? e1.y : -INFINITY;  // lo of opacity 0 -> alpha 0 -> "skip"
                     al[u] = entry_alpha(e0.x, e0.y, e0.z, e0.w, e1.x, eo, pfx, pfy);
                     const float cv[4] = {e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
@@ -1247,7 +1303,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
 //    a quarter of the tasks, and these kernels live on many short independent chains; one WAVE per task walking its four quadrants
 //    without any barrier -- 218-259 us: it needs ~100 VGPRs, and at five waves per SIMD with spills the gain is gone.)
 #ifndef GOM_BWDP_WAVES
-#define GOM_BWDP_WAVES 5   // (at 6 waves per SIMD = 80 registers, 7 of them spill: same speed, +40 MB of scratch traffic per launch; both pieces' loads issued ahead of the first replay at 4 waves / 128 registers: 177 us instead of 153)
+#define GOM_BWDP_WAVES 4   // (127 registers, none spilled: 152 us; at 5 waves per SIMD = 96 registers a handful spill inside the task: 158; both pieces' loads issued ahead of the first replay: 177)
 #endif
 template <int C>
 __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t seg_shift, int H, int W, int gx, int gy, float bg0, float bg1, float bg2, float bg3,

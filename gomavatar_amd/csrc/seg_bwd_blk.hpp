@@ -156,14 +156,15 @@ __global__ void __launch_bounds__(256, GOM_BWDB_WAVES) k_seg_bwd_blk(uint32_t se
                     s_e2[lane] = cl;
                 }
                 const uint32_t bm = row_max_u32(nl);   // last contributor over the block's 16 pixels
-                const CullPre cp = cull_pre(r.a, r.b, r.c, r.o);
+                const float4 ur = entry_unrecord(r.a, r.b, r.c, r.o);   // (conic, opacity) back from the list record for the conservative block cull
+                const CullPre cp = cull_pre(ur.x, ur.y, ur.z, ur.w);
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)bm, 16 * b);
                     unsigned long long m = 0ull;
                     if (bmax > s0) {   // (wave-uniform) the block still had a pixel alive when the list reached this sub-range
                         const float x0 = (float)(tx * 16 + (bxq + (b & 1)) * 4), y0 = (float)(ty * 16 + (byq + (b >> 1)) * 4);
-                        const bool keep = r.keep && s0 + (uint32_t)lane < bmax && !cull_rect(cp, r.x, r.y, r.a, r.b, r.c, x0, y0, x0 + 3.f, y0 + 3.f);
+                        const bool keep = r.keep && s0 + (uint32_t)lane < bmax && !cull_rect(cp, r.x, r.y, ur.x, ur.y, ur.z, x0, y0, x0 + 3.f, y0 + 3.f);
                         m = __ballot(keep);
                     }
                     if (lane == 0) s_bmask[parity][wv * 4 + b] = m;
@@ -243,16 +244,12 @@ __global__ void __launch_bounds__(256, GOM_BWDB_WAVES) k_seg_bwd_blk(uint32_t se
                     const float4 g0 = s_e0[k], c4 = s_e2[k];
                     const float2 g1 = s_e1[k];
                     float *dst = &s_acc[wv][row][t & (GOM_BWDB_POS - 1u)][slot];
-                    const float dx = g0.x - pfx, dy = g0.y - pfy;
-                    const float power = gauss_power(g0.z, g0.w, g1.x, dx, dy);
-                    const float gv = __expf(power);
-                    float a = fminf(kMaxAlpha, g1.y * gv);
-                    a = (power <= 0.f) ? a : 0.f;
-                    a = (a >= kMinAlpha) ? a : 0.f;
-                    a = (s0 + k < my_last) ? a : 0.f;   // beyond this pixel's last contributor (the null entry: opacity 0)
+                    const AlphaEval<float> ev = alpha_eval<float>(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, pfx, pfy);   // (the forward's alphas, bit for bit)
+                    const float dx = ev.dx, dy = ev.dy;
+                    const float a = (s0 + k < my_last) ? ev.al : 0.f;   // beyond this pixel's last contributor (the null entry: opacity 0)
                     if (__ballot(a > 0.f) == 0ull) { *dst = 0.f; GOM_BLK_STAT(2, 1); continue; }   // wave-uniform: four zero records
                     GOM_BLK_STAT(6, __popcll(__ballot(a > 0.f)));
-                    const float G0 = (a > 0.f) ? gv : 0.f;
+                    const float G0 = (a > 0.f) ? ev.og : 0.f;   // (opacity * G: the records carry the opacity since round 3)
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - a);
                     T = T * inv1ma;
                     const float w = a * T;

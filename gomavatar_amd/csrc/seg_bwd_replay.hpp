@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t stage_bwd_pairs(float4 *slab, const EntryReg
     if ((n & 1u) && lane == 0) {
         float *d = f + 20u * (n >> 1) + 1u;
 #pragma unroll
-        for (int i = 0; i < 10; i++) d[2 * i] = 0.f;
+        for (int i = 0; i < 10; i++) d[2 * i] = i == 5 ? -INFINITY : 0.f;   // (lo = log2 of opacity 0)
     }
     return (n + 1u) >> 1;
 }
@@ -63,7 +63,7 @@ __device__ __forceinline__ void wave_sum20_banks(const v2f (&z)[10], float &n0_o
     const v2f s0 = swap_add16_2(p0, p1), s1 = swap_add16_2(p2, p3);
     const float s2 = swap_add16(p4.x, p4.y);
     float m0, m1, m2, n0, n1;
-    asm volatile("s_nop 1\n"
+    asm("s_nop 1\n"
                  "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n"           // m0: banks 0,1 <- s0.x (lane ^ 8)
                  "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n"           // m1: banks 0,1 <- s1.x
                  "v_add_f32_dpp %2, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"           // m2: s2
@@ -109,29 +109,89 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
     unsigned long long done = 0ull;
     float U_last = 0.f, last_alpha = 0.f, one_minus_last = 1.f;
     const v2f px = {pfx, pfx}, py = {pfy, pfy};
-    const v2f mh = {-0.5f, -0.5f}, l2e = {1.44269504088896340736f, 1.44269504088896340736f}, one = {1.f, 1.f};
+    const v2f one = {1.f, 1.f};
+    const v2f lim = {(float)pos_limit, (float)pos_limit};
+    v2f pos = {(float)(2u * npairs), (float)(2u * npairs + 1u)};
     const float ntf = -T_final;
 #ifdef GOM_KO_REPLAY   // development knock-outs (scripts/exp_build.py NAME -DGOM_KO_REPLAY=1|2|3): no replay / alphas only / no reduction
     if (GOM_KO_REPLAY == 1 || GOM_KO_REPLAY >= 4) npairs = 0;
 #endif
+#ifndef GOM_BWD_PIPE
+#define GOM_BWD_PIPE 0
+#endif
+#if GOM_BWD_PIPE
+    // Software-pipelined by hand: the evaluation of pair j - 1 (three LDS broadcasts, the alpha chain, two v_exp and two v_rcp -- independent of
+    // the T / accum_rec recurrences) is written INTO the block that replays pair j, so that the compiler interleaves it with that pair's
+    // reduction chain (six dependent cross-lane levels).  A wave executes in order: as two separate stretches each waited for its own
+    // latencies -- the backward's waves were bound by that dependent chain, not by what they issue (45 M instead of 63 M VALU instructions
+    // had left the kernel's duration where it was).  No skip of a pair nobody blends (it would split the block; 6 % of the pairs): it is
+    // replayed as two zero-alpha layers, which leaves T / accum_rec exactly as skipping would.
+    struct PairEval { v2f al, oma, inv, qf, dx, dy; };
+    auto eval_pair = [&](int jj) {
+        const float4 *p = slab + 5 * jj;
+        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+        pos = pos - v2f{2.f, 2.f};   // (2 jj, 2 jj + 1) as floats, carried: there is no scalar int -> float on gfx950
+        const AlphaEval<v2f> e = alpha_eval_lim(v2f{p0.x, p0.y}, v2f{p0.z, p0.w}, v2f{p1.x, p1.y}, v2f{p1.z, p1.w}, v2f{p2.x, p2.y}, v2f{p2.z, p2.w}, px, py, lim, pos);
+        PairEval r;
+        r.al = e.al;
+        r.qf = e.og * e.mm;
+        r.oma = one - r.al;
+        r.inv = v2f{__builtin_amdgcn_rcpf(r.oma.x), __builtin_amdgcn_rcpf(r.oma.y)};   // v_rcp_f32 (1 ulp), shared by both divisions
+        r.dx = e.dx;
+        r.dy = e.dy;
+        return r;
+    };
+    PairEval nx = {};
+    if (npairs) nx = eval_pair((int)npairs - 1);
+    for (int j = (int)npairs - 1; j >= 0; j--) {
+        const PairEval e = nx;
+        const float4 p3 = slab[5 * j + 3], p4 = slab[5 * j + 4];
+        nx = eval_pair(j > 0 ? j - 1 : 0);   // (the last trip evaluates pair 0 again: no branch in the block)
+        const v2f al = e.al, oma = e.oma, inv = e.inv, dx = e.dx, dy = e.dy;
+#ifdef GOM_BLK_STATS
+        { GOM_PAIR_STAT(2, 1); const unsigned long long a0_ = __ballot(al.x > 0.f), a1_ = __ballot(al.y > 0.f); GOM_PAIR_STAT(3, __popcll(a0_) + __popcll(a1_)); }
+#endif
+        const float T1 = T * inv.y, T0 = T1 * inv.x;   // T in front of the second entry of the pair (the later one: replayed first), then of the first
+        const v2f Tv = {T0, T1};
+        T = T0;
+        const v2f w = al * Tv;
+        v2f z[10];
+        const v2f c0 = {p3.x, p3.y}, c1 = {p3.z, p3.w}, c2 = {p4.x, p4.y}, c3 = {p4.z, p4.w};
+        v2f U = c0 * v2f{dpix[0], dpix[0]};
+        z[0] = w * v2f{dpix[0], dpix[0]};
+        if (C > 1) { U = __builtin_elementwise_fma(c1, v2f{dpix[1 % C], dpix[1 % C]}, U); z[1] = w * v2f{dpix[1 % C], dpix[1 % C]}; } else z[1] = v2f{0.f, 0.f};
+        if (C > 2) { U = __builtin_elementwise_fma(c2, v2f{dpix[2 % C], dpix[2 % C]}, U); z[2] = w * v2f{dpix[2 % C], dpix[2 % C]}; } else z[2] = v2f{0.f, 0.f};
+        if (C > 3) { U = __builtin_elementwise_fma(c3, v2f{dpix[3 % C], dpix[3 % C]}, U); z[3] = w * v2f{dpix[3 % C], dpix[3 % C]}; } else z[3] = v2f{0.f, 0.f};
+        // App. A.4's accum_rec / last_color only meet the gradient through their dot product with dL/dpix: carried as R = accum_rec . dpix, U_last
+        const float R1 = __fmaf_rn(last_alpha, U_last, one_minus_last * R_acc);
+        const float R0 = __fmaf_rn(al.y, U.y, oma.y * R1);
+        const v2f Rv = {R0, R1};
+        R_acc = R0;
+        U_last = U.x;
+        last_alpha = al.x;
+        one_minus_last = oma.x;
+        const v2f dLa = __builtin_elementwise_fma(U - Rv, Tv, (inv * v2f{ntf, ntf}) * v2f{bg_dot, bg_dot});
+        const v2f Q = e.qf * dLa;   // Q = opacity * G * dL/dalpha where the entry blends (the per-Gaussian backward no longer multiplies by the opacity)
+        z[4] = Q;
+        z[5] = Q * dx;
+        z[6] = Q * dy;
+        z[7] = z[5] * dx;
+        z[8] = z[5] * dy;
+        z[9] = z[6] * dy;
+        float n0, n1;
+        wave_sum20_banks(z, n0, n1);
+        if (slot20 >= 0) acc[20 * j + slot20] = from_n1 ? n1 : n0;
+    }
+    done = npairs >= 64u ? ~0ull : ((1ull << npairs) - 1ull);   // every staged pair's two rows are written
+#else
     for (int j = (int)npairs - 1; j >= 0; j--) {
         const float4 *p = slab + 5 * j;
         const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
-        const v2f ex = {p0.x, p0.y}, ey = {p0.z, p0.w}, ea = {p1.x, p1.y}, eb = {p1.z, p1.w}, ec = {p2.x, p2.y}, eo = {p2.z, p2.w};
-        // (the operations of entry_alpha / pair_alpha, in their order: the forward's alphas, bit for bit)
-        const v2f dx = ex - px, dy = ey - py;
-        const v2f q = __builtin_elementwise_fma(dx, ea * dx, dy * (ec * dy));
-        const v2f power = mh * q - dx * (eb * dy);
-        const v2f t = power * l2e;
-        const v2f g = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-        const v2f og = eo * g;
-        v2f al;
-        al.x = (power.x <= 0.f) ? fminf(kMaxAlpha, og.x) : 0.f;
-        al.y = (power.y <= 0.f) ? fminf(kMaxAlpha, og.y) : 0.f;
-        al.x = (al.x >= kMinAlpha) ? al.x : 0.f;
-        al.y = (al.y >= kMinAlpha) ? al.y : 0.f;
-        al.x = (2u * (uint32_t)j < pos_limit) ? al.x : 0.f;          // beyond this pixel's last contributor
-        al.y = (2u * (uint32_t)j + 1u < pos_limit) ? al.y : 0.f;
+        // alpha_eval: the forward's alphas, bit for bit; `lim` - position, clamped, is the third 0 / 1 factor (entries at or beyond this
+        // pixel's last contributor)
+        pos = pos - v2f{2.f, 2.f};   // (2 j, 2 j + 1) as floats, carried: there is no scalar int -> float on gfx950
+        const AlphaEval<v2f> e = alpha_eval_lim(v2f{p0.x, p0.y}, v2f{p0.z, p0.w}, v2f{p1.x, p1.y}, v2f{p1.z, p1.w}, v2f{p2.x, p2.y}, v2f{p2.z, p2.w}, px, py, lim, pos);
+        const v2f mm = e.mm, al = e.al, dx = e.dx, dy = e.dy;
 #if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 2
         if (__ballot(fmaxf(al.x, al.y) > 1.f) == 0ull) continue;
 #endif
@@ -162,10 +222,7 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         last_alpha = al.x;
         one_minus_last = oma.x;
         const v2f dLa = __builtin_elementwise_fma(U - Rv, Tv, (inv * v2f{ntf, ntf}) * v2f{bg_dot, bg_dot});
-        v2f G0;
-        G0.x = (al.x > 0.f) ? g.x : 0.f;
-        G0.y = (al.y > 0.f) ? g.y : 0.f;
-        const v2f Q = G0 * dLa;
+        const v2f Q = (e.og * mm) * dLa;   // Q = opacity * G * dL/dalpha where the entry blends (the per-Gaussian backward no longer multiplies by the opacity)
         z[4] = Q;
         z[5] = Q * dx;
         z[6] = Q * dy;
@@ -181,6 +238,7 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         done |= 1ull << j;
         if (slot20 >= 0) acc[20 * j + slot20] = from_n1 ? n1 : n0;
     }
+#endif
     return done;
 }
 

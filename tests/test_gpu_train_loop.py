@@ -22,9 +22,11 @@ KEYS = ("rgb", "mask", "laplacian_observation", "normal_mask", "normal_consist",
 # deviation grows with the iteration (rgb loss: 2e-7 at iteration 0, 2e-4 at 4, 6e-3 at 29).  EARLY = iterations 0-4, LATE = the rest.
 EARLY = dict(rgb=6e-4, mask=4e-3, laplacian_observation=2e-3, normal_mask=3e-3, normal_consist=2e-3, color_consist=1e-4)
 LATE = dict(rgb=2e-2, mask=4e-2, laplacian_observation=2e-2, normal_mask=3e-2, normal_consist=1.5e-2, color_consist=1e-4)
-GRADNORM = (0.1, 0.1, 0.15, 0.25, 0.12)    # appearance, vertices, scale, so3 (norm 3e-5 .. 2e-4: the noisiest), shadow (first 12 iterations)
-# (scale and PARAMNORM: two builds of the render backward that differ only in the order of their fp32 sums -- bitwise different gradients,
-#  the same accuracy against the float64 oracle -- measured 0.033 / 0.115 and 3e-5 / 1.5e-4: the spread between two valid fp32 trajectories)
+GRADNORM = (0.1, 0.25, 0.2, 0.25, 0.12)    # appearance, vertices, scale, so3 (norm 3e-5 .. 2e-4: the noisiest), shadow (first 12 iterations)
+# (vertices, scale and PARAMNORM: three builds of the render kernels that differ only in the order / grouping of their fp32 operations --
+#  bitwise different gradients, the same accuracy against the float64 oracle (tests/test_gpu_metric_workload.py) -- measured worst
+#  deviations of 0.033 / 0.115 / 0.084 (scale), 0.03 / 0.03 / 0.15 (vertices, at iteration 26 of 30) and 3e-5 / 1.5e-4 / 4e-5: the spread
+#  between valid fp32 trajectories of this optimisation, which is what these bounds are about)
 PARAMNORM = 2e-4
 
 
