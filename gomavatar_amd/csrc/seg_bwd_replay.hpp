@@ -1,18 +1,18 @@
 // The replay loop of the render backward, shared by k_seg_bwd and k_seg_bwd_pair (included inside raster_render.hip's anonymous namespace).
 //
-// Round 3, second pass.  The SQ counters say the backward is bound by VALU ISSUE, not by memory: 63 M wave instructions per 8-frame
-// launch x 4 cycles on 1 024 SIMDs = 0.25 M cycles of the 0.33 M the launch lasts (SQ_ACTIVE_INST_VALU x 4 / SIMDs / SQ_BUSY_CYCLES per
-// SE = 0.83-0.9; "waves parked 51 %" is the same fact seen from one of the five waves that share a SIMD).  So the loop is rewritten
-// around the instruction count: the survivors of a piece are compacted into PAIR records (as in k_seg_T) and two entries are replayed
-// per trip on register pairs --
-//   * alpha, the colour dot products, the weights and the six geometry moments of BOTH entries are v_pk_mul / v_pk_fma / v_pk_add_f32
-//     (one issue slot for two entries; gfx950 runs packed fp32 at full rate);
-//   * one LDS address per pair (five broadcast ds_read_b128 off one register) instead of four per entry;
-//   * the 20 values of the two entries go down ONE transposed tree: 15 lane swaps, 8 (packed) adds and 12 bank-masked DPP adds, against
-//     2 x (7 swaps + 7 adds + 8 DPP adds) -- the swap levels pair the two entries in the halves of a register pair, the in-row levels
-//     fill all four banks of a row (20 values = 5 registers x 4 rows after the swaps: no half-empty register as with 10);
-//   * the record address is a scalar multiply + one add (the 10-float record stride made the compiler emit a quarter-rate v_mad_u64_u32).
-// ~90 -> ~55 VALU issue cycles per entry.  Only the T / accum_rec recurrences stay scalar (they are serial by nature).
+// Round 3, second pass.  The survivors of a piece are compacted into PAIR records (as in k_seg_T) and two entries are replayed per trip
+// on register pairs: alpha (alpha_eval), the colour dot products, the weights and the six geometry moments of both entries as
+// v_pk_mul / v_pk_fma / v_pk_add_f32; one LDS address per pair (five broadcast ds_read_b128 off one register); the 20 values of the two
+// entries down ONE transposed tree (15 lane swaps, 8 packed adds, 12 bank-masked DPP adds: after the swaps 20 values are exactly 5
+// registers x 4 rows, and the in-row levels fill all four banks); the record address a scalar multiply + one add.
+// What it bought, measured ("Round 3, second pass"): 63 M -> 48 M VALU instructions per 8-frame launch and 158 -> 151 us.
+// The instruction count is not what bounds this kernel -- scripts/ubench/valu_rate.hip: a packed fp32 operation issues in 4.2 cycles
+// against 2.25 for a plain one (no gain per flop), a lane swap in 8, a compare / select / DPP add in ~4; knock-out builds (GOM_KO_REPLAY):
+// 60 us without the replay at all, +58 for the alphas, +19 for the gradient terms, +21 for the reduction.  Built on top and measured
+// slower, each parity-green: the next pair's evaluation software-pipelined into the current pair's reduction (165 us at 127 registers;
+// 185 at 96 with spills in the loop), both pieces' loads issued ahead of the first replay (177), the next task's descriptors fetched
+// through LDS a task ahead (165-182), the forward's "some pixel blended this entry" bits narrowing the survivor list (-24 % entries
+// evaluated: 148 us, but k_seg_fwd +7 for producing them).
 // Per value the summation tree is the one wave_sum10_banks had (lane ^ 32, ^ 16, ^ 8, ^ 7, ^ 1, ^ 2).
 #pragma once
 
@@ -116,74 +116,6 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
 #ifdef GOM_KO_REPLAY   // development knock-outs (scripts/exp_build.py NAME -DGOM_KO_REPLAY=1|2|3): no replay / alphas only / no reduction
     if (GOM_KO_REPLAY == 1 || GOM_KO_REPLAY >= 4) npairs = 0;
 #endif
-#ifndef GOM_BWD_PIPE
-#define GOM_BWD_PIPE 0
-#endif
-#if GOM_BWD_PIPE
-    // Software-pipelined by hand: the evaluation of pair j - 1 (three LDS broadcasts, the alpha chain, two v_exp and two v_rcp -- independent of
-    // the T / accum_rec recurrences) is written INTO the block that replays pair j, so that the compiler interleaves it with that pair's
-    // reduction chain (six dependent cross-lane levels).  A wave executes in order: as two separate stretches each waited for its own
-    // latencies -- the backward's waves were bound by that dependent chain, not by what they issue (45 M instead of 63 M VALU instructions
-    // had left the kernel's duration where it was).  No skip of a pair nobody blends (it would split the block; 6 % of the pairs): it is
-    // replayed as two zero-alpha layers, which leaves T / accum_rec exactly as skipping would.
-    struct PairEval { v2f al, oma, inv, qf, dx, dy; };
-    auto eval_pair = [&](int jj) {
-        const float4 *p = slab + 5 * jj;
-        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-        pos = pos - v2f{2.f, 2.f};   // (2 jj, 2 jj + 1) as floats, carried: there is no scalar int -> float on gfx950
-        const AlphaEval<v2f> e = alpha_eval_lim(v2f{p0.x, p0.y}, v2f{p0.z, p0.w}, v2f{p1.x, p1.y}, v2f{p1.z, p1.w}, v2f{p2.x, p2.y}, v2f{p2.z, p2.w}, px, py, lim, pos);
-        PairEval r;
-        r.al = e.al;
-        r.qf = e.og * e.mm;
-        r.oma = one - r.al;
-        r.inv = v2f{__builtin_amdgcn_rcpf(r.oma.x), __builtin_amdgcn_rcpf(r.oma.y)};   // v_rcp_f32 (1 ulp), shared by both divisions
-        r.dx = e.dx;
-        r.dy = e.dy;
-        return r;
-    };
-    PairEval nx = {};
-    if (npairs) nx = eval_pair((int)npairs - 1);
-    for (int j = (int)npairs - 1; j >= 0; j--) {
-        const PairEval e = nx;
-        const float4 p3 = slab[5 * j + 3], p4 = slab[5 * j + 4];
-        nx = eval_pair(j > 0 ? j - 1 : 0);   // (the last trip evaluates pair 0 again: no branch in the block)
-        const v2f al = e.al, oma = e.oma, inv = e.inv, dx = e.dx, dy = e.dy;
-#ifdef GOM_BLK_STATS
-        { GOM_PAIR_STAT(2, 1); const unsigned long long a0_ = __ballot(al.x > 0.f), a1_ = __ballot(al.y > 0.f); GOM_PAIR_STAT(3, __popcll(a0_) + __popcll(a1_)); }
-#endif
-        const float T1 = T * inv.y, T0 = T1 * inv.x;   // T in front of the second entry of the pair (the later one: replayed first), then of the first
-        const v2f Tv = {T0, T1};
-        T = T0;
-        const v2f w = al * Tv;
-        v2f z[10];
-        const v2f c0 = {p3.x, p3.y}, c1 = {p3.z, p3.w}, c2 = {p4.x, p4.y}, c3 = {p4.z, p4.w};
-        v2f U = c0 * v2f{dpix[0], dpix[0]};
-        z[0] = w * v2f{dpix[0], dpix[0]};
-        if (C > 1) { U = __builtin_elementwise_fma(c1, v2f{dpix[1 % C], dpix[1 % C]}, U); z[1] = w * v2f{dpix[1 % C], dpix[1 % C]}; } else z[1] = v2f{0.f, 0.f};
-        if (C > 2) { U = __builtin_elementwise_fma(c2, v2f{dpix[2 % C], dpix[2 % C]}, U); z[2] = w * v2f{dpix[2 % C], dpix[2 % C]}; } else z[2] = v2f{0.f, 0.f};
-        if (C > 3) { U = __builtin_elementwise_fma(c3, v2f{dpix[3 % C], dpix[3 % C]}, U); z[3] = w * v2f{dpix[3 % C], dpix[3 % C]}; } else z[3] = v2f{0.f, 0.f};
-        // App. A.4's accum_rec / last_color only meet the gradient through their dot product with dL/dpix: carried as R = accum_rec . dpix, U_last
-        const float R1 = __fmaf_rn(last_alpha, U_last, one_minus_last * R_acc);
-        const float R0 = __fmaf_rn(al.y, U.y, oma.y * R1);
-        const v2f Rv = {R0, R1};
-        R_acc = R0;
-        U_last = U.x;
-        last_alpha = al.x;
-        one_minus_last = oma.x;
-        const v2f dLa = __builtin_elementwise_fma(U - Rv, Tv, (inv * v2f{ntf, ntf}) * v2f{bg_dot, bg_dot});
-        const v2f Q = e.qf * dLa;   // Q = opacity * G * dL/dalpha where the entry blends (the per-Gaussian backward no longer multiplies by the opacity)
-        z[4] = Q;
-        z[5] = Q * dx;
-        z[6] = Q * dy;
-        z[7] = z[5] * dx;
-        z[8] = z[5] * dy;
-        z[9] = z[6] * dy;
-        float n0, n1;
-        wave_sum20_banks(z, n0, n1);
-        if (slot20 >= 0) acc[20 * j + slot20] = from_n1 ? n1 : n0;
-    }
-    done = npairs >= 64u ? ~0ull : ((1ull << npairs) - 1ull);   // every staged pair's two rows are written
-#else
     for (int j = (int)npairs - 1; j >= 0; j--) {
         const float4 *p = slab + 5 * j;
         const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
@@ -238,7 +170,6 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         done |= 1ull << j;
         if (slot20 >= 0) acc[20 * j + slot20] = from_n1 ? n1 : n0;
     }
-#endif
     return done;
 }
 
