@@ -645,6 +645,12 @@ struct PairQueue {
     }
 };
 
+#ifdef GOM_BLK_STATS
+__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] survivors k_seg_T evaluates (all pieces, live or not)
+#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
+#else
+#define GOM_PAIR_STAT(I, V) do { } while (0)
+#endif
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
@@ -694,6 +700,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             tq.request();
             unsigned long long mask = __ballot(r.keep);
             if (lane == 0) cull_masks[((size_t)seg * GOM_NSUB + sub) * 4 + q] = mask;   // for the two passes that follow
+            GOM_PAIR_STAT(4, __popcll(mask));
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
             ph_lastsurv = __popcll(mask);
 #endif
@@ -1126,12 +1133,6 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 }
 
 // ---------------------------------------------------------------- backward -
-#ifdef GOM_BLK_STATS
-__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] lanes with alpha >= 1/255 before the my_last test
-#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
-#else
-#define GOM_PAIR_STAT(I, V) do { } while (0)
-#endif
 #include "seg_bwd_replay.hpp"
 #ifndef GOM_BWD_EPT
 #define GOM_BWD_EPT 2   // entries evaluated per trip of the backward loop (4: 8 VGPRs spilled at 6 waves per SIMD, 215 us; 3: 205; 2: 203)
@@ -1439,6 +1440,19 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         if (!requested) tq.request();
         tq.publish(s_task);
         __syncthreads();
+#ifdef GOM_BLK_STATS
+        if (threadIdx.x == 0) {   // development: how even the eight pieces of a task are -- [5] sum of the survivors, [6] the busiest wave as assigned (w, 3 - w), [7] as a largest-first deal would have it
+            uint32_t c[8], tot = 0;
+            for (int i = 0; i < 8; i++) { c[i] = (uint32_t)__popcll(s_mask[i >> 2][i & 3]); tot += c[i]; }
+            uint32_t cur = 0;
+            for (int w = 0; w < 4; w++) cur = max(cur, c[w] + c[4 + 3 - w]);
+            for (int i = 0; i < 8; i++) for (int k = i + 1; k < 8; k++) if (c[k] > c[i]) { const uint32_t t = c[i]; c[i] = c[k]; c[k] = t; }
+            uint32_t ld[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 8; i++) { int m = 0; for (int w = 1; w < 4; w++) if (ld[w] < ld[m]) m = w; ld[m] += c[i]; }
+            const uint32_t lpt = max(max(ld[0], ld[1]), max(ld[2], ld[3]));
+            atomicAdd(&g_pair_stats[5], (unsigned long long)tot); atomicAdd(&g_pair_stats[6], (unsigned long long)cur); atomicAdd(&g_pair_stats[7], (unsigned long long)lpt);
+        }
+#endif
         {   // one 48-byte record per entry of the two sub-ranges (threads 0..127), quadrants summed in a fixed order
             const int half = (threadIdx.x >> 6) & 1, e = threadIdx.x & 63;
 #if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 5

@@ -28,3 +28,6 @@ if MODE == 0:
     pieces, surv, act, lanes = [int(x) for x in out[8:12]]
     print(f"pair kernel: live (sub-range, quadrant) pieces {pieces}; survivors of the stored cull evaluated {surv} ({surv / max(pieces, 1):.1f} per piece); with a lane alive {act} = {act / max(surv, 1):.2f}; "
           f"lanes alive in those {lanes} = {lanes / max(act * 64, 1):.3f} of 64; of all evaluated lanes {lanes / max(surv * 64, 1):.3f}")
+    print(f"k_seg_T evaluates {int(out[12])} survivors over ALL pieces; the pieces some pixel is still alive in hold {surv}")
+    tot, cur, lpt = [int(x) for x in out[13:16]]
+    print(f"pieces of a task over its four waves: survivors {tot}; busiest wave as assigned (w, 3 - w) {cur} = {4 * cur / max(tot, 1):.2f} x the mean; dealt largest first {lpt} = {4 * lpt / max(tot, 1):.2f} x")
