@@ -809,7 +809,11 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
         float wl = T > 0.f ? 1.f : 0.f;  // lane still compositing (float mask: no SALU in the chain)
         tq.request();  // (behind every load of this task)
         const bool any_alive = __syncthreads_or(wl != 0.f ? 1 : 0) != 0;  // also fences the LDS of the previous segment
+#if defined(GOM_KO_FWD) && GOM_KO_FWD == 2   // development knock-outs (scripts/exp_build.py NAME -DGOM_KO_FWD=1|2): no compositing loop / every segment treated as dead
+        if (true) {
+#else
         if (!any_alive) {  // every pixel of the quadrant stopped before this segment
+#endif
             if (sub == 0) {
                 const size_t o = (size_t)seg * GOM_TPX + pxi;
                 seg_Tend[o] = 0.f;
@@ -827,6 +831,9 @@ __global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, 
         uint32_t last = 0;
         if (__ballot(wl != 0.f) != 0ull) {
             unsigned long long mask = __ballot(r.keep);
+#if defined(GOM_KO_FWD) && GOM_KO_FWD == 1
+            mask = 0ull;
+#endif
             // what the backward will pay for this piece, roughly: the entries that reach alive pixels here (GomBwdOrderRider)
             if (seg_cost && lane == 0 && mask) seg_cost[16 * (size_t)seg + 4 * sub + q] = (uint32_t)__popcll(mask);   // (one writer per word)
             s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
