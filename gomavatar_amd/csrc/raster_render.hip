@@ -739,8 +739,11 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
 // the earlier pieces' prod(1-alpha)).  The four sub-ranges are then folded in LDS: the segment stores its
 // contribution, T after it (negated if the stop rule fired inside) and the last contributor; the per-sub-range
 // pieces are kept as checkpoints for the backward.
+#ifndef GOM_FWD_WAVES
+#define GOM_FWD_WAVES 7
+#endif
 template <int C>
-__global__ void __launch_bounds__(256, 7) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+__global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
