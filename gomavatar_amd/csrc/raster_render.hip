@@ -1551,6 +1551,14 @@ static int task_grid(int resident, int pct) {   // GOM_OPT_TASK_GRID_PCT of the 
 // has fewer tasks than two rounds of that grid, where one task per workgroup and no queue is the shorter path.
 #define GOM_RESIDENT(KERNEL) (s->B > 1 ? task_grid([&]() { static const int g = resident_grid(KERNEL, s->device); return g; }(), s->taskGridPct) : GOM_SEG_GRID * 4)
 #define GOM_TASK_CTR (s->B > 1 ? s->task_ctr : nullptr)
+// 1 = the kernel strides over its tasks (no dequeue) also in a batched launch.  The transmittance pre-pass's tasks are alike (every piece is
+// evaluated): striding measures 75 us against 78 through the queue.  The compositing pass's are not (two thirds are dead): 130 against 110.
+#ifndef GOM_STATIC_T
+#define GOM_STATIC_T 1
+#endif
+#ifndef GOM_STATIC_FWD
+#define GOM_STATIC_FWD 0
+#endif
 
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st) {
@@ -1561,10 +1569,10 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
             if (C == 3)
                 hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_RESIDENT(k_seg_T<3>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR, s->cull_masks);
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks);
             else
                 hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_RESIDENT(k_seg_T<4>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_TASK_CTR, s->cull_masks);
+                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks);
         } else {  // only the colours changed: bring them into list order
             if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
             else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
@@ -1575,7 +1583,7 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
 #define GOM_SF(CC)                                                                                                        \
     hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_RESIDENT(k_seg_fwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
-                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks)
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_STATIC_FWD ? nullptr : GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks)
         if (C == 3) GOM_SF(3); else GOM_SF(4);
 #undef GOM_SF
     }
