@@ -394,6 +394,17 @@ def extra_figures(torch, wl):
                 tu.train_iteration(model, optm, frames[it_[0] % 4], tcfg, it_[0] + 1, lpips_func=mcl)
                 it_[0] += 1
             out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=5, chunk=5), 1)
+            if prec == "bf16x3":   # the same iteration captured once in a HIP graph and replayed per frame (train_util.GraphedTrainStep; Adam capturable, lr frozen at capture)
+                model_g = Model(cfg, wl.body).train()
+                opt_g = torch.optim.Adam(model_g.get_param_groups(tcfg), betas=(0.9, 0.999), capturable=True)
+                gstep = tu.GraphedTrainStep(model_g, opt_g, tcfg.losses, mcl)
+                jt = [0]
+
+                def train_graphed():
+                    gstep(frames[jt[0] % 4], i_iter=1)
+                    jt[0] += 1
+                out["model_train_iteration_lpips_bf16x3_b1_graphed_ips"] = round(timeit(torch, train_graphed, warm=6, chunk=5), 1)
+                del model_g, opt_g, gstep
             del model, mcl, optm
     except Exception as e:  # report, do not hide
         out["model_train_iteration_b1_ips"] = f"failed: {type(e).__name__}: {e}"
