@@ -79,59 +79,15 @@ constexpr float kStopT = 0.0001f;          // App. A.3: stop when T(1-alpha) < 1
 constexpr float kMinAlpha = 1.0f / 255.0f;
 constexpr float kMaxAlpha = 0.99f;
 
-__device__ __forceinline__ float rl(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
-// Sum of 10 registers over the 64 lanes, transposed tree: v_permlane32_swap / v_permlane16_swap exchange halves (rows) of two registers, so
-// one swap + one add folds a level of the tree for TWO values and halves the number of live registers (10 -> 5 -> 3: every ROW then holds
-// partials of its own value).  Round 3: the four in-row steps are transposed too -- DPP bank_mask (one bit per quad of lanes) lets two source
-// registers fold into one destination, csrc/row_reduce.hpp -- lane ^ 8 (3 adds: 3 -> 2 registers), lane ^ 7 (2 adds: -> 1), two quad
-// butterflies (2 adds), one row_bcast for the value that was split over two rows: 8 cross-lane adds where four row_shr steps on three
-// registers took 13 (29 instead of 34 per entry).  Where the totals land in the ONE result register n, all four lanes of the quad alike:
-//   bank 0 (lanes 0-3 of the row):  rows 0..3 = values 0, 2, 1, 3        bank 2 (lanes 8-11):  rows 0..3 = values 4, 6, 5, 7
-//   bank 3 (lanes 12-15):  row 1 = value 8, row 3 = value 9              (bank 1 and bank 3 of rows 0, 2: partial sums, unused)
-// (layout of the swap levels checked by scripts/ubench/permlane_probe.hip, of the bank-masked steps by scripts/ubench/row_reduce_probe.hip).
-__device__ __forceinline__ float swap_add32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// Building blocks of the backward's transposed 64-lane reduction (csrc/seg_bwd_replay.hpp: wave_sum20_banks): v_permlane32_swap /
+// v_permlane16_swap exchange halves (rows) of two registers, so one swap + one add folds a level of the tree for TWO values and halves the
+// number of live registers (layout of the swap levels checked by scripts/ubench/permlane_probe.hip, of the bank-masked in-row levels by
+// scripts/ubench/row_reduce_probe.hip).
 __device__ __forceinline__ float swap_add16(float a, float b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float wave_sum10_banks(const float (&w)[10]) {
-    const float p0 = swap_add32(w[0], w[1]), p1 = swap_add32(w[2], w[3]), p2 = swap_add32(w[4], w[5]), p3 = swap_add32(w[6], w[7]);
-    const float s2 = swap_add32(w[8], w[9]);
-    const float s0 = swap_add16(p0, p1);
-    const float s1 = swap_add16(p2, p3);
-    float m, t, n;
-    asm volatile("s_nop 1\n"
-                 "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n"          // m: banks 0,1 <- s0 (lane ^ 8)
-                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"          // t: s2 (lane ^ 8)
-                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n"          // m: banks 2,3 <- s1
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n"    // n: banks 0,2 <- m (lane ^ 7)
-                 "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n"    // n: banks 1,3 <- t
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0x8\n"        // rows 1, 3, bank 3: + lane 15 of the row in front (the other half of values 8, 9)
-                 : "=&v"(m), "=&v"(t), "=&v"(n)
-                 : "v"(s0), "v"(s1), "v"(s2));
-    return n;
-}
-// the float index inside an entry's 10-value LDS record that this lane's share of wave_sum10_banks goes to, or -1
-__device__ __forceinline__ int wave_sum10_slot(int lane) {
-    const int l = lane & 15, row_slot = (((lane >> 4) & 1) << 1) | (lane >> 5);   // rows 0..3 -> 0, 2, 1, 3
-    if (l == 0) return row_slot;
-    if (l == 8) return 4 + row_slot;
-    if (l == 15 && (lane & 16)) return 8 + (lane >> 5);
-    return -1;
-}
-
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1144,9 +1100,6 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
 
 // ---------------------------------------------------------------- backward -
 #include "seg_bwd_replay.hpp"
-#ifndef GOM_BWD_EPT
-#define GOM_BWD_EPT 2   // entries evaluated per trip of the backward loop (4: 8 VGPRs spilled at 6 waves per SIMD, 215 us; 3: 205; 2: 203)
-#endif
 #ifndef GOM_BWD_WAVES
 #define GOM_BWD_WAVES 6
 #endif
