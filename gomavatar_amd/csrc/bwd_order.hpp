@@ -9,8 +9,8 @@ __device__ __forceinline__ void gom_bwd_order_rider(const GomBwdOrderRider &ride
     if (rider.status->overflow) return;
     __shared__ uint32_t s_lvl[512];
     const uint32_t nsegs = rider.status->num_segs;
-    const uint32_t npairs = nsegs > x ? 2u * ((nsegs - x + 7u) / 8u) : 0u;       // (segment, pair) units of this shard
-    const uint32_t region = 4u * ((nsegs + 7u) / 8u);
+    const uint32_t npairs = 2u * gom_shard_segments(nsegs, x);                   // (segment, pair) units of this shard
+    const uint32_t region = gom_bwd_order_region(nsegs);
     uint32_t *out = rider.bwd_order + GOM_BWD_ORDER_BASE + (size_t)x * region;
     for (int k = threadIdx.x; k < 512; k += 256) s_lvl[k] = 0u;
     __syncthreads();
@@ -19,7 +19,7 @@ __device__ __forceinline__ void gom_bwd_order_rider(const GomBwdOrderRider &ride
     // (k_seg_bwd_pair), and the task lasts as long as its busiest wave; a sub-range alone: its busiest quadrant.
     // -> (.x, .y) = the two single sub-ranges' costs, or (cost of the pair, 0xfffffffe) when it is not split; .x = 0xffffffff: no unit
     auto cost_of = [&](uint32_t j) {
-        const uint32_t seg = (j >> 1) * 8u + x;
+        const uint32_t seg = gom_shard_segment(x, j >> 1);
         uint2 c = make_uint2(0xffffffffu, 0u);
         if (j < npairs && seg < nsegs) {
             const uint4 a = *reinterpret_cast<const uint4 *>(rider.seg_cost + 16 * (size_t)seg + 8 * (j & 1u));
@@ -32,7 +32,7 @@ __device__ __forceinline__ void gom_bwd_order_rider(const GomBwdOrderRider &ride
     };
     auto account = [&](int pass, uint32_t j, uint2 c) {
         if (c.x == 0xffffffffu) return;
-        const uint32_t seg = (j >> 1) * 8u + x, pair = j & 1u;
+        const uint32_t seg = gom_shard_segment(x, j >> 1), pair = j & 1u;
         if (c.y != 0xfffffffeu) {
             if (pass == 0) { atomicAdd(&s_lvl[level(c.x)], 1u); atomicAdd(&s_lvl[level(c.y)], 1u); }
             else {

@@ -205,7 +205,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     const int64_t wantSegs = s->capPairs / GOM_SEG + s->capTiles + 1;
     if (wantSegs > s->capSegs) {
         const size_t n = (size_t)wantSegs;
-        if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, 4 * n + 64) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
+        if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, GOM_BWD_ORDER_BASE + GOM_TQ_SHARDS * (size_t)gom_bwd_order_region((uint32_t)n)) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
             grow_s(s, &s->seg_Tend, n * GOM_TPX) || grow_s(s, &s->seg_Sbehind, n * 4 * GOM_TPX) || grow_s(s, &s->sub_T, n * 4 * GOM_TPX) || grow_s(s, &s->cull_masks, n * 16) ||
             grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX))
             return -2;

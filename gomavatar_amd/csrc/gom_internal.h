@@ -24,6 +24,24 @@
 #define GOM_TQ_SHARDS 8               // heads per task queue (raster_render.hip: TaskQueue)
 #endif
 #define GOM_TASK_CTR_WORDS (3 * (32 * GOM_TQ_SHARDS + 32))   // three sharded task queues
+// Which segments a queue shard owns.  A workgroup's shard is blockIdx % 8 = the XCD it runs on (workgroups are dealt to the XCDs round-robin),
+// and every XCD has its own L2: the segments of ONE tile (consecutive segment numbers) should meet in one of them -- a compositing task reads
+// the transmittance rows of every segment in front of it, a backward task the tile's image-gradient / last-contributor rows.  So the shards
+// take GROUPS of 2^GOM_TQ_GROUP_LOG2 consecutive segments in turn (0: segment s to shard s % 8, rounds 1-3 until here).  Measured (FETCH_SIZE per
+// 8-frame launch, KB): k_seg_bwd_pair 85.7 k at 0, 67.8 k at 3, 61.8 k at 5, 60.5 k at 7; k_seg_fwd 40.5 k -> 35.1 k; durations unchanged up to 6.
+#ifndef GOM_TQ_GROUP_LOG2
+#define GOM_TQ_GROUP_LOG2 5
+#endif
+__host__ __device__ inline uint32_t gom_shard_segments(uint32_t nsegs, uint32_t x) {   // how many segments shard x owns
+    const uint32_t G = 1u << GOM_TQ_GROUP_LOG2, per = G * GOM_TQ_SHARDS, rem = nsegs % per, lo = x * G;
+    return (nsegs / per) * G + (rem > lo ? (rem - lo < G ? rem - lo : G) : 0u);
+}
+__host__ __device__ inline uint32_t gom_shard_segment(uint32_t x, uint32_t k) {        // its k-th segment
+    return (((k >> GOM_TQ_GROUP_LOG2) * GOM_TQ_SHARDS + x) << GOM_TQ_GROUP_LOG2) | (k & ((1u << GOM_TQ_GROUP_LOG2) - 1u));
+}
+__host__ __device__ inline uint32_t gom_bwd_order_region(uint32_t nsegs) {              // entries of a shard's part of the backward's order table (two per (segment, pair) unit)
+    return 4u * ((nsegs + GOM_TQ_SHARDS - 1u) / GOM_TQ_SHARDS + (1u << GOM_TQ_GROUP_LOG2));
+}
 
 struct GomDevStatus {
     uint32_t num_pairs;
@@ -294,7 +312,7 @@ int gom_vertex_backward_batch(int B, int F, int N, int J, const float *xyz, cons
                               float *d_xyz, float *dRT, void *stream);
 // The backward's task word: (segment << 3) | code, code 0 / 1 = the pair of sub-ranges (0,1) / (2,3), code 4 + j = sub-range j alone (the riders
 // split a pair whose busiest wave would see more than GOM_BWD_SPLIT_COST surviving entries: the densest pairs are 120 us tasks).
-// Order table: [0, 8) tasks of shard x; then shard x's tasks at GOM_BWD_ORDER_BASE + x * region, region = 4 * ceil(nsegs / 8) entries.
+// Order table: [0, 8) tasks of shard x; then shard x's tasks at GOM_BWD_ORDER_BASE + x * region, region = gom_bwd_order_region(nsegs) entries.
 #ifndef GOM_BWD_SPLIT_COST
 #define GOM_BWD_SPLIT_COST 110u
 #endif

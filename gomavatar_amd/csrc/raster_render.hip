@@ -492,10 +492,10 @@ struct TaskQueueT {
     uint32_t *ctr;
     uint32_t nsegs, per_shard_wgs, shard, tried, pend, it, next;
     bool have_next;
-    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return nsegs > x ? (uint32_t)PER_SEG * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u; }
+    __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const { return (uint32_t)PER_SEG * gom_shard_segments(nsegs, x); }
     __device__ __forceinline__ uint32_t task_of(uint32_t x, uint32_t j) const {
         constexpr uint32_t SH = PER_SEG == 4 ? 2u : (PER_SEG == 2 ? 1u : 0u);   // PER_SEG queue items per segment: (segment << SH) | piece
-        return (((j >> SH) * GOM_TQ_SHARDS + x) << SH) | (j & ((1u << SH) - 1u));
+        return (gom_shard_segment(x, j >> SH) << SH) | (j & ((1u << SH) - 1u));
     }
     // thread 0 only: local index j on the current shard -> queue item, moving to the next shards while the current one is empty
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {
@@ -552,11 +552,11 @@ struct PairQueue {
     bool have_next;
     __device__ __forceinline__ uint32_t shard_tasks(uint32_t x) const {
         if (order) return order[x];
-        return nsegs > x ? 2u * ((nsegs - x + GOM_TQ_SHARDS - 1) / GOM_TQ_SHARDS) : 0u;
+        return 2u * gom_shard_segments(nsegs, x);
     }
     __device__ __forceinline__ uint32_t task_at(uint32_t x, uint32_t j) const {
         if (order) return order[GOM_BWD_ORDER_BASE + (size_t)x * region + j];
-        return (((j >> 1) * GOM_TQ_SHARDS + x) << 3) | (j & 1u);
+        return (gom_shard_segment(x, j >> 1) << 3) | (j & 1u);
     }
     __device__ __forceinline__ uint32_t resolve(uint32_t j) {   // thread 0 only
         while (j >= ntasks) {
@@ -568,7 +568,7 @@ struct PairQueue {
         return task_at(shard, j);
     }
     __device__ __forceinline__ void init(uint32_t *c, uint32_t n_segs, uint32_t *s_task, const uint32_t *task_order) {
-        ctr = c; order = c ? task_order : nullptr; nsegs = n_segs; region = 4u * ((n_segs + 7u) / 8u); it = 0; tried = 0; pend = 0; next = 0; have_next = false;
+        ctr = c; order = c ? task_order : nullptr; nsegs = n_segs; region = gom_bwd_order_region(n_segs); it = 0; tried = 0; pend = 0; next = 0; have_next = false;
         if (!ctr) return;  // static mode: plain grid-stride over the (segment, pair) grid
         per_shard_wgs = gridDim.x / GOM_TQ_SHARDS;
         shard = blockIdx.x % GOM_TQ_SHARDS;
