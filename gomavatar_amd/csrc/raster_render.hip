@@ -515,9 +515,13 @@ struct TaskQueueT {
         __syncthreads();
     }
     __device__ __forceinline__ uint32_t current(const uint32_t *s_task) const {
-        if (!ctr) {
-            const uint32_t t = blockIdx.x + it * gridDim.x;
-            return t < nsegs * (uint32_t)PER_SEG ? t : 0xffffffffu;
+        if (!ctr) {   // striding: workgroup (XCD x = blockIdx % 8, rank r) takes items r, r + grid / 8, ... of shard x -- the same XCD as through the queue
+            if (gridDim.x % GOM_TQ_SHARDS) {   // (a grid that is not a multiple of the shard count: plain stride)
+                const uint32_t t = blockIdx.x + it * gridDim.x;
+                return t < nsegs * (uint32_t)PER_SEG ? t : 0xffffffffu;
+            }
+            const uint32_t x = blockIdx.x % GOM_TQ_SHARDS, j = blockIdx.x / GOM_TQ_SHARDS + it * (gridDim.x / GOM_TQ_SHARDS);
+            return j < shard_tasks(x) ? task_of(x, j) : 0xffffffffu;
         }
         return s_task[it & 1];
     }
