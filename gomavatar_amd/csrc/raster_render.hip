@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
                 T = T * (1.f - a1.y);
             }
         }
-        sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;
+        sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;   // (the last piece's row is never read; leaving it out measured 82 us instead of 76)
         float(*sp)[64] = s_P[tq.it & 1];  // double-buffered: the readers of the previous task use the other half
         sp[sub][lane] = T;
         tq.publish(s_task);
@@ -739,8 +739,12 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
         const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
-        // issued early: the entry loads overlap the transmittance prefix below
+#ifndef GOM_FWD_LATE_ENTRIES
+#define GOM_FWD_LATE_ENTRIES 1   // 1: the entries are loaded once the task is known to be alive (two thirds are not); 0: with the transmittance prefix
+#endif
+#if !GOM_FWD_LATE_ENTRIES
         const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz, cull_masks + ((size_t)seg * GOM_NSUB + sub) * 4 + q);
+#endif
         // transmittance at the start of this sub-range; 0 = the pixel has certainly stopped earlier.
         // (In the 1e-5-wide borderline band the pixel stays alive; the fold below / the combine pass honour
         //  the exact stop flag of the earlier piece.)
@@ -777,7 +781,8 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
 #else
         if (!any_alive) {  // every pixel of the quadrant stopped before this segment
 #endif
-            if (sub == 0) {
+            if (sub == 0) {   // (the assembly pass needs seg_Tend = 0 only, but loads all three rows of a segment in one batch: with the other two
+                              //  left unwritten -- 24 MB of stores less per 8-frame launch -- its loads came from HBM instead of the L2 / MALL: k_combine_fwd 25 -> 29 us)
                 const size_t o = (size_t)seg * GOM_TPX + pxi;
                 seg_Tend[o] = 0.f;
                 seg_last[o] = 0;
@@ -788,6 +793,9 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
             __syncthreads();
             continue;
         }
+#if GOM_FWD_LATE_ENTRIES
+        const EntryRegs<C> r = load_sub<C>(ent_geo, ent_col, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz, cull_masks + ((size_t)seg * GOM_NSUB + sub) * 4 + q);
+#endif
         float acc[C];
 #pragma unroll
         for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
