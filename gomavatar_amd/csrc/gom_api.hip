@@ -214,7 +214,10 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     s->gx = gx;
     s->gy = gy;
     s->B = B;
-    s->segShift = s->wantSegShift ? s->wantSegShift : (B > 1 ? 8 : 7);   // (capSegs above is sized for the 128-entry case)
+    // auto: 256-entry segments for a batch; for one frame too when its tiles are busy -- at >= 32 Gaussians per tile of the image (55 104 at 512^2 or
+    // 540^2: 54 / 48; 220 416 at 1024^2: 54) the halved number of segments pays (B = 1: 4.78 -> 5.00 k, 4.69 -> 4.99 k, 2.08 -> 2.40 k frames/s), at
+    // 13 per tile (55 104 at 1024^2) a frame is short of independent tasks and 128-entry segments win (3.27 k against 2.31 k).
+    s->segShift = s->wantSegShift ? s->wantSegShift : ((B > 1 || (int64_t)P_frame >= 32 * (int64_t)gx * gy) ? 8 : 7);   // (capSegs above is sized for the 128-entry case)
     return 0;
 }
 

@@ -88,8 +88,8 @@ enum {
                                two; default 8192); longer lists take the chunked merge path -- lowered by tests */
     GOM_OPT_PAIR_CAPACITY = 1, /* capacity (entries) of the (tile, gaussian) pair buffers */
     GOM_OPT_PROFILE = 2,       /* 1: bracket every raster kernel launch with HIP events on the caller's stream */
-    GOM_OPT_SEG_SHIFT = 3,     /* log2 of the tile-list segment size: 7 (128 entries), 8 (256) or 0 = auto (7 for one frame,
-                                  8 for a batched launch).  Results for different sizes agree to fp32 round-off, not bitwise. */
+    GOM_OPT_SEG_SHIFT = 3,     /* log2 of the tile-list segment size: 7 (128 entries), 8 (256) or 0 = auto (8 for a batched launch and for
+                                  one frame with >= 32 Gaussians per tile of the image, else 7).  Results for different sizes agree to fp32 round-off, not bitwise. */
     GOM_OPT_TASK_GRID_PCT = 4, /* 10..100 (default 100): share of the chip the persistent task-queue grids of a batched launch
                                   occupy.  100 is fastest when the step has the GPU to itself; with several steps in flight on
                                   separate streams ~50 lets their kernels run side by side (a full grid holds every workgroup
