@@ -62,7 +62,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count, s->vdepth_minmax, s->cull_masks};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count, s->vdepth_minmax, s->cull_masks, s->piece_ub, s->piece_rec, s->rec_ti, s->rec_acc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -98,7 +98,7 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
         case GOM_OPT_BWD_MODE:
-            if (value < -1 || value > 2) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges), 1 (one sub-range per barrier) or 2 (4x4-block items per DPP row)"); return -1; }
+            if (value < -1 || value > 3) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges), 1 (one sub-range per barrier), 2 (4x4-block items per DPP row, GOM_LAB builds) or 3 (lane per (pixel, entry) record)"); return -1; }
             s->bwdMode = (int)value;
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
@@ -194,6 +194,14 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         s->capPairs = want;
         s->capSegs = 0;
     }
+    {   // records of the render backward: one per blending (pixel, entry) pair, GOM_REC_SHARDS equal regions
+        int64_t wantRec = s->capPairs * GOM_REC_PER_PAIR / GOM_REC_SHARDS * GOM_REC_SHARDS;
+        if (wantRec > 0xf0000000LL) wantRec = 0xf0000000LL / GOM_REC_SHARDS * GOM_REC_SHARDS;
+        if (wantRec != s->capRec) {
+            if (grow_s(s, &s->rec_ti, (size_t)wantRec) || grow_s(s, &s->rec_acc, (size_t)wantRec)) return -2;
+            s->capRec = wantRec;
+        }
+    }
     {
         const int64_t wantItems = s->capTiles + s->capPairs / GOM_RANK_WIN + 1;
         if (wantItems > s->capItems) {
@@ -207,7 +215,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const size_t n = (size_t)wantSegs;
         if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, GOM_BWD_ORDER_BASE + GOM_TQ_SHARDS * (size_t)gom_bwd_order_region((uint32_t)n)) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
             grow_s(s, &s->seg_Tend, n * GOM_TPX) || grow_s(s, &s->seg_Sbehind, n * 4 * GOM_TPX) || grow_s(s, &s->sub_T, n * 4 * GOM_TPX) || grow_s(s, &s->cull_masks, n * 16) ||
-            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX))
+            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX) || grow_s(s, &s->piece_ub, n * 16) || grow_s(s, &s->piece_rec, n * 16))
             return -2;
         s->capSegs = wantSegs;
     }
@@ -349,7 +357,7 @@ extern "C" int gom_state_poll(GomState *s, int64_t *num_pairs, int32_t *overflow
     GOM_HIP_CHECK(hipMemcpyAsync(&h, s->status, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GOM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (num_pairs) *num_pairs = h.num_pairs;
-    if (overflow) *overflow = (int32_t)h.overflow;
+    if (overflow) *overflow = (int32_t)(h.overflow | (h.rec_overflow ? 2u : 0u));   // bit 0: pair buffers (image poisoned); bit 1: records of the render backward (gradients poisoned)
     return 0;
 }
 
@@ -435,7 +443,7 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
             g.last_use = s->graphClock;
             GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
             s->P = f->F; s->H = f->H; s->W = f->W; s->C = 4; s->B = B; s->cams = cams; s->haveForward = true;
-            s->gx = g.gx; s->gy = g.gy; s->segShift = g.segShift; s->rankSort = g.rankSort; s->bwdOrderReady = g.bwdOrderReady;
+            s->gx = g.gx; s->gy = g.gy; s->segShift = g.segShift; s->rankSort = g.rankSort; s->bwdOrderReady = g.bwdOrderReady; s->recCounts = g.recCounts; s->recForward = g.recForward;
             s->emptyFilled = false;
             return 0;
         }
@@ -455,7 +463,7 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     hipError_t ce = hipStreamEndCapture(st, &e.graph);
     if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return rc; }
     if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return -2; }
-    e.gx = s->gx; e.gy = s->gy; e.segShift = s->segShift; e.rankSort = s->rankSort; e.bwdOrderReady = s->bwdOrderReady;
+    e.gx = s->gx; e.gy = s->gy; e.segShift = s->segShift; e.rankSort = s->rankSort; e.bwdOrderReady = s->bwdOrderReady; e.recCounts = s->recCounts; e.recForward = s->recForward;
     GOM_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
     if (s->graphs.size() >= 64) {  // evict the least recently used capture
         size_t victim = 0;

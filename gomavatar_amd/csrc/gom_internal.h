@@ -43,6 +43,8 @@ __host__ __device__ inline uint32_t gom_bwd_order_region(uint32_t nsegs) {      
     return 4u * ((nsegs + GOM_TQ_SHARDS - 1u) / GOM_TQ_SHARDS + (1u << GOM_TQ_GROUP_LOG2));
 }
 
+#define GOM_REC_SHARDS 32            // cursors of the record allocator (one device-scope word takes ~88 atomics per microsecond)
+#define GOM_REC_PER_PAIR 8           // record capacity per unit of pair capacity (the metric workload writes ~4.7 records per (tile, entry) pair)
 struct GomDevStatus {
     uint32_t num_pairs;
     uint32_t overflow;
@@ -52,8 +54,10 @@ struct GomDevStatus {
     // ~88 atomics per microsecond (MI355X_MICROARCH.md), and 1 728 workgroups of a batched launch queued ~20 us on it.
     uint32_t shard_overflow;   // a shard ran past its eighth of the buffer (folded into `overflow` by the scan kernel)
     uint32_t n_work_items;     // length of the work list of k_tile_rank
-    uint32_t pad_[26];
+    uint32_t rec_overflow;     // the forward's per-(pixel, entry) records ran past a shard of their buffer (render backward, records mode): gradients poisoned
+    uint32_t pad_[25];
     uint32_t shard_cursor[8][32];   // [shard][0] used
+    uint32_t rec_cursor[GOM_REC_SHARDS][32];   // [shard][0] used: allocator of the record regions of the live (segment, sub-range, quadrant) pieces (k_seg_fwd)
 };
 
 struct GomGraphEntry {
@@ -68,7 +72,7 @@ struct GomGraphEntry {
     // host-side state the recorded sequence left behind (a replay skips the host code that derives it; a later stand-alone call on
     // the state -- gom_raster_backward, REUSE_BINNING -- must see what the replayed forward really did)
     int gx, gy, segShift;
-    bool rankSort, bwdOrderReady;
+    bool rankSort, bwdOrderReady, recCounts, recForward;
 };
 
 struct GomState {
@@ -87,8 +91,10 @@ struct GomState {
     bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write
     bool bwdOrder = true;             // development switch: cost-ordered backward queue in the frame step
     bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
-    int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 0 = two sub-ranges between barriers with opposite quadrants per wave, 1 = one sub-range per
-                                      // barrier (round 1); -1 = auto: 0 for a batched launch (+2 %), 1 for a single frame (+1 %)
+    int bwdMode = -1;                 // GOM_OPT_BWD_MODE: 3 = lane per (pixel, entry) record the forward left (round 4); 0 = two sub-ranges between barriers
+                                      // with opposite quadrants per wave, 1 = one sub-range per barrier (round 1); -1 = auto
+    bool recCounts = false;           // the current binning's transmittance pre-pass counted the pieces' records (piece_ub)
+    bool recForward = false;          // the checkpoints of the last render forward are those of the records mode (records + inclusive sub_C rows)
     int segShift = 7;                 // log2 of the segment size of the current binning: 7 for one frame, 8 for a batch
     const GomCamera *cams = nullptr;  // device array of B cameras for a batched launch; nullptr: the by-value camera
     bool haveForward = false;
@@ -152,6 +158,12 @@ struct GomState {
     float *sub_T = nullptr;           // [capSegs][4][256]     product of (1-alpha) over the sub-range
     float *sub_C = nullptr;           // [capSegs][4][4][256]  colour the sub-range really added to the pixel
     float *sub_Tend = nullptr;        // [capSegs][4][256]     transmittance behind the sub-range
+    // records mode of the render backward: per (segment, sub-range, quadrant) piece and per blending (pixel, entry) pair
+    uint32_t *piece_ub = nullptr;     // [capSegs][4][4]  lanes x surviving entries with alpha > 0 (k_seg_T): upper bound of the piece's records
+    uint2 *piece_rec = nullptr;       // [capSegs][4][4]  (first record, number of records) of a piece k_seg_fwd found alive
+    float2 *rec_ti = nullptr;         // [capRec] (T in front of the entry at the pixel, bits: entry of the sub-range << 6 | pixel of the quadrant)
+    float4 *rec_acc = nullptr;        // [capRec] colour the piece had added to the pixel in front of the entry
+    int64_t capRec = 0;
     // per pixel
     // depth ranking of the splat path (raster_rank.hip)
     bool rankSort = false;            // this binning used it (decided per forward: GOM_OPT_SORT_MODE, P small enough for the LDS bitmap)

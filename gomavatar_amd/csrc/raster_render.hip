@@ -97,6 +97,30 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Records mode of the render backward (round 4).  The compositing pass leaves ONE record per blending (pixel, entry) pair -- the lanes of
+// its serial chain with w = alpha T > 0 -- compacted per entry (ballot + mbcnt), entry-major inside the piece's region:
+//     rec_ti  = (T in front of the entry at the pixel, bits: entry of the sub-range << 6 | pixel of the quadrant)
+//     rec_acc = colour the PIECE had added to the pixel in front of the entry
+// and the backward (k_rec_bwd) is a lane per record: no replay, no 64-lane reduction per entry, every lane alive.  What it needs beside
+// the record is per pixel (dL/dpix, the colour from the piece's first entry to the end of the list, T_final, n_contrib) and per entry.
+// A piece's region is allocated when k_seg_fwd finds the piece alive, with the number of (lane, surviving entry) pairs with alpha > 0
+// that k_seg_T counted as the upper bound (w > 0 implies alpha > 0, and the two passes see bit-identical alphas).
+struct GomRecArgs {
+    uint32_t *piece_ub;      // null: records off
+    uint2 *piece_rec;
+    float2 *rec_ti;
+    float4 *rec_acc;
+    uint32_t *cursor;        // GOM_REC_SHARDS heads, 32 words apart
+    uint32_t *overflow;
+    uint32_t shard_cap;      // records per shard
+};
+
 // True when the entry can be skipped for EVERY pixel centre in
 // [x0,x1]x[y0,y1]: the largest alpha it reaches there is provably < 1/255
 // (with a rounding margin).  Never culls when unsure.
@@ -437,7 +461,12 @@ __device__ __forceinline__ EntryRegs<C> load_sub(const float2 *__restrict__ ent_
 // kernel when a colour pass re-uses an existing binning
 template <int C>
 __global__ void __launch_bounds__(256) k_gather_colors(const uint32_t *__restrict__ point_list, const float *__restrict__ colors,
-                                                       float *__restrict__ ent_col, const GomDevStatus *__restrict__ status) {
+                                                       float *__restrict__ ent_col, const GomDevStatus *__restrict__ status, uint32_t *__restrict__ rec_cursor,
+                                                       uint32_t *__restrict__ rec_overflow) {
+    if (rec_cursor && blockIdx.x == 0) {   // the record allocator of this colour pass (k_seg_T's job when it runs)
+        if (threadIdx.x < GOM_REC_SHARDS) rec_cursor[32 * threadIdx.x] = 0;
+        if (threadIdx.x == 0) *rec_overflow = 0;
+    }
     if (status->overflow) return;
     const uint32_t D = status->num_pairs;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < D; i += gridDim.x * 256) {
@@ -615,17 +644,22 @@ __device__ unsigned long long g_pair_stats[8];   // development: [0] live (half,
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
 // starts without walking the list serially.
-template <int C>
+template <int C, bool REC>
 __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const uint32_t *__restrict__ point_list,
                                                 const float2 *__restrict__ ent_geo, const float *__restrict__ colors,
                                                 float *__restrict__ ent_col, float *__restrict__ seg_T, float *__restrict__ sub_T,
-                                                const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, unsigned long long *__restrict__ cull_masks) {
+                                                const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, unsigned long long *__restrict__ cull_masks,
+                                                GomRecArgs rec) {
     __shared__ float s_P[2][GOM_NSUB][64];
     __shared__ uint32_t s_task[2];
     // Survivors' attributes reach the lanes through a wave-private LDS slab (uniform addresses = broadcast reads) instead of six
     // v_readlane (~6.6 issue cycles each): k_seg_T 117 -> 100 us; as PAIR records (stage_pairs) for the packed evaluation.
     __shared__ float4 s_pr[GOM_NSUB][GOM_PAIR_F4];
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
+    if (REC && blockIdx.x == 0) {   // the record allocator of this forward (k_seg_fwd draws from it)
+        if (threadIdx.x < GOM_REC_SHARDS) rec.cursor[32 * threadIdx.x] = 0;
+        if (threadIdx.x == 0) *rec.overflow = 0;
+    }
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
@@ -655,6 +689,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             *reinterpret_cast<float4 *>(ent_col + 4 * (size_t)(start + threadIdx.x)) = cl;
         }
         float T = 1.f;
+        uint32_t n_pos = 0;   // (REC) surviving entries with alpha > 0 at this lane's pixel
         {
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
             tq.request();
@@ -672,7 +707,12 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
                 T = T * (1.f - a0.y);
                 T = T * (1.f - a1.x);
                 T = T * (1.f - a1.y);
+                if (REC) n_pos += (uint32_t)(a0.x > 0.f) + (uint32_t)(a0.y > 0.f) + (uint32_t)(a1.x > 0.f) + (uint32_t)(a1.y > 0.f);
             }
+        }
+        if (REC) {
+            const uint32_t tot = wave_sum_u32(n_pos);
+            if (lane == 0) rec.piece_ub[((size_t)seg * GOM_NSUB + sub) * 4 + q] = tot;
         }
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;   // (the last piece's row is never read; leaving it out measured 82 us instead of 76)
         float(*sp)[64] = s_P[tq.it & 1];  // double-buffered: the readers of the previous task use the other half
@@ -702,12 +742,16 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
 #ifndef GOM_FWD_WAVES
 #define GOM_FWD_WAVES 7
 #endif
-template <int C>
-__global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
+#ifndef GOM_FWD_WAVES_REC
+#define GOM_FWD_WAVES_REC 6   // (records mode: the emission's addresses and the colour in front of the entry cost ~10 registers)
+#endif
+template <int C, bool REC>
+__global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shift, int gx, int gy, const uint4 *__restrict__ seg_desc, const float2 *__restrict__ ent_geo,
                                                   const float *__restrict__ ent_col, const float *__restrict__ seg_T,
                                                   const float *__restrict__ sub_T, float *__restrict__ seg_C, float *__restrict__ seg_Tend,
                                                   uint32_t *__restrict__ seg_last, float *__restrict__ sub_C, float *__restrict__ sub_Tend,
-                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, uint32_t *__restrict__ seg_cost, const unsigned long long *__restrict__ cull_masks) {
+                                                  const GomDevStatus *__restrict__ status, uint32_t *__restrict__ task_ctr, uint32_t *__restrict__ seg_cost, const unsigned long long *__restrict__ cull_masks,
+                                                  GomRecArgs rec) {
     __shared__ float s_c[GOM_NSUB][C][64];
     __shared__ float s_t[GOM_NSUB][64];
     __shared__ uint32_t s_l[GOM_NSUB][64];
@@ -805,6 +849,25 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
 #if defined(GOM_KO_FWD) && GOM_KO_FWD == 1
             mask = 0ull;
 #endif
+            // (REC) the piece's record region: upper bound from k_seg_T, one dequeue-like atomic per live piece
+            const uint32_t piece = ((seg * GOM_NSUB + (uint32_t)sub) << 2) | (uint32_t)q;
+            uint32_t rbase = 0, rcur = 0, rub = 0;
+            bool rec_on = false;
+            if (REC) {
+                rub = __builtin_amdgcn_readfirstlane(rec.piece_ub[piece]);
+                const uint32_t shard = piece % GOM_REC_SHARDS;
+                uint32_t b = 0;
+#if defined(GOM_KO_FWDREC) && (GOM_KO_FWDREC & 2)   // development knock-out: no allocation (a fixed region per piece, results invalid)
+                b = (piece & 1023u) * 4096u;
+#else
+                if (lane == 0 && rub) b = atomicAdd(rec.cursor + 32 * shard, rub);
+#endif
+                b = __builtin_amdgcn_readfirstlane(b);
+                rec_on = rub != 0u && b + rub <= rec.shard_cap;
+                if (rub != 0u && !rec_on && lane == 0) atomicOr(rec.overflow, 1u);
+                rbase = shard * rec.shard_cap + b;
+                rcur = rbase;
+            }
             // what the backward will pay for this piece, roughly: the entries that reach alive pixels here (GomBwdOrderRider)
             if (seg_cost && lane == 0 && mask) seg_cost[16 * (size_t)seg + 4 * sub + q] = (uint32_t)__popcll(mask);   // (one writer per word)
             s_e0[sub][lane] = make_float4(r.x, r.y, r.a, r.b);   // (LDS operations of one wave execute in order: no barrier)
@@ -842,6 +905,22 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
                     const float test_T = T * (1.f - a);
                     const bool cont = test_T >= kStopT;  // reference: `test_T < 0.0001f -> done`
                     const float w = cont ? a * T : 0.f;
+                    if (REC) {   // one record per blending lane, compacted: T and the piece's colour IN FRONT of the entry
+                        const bool em = w > 0.f;
+                        const unsigned long long bm = __ballot(em);
+                        if (bm != 0ull && rec_on) {
+#if defined(GOM_KO_FWDREC) && (GOM_KO_FWDREC & 1)   // development knock-out: no record stores
+                            if (em && T == 123.456f) {
+#else
+                            if (em) {
+#endif
+                                const uint32_t idx = rcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                rec.rec_acc[idx] = make_float4(acc[0], C > 1 ? acc[1 % C] : 0.f, C > 2 ? acc[2 % C] : 0.f, C > 3 ? acc[3 % C] : 0.f);
+                                rec.rec_ti[idx] = make_float2(T, __uint_as_float(((uint32_t)kk[u] << 6) | (uint32_t)lane));
+                            }
+                            rcur += (uint32_t)__popcll(bm);
+                        }
+                    }
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) acc[ch] += ecol[u][ch] * w;
                     T = cont ? test_T : T;
@@ -850,6 +929,7 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
                 }
                 if (__ballot(wl != 0.f) == 0ull) break;
             }
+            if (REC && lane == 0) rec.piece_rec[piece] = make_uint2(rbase, rec_on ? rcur - rbase : (rub ? 0xffffffffu : 0u));
         }
         // dead on arrival: T = 0.  stopped inside: -T.  still going: +T.
         s_t[sub][lane] = (T > 0.f && wl == 0.f) ? -T : T;
@@ -884,7 +964,7 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
                     if (te < 0.f) { going = false; stopped = true; }
                 }
                 // checkpoints for the backward: T behind this piece, and (below) the colour the LATER pieces of the segment really added
-                if (u < n_live) sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;
+                if (!REC && u < n_live) sub_Tend[((size_t)seg * GOM_NSUB + u) * GOM_TPX + pxi] = Tc;   // (REC: T travels in the records)
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) cadd[u][ch] = counts ? s_c[u][ch][lane] : 0.f;
             }
@@ -895,9 +975,10 @@ __global__ void __launch_bounds__(256, GOM_FWD_WAVES) k_seg_fwd(uint32_t seg_shi
                 for (int ch = 0; ch < C; ch++) run[ch] = 0.f;
 #pragma unroll
                 for (int u = GOM_NSUB - 1; u >= 0; u--) {
-                    if (u < GOM_NSUB - 1 && u < n_live) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);
+                    if (!REC && u < GOM_NSUB - 1 && u < n_live) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) run[ch] += cadd[u][ch];
+                    if (REC && u < n_live) st4<C>(sub_C, (size_t)seg * GOM_NSUB + u, pxi, run);   // (REC) INCLUSIVE: from the piece's first entry to the end of the segment
                 }
             }
             const size_t o = (size_t)seg * GOM_TPX + pxi;
@@ -1468,6 +1549,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 }
 
 #include "seg_bwd_blk.hpp"
+#include "rec_bwd.hpp"
 
 }  // namespace
 
@@ -1525,32 +1607,46 @@ static int task_grid(int resident, int pct) {   // GOM_OPT_TASK_GRID_PCT of the 
 #define GOM_STATIC_FWD 0
 #endif
 
+static GomRecArgs rec_args(GomState *s) {
+    return GomRecArgs{s->piece_ub, s->piece_rec, s->rec_ti, s->rec_acc, &s->status->rec_cursor[0][0], &s->status->rec_overflow, (uint32_t)(s->capRec / GOM_REC_SHARDS)};
+}
+// which render backward a forward prepares for: records only on request (GOM_OPT_BWD_MODE 3) -- measured slower than the replay on the
+// metric workload (profiles/r04_records_backward.txt), auto (-1) keeps the replay kernels
+static bool records_mode(const GomState *s) { return s->bwdMode == 3; }
+
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st) {
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
+    // Records mode: the transmittance pre-pass counts every piece's (lane, entry) pairs with alpha > 0 (a binning made in another mode has no
+    // counts: the colour pass over it keeps that mode's checkpoints)
+    const bool rec = records_mode(s) && (!reuse_T || s->recCounts);
+    const GomRecArgs ra = rec ? rec_args(s) : GomRecArgs{};
     {
         GomKernelTimer timer(s, GOM_K_SEG_T, st);
         if (!reuse_T) {  // transmittances depend on geometry only: shared by every colour pass over the same binning
-            if (C == 3)
-                hipLaunchKernelGGL((k_seg_T<3>), dim3(GOM_RESIDENT(k_seg_T<3>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks);
-            else
-                hipLaunchKernelGGL((k_seg_T<4>), dim3(GOM_RESIDENT(k_seg_T<4>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors,
-                                   s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks);
+#define GOM_ST(CC, RR)                                                                                                    \
+    hipLaunchKernelGGL((k_seg_T<CC, RR>), dim3(GOM_RESIDENT((k_seg_T<CC, RR>))), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors, \
+                       s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks, ra)
+            if (rec) { if (C == 3) GOM_ST(3, true); else GOM_ST(4, true); }
+            else { if (C == 3) GOM_ST(3, false); else GOM_ST(4, false); }
+#undef GOM_ST
+            s->recCounts = rec;
         } else {  // only the colours changed: bring them into list order
-            if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
-            else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status);
+            if (C == 3) hipLaunchKernelGGL((k_gather_colors<3>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status, rec ? ra.cursor : nullptr, ra.overflow);
+            else hipLaunchKernelGGL((k_gather_colors<4>), dim3(1024), dim3(256), 0, st, s->point_list, colors, s->ent_col, s->status, rec ? ra.cursor : nullptr, ra.overflow);
         }
     }
     GOM_LAUNCH_CHECK();
     {
         GomKernelTimer timer(s, GOM_K_SEG_FWD, st);
-#define GOM_SF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_seg_fwd<CC>), dim3(GOM_RESIDENT(k_seg_fwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
-                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_STATIC_FWD ? nullptr : GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks)
-        if (C == 3) GOM_SF(3); else GOM_SF(4);
+#define GOM_SF(CC, RR)                                                                                                    \
+    hipLaunchKernelGGL((k_seg_fwd<CC, RR>), dim3(GOM_RESIDENT((k_seg_fwd<CC, RR>))), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
+                       s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_STATIC_FWD ? nullptr : GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks, ra)
+        if (rec) { if (C == 3) GOM_SF(3, true); else GOM_SF(4, true); }
+        else { if (C == 3) GOM_SF(3, false); else GOM_SF(4, false); }
 #undef GOM_SF
+        s->recForward = rec;
     }
     GOM_LAUNCH_CHECK();
     {
@@ -1575,6 +1671,17 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
+    if (s->recForward) {   // the forward left records: a lane per blending (pixel, entry) pair (rec_bwd.hpp)
+        const GomRecArgs ra = rec_args(s);
+#define GOM_RB(CC)                                                                                                        \
+    hipLaunchKernelGGL((k_rec_bwd<CC>), dim3(GOM_RESIDENT(k_rec_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+                       cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
+                       s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, ra)
+        if (C == 3) GOM_RB(3); else GOM_RB(4);
+#undef GOM_RB
+        GOM_LAUNCH_CHECK();
+        return 0;
+    }
     if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (seg_bwd_blk.hpp)
 #define GOM_SBB(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_blk<CC>), dim3(GOM_RESIDENT(k_seg_bwd_blk<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \

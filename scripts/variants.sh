@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 for v in main "$@"; do
   if [ $v = main ]; then unset GOM_HIP_LIB; else export GOM_HIP_LIB=$GRAFT_REPO_ROOT/gomavatar_amd/_variants/libgom_hip_$v.so; fi
-  python bench.py --no-modes --no-cpu-baseline --steps 150 --warmup 20 2>&1 | grep "^{" | python -c "
+  python bench.py --no-modes --no-configs --no-cpu-baseline --steps 150 --warmup 20 2>&1 | grep "^{" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['all_kernels_us']
 print('$v'.ljust(10), 'fps', d['value'], ' '.join(f'{n}={v:.0f}' for n,v in k.items()))"

@@ -424,7 +424,7 @@ def test_backward_task_shapes_agree(seg_shift):
     g = orast.backward(f, wimg.astype(np.float64))
     assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 600          # several segments per tile
     got = []
-    for mode in (0, 1, 2, 2):
+    for mode in (0, 1, 2, 2, 3, 3):
         st = R.RasterState()
         st.set_option(_lib.OPT_BWD_MODE, mode)
         st.set_option(_lib.OPT_SEG_SHIFT, seg_shift)
@@ -440,5 +440,10 @@ def test_backward_task_shapes_agree(seg_shift):
     # mode 2 -- (sub-range, 4x4 block) items, one per DPP row (csrc/seg_bwd_blk.hpp) -- sums a Gaussian's pixels block by block instead of
     # quadrant by quadrant: fp32 round-off away from the other two (both are held to the fp64 oracle above), bitwise equal to itself
     for a, b, c in zip(got[0], got[2], got[3]):
+        np.testing.assert_array_equal(b, c)
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
+    # mode 3 -- a lane per (pixel, entry) record the forward left (csrc/rec_bwd.hpp): the suffix colour comes from a difference of the piece's
+    # totals instead of the replay's recurrence: round-off away from the replay kernels, bitwise equal to itself (one summation order per entry)
+    for a, b, c in zip(got[0], got[4], got[5]):
         np.testing.assert_array_equal(b, c)
         assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
