@@ -181,7 +181,7 @@ class Runner:
             sl["step"].forward_backward(sl["params"], bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], graph=self.graph)
             if collective and sl["fp"].peer is not None and sl["opt"] is not None:
                 # the peer exchange carries the optimizer in its all-gather kernel (1 / B: mean over the frames of the batch as well)
-                sl["fp"].peer.run_adam(sl["opt"], 1.0 / (self.world * self.B))
+                sl["fp"].peer.run_adam(sl["opt"], 1.0 / (self.world * self.B), zero1=sl["fp"].impl == "peer-zero1")
                 return
             if collective:
                 sl["fp"].all_reduce_grads()  # no-op at world size 1
@@ -607,6 +607,19 @@ def main():
                 peer_info.update(us=round((time.perf_counter() - t0) / 50 * 1e6, 1), fps=round(world * B * ns_p / el_p, 1), frames_per_gpu_per_step=B)
                 fp_p.peer.check()
                 peer_info["status"] = "ok"
+                # the same exchange with the optimizer sharded over the ranks (ZeRO-1: gom_peer_reduce_run_zero1; bitwise the same replicas)
+                for sl in peer_run.slots:
+                    sl["fp"].close()
+                peer_run = None
+                z_run = Runner(wl, B, 1, not args.no_graph, world, args, impl="peer-zero1")
+                el_z, ns_z, _ = z_run.measure(max(20, args.steps // 2), 10)
+                z_run.slots[0]["fp"].peer.check()
+                peer_info["zero1_fps"] = round(world * B * ns_z / el_z, 1)
+                if peer_info["zero1_fps"] > peer_info["fps"]:
+                    peer_info["impl"] = "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum, ZeRO-1: Adam of the own slice inside the reduce-scatter kernel, parameters gathered (gom_peer_reduce_run_zero1)"
+                    peer_info["replicated_adam_fps"], peer_info["fps"], el_p, ns_p = peer_info["fps"], peer_info["zero1_fps"], el_z, ns_z
+                for sl in z_run.slots:
+                    sl["fp"].close()
             except Exception as e:
                 peer_info["status"] = f"failed: {type(e).__name__}: {e}"
         else:

@@ -119,8 +119,6 @@ SIGNATURES = {
                               c_float, c_float, c_void_p]),
     "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_void_p, c_float,
                                         c_float, c_float, c_float, c_float, c_void_p]),
-    "gom_state_set_frame_optimizer": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_void_p, c_float,
-                                              c_float, c_float, c_float, c_float]),
     "gom_peer_reduce_create": (c_void_p, [c_int32, c_int32, c_int64]),
     "gom_peer_reduce_handle": (c_int, [c_void_p, c_void_p]),
     "gom_peer_reduce_connect": (c_int, [c_void_p, c_void_p]),
@@ -128,6 +126,12 @@ SIGNATURES = {
     "gom_peer_reduce_run": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "gom_peer_reduce_run_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
                                          c_float, c_void_p]),
+    "gom_peer_reduce_run_zero1": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
+                                          c_float, c_void_p]),
+    "gom_peer_reduce_set_timeout": (c_int, [c_void_p, ctypes.c_double]),
+    "gom_peer_reduce_poll": (c_int, [c_void_p]),
+    "gom_peer_reduce_reset": (c_int, [c_void_p, ctypes.c_uint32]),
+    "gom_peer_reduce_epoch": (ctypes.c_uint32, [c_void_p]),
     "gom_peer_reduce_status": (c_int, [c_void_p]),
     "gom_peer_reduce_destroy": (None, [c_void_p]),
     "gom_l1_loss": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
@@ -135,6 +139,18 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+# include/gom_hip_lab.h: present only in a library built with -DGOM_LAB (experiments that were measured and not adopted)
+LAB_SIGNATURES = {
+    "gom_state_set_frame_optimizer": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_void_p, c_float,
+                                              c_float, c_float, c_float, c_float]),
+}
+
+
+def has_lab() -> bool:
+    """True when the loaded library is a -DGOM_LAB build (GOM_HIP_LIB=.../libgom_hip_lab.so)."""
+    return hasattr(load(), "gom_state_set_frame_optimizer")
 
 
 def load() -> ctypes.CDLL:
@@ -147,6 +163,9 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -m gomavatar_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in LAB_SIGNATURES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

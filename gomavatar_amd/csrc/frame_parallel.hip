@@ -42,14 +42,26 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
     // the step number is baked into the launch, so the optimizer can sit inside a captured graph.  Every workgroup reads the count
     // before it works; the last one to finish advances it.
     if (step_dev) {
-        const double t = (double)(step_dev[0] + 1);
-        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-        // update_lr (train.py:166-175) runs after the step of iteration n_iters (which counts from 1, train.py:268) with n_iters as its
-        // argument: step t uses base * 0.1^((t - 1) / D)
-        const double decay = lr_decay_steps > 0.f ? pow(0.1, (t - 1.0) / (double)lr_decay_steps) : 1.0;
+        // Once per workgroup: threads 0 .. GOM_ADAM_MAX_SEGMENTS-1 derive one segment's step size each (three double-precision pow() per
+        // THREAD of the launch used to be most of this ~6 us kernel's arithmetic), LDS hands the results to everyone.  Same expressions, same bits.
+        __shared__ float s_step[GOM_ADAM_MAX_SEGMENTS], s_isb2;
+        if (threadIdx.x < GOM_ADAM_MAX_SEGMENTS) {
+            // (the only writer of step_dev[0] is the last workgroup of a launch, behind every workgroup's read: the atomic load states that)
+            const double t = (double)(__hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
+            const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+            // update_lr (train.py:166-175) runs after the step of iteration n_iters (which counts from 1, train.py:268) with n_iters as its
+            // argument: step t uses base * 0.1^((t - 1) / D)
+            const double decay = lr_decay_steps > 0.f ? pow(0.1, (t - 1.0) / (double)lr_decay_steps) : 1.0;
+            float base = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) segs.step_size[s2] = (float)((double)segs.step_size[s2] * decay / bc1);
-        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+            for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) base = (int)threadIdx.x == s2 ? segs.step_size[s2] : base;   // (no dynamic index into the kernel arguments)
+            s_step[threadIdx.x] = (float)((double)base * decay / bc1);
+            if (threadIdx.x == 0) s_isb2 = (float)(1.0 / sqrt(bc2));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) segs.step_size[s2] = s_step[s2];
+        inv_sqrt_bc2 = s_isb2;
     }
     // 4 consecutive parameters per thread and trip (the buffers come from hipMalloc / torch: 16-byte aligned); the ragged end one by one
     const uint32_t n4 = n >> 2;
@@ -138,12 +150,24 @@ extern "C" int gom_adam_flat_graphable(int64_t n, float *params, const float *gr
 // Every element is summed by exactly one rank in a fixed order, so all ranks end with the same bits -- bitwise equal to
 // ((g_0 + g_1) + g_2) + ... scaled.  The payload (3.8 MB at 55 104 Gaussians) is latency-bound on xGMI: a two-shot exchange moves
 // 2 x (world - 1) / world of it per rank over 7 point-to-point links in parallel, where a ring serialises 2 (world - 1) steps.
+// The kernels are instantiated for world = 2, 4, 8 (and a generic one): the loads of ALL peers' copies of an element are issued before the
+// first (rank-ordered) add, so an element costs one xGMI round trip, not world - 1 of them one behind the other.
 // Flags are epoch counters (no reset, no ABA) written with system-scope release stores and polled with system-scope acquire loads; the
-// region is fine-grained memory (coherent across devices -- and across the XCDs of one device, which is what the 1-GPU test exercises
-// with several processes on one MI355X).  A wait gives up after ~1 s, sets the status word and lets the kernel finish: never a hang.
+// region is FINE-GRAINED memory (coherent across devices without a kernel boundary -- the flags are polled inside a running kernel; creation
+// fails where it cannot be had, and the caller falls back to the library collective).
+// Failure is loud: a wait gives up after `timeout_s` of wall clock (default 30 s: a peer inside a checkpoint write, an evaluation pass or
+// a graph capture is late, not gone), sets the status word -- mirrored into pinned host memory, which gom_peer_reduce_poll reads without
+// a device synchronisation, so the host layer checks it every step -- and the rank that timed out raises NO "reduced" flag: its peers'
+// all-gathers then time out as well and every rank reports the failure instead of some of them stepping on unreduced data.
+// gom_peer_reduce_reset (collective: between two barriers of the group) clears the condition.
 // Reuse: a rank overwrites its gradient only after its own all-gather kernel, which has seen every peer's "reduced" flag (= the peer is
 // done reading it); it overwrites its reduced slice only in the next scatter kernel, behind the peers' next "ready" flags (= their
 // previous all-gather has completed).
+//
+// ZeRO-1 variant (gom_peer_reduce_run_zero1; SURVEY.md 8(e) "or"): the rank that reduced a slice also applies the Adam step of THAT slice
+// -- moments are only ever touched for the own slice -- and leaves the updated PARAMETERS in its region; the second kernel gathers
+// parameters instead of gradients.  Same element arithmetic, every element computed once by its owner instead of world times: the
+// replicas end with the bits gom_peer_reduce_run_adam gives them.
 struct GomPeerReduce {
     int rank = 0, world = 1;
     int64_t n = 0;
@@ -152,57 +176,106 @@ struct GomPeerReduce {
     unsigned char *peer[GOM_PEER_MAX_RANKS] = {};    // mapped regions, own entry = local
     bool opened[GOM_PEER_MAX_RANKS] = {};
     uint32_t epoch = 0;
-    uint32_t *status = nullptr;                      // device word: 1 = a wait timed out
+    uint32_t *status = nullptr;                      // device word: 1 = a wait timed out (sticky until gom_peer_reduce_reset)
     uint32_t *done_ctr = nullptr;                    // workgroups of the scatter kernel that have finished
-    int finegrained = 0;
+    uint32_t *status_host = nullptr;                 // pinned host mirror of the status word (written by the kernel that times out)
+    uint32_t *status_host_dev = nullptr;             // its device address
+    unsigned long long timeout_ticks = 3000000000ull;   // 30 s of the 100 MHz wall clock
 };
 
 namespace {
 constexpr int kPeerFlagStride = 16;   // uint32 per flag slot (64 bytes: one line per writer)
 struct PeerPtrs { unsigned char *p[GOM_PEER_MAX_RANKS]; };
+struct PeerStatus { uint32_t *dev, *host; unsigned long long timeout_ticks; };
 
 __device__ __forceinline__ uint32_t *peer_flags(unsigned char *region, int64_t n, int which) {   // which: 0 = ready, 1 = reduced
     return reinterpret_cast<uint32_t *>(region + 2 * (size_t)n * sizeof(float)) + (size_t)which * GOM_PEER_MAX_RANKS * kPeerFlagStride;
 }
-// true when the flag reached `epoch`; gives up (status = 1) after ~1 s so that a missing peer can never hang the GPU
-__device__ __forceinline__ bool peer_wait(const uint32_t *flag, uint32_t epoch, uint32_t *status) {
-    for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+// true when the flag reached `epoch`; gives up (status = 1, on the device and in the host mirror) after the time limit so that a missing
+// peer can never hang the GPU, and at once when another wait of this rank has already given up
+__device__ __forceinline__ bool peer_wait(const uint32_t *flag, uint32_t epoch, const PeerStatus &st) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
         if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) >= 0) return true;
         __builtin_amdgcn_s_sleep(32);
-        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (__hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (wall_clock64() - t0 > st.timeout_ticks) break;
     }
-    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(st.dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(st.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return false;
 }
 
-__global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, float scale, uint32_t *status,
-                                                             uint32_t *done_ctr) {
+// W = world size known at compile time (2, 4, 8) or 0: generic.  ZERO1: apply Adam to the slice and publish the PARAMETERS.
+template <int W, bool ZERO1>
+__global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int rank, int world_rt, int64_t n, uint32_t epoch, float scale, PeerStatus st,
+                                                             uint32_t *done_ctr, float *__restrict__ prm, float *__restrict__ m, float *__restrict__ v,
+                                                             AdamSegs segs, float beta1, float beta2, float eps, float inv_sqrt_bc2) {
     __shared__ int s_ok;
+    const int world = W ? W : world_rt;
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)world)   // "my gradient of this epoch is complete" (the kernels that wrote it precede this one on the stream)
         __hip_atomic_store(peer_flags(pp.p[threadIdx.x], n, 0) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (threadIdx.x == 0) {
         bool ok = true;
-        for (int p = 0; p < world && ok; p++) ok = peer_wait(peer_flags(pp.p[rank], n, 0) + p * kPeerFlagStride, epoch, status);
+        for (int p = 0; p < world && ok; p++) ok = peer_wait(peer_flags(pp.p[rank], n, 0) + p * kPeerFlagStride, epoch, st);
         s_ok = ok ? 1 : 0;
     }
     __syncthreads();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (the waits were thread 0's: the other threads' loads must not be older than the flags)
-    if (s_ok) {
+    const bool ok = s_ok != 0;
+    if (ok) {
         const int64_t n4 = n / 4, per = (n4 + world - 1) / world, lo = per * rank, hi = lo + per < n4 ? lo + per : n4;   // float4 units of my slice
         float4 *dst = reinterpret_cast<float4 *>(pp.p[rank] + (size_t)n * sizeof(float));
+        const int64_t pend = ZERO1 ? (int64_t)segs.begin[segs.n] : 0;   // the parameter buffers end where the last segment ends; the payload may be padded beyond
         for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
-            float4 a = reinterpret_cast<const float4 *>(pp.p[0])[i];
-            for (int p = 1; p < world; p++) {
-                const float4 b = reinterpret_cast<const float4 *>(pp.p[p])[i];
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            float4 a;
+            if (W) {   // every peer's copy in flight before the first add; the adds in rank order
+                float4 b[W ? W : 1];
+#pragma unroll
+                for (int p = 0; p < W; p++) b[p] = reinterpret_cast<const float4 *>(pp.p[p])[i];
+                a = b[0];
+#pragma unroll
+                for (int p = 1; p < W; p++) { a.x += b[p].x; a.y += b[p].y; a.z += b[p].z; a.w += b[p].w; }
+            } else {
+                a = reinterpret_cast<const float4 *>(pp.p[0])[i];
+                for (int p = 1; p < world; p++) {
+                    const float4 b = reinterpret_cast<const float4 *>(pp.p[p])[i];
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
             }
-            dst[i] = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+            a = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+            if (ZERO1) {   // my slice's optimizer step; what the peers gather is the updated parameters
+                const uint32_t e = (uint32_t)(4 * i);
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (4 * i + 3 < pend) {
+                    float4 c = reinterpret_cast<float4 *>(m)[i], d = reinterpret_cast<float4 *>(v)[i];
+                    q = reinterpret_cast<float4 *>(prm)[i];
+                    adam_element(segs, e, a.x, q.x, c.x, d.x, beta1, beta2, eps, inv_sqrt_bc2);
+                    adam_element(segs, e + 1, a.y, q.y, c.y, d.y, beta1, beta2, eps, inv_sqrt_bc2);
+                    adam_element(segs, e + 2, a.z, q.z, c.z, d.z, beta1, beta2, eps, inv_sqrt_bc2);
+                    adam_element(segs, e + 3, a.w, q.w, c.w, d.w, beta1, beta2, eps, inv_sqrt_bc2);
+                    reinterpret_cast<float4 *>(prm)[i] = q; reinterpret_cast<float4 *>(m)[i] = c; reinterpret_cast<float4 *>(v)[i] = d;
+                } else {
+                    const float gq[4] = {a.x, a.y, a.z, a.w};
+                    float qq[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < 4; u++)
+                        if (4 * i + u < pend) { adam_element(segs, e + (uint32_t)u, gq[u], prm[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps, inv_sqrt_bc2); qq[u] = prm[4 * i + u]; }
+                    q = make_float4(qq[0], qq[1], qq[2], qq[3]);
+                }
+                a = q;
+            }
+            dst[i] = a;
         }
         if (rank == world - 1) {   // the ragged end (n not a multiple of 4) belongs to the last rank
             for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
                 float a = reinterpret_cast<const float *>(pp.p[0])[i];
                 for (int p = 1; p < world; p++) a += reinterpret_cast<const float *>(pp.p[p])[i];
-                reinterpret_cast<float *>(pp.p[rank] + (size_t)n * sizeof(float))[i] = a * scale;
+                a *= scale;
+                if (ZERO1) {
+                    if (i < pend) { adam_element(segs, (uint32_t)i, a, prm[i], m[i], v[i], beta1, beta2, eps, inv_sqrt_bc2); a = prm[i]; }
+                    else a = 0.f;
+                }
+                reinterpret_cast<float *>(pp.p[rank] + (size_t)n * sizeof(float))[i] = a;
             }
         }
     }
@@ -212,53 +285,40 @@ __global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int ra
         if (atomicAdd(done_ctr, 1u) == gridDim.x - 1) {   // the last workgroup: my slice is complete everywhere -> tell the peers
             __atomic_thread_fence(__ATOMIC_ACQUIRE);      // (pairs with the other workgroups' release fences in front of their increments)
             *done_ctr = 0;
-            for (int p = 0; p < world; p++)
-                __hip_atomic_store(peer_flags(pp.p[p], n, 1) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // A rank whose wait gave up has summed nothing: it raises NO flag, its peers' all-gathers give up in turn and every rank reports.
+            if (__hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                for (int p = 0; p < world; p++)
+                    __hip_atomic_store(peer_flags(pp.p[p], n, 1) + rank * kPeerFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-__global__ void __launch_bounds__(256) k_peer_all_gather(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, float *__restrict__ out, uint32_t *status) {
+// MODE 0: copy every rank's reduced slice to `out`.  MODE 1: the optimizer inside the gather -- instead of copying a rank's reduced slice and
+// running Adam over the copy afterwards, every rank applies the Adam step of ITS replica of the parameters straight from the slice as it reads
+// it (one launch and one pass over the gradient less: ~6 us of kernel and the ~9 us that follow a plain launch, of a 0.2 ms single-frame
+// step).  MODE 2 (ZeRO-1): the slices hold updated PARAMETERS; the own slice is already in place, the others are copied into `p`.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_peer_all_gather(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, PeerStatus st, float *__restrict__ p,
+                                                         float *__restrict__ m, float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
+                                                         float inv_sqrt_bc2, float *__restrict__ out) {
     __shared__ int s_ok;
     const int64_t n4 = n / 4, per = (n4 + world - 1) / world;
+    const int64_t pend = MODE ? (int64_t)segs.begin[segs.n] : n;   // the parameter buffers end where the last segment ends; the payload may be padded beyond
     for (int src = 0; src < world; src++) {   // start with my own slice (ready first), then the others in ring order
-        const int p = (rank + src) % world;
-        if (threadIdx.x == 0) s_ok = peer_wait(peer_flags(pp.p[rank], n, 1) + p * kPeerFlagStride, epoch, status) ? 1 : 0;
-        __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (s_ok) {
-            const int64_t lo = per * p, hi = lo + per < n4 ? lo + per : n4;
-            const float4 *srcp = reinterpret_cast<const float4 *>(pp.p[p] + (size_t)n * sizeof(float));
-            for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4 *>(out)[i] = srcp[i];
-            if (p == world - 1)
-                for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-                    out[i] = reinterpret_cast<const float *>(pp.p[p] + (size_t)n * sizeof(float))[i];
-        }
-        __syncthreads();
-    }
-}
-// The all-gather with the optimizer in it: instead of copying a rank's reduced slice and running Adam over the copy afterwards, every rank
-// applies the Adam step of ITS replica of the parameters straight from the slice as it reads it (one launch and one pass over the gradient
-// less: ~6 us of kernel and the ~9 us that follow a plain launch, of a 0.2 ms single-frame step).  Same element arithmetic as k_adam_flat.
-__global__ void __launch_bounds__(256) k_peer_all_gather_adam(PeerPtrs pp, int rank, int world, int64_t n, uint32_t epoch, uint32_t *status, float *__restrict__ p,
-                                                              float *__restrict__ m, float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
-                                                              float inv_sqrt_bc2, float *__restrict__ out) {
-    __shared__ int s_ok;
-    const int64_t n4 = n / 4, per = (n4 + world - 1) / world;
-    for (int src = 0; src < world; src++) {
         const int q = (rank + src) % world;
-        if (threadIdx.x == 0) s_ok = peer_wait(peer_flags(pp.p[rank], n, 1) + q * kPeerFlagStride, epoch, status) ? 1 : 0;
+        if (threadIdx.x == 0) s_ok = peer_wait(peer_flags(pp.p[rank], n, 1) + q * kPeerFlagStride, epoch, st) ? 1 : 0;
         __syncthreads();
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (s_ok) {
+        if (s_ok && !(MODE == 2 && q == rank)) {
             const int64_t lo = per * q, hi = lo + per < n4 ? lo + per : n4;
             const float4 *srcp = reinterpret_cast<const float4 *>(pp.p[q] + (size_t)n * sizeof(float));
-            const int64_t pend = (int64_t)segs.begin[segs.n];   // the parameter buffers end where the last segment ends; the payload may be padded beyond
             for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
                 const float4 g4 = srcp[i];
-                if (out) reinterpret_cast<float4 *>(out)[i] = g4;
+                if (MODE == 0) { reinterpret_cast<float4 *>(out)[i] = g4; continue; }
+                if (MODE == 1 && out) reinterpret_cast<float4 *>(out)[i] = g4;
                 const uint32_t e = (uint32_t)(4 * i);
                 if (4 * i + 3 < pend) {
+                    if (MODE == 2) { reinterpret_cast<float4 *>(p)[i] = g4; continue; }
                     float4 a = reinterpret_cast<float4 *>(p)[i], c = reinterpret_cast<float4 *>(m)[i], d = reinterpret_cast<float4 *>(v)[i];
                     adam_element(segs, e, g4.x, a.x, c.x, d.x, beta1, beta2, eps, inv_sqrt_bc2);
                     adam_element(segs, e + 1, g4.y, a.y, c.y, d.y, beta1, beta2, eps, inv_sqrt_bc2);
@@ -268,14 +328,21 @@ __global__ void __launch_bounds__(256) k_peer_all_gather_adam(PeerPtrs pp, int r
                 } else {
                     const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
                     for (int u = 0; u < 4; u++)
-                        if (4 * i + u < pend) adam_element(segs, e + (uint32_t)u, gq[u], p[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps, inv_sqrt_bc2);
+                        if (4 * i + u < pend) {
+                            if (MODE == 2) p[4 * i + u] = gq[u];
+                            else adam_element(segs, e + (uint32_t)u, gq[u], p[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps, inv_sqrt_bc2);
+                        }
                 }
             }
             if (q == world - 1)
                 for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
                     const float g1 = reinterpret_cast<const float *>(pp.p[q] + (size_t)n * sizeof(float))[i];
-                    if (i < pend) adam_element(segs, (uint32_t)i, g1, p[i], m[i], v[i], beta1, beta2, eps, inv_sqrt_bc2);
-                    if (out) out[i] = g1;
+                    if (MODE == 0) { out[i] = g1; continue; }
+                    if (MODE == 1 && out) out[i] = g1;
+                    if (i < pend) {
+                        if (MODE == 2) p[i] = g1;
+                        else adam_element(segs, (uint32_t)i, g1, p[i], m[i], v[i], beta1, beta2, eps, inv_sqrt_bc2);
+                    }
                 }
         }
         __syncthreads();
@@ -289,16 +356,25 @@ extern "C" GomPeerReduce *gom_peer_reduce_create(int32_t rank, int32_t world, in
     h->rank = rank; h->world = world; h->n = n_floats;
     h->bytes = 2 * (size_t)n_floats * sizeof(float) + 2 * GOM_PEER_MAX_RANKS * kPeerFlagStride * sizeof(uint32_t);
     h->bytes = (h->bytes + 4095) & ~(size_t)4095;
-    // fine-grained: coherent across devices without a kernel boundary (the flags are polled INSIDE a kernel)
-    if (hipExtMallocWithFlags((void **)&h->local, h->bytes, hipDeviceMallocFinegrained) == hipSuccess) h->finegrained = 1;
-    else { (void)hipGetLastError(); if (hipMalloc((void **)&h->local, h->bytes) != hipSuccess) { gom_set_error("gom_peer_reduce_create: allocation failed"); delete h; return nullptr; } }
-    if (hipMemset(h->local, 0, h->bytes) != hipSuccess || hipMalloc((void **)&h->status, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(h->status, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
-        gom_set_error("gom_peer_reduce_create: initialisation failed");
-        if (h->local) (void)hipFree(h->local);
+    // Fine-grained: coherent across devices without a kernel boundary (the flags are polled, and the peers' data read, INSIDE a running kernel).
+    // Plain (coarse-grained) memory would let the polls see stale lines: no fallback -- the caller uses the library collective instead.
+    if (hipExtMallocWithFlags((void **)&h->local, h->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        gom_set_error("gom_peer_reduce_create: fine-grained device memory is not available on this device (the peer exchange needs it; use the collective)");
         delete h;
         return nullptr;
     }
+    if (hipMemset(h->local, 0, h->bytes) != hipSuccess || hipMalloc((void **)&h->status, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(h->status, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&h->status_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&h->status_host_dev, h->status_host, 0) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        gom_set_error("gom_peer_reduce_create: initialisation failed");
+        if (h->local) (void)hipFree(h->local);
+        if (h->status) (void)hipFree(h->status);
+        if (h->status_host) (void)hipHostFree(h->status_host);
+        delete h;
+        return nullptr;
+    }
+    *h->status_host = 0;
     h->done_ctr = h->status + 1;
     h->peer[rank] = h->local;
     return h;
@@ -325,41 +401,104 @@ extern "C" int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles) {
 
 extern "C" float *gom_peer_reduce_buffer(GomPeerReduce *h) { return h ? reinterpret_cast<float *>(h->local) : nullptr; }
 
-extern "C" int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream) {
-    if (!h || !out) { gom_set_error("gom_peer_reduce_run: null argument"); return -1; }
+extern "C" int gom_peer_reduce_set_timeout(GomPeerReduce *h, double seconds) {
+    if (!h || !(seconds > 0.0) || seconds > 3600.0) { gom_set_error("gom_peer_reduce_set_timeout: 0 < seconds <= 3600"); return -1; }
+    h->timeout_ticks = (unsigned long long)(seconds * 1e8);   // wall_clock64 counts at 100 MHz
+    return 0;
+}
+
+static bool peer_ready(GomPeerReduce *h, const char *who) {
+    if (!h) { gom_set_error("%s: null handle", who); return false; }
     for (int p = 0; p < h->world; p++)
-        if (!h->peer[p]) { gom_set_error("gom_peer_reduce_run: rank %d is not connected", p); return -1; }
+        if (!h->peer[p]) { gom_set_error("%s: rank %d is not connected", who, p); return false; }
+    if (*reinterpret_cast<volatile uint32_t *>(h->status_host)) { gom_set_error("%s: an earlier exchange timed out (a peer did not answer); gom_peer_reduce_reset on every rank first", who); return false; }
+    return true;
+}
+
+// scatter kernel of the right instantiation
+template <bool ZERO1>
+static void launch_scatter(GomPeerReduce *h, const PeerPtrs &pp, float scale, const PeerStatus &st, float *prm, float *m, float *v, const AdamSegs &segs, float beta1,
+                           float beta2, float eps, float isb2, hipStream_t stream) {
+    // small resident grids: every workgroup polls flags, so all of them must fit on the chip next to whatever else runs
+    const dim3 grid(64), block(256);
+#define GOM_PS(WW) hipLaunchKernelGGL((k_peer_reduce_scatter<WW, ZERO1>), grid, block, 0, stream, pp, h->rank, h->world, h->n, h->epoch, scale, st, h->done_ctr, prm, m, v, segs, beta1, beta2, eps, isb2)
+    switch (h->world) {
+        case 2: GOM_PS(2); break;
+        case 4: GOM_PS(4); break;
+        case 8: GOM_PS(8); break;
+        default: GOM_PS(0); break;
+    }
+#undef GOM_PS
+}
+
+extern "C" int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream) {
+    if (!out) { gom_set_error("gom_peer_reduce_run: null argument"); return -1; }
+    if (!peer_ready(h, "gom_peer_reduce_run")) return -1;
     h->epoch++;
     PeerPtrs pp{};
     for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];
-    // small resident grids: every workgroup polls flags, so all of them must fit on the chip next to whatever else runs
-    const int grid = 64;
-    hipLaunchKernelGGL(k_peer_reduce_scatter, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, scale, h->status, h->done_ctr);
+    const PeerStatus st{h->status, h->status_host_dev, h->timeout_ticks};
+    const AdamSegs none{};
+    launch_scatter<false>(h, pp, scale, st, nullptr, nullptr, nullptr, none, 0.f, 0.f, 0.f, 0.f, (hipStream_t)stream);
     GOM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_peer_all_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, out, h->status);
+    hipLaunchKernelGGL(k_peer_all_gather<0>, dim3(64), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, st, nullptr, nullptr, nullptr, none, 0.f, 0.f, 0.f,
+                       0.f, out);
     GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int peer_adam_common(GomPeerReduce *h, const char *who, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments, const int64_t *seg_begin,
+                            const float *seg_lr, int64_t step, float beta1, float beta2, AdamSegs &segs, float &isb2) {
+    if (!params || !exp_avg || !exp_avg_sq) { gom_set_error("%s: null argument", who); return -1; }
+    if (step < 1) { gom_set_error("%s: step counts from 1", who); return -1; }
+    if (!peer_ready(h, who)) return -1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    if (int rc = adam_segments(segs, h->n, n_segments, seg_begin, seg_lr, bc1)) return rc;
+    isb2 = (float)(1.0 / sqrt(bc2));
     return 0;
 }
 
 extern "C" int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *out, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
                                         const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream) {
-    if (!h || !params || !exp_avg || !exp_avg_sq) { gom_set_error("gom_peer_reduce_run_adam: null argument"); return -1; }
-    if (step < 1) { gom_set_error("gom_peer_reduce_run_adam: step counts from 1"); return -1; }
-    for (int p = 0; p < h->world; p++)
-        if (!h->peer[p]) { gom_set_error("gom_peer_reduce_run_adam: rank %d is not connected", p); return -1; }
     AdamSegs segs{};
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    if (int rc = adam_segments(segs, h->n, n_segments, seg_begin, seg_lr, bc1)) return rc;
+    float isb2 = 0.f;
+    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_adam", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, beta1, beta2, segs, isb2)) return rc;
     h->epoch++;
     PeerPtrs pp{};
     for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];
-    const int grid = 64;
-    hipLaunchKernelGGL(k_peer_reduce_scatter, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, scale, h->status, h->done_ctr);
+    const PeerStatus st{h->status, h->status_host_dev, h->timeout_ticks};
+    launch_scatter<false>(h, pp, scale, st, nullptr, nullptr, nullptr, segs, 0.f, 0.f, 0.f, 0.f, (hipStream_t)stream);
     GOM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_peer_all_gather_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, h->status, params, exp_avg,
-                       exp_avg_sq, segs, beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), out);
+    hipLaunchKernelGGL(k_peer_all_gather<1>, dim3(64), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, st, params, exp_avg, exp_avg_sq, segs, beta1,
+                       beta2, eps, isb2, out);
     GOM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gom_peer_reduce_run_zero1(GomPeerReduce *h, float scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                                         const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream) {
+    AdamSegs segs{};
+    float isb2 = 0.f;
+    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_zero1", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, beta1, beta2, segs, isb2)) return rc;
+    h->epoch++;
+    PeerPtrs pp{};
+    for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];
+    const PeerStatus st{h->status, h->status_host_dev, h->timeout_ticks};
+    launch_scatter<true>(h, pp, scale, st, params, exp_avg, exp_avg_sq, segs, beta1, beta2, eps, isb2, (hipStream_t)stream);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_peer_all_gather<2>, dim3(64), dim3(256), 0, (hipStream_t)stream, pp, h->rank, h->world, h->n, h->epoch, st, params, nullptr, nullptr, segs, 0.f, 0.f, 0.f,
+                       0.f, nullptr);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Non-blocking: the pinned host mirror of the status word (a kernel that gives up writes it through the mapping).  0 = no wait has timed out
+// SO FAR -- a step's own kernels may still be running; the host layer calls this every step and so learns of a failure one step late at most.
+extern "C" int gom_peer_reduce_poll(GomPeerReduce *h) {
+    if (!h) return -1;
+    const uint32_t s = *reinterpret_cast<volatile uint32_t *>(h->status_host);
+    if (s) gom_set_error("gom_peer_reduce: a peer did not answer within the wait limit");
+    return (int)s;
 }
 
 extern "C" int gom_peer_reduce_status(GomPeerReduce *h) {   // host-side check (synchronises the device): 0 = every wait was answered
@@ -370,6 +509,21 @@ extern "C" int gom_peer_reduce_status(GomPeerReduce *h) {   // host-side check (
     return (int)s;
 }
 
+// After a timeout.  COLLECTIVE in spirit: the caller brackets it with two barriers of the process group (every rank idle before anybody
+// clears; everybody cleared before anybody starts an exchange).  Flags are epoch counters: this rank's epoch moves to `epoch` (the maximum
+// over the ranks, agreed by the caller) so that stale flags of the failed exchange can never satisfy a later wait.
+extern "C" int gom_peer_reduce_reset(GomPeerReduce *h, uint32_t epoch) {
+    if (!h) { gom_set_error("gom_peer_reduce_reset: null handle"); return -1; }
+    GOM_HIP_CHECK(hipDeviceSynchronize());
+    GOM_HIP_CHECK(hipMemset(h->status, 0, 2 * sizeof(uint32_t)));
+    GOM_HIP_CHECK(hipDeviceSynchronize());
+    *h->status_host = 0;
+    if ((int32_t)(epoch - h->epoch) > 0) h->epoch = epoch;
+    return 0;
+}
+extern "C" uint32_t gom_peer_reduce_epoch(GomPeerReduce *h) { return h ? h->epoch : 0u; }
+
+// The caller has synchronised its device AND passed a barrier of the process group: no peer kernel may still be reading this region.
 extern "C" void gom_peer_reduce_destroy(GomPeerReduce *h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
@@ -377,5 +531,6 @@ extern "C" void gom_peer_reduce_destroy(GomPeerReduce *h) {
         if (h->opened[p] && h->peer[p]) (void)hipIpcCloseMemHandle(h->peer[p]);
     if (h->local) (void)hipFree(h->local);
     if (h->status) (void)hipFree(h->status);
+    if (h->status_host) (void)hipHostFree(h->status_host);
     delete h;
 }

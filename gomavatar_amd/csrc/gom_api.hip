@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include "gom_internal.h"
+#ifdef GOM_LAB
+#include "gom_hip_lab.h"
+#endif
 #include <cstdlib>
 
 static thread_local char g_err[512] = "";
@@ -99,6 +102,9 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             return 0;
         case GOM_OPT_BWD_MODE:
             if (value < -1 || value > 3) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges), 1 (one sub-range per barrier), 2 (4x4-block items per DPP row, GOM_LAB builds) or 3 (lane per (pixel, entry) record)"); return -1; }
+#ifndef GOM_LAB
+            if (value == 2) { gom_set_error("backward mode 2 (4x4-block items) exists in -DGOM_LAB builds only (include/gom_hip_lab.h)"); return -1; }
+#endif
             s->bwdMode = (int)value;
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
             return 0;
@@ -479,6 +485,7 @@ static int frame_call(GomState *s, const GomFrame *f, int B, const GomCamera *ca
     return 0;
 }
 
+#ifdef GOM_LAB   // (include/gom_hip_lab.h)
 extern "C" int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
                                              const int64_t *seg_begin, const float *seg_lr, int64_t *step_device, float lr_decay_steps, float beta1, float beta2,
                                              float eps, float grad_scale) {
@@ -496,6 +503,7 @@ extern "C" int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *para
     s->adam.step_device = step_device; s->adam.lr_decay_steps = lr_decay_steps; s->adam.beta1 = beta1; s->adam.beta2 = beta2; s->adam.eps = eps; s->adam.grad_scale = grad_scale;
     return 0;
 }
+#endif
 
 extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
     return frame_call(s, f, 1, nullptr, flags, stream);

@@ -1548,7 +1548,9 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     tq.finish();
 }
 
+#ifdef GOM_LAB   // (include/gom_hip_lab.h: built, measured, not adopted)
 #include "seg_bwd_blk.hpp"
+#endif
 #include "rec_bwd.hpp"
 
 }  // namespace
@@ -1682,6 +1684,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
         GOM_LAUNCH_CHECK();
         return 0;
     }
+#ifdef GOM_LAB
     if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (seg_bwd_blk.hpp)
 #define GOM_SBB(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_blk<CC>), dim3(GOM_RESIDENT(k_seg_bwd_blk<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
@@ -1692,6 +1695,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
         GOM_LAUNCH_CHECK();
         return 0;
     }
+#endif
     if (s->bwdMode == 0 || (s->bwdMode < 0 && s->B > 1)) {   // two sub-ranges between barriers, opposite quadrants per wave (GOM_OPT_BWD_MODE 1: one sub-range per barrier, round 1)
 #define GOM_SBW(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_pair<CC>), dim3(GOM_RESIDENT(k_seg_bwd_pair<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \

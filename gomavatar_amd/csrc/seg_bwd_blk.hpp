@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256, GOM_BWDB_WAVES) k_seg_bwd_blk(uint32_t se
     const size_t HW = (size_t)H * W;
     const int slot = row_sum10_slot(lane);
     if (threadIdx.x == 0) {
-        s_e0[GOM_SUB_MAX] = make_float4(0.f, 0.f, 0.f, 0.f); s_e1[GOM_SUB_MAX] = make_float2(0.f, 0.f); s_e2[GOM_SUB_MAX] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_e0[GOM_SUB_MAX] = make_float4(0.f, 0.f, 0.f, 0.f); s_e1[GOM_SUB_MAX] = make_float2(0.f, -INFINITY);   /* (Cq, lo = log2 of opacity 0: alpha 0) */ s_e2[GOM_SUB_MAX] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     uint32_t parity = 0;
     PairQueue tq;

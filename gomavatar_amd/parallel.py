@@ -51,11 +51,12 @@ class PeerAllReduce:
     the other ranks map through IPC handles (exchanged once over the process group); `run()` enqueues two kernels -- reduce-scatter in
     rank order, all-gather -- on the current stream.  One process per GPU; several processes on ONE device work too (the 1-GPU test)."""
 
-    def __init__(self, numel: int, device, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, numel: int, device, group: Optional[dist.ProcessGroup] = None, timeout_s: Optional[float] = None):
         import ctypes
         from . import _lib
         self._lib, self._ct = _lib, ctypes
         self.lib = _lib.load()
+        self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.numel = int(numel)
         torch.cuda.set_device(device)
@@ -66,6 +67,8 @@ class PeerAllReduce:
             self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
             if not self._h:
                 _lib.check(-1)
+            if timeout_s is not None:
+                _lib.check(self.lib.gom_peer_reduce_set_timeout(self._h, float(timeout_s)))
             buf = (ctypes.c_ubyte * 64)()
             _lib.check(self.lib.gom_peer_reduce_handle(self._h, buf))
             mine = bytes(buf)
@@ -87,31 +90,65 @@ class PeerAllReduce:
     def _raise_together(self, errs) -> None:
         bad = [e for e in errs if e]
         if bad:
-            self.close()
+            self.close(collective=False)   # (nobody has raised a flag in anybody's region yet)
             raise RuntimeError("peer all-reduce unavailable (" + bad[0] + ")")
+
+    def poll(self) -> None:
+        """Every step, before the exchange is enqueued: raises if a wait of an EARLIER exchange gave up (the kernel that times out writes a
+        pinned host word; reading it costs no synchronisation).  The native run calls refuse to enqueue on a failed handle as well."""
+        if self.lib.gom_peer_reduce_poll(self._h):
+            raise RuntimeError("peer all-reduce: a peer did not answer within the wait limit -- the gradients of that step were NOT reduced "
+                               "(reset() on every rank, or rebuild the exchange, before stepping again)")
 
     def run(self, out: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
         out = self.buffer if out is None else out
         assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self.numel
+        self.poll()
         self._lib.check(self.lib.gom_peer_reduce_run(self._h, out.data_ptr(), float(scale), self._lib.stream_ptr()))
         return out
 
-    def run_adam(self, opt: "FlatAdam", scale: float = 1.0, out: Optional[torch.Tensor] = None) -> None:
-        """The exchange with `opt`'s Adam step inside its second kernel (`gom_peer_reduce_run_adam`): every rank updates its parameter
-        replica straight from the reduced slices; `out` (optional) receives the reduced gradient."""
-        opt.t += 1
+    def run_adam(self, opt: "FlatAdam", scale: float = 1.0, out: Optional[torch.Tensor] = None, zero1: bool = False) -> None:
+        """The exchange with `opt`'s Adam step inside it.  Default (`gom_peer_reduce_run_adam`): every rank updates its parameter replica
+        straight from the reduced slices in the all-gather; `out` (optional) receives the reduced gradient.  zero1 (`gom_peer_reduce_run_zero1`,
+        SURVEY.md 8(e)): the rank that reduced a slice steps THAT slice and the all-gather moves parameters -- the same bits, 1 / world of
+        the optimizer arithmetic and of the moment traffic per rank."""
+        self.poll()
         lr = (self._ct.c_float * len(opt.lr))(*opt.lr)
         P = self._lib.ptr
-        self._lib.check(self.lib.gom_peer_reduce_run_adam(self._h, float(scale), P(out), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
-                                                          opt._begin, lr, opt.t, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+        if zero1:
+            assert out is None, "the ZeRO-1 exchange gathers parameters: there is no reduced gradient to hand out"
+            self._lib.check(self.lib.gom_peer_reduce_run_zero1(self._h, float(scale), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
+                                                               opt._begin, lr, opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+        else:
+            self._lib.check(self.lib.gom_peer_reduce_run_adam(self._h, float(scale), P(out), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
+                                                              opt._begin, lr, opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+        opt.t += 1   # (only a step that was enqueued counts)
 
     def check(self) -> None:
-        """Synchronises; raises if a peer never answered (the kernels give up after ~1 s instead of hanging)."""
+        """Synchronises; raises if a peer never answered (the kernels give up after the wait limit instead of hanging)."""
         self._lib.check(-self.lib.gom_peer_reduce_status(self._h))
 
-    def close(self) -> None:
+    def reset(self) -> None:
+        """After a timeout, on EVERY rank: clears the condition between two barriers of the group and moves all ranks to a common epoch."""
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        ep = torch.tensor([int(self.lib.gom_peer_reduce_epoch(self._h))], dtype=torch.int64)
+        got = [None] * self.world
+        dist.all_gather_object(got, int(ep.item()), group=self.group)
+        self._lib.check(self.lib.gom_peer_reduce_reset(self._h, max(got) & 0xffffffff))
+        dist.barrier(group=self.group)
+
+    def close(self, collective: bool = True) -> None:
+        """Frees the region.  A peer's all-gather may still be reading this rank's reduced slice: the device is synchronised and the group
+        passes a barrier first (collective=False only where no exchange can be in flight)."""
         if getattr(self, "_h", None):
             self.buffer = None
+            if collective and dist.is_initialized():
+                try:
+                    torch.cuda.synchronize()
+                    dist.barrier(group=self.group)
+                except Exception:   # (interpreter shutdown, a peer already gone: free anyway)
+                    pass
             self.lib.gom_peer_reduce_destroy(self._h)
             self._h = None
 
@@ -129,7 +166,8 @@ class FrameParallel:
     def __init__(self, shapes: Sequence[Tuple[str, Tuple[int, ...]]], device, group: Optional[dist.ProcessGroup] = None,
                  average: bool = True, pad_to: int = 0, impl: str = "collective"):
         """impl: "collective" = torch.distributed all_reduce (RCCL on GPUs, gloo on the host); "peer" = the direct two-shot all-reduce
-        over IPC-mapped peer buffers (`PeerAllReduce`; the gradient buffer then lives in the peer-mapped region)."""
+        over IPC-mapped peer buffers (`PeerAllReduce`; the gradient buffer then lives in the peer-mapped region); "peer-zero1" = the same
+        exchange with the optimizer sharded over the ranks (`all_reduce_and_step` only: each rank steps its slice, parameters are gathered)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -140,7 +178,9 @@ class FrameParallel:
         self.params = FlatBuffer(shapes, device)
         self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
         self.impl, self.peer = impl, None
-        if impl == "peer" and self.world > 1:
+        if impl not in ("collective", "peer", "peer-zero1"):
+            raise ValueError(f"unknown all-reduce implementation {impl!r}")
+        if impl in ("peer", "peer-zero1") and self.world > 1:
             self.peer = PeerAllReduce(self.grads.numel, device, group)
             self.grads.flat = self.peer.buffer          # gradients are written straight into the peer-mapped region
             self.grads.views = {name: self.grads.flat[o:o + n].view(shape) for name, shape, o, n in self.grads.layout}
@@ -191,10 +231,31 @@ class FrameParallel:
         """Mean of the gradients over the ranks + `opt`'s Adam step.  Over the peer exchange that is two launches (the optimizer rides in
         the all-gather); otherwise the collective followed by `opt.step()`."""
         if self.peer is not None and not opt.graphable:
-            self.peer.run_adam(opt, 1.0 / self.world if self.average else 1.0)
+            self.peer.run_adam(opt, 1.0 / self.world if self.average else 1.0, zero1=self.impl == "peer-zero1")
         else:
             self.all_reduce_grads()
             opt.step()
+
+    def barrier_after_pause(self) -> None:
+        """Call after a long host-side pause on SOME ranks only (checkpoint write, evaluation, subdivision + optimizer rebuild, first-step
+        graph capture) and before the next exchange: the peer exchange's waits are bounded (30 s by default), a barrier makes the ranks meet
+        on the host first, where waiting is free."""
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def close(self) -> None:
+        """Collective: releases the peer-mapped region behind a device synchronisation and a barrier of the group."""
+        if self.peer is not None:
+            self.grads.views, self.grads.flat = {}, None
+            self.peer.close()
+            self.peer = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "peer", None) is not None:
+                self.peer.close(collective=False)   # (garbage collection is not a collective point: close() is the orderly way)
+        except Exception:
+            pass
 
     def make_adam(self, lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8) -> torch.optim.Adam:
         """Adam with one param group per tensor (the reference uses per-group
@@ -237,6 +298,9 @@ class FlatAdam:
         """Make this optimizer's step the LAST launch of `state`'s frame step (`gom_state_set_frame_optimizer`): forward, backward and Adam
         are then one recorded graph.  Needs `graphable=True` (the step count lives on the device); do not call `step()` as well."""
         assert self.graphable, "attach() needs FlatAdam(graphable=True)"
+        if not self._lib.has_lab():
+            raise RuntimeError("FlatAdam.attach needs a -DGOM_LAB build of libgom_hip.so (include/gom_hip_lab.h): measured slower than a plain launch "
+                               "behind the frame step's graph, it is not part of the product library")
         fp, P = self.fp, self._lib.ptr
         lr = (self._ct.c_float * len(self.base_lr))(*self.base_lr)
         self._lib.check(self._lib.load().gom_state_set_frame_optimizer(state.handle, fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq),
@@ -249,17 +313,18 @@ class FlatAdam:
 
     def step(self, grad_scale: float = 1.0) -> None:
         """One Adam step on the current stream, reading `fp.grads.flat` (as the all-reduce left it)."""
-        self.t += 1
         fp, P = self.fp, self._lib.ptr
         if self.graphable:
             lr = (self._ct.c_float * len(self.base_lr))(*self.base_lr)
             self._lib.check(self._lib.load().gom_adam_flat_graphable(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq),
                                                                      len(self.base_lr), self._begin, lr, 1, P(self.step_dev), self.lr_decay_steps, self.betas[0],
                                                                      self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+            self.t += 1
             return
         lr = (self._ct.c_float * len(self.lr))(*self.lr)
         self._lib.check(self._lib.load().gom_adam_flat(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq), len(self.lr),
-                                                       self._begin, lr, self.t, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+                                                       self._begin, lr, self.t + 1, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+        self.t += 1   # (only a step that was enqueued counts)
 
 
 def shapes_for_model(n_verts: int, n_faces: int, extra: Iterable[Tuple[str, Tuple[int, ...]]] = ()):

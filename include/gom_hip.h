@@ -451,19 +451,15 @@ int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float 
                             const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
                             float beta2, float eps, float grad_scale, void *stream);
 
-/* Attach that step to a state's frame step: gom_frame_forward_backward / gom_batch_forward_backward then end with the Adam launch
- * (`grads` = the flat buffer the frame's g_* pointers are views of; the device step counter is required), so that forward, backward AND the
- * optimizer are one recorded graph (a plain launch behind a graph launch starts ~9 us late).  Not applied by GOM_FRAME_FORWARD_ONLY calls.
- * n == 0 or params == NULL detaches it. */
-int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                                  const int64_t *seg_begin, const float *seg_lr, int64_t *step_device, float lr_decay_steps, float beta1, float beta2,
-                                  float eps, float grad_scale);
-
 /* Direct all-reduce of the flat gradient buffer over peer pointers ("for this latency-bound size use a direct one-/two-shot
  * algorithm, not a ring"): one process per GPU; every rank creates a region, the 64-byte IPC handles are exchanged once (any transport:
  * the process group), and `run` enqueues two kernels that leave scale x (sum over the ranks, in RANK ORDER) in `out` -- the same bits on
  * every rank.  `buffer` is this rank's input (n_floats, device memory inside the region): the backward writes the gradient there.
- * `out` may be that same buffer.  A peer that never answers makes the waits give up after ~1 s (status 1), never a hang. */
+ * `out` may be that same buffer.  The region is fine-grained device memory (flags are polled inside a running kernel): create fails
+ * where that cannot be had -- use the library collective then.
+ * Failure is loud, never a hang: a wait gives up after the time limit (30 s unless gom_peer_reduce_set_timeout), the rank that gave up
+ * publishes nothing, so its peers give up in turn; gom_peer_reduce_poll (no synchronisation: a pinned host word the kernel writes) is 1
+ * from then on and every later run/run_adam/run_zero1 on the handle fails until gom_peer_reduce_reset. */
 #define GOM_PEER_MAX_RANKS 16
 typedef struct GomPeerReduce GomPeerReduce;
 GomPeerReduce *gom_peer_reduce_create(int32_t rank, int32_t world, int64_t n_floats);
@@ -475,7 +471,17 @@ int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream)
  * the reduced slices as it reads them (n_floats = the flat parameter count; out may be NULL: the reduced gradient is then not materialised). */
 int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *out, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
                              const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream);
-int gom_peer_reduce_status(GomPeerReduce *h);
+/* ZeRO-1: the rank that reduced a slice applies THAT slice's Adam step (moments are touched for the own slice only) and
+ * publishes the updated parameters; the second kernel gathers parameters.  Replicas end with the bits gom_peer_reduce_run_adam gives. */
+int gom_peer_reduce_run_zero1(GomPeerReduce *h, float scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
+                              const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream);
+int gom_peer_reduce_set_timeout(GomPeerReduce *h, double seconds);
+int gom_peer_reduce_poll(GomPeerReduce *h);     /* 0 / 1, non-blocking (one step late at most) */
+int gom_peer_reduce_status(GomPeerReduce *h);   /* 0 / 1, synchronises the device */
+/* After a timeout, on every rank, between two barriers of the process group; `epoch` = the largest gom_peer_reduce_epoch over the ranks. */
+int gom_peer_reduce_reset(GomPeerReduce *h, uint32_t epoch);
+uint32_t gom_peer_reduce_epoch(GomPeerReduce *h);
+/* Call with the device synchronised and behind a barrier of the process group: no peer may still be reading this rank's region. */
 void gom_peer_reduce_destroy(GomPeerReduce *h);
 
 #ifdef __cplusplus

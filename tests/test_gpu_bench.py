@@ -119,8 +119,11 @@ def test_optimizer_attached_to_the_frame_graph_takes_the_same_steps():
     one graph replay) against the frame step followed by a separate gom_adam_flat: same parameters and moments, bit for bit, over three steps
     in which step k + 1 renders with what step k wrote."""
     import torch
+    from gomavatar_amd import _lib
     from gomavatar_amd.parallel import FlatAdam, FrameParallel, shapes_for_model
     from gomavatar_amd.workload import MetricWorkload
+    if not _lib.has_lab():
+        pytest.skip("laboratory entry point (include/gom_hip_lab.h): run with GOM_HIP_LIB pointing at a -DGOM_LAB build (scripts/exp_build.py lab -DGOM_LAB)")
     wl = MetricWorkload("cuda", subdiv=0, img=128, n_frames=4)
     runs = []
     for attached in (False, True):

@@ -1,5 +1,5 @@
-"""The direct two-shot all-reduce over IPC-mapped peer buffers (csrc/frame_parallel.hip, parallel.PeerAllReduce) with 2 and 4 PROCESSES
-on the one MI355X of the lease: every rank's gradient region is mapped into the others through hipIpc handles, two kernels per rank
+"""The direct two-shot all-reduce over IPC-mapped peer buffers (csrc/frame_parallel.hip, parallel.PeerAllReduce) with 2, 3, 4 and 8 PROCESSES
+on the one MI355X of the lease (8 = the node size of BASELINE.json's cfg 4; 3 = the generic, non-templated kernels): every rank's gradient region is mapped into the others through hipIpc handles, two kernels per rank
 form the sum.  Held: bitwise equal to ((g0 + g1) + g2) + g3 scaled -- the rank-order sum -- on every rank, over several epochs with the
 buffers rewritten in between (flag reuse), in place; timed against torch.distributed.all_reduce on the same tensors (gloo through pinned
 host memory here -- the transport a 1-GPU box offers -- so the ratio says nothing about RCCL).  What this cannot show is xGMI itself."""
@@ -49,7 +49,7 @@ for epoch in range(6):
 from gomavatar_amd.parallel import FrameParallel, FlatAdam, shapes_for_model
 if n > 5000:
     shapes = shapes_for_model(1001, 2003)
-    fps = [FrameParallel(shapes, "cuda:0", pad_to=3 * 1001 + 9 * 2003 + 37, impl="peer") for _ in range(2)]
+    fps = [FrameParallel(shapes, "cuda:0", pad_to=3 * 1001 + 9 * 2003 + 37, impl=impl) for impl in ("peer", "peer", "peer-zero1")]
     opts = [FlatAdam(f, {"vertices": 5e-4, "default": 1e-3}) for f in fps]
     for f in fps:
         f.params.flat.copy_(torch.randn(f.params.numel, generator=torch.Generator().manual_seed(7)).cuda())
@@ -59,11 +59,46 @@ if n > 5000:
             f.grads.flat.copy_(gsrc)
         fps[0].all_reduce_grads(); opts[0].step()             # two kernels + Adam
         fps[1].all_reduce_and_step(opts[1])                   # two kernels, Adam inside the second
+        fps[2].all_reduce_and_step(opts[2])                   # ZeRO-1: Adam of the own slice inside the first, parameters gathered by the second
         torch.cuda.synchronize()
-        fps[0].peer.check(); fps[1].peer.check()
+        for f in fps:
+            f.peer.check()
         ok = ok and bool(torch.equal(fps[0].params.flat, fps[1].params.flat)) and bool(torch.equal(opts[0].exp_avg, opts[1].exp_avg)) and bool(torch.equal(opts[0].exp_avg_sq, opts[1].exp_avg_sq))
+        ok = ok and bool(torch.equal(fps[0].params.flat, fps[2].params.flat)) and opts[2].t == opts[0].t
+        # ZeRO-1 touches the moments of the own slice only (float4 units dealt in rank order), and there they are the replicated optimizer's
+        n4 = fps[2].grads.numel // 4; per = (n4 + world - 1) // world
+        lo, hi = 4 * per * rank, min(4 * min(per * (rank + 1), n4), fps[2].params.numel)
+        ok = ok and bool(torch.equal(opts[0].exp_avg[lo:hi], opts[2].exp_avg[lo:hi])) and bool(torch.equal(opts[0].exp_avg_sq[lo:hi], opts[2].exp_avg_sq[lo:hi]))
+        if world > 1 and lo > 0:
+            ok = ok and float(opts[2].exp_avg[:lo].abs().max()) == 0.0
     for f in fps:
-        f.peer.close()
+        f.close()
+    # A peer that does not show up: the others give up after the wait limit (1 s here), LOUDLY -- check() and the next step's poll() raise, no
+    # "reduced" flag is raised over unreduced data -- and after reset() on every rank the exchange works again.
+    ar2 = PeerAllReduce(n, "cuda:0", timeout_s=1.0)
+    ar2.buffer.copy_(grad(rank, 7)); ar2.run(scale=1.0); ar2.check()
+    if rank == 0:
+        time.sleep(2.5)                                        # (a checkpoint write, an evaluation pass ...)
+        failed = True
+    else:
+        ar2.buffer.copy_(grad(rank, 8)); ar2.run(scale=1.0)
+        failed = False
+        try:
+            ar2.check()
+        except RuntimeError:
+            failed = True
+        try:
+            ar2.run(scale=1.0); failed = False               # the failed handle refuses to enqueue
+        except RuntimeError:
+            pass
+    ok = ok and failed
+    ar2.reset()
+    ar2.buffer.copy_(grad(rank, 9)); out = ar2.run(torch.empty(n, device="cuda"), scale=1.0); ar2.check()
+    ref = grad(0, 9)
+    for r in range(1, world):
+        ref = ref + grad(r, 9)
+    ok = ok and bool(torch.equal(out, ref))
+    ar2.close()
 # timing (one device shared by all ranks: a functional number)
 t = grad(rank, 99); host = torch.empty(n).pin_memory()
 torch.cuda.synchronize(); dist.barrier()
@@ -93,7 +128,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n", [(2, 951023), (4, 951023), (2, 1030)])
+@pytest.mark.parametrize("world,n", [(2, 951023), (4, 951023), (8, 951023), (3, 951023), (2, 1030), (8, 1030)])
 def test_peer_allreduce_equals_rank_order_sum_bitwise(world, n, tmp_path, capsys):
     import json
     script = tmp_path / "worker.py"
@@ -105,7 +140,7 @@ def test_peer_allreduce_equals_rank_order_sum_bitwise(world, n, tmp_path, capsys
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=240))
+            outs.append(p.communicate(timeout=400))
     finally:
         for p in procs:
             if p.poll() is None:
@@ -121,3 +156,38 @@ def test_peer_allreduce_equals_rank_order_sum_bitwise(world, n, tmp_path, capsys
         print(f"\n[peer all-reduce, {world} processes on one device, {n} floats] bitwise = rank-order sum: {d['ok']};  {d['peer_us']} us per call "
               f"(copy-in + two kernels; torch all_reduce over gloo through pinned host memory: {d['gloo_host_us']} us)")
     assert d["ok"]
+
+
+RCCL_WORKER = r'''
+import os, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from gomavatar_amd.parallel import FrameParallel, shapes_for_model
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+t = torch.arange(1000, dtype=torch.float32, device="cuda")
+ref = t.clone()
+dist.all_reduce(t, op=dist.ReduceOp.AVG)            # ncclAvg through RCCL: the collective FrameParallel.all_reduce_grads issues at N > 1
+fp = FrameParallel(shapes_for_model(101, 203), "cuda:0")
+fp.grads.flat.normal_(); g = fp.grads.flat.clone()
+fp.world = 2; fp.all_reduce_grads(); fp.world = 1    # (drive the N > 1 branch on the world-1 group: AVG over one rank = identity)
+torch.cuda.synchronize()
+print(json.dumps({"avg_ok": bool(torch.equal(t, ref)), "fp_ok": bool(torch.equal(fp.grads.flat, g)), "native_avg": bool(fp._native_avg), "backend": dist.get_backend()}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_world1_avg_smoke(tmp_path, capsys):
+    """RCCL itself (torch.distributed backend "nccl") on the lease's one GPU: a world-1 process group loads the library, and ReduceOp.AVG -- the
+    collective of the N > 1 frame-parallel step -- resolves and runs.  What a 1-GPU box can show of cfg 4's library path; xGMI it cannot."""
+    import json
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2500:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    with capsys.disabled():
+        print(f"\n[RCCL, world 1] backend {d['backend']}: all_reduce(AVG) ran: {d['avg_ok']}; FrameParallel's N > 1 branch: {d['fp_ok']} (native AVG: {d['native_avg']})")
+    assert d["avg_ok"] and d["fp_ok"] and d["backend"] == "nccl"
