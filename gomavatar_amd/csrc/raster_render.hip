@@ -158,7 +158,10 @@ __device__ __forceinline__ bool cull_entry(float cx, float cy, float a, float b,
 // in five multiply-adds, one add and the v_exp_f32 (the reference's expression -- forward.cu:330-340, three products per term, the
 // -0.5, the log2(e) of __expf and the opacity as separate factors -- took eleven).  The two skip rules are 0 / 1 factors made by
 // clamped multiply-adds instead of compare + select pairs:  m1 = clamp(2^64 (og - pred(1/255))) is 1 exactly when og >= 1/255 (the
-// difference is then at least an ulp of 1/255 = 2^-31), m2 = clamp(1 - 2^126 pw) is 1 exactly when pw <= 0 (and 0 for pw >= 2^-126).
+// difference is then at least an ulp of 1/255 = 2^-31), m2 = clamp(1 - 2^126 pw) is 1 exactly when pw <= 0 and 0 for pw >= 2^-126.
+// NOT exact in between: a DENORMAL positive exponent, 0 < pw < 2^-126 (only an indefinite conic makes pw positive at all), gives a
+// fractional factor where the reference skips the pixel.  The contribution it lets through is alpha * m2 with alpha = opacity * 2^pw =
+// opacity to within 1e-38: a set of measure zero, documented rather than guarded (tests/test_gpu_raster.py::test_fuzz_indefinite_covariances).
 // Why: the three segment kernels are bound by VALU issue, the alpha evaluation is half of what they issue, and on gfx950 a compare or a
 // select costs 4.2 issue cycles where a multiply-add costs 2.25 (scripts/ubench/valu_rate.hip).  Every operation is written out, nothing
 // is left to contraction, and the float and the register-pair version below are the same sequence: the transmittance pre-pass, the

@@ -144,6 +144,7 @@ void or_preprocess(const OrCamera *cam, int P, const REAL *means, const REAL *co
     const int gx = (cam->W + TILE - 1) / TILE, gy = (cam->H + TILE - 1) / TILE;
     const REAL fx = (REAL)cam->W / ((REAL)2 * cam->tanfovx);
     const REAL fy = (REAL)cam->H / ((REAL)2 * cam->tanfovy);
+#pragma omp parallel for schedule(static) num_threads(g_threads)   /* (every Gaussian on its own: the thread count changes no bit) */
     for (int i = 0; i < P; i++) {
         radii[i] = 0; tiles_touched[i] = 0; depth[i] = 0;
         xy[2 * i] = xy[2 * i + 1] = 0;
@@ -188,24 +189,42 @@ void or_preprocess(const OrCamera *cam, int P, const REAL *means, const REAL *co
 }
 
 /* ------------------------------------------------------------------ A.2 */
+/* Stable LSD radix sort, 8 passes of 8 bits.  Threads take CONTIGUOUS chunks of the input; a pass counts per (thread, digit), offsets are
+ * the prefix over (digit, then thread) and every thread scatters its chunk in order -- the output is the serial algorithm's, bit for bit,
+ * whatever the thread count (stability is the contract: cub::DeviceRadixSort's, which the reference's tile lists inherit). */
 static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n) {
     uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
     uint32_t *v2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+    int nt = g_threads;
+    if (nt > 64) nt = 64;
+    if ((int64_t)nt * 4096 > n) nt = (int)(n / 4096) > 0 ? (int)(n / 4096) : 1;
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * 256 * (size_t)nt);
     for (int pass = 0; pass < 8; pass++) {
-        int64_t cnt[257];
-        memset(cnt, 0, sizeof(cnt));
         const int sh = pass * 8;
-        for (int64_t i = 0; i < n; i++) cnt[((keys[i] >> sh) & 0xff) + 1]++;
-        for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t d = cnt[(keys[i] >> sh) & 0xff]++;
-            k2[d] = keys[i]; v2[d] = vals[i];
+        memset(cnt, 0, sizeof(int64_t) * 256 * (size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            int64_t *c = cnt + 256 * (size_t)t;
+            for (int64_t i = lo; i < hi; i++) c[(keys[i] >> sh) & 0xff]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                int64_t run = 0;
+                for (int b = 0; b < 256; b++)
+                    for (int u = 0; u < nt; u++) { const int64_t x = cnt[256 * (size_t)u + b]; cnt[256 * (size_t)u + b] = run; run += x; }
+            }   /* (implicit barrier) */
+            for (int64_t i = lo; i < hi; i++) {
+                const int64_t d = c[(keys[i] >> sh) & 0xff]++;
+                k2[d] = keys[i]; v2[d] = vals[i];
+            }
         }
         uint64_t *tk = keys; keys = k2; k2 = tk;
         uint32_t *tv = vals; vals = v2; v2 = tv;
     }
     /* 8 passes: data is back in the caller's arrays */
-    free(k2); free(v2);
+    free(k2); free(v2); free(cnt);
 }
 
 /* Inclusive prefix sum of tiles_touched -> offsets; returns D. */
@@ -220,6 +239,7 @@ int64_t or_scan(int P, const uint32_t *tiles_touched, uint32_t *offsets) {
 void or_bin(const OrCamera *cam, int P, const REAL *depth, const int32_t *radii, const int32_t *rect,
             const uint32_t *offsets, int64_t D, uint64_t *keys, uint32_t *vals, uint32_t *ranges) {
     const int gx = (cam->W + TILE - 1) / TILE, gy = (cam->H + TILE - 1) / TILE;
+#pragma omp parallel for schedule(static) num_threads(g_threads)   /* (a Gaussian writes its own range of the pair arrays) */
     for (int i = 0; i < P; i++) {
         if (radii[i] <= 0) continue;
         uint32_t off = (i == 0) ? 0 : offsets[i - 1];
@@ -235,6 +255,7 @@ void or_bin(const OrCamera *cam, int P, const REAL *depth, const int32_t *radii,
     }
     radix_sort_pairs(keys, vals, D);
     memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)(gx * gy));
+#pragma omp parallel for schedule(static) num_threads(g_threads)   /* (a tile's first / last position is written by exactly one i) */
     for (int64_t i = 0; i < D; i++) {
         const uint32_t t = (uint32_t)(keys[i] >> 32);
         if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * t] = (uint32_t)i;
@@ -362,6 +383,7 @@ void or_preprocess_bwd(const OrCamera *cam, int P, const REAL *means, const REAL
     const REAL fx = (REAL)cam->W / ((REAL)2 * cam->tanfovx);
     const REAL fy = (REAL)cam->H / ((REAL)2 * cam->tanfovy);
     const REAL *v = cam->view, *pr = cam->proj;
+#pragma omp parallel for schedule(static) num_threads(g_threads)   /* (every Gaussian on its own) */
     for (int i = 0; i < P; i++) {
         REAL *gm = dL_dmeans + 3 * i, *gc = dL_dcov6 + 6 * i;
         gm[0] = gm[1] = gm[2] = 0;

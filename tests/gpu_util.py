@@ -16,13 +16,19 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
 
 
-def hip_forward(cam, means, cov6, colors, op, state=None, requires_grad=False, reuse=False):
+def hip_forward(cam, means, cov6, colors, op, state=None, requires_grad=False, reuse=False, means2D=False):
+    """means2D: also pass a (P, 3) screen-space dummy that requires grad -- the reference's `screenspace_points`, whose .grad is the fifth
+    gradient of the boundary (appended to the returned tensor list)."""
     st = state if state is not None else R.RasterState()
     t = [dev(means), dev(cov6), dev(colors), dev(op)]
     if requires_grad:
         for x in t:
             x.requires_grad_()
-    out, radii = R.rasterize(t[0], t[1], t[2], t[3], gom_camera(cam), state=st, reuse_binning=reuse)
+    m2 = None
+    if means2D:
+        m2 = torch.zeros((t[0].shape[0], 3), dtype=torch.float32, device="cuda", requires_grad=True)
+        t.append(m2)
+    out, radii = R.rasterize(t[0], t[1], t[2], t[3], gom_camera(cam), state=st, reuse_binning=reuse, means2D=m2)
     return out, radii, st, t
 
 

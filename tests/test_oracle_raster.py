@@ -109,3 +109,26 @@ def test_backward_against_finite_differences(C):
             assert min(errs) <= 1e-4, (name, idx, an, errs)
             checked += 1
     assert checked == 48
+
+
+def test_thread_count_changes_no_bit():
+    """The oracle's per-Gaussian stages and its (stable, chunked) radix sort are OpenMP loops since round 4 -- bench.py's `cpu_baseline`
+    row for all cores is then a real multi-core number.  Every forward output, integer or float, must be the 1-thread one bit for bit."""
+    cam, means, cov6, colors, op = small_scene(seed=5, P=30000, H=128, W=128, opacity=(0.05, 1.0), spread=0.3, scale=0.02, C=4)
+    w = np.random.default_rng(1).normal(size=(4, 128, 128))
+    outs = []
+    for nt in (1, 8):
+        orast.set_threads(nt)
+        f = orast.forward(cam, means, cov6, colors, op, dtype=np.float32)
+        g = orast.backward(f, w.astype(np.float32))
+        outs.append((f, g))
+    orast.set_threads(1)
+    (f1, g1), (f8, g8) = outs
+    assert f1["D"] == f8["D"] and f1["D"] > 20000      # (enough pairs for the sort to really run on several threads)
+    for k in ("radii", "tiles_touched", "ranges", "point_list", "n_contrib", "color", "final_T", "xy", "conic_opacity", "depth"):
+        if k in f1:
+            np.testing.assert_array_equal(f1[k], f8[k], err_msg=k)
+    # (the render backward adds a Gaussian's per-tile terms with `omp atomic` in whatever order the tiles finish: that sum, not the new loops,
+    #  moves by round-off with the thread count -- as it did before)
+    for k in ("dL_dmeans3D", "dL_dcov6", "dL_dopacity"):
+        assert np.abs(g1[k] - g8[k]).max() <= 2e-5 * np.abs(g1[k]).max(), k
