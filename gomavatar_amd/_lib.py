@@ -119,6 +119,8 @@ SIGNATURES = {
                               c_float, c_float, c_void_p]),
     "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_void_p, c_float,
                                         c_float, c_float, c_float, c_float, c_void_p]),
+    "gom_adam_multi": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_float), c_int64, c_void_p,
+                               c_double, c_double, c_double, c_void_p]),
     "gom_peer_reduce_create": (c_void_p, [c_int32, c_int32, c_int64]),
     "gom_peer_reduce_handle": (c_int, [c_void_p, c_void_p]),
     "gom_peer_reduce_connect": (c_int, [c_void_p, c_void_p]),

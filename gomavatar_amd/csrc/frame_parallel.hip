@@ -16,7 +16,13 @@ struct AdamSegs {
     uint32_t begin[GOM_ADAM_MAX_SEGMENTS + 1];   // segment i = [begin[i], begin[i + 1]) of the flat buffer
     float step_size[GOM_ADAM_MAX_SEGMENTS];      // lr_i / (1 - beta1^t); with a device step counter: lr_i, corrected in the kernel
     int n;
+    float omb1, omb2;                            // 1 - beta as torch forms it: in DOUBLE from the decimal the caller wrote, rounded once (one_minus_beta below)
 };
+
+// torch computes `1 - beta2` in double from the Python float 0.999 and hands 0.001f to its kernels; this ABI receives beta2 as a FLOAT
+// (0.999f = 0.99900001287...), and 1.f - 0.999f = 0.00100004673f is 4.7e-5 away from that.  A float beta only pins 1 - beta to ~6e-8 absolute
+// anyway, so the decimal the caller most plausibly wrote (7 digits) is as good a reading as any -- and it is torch's bits for 0.9 / 0.999.
+static float one_minus_beta(float beta) { return (float)(1.0 - round((double)beta * 1e7) / 1e7); }
 
 // torch.optim.Adam (no weight decay, no amsgrad, maximize = False), the arithmetic of torch/optim/adam.py::_single_tensor_adam:
 //   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g g;  p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
@@ -29,8 +35,8 @@ __device__ __forceinline__ bool adam_element(const AdamSegs &segs, uint32_t e, f
     for (int s = 0; s < GOM_ADAM_MAX_SEGMENTS; s++)
         if (s < segs.n && e >= segs.begin[s] && e < segs.begin[s + 1]) { ss = segs.step_size[s]; in = true; }
     if (!in) return false;
-    mm = __fmaf_rn(beta1, mm, __fmul_rn(1.f - beta1, gr));              // exp_avg.lerp_(grad, 1 - beta1) up to rounding
-    vv = __fmaf_rn(beta2, vv, __fmul_rn(__fmul_rn(1.f - beta2, gr), gr));
+    mm = __fmaf_rn(beta1, mm, __fmul_rn(segs.omb1, gr));              // exp_avg.lerp_(grad, 1 - beta1) up to rounding
+    vv = __fmaf_rn(beta2, vv, __fmul_rn(__fmul_rn(segs.omb2, gr), gr));
     const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vv), inv_sqrt_bc2), eps);
     pp = __fsub_rn(pp, __fmul_rn(ss, __fdiv_rn(mm, denom)));
     return true;
@@ -131,11 +137,100 @@ extern "C" int gom_adam_flat_graphable(int64_t n, float *params, const float *gr
     AdamSegs segs{};
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     if (int rc = adam_segments(segs, n, n_segments, seg_begin, seg_lr, step_device ? 1.0 : bc1)) return rc;
+    segs.omb1 = one_minus_beta(beta1); segs.omb2 = one_minus_beta(beta2);
     const uint32_t work = (uint32_t)(n >> 2) + (uint32_t)(n & 3);
     const unsigned blocks = (unsigned)((work + 255) / 256);
     hipLaunchKernelGGL(k_adam_flat, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, params, grads, exp_avg, exp_avg_sq, segs,
                        beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, reinterpret_cast<long long *>(step_device), lr_decay_steps);
     GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------------------
+// The same step over a LIST of tensors (gom_adam_multi): the reference's optimizer as the reference builds it -- torch.optim.Adam over
+// Model.get_param_groups() (train.py:263-267; parameters, gradients and moments are separate allocations owned by torch) -- is ~35
+// multi_tensor_apply launches and 0.58 ms per iteration of the drop-in Model's 4.4 ms (profiles/r03_model_train_iteration_kernel_stats.csv).
+// One launch here: the tensors' pointers, sizes and step sizes travel in the kernel arguments, a workgroup owns 1 024 consecutive
+// elements of one tensor.  gomavatar_amd.optim.GomAdam (a torch.optim.Optimizer) sits on top.
+namespace {
+struct AdamMulti {
+    float *p[GOM_ADAM_MULTI_MAX];
+    const float *g[GOM_ADAM_MULTI_MAX];
+    float *m[GOM_ADAM_MULTI_MAX], *v[GOM_ADAM_MULTI_MAX];
+    uint32_t n[GOM_ADAM_MULTI_MAX];
+    uint32_t blk0[GOM_ADAM_MULTI_MAX + 1];   // first workgroup of tensor i
+    float lr[GOM_ADAM_MULTI_MAX];
+    int nt;
+};
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti a, float beta1, float beta2, float omb1, float omb2, float eps, float inv_bc1, float inv_sqrt_bc2,
+                                                    const long long *__restrict__ step_dev) {
+    if (step_dev) {   // device-resident step count (captured graphs): step_dev[0] = steps taken so far; the caller advances it (gom_adam_multi enqueues k_adam_multi_tick)
+        __shared__ float s_c[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)(__hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
+            s_c[0] = (float)(1.0 / (1.0 - pow((double)beta1, t)));
+            s_c[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+        }
+        __syncthreads();
+        inv_bc1 = s_c[0]; inv_sqrt_bc2 = s_c[1];
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < GOM_ADAM_MULTI_MAX; i++) t = (i < a.nt && blockIdx.x >= a.blk0[i]) ? i : t;
+    float *p = nullptr, *m = nullptr, *v = nullptr;
+    const float *g = nullptr;
+    uint32_t n = 0, b0 = 0;
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < GOM_ADAM_MULTI_MAX; i++)   // (no dynamic index into the kernel arguments)
+        if (i == t) { p = a.p[i]; g = a.g[i]; m = a.m[i]; v = a.v[i]; n = a.n[i]; b0 = a.blk0[i]; lr = a.lr[i]; }
+    const float ss = __fmul_rn(lr, inv_bc1);   // torch: step_size = lr / bias_correction1
+    const uint32_t base = (blockIdx.x - b0) * 1024u + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t e = base + 256u * (uint32_t)k;
+        if (e < n) {
+            const float gr = g[e];
+            float mm = m[e], vv = v[e], pp = p[e];
+            // (omb = 1 - beta rounded from DOUBLE, as torch passes `1 - beta2` to lerp_ / addcmul_: 1.f - 0.999f is 4.7e-5 away from 0.001f)
+            mm = __fmaf_rn(beta1, mm, __fmul_rn(omb1, gr));
+            vv = __fmaf_rn(beta2, vv, __fmul_rn(__fmul_rn(omb2, gr), gr));
+            const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vv), inv_sqrt_bc2), eps);
+            pp = __fsub_rn(pp, __fmul_rn(ss, __fdiv_rn(mm, denom)));
+            p[e] = pp; m[e] = mm; v[e] = vv;
+        }
+    }
+}
+__global__ void k_adam_multi_tick(long long *step_dev) { step_dev[0] = step_dev[0] + 1; }
+}  // namespace
+
+extern "C" int gom_adam_multi(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel,
+                              const float *lr, int64_t step, int64_t *step_device, double beta1, double beta2, double eps, void *stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr))) { gom_set_error("gom_adam_multi: null argument"); return -1; }
+    if (!step_device && step < 1) { gom_set_error("gom_adam_multi: step counts from 1"); return -1; }
+    const double bc1 = 1.0 - pow(beta1, (double)(step_device ? 1 : step)), bc2 = 1.0 - pow(beta2, (double)(step_device ? 1 : step));
+    for (int t0 = 0; t0 < n_tensors; t0 += GOM_ADAM_MULTI_MAX) {   // (more tensors than one launch carries: several launches)
+        AdamMulti a{};
+        uint32_t blocks = 0;
+        for (int i = t0; i < n_tensors && i < t0 + GOM_ADAM_MULTI_MAX; i++) {
+            if (numel[i] < 0 || numel[i] > 0xffffffffLL) { gom_set_error("gom_adam_multi: bad tensor size"); return -1; }
+            if (numel[i] == 0) continue;
+            if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) { gom_set_error("gom_adam_multi: null tensor %d", i); return -1; }
+            const int k = a.nt++;
+            a.p[k] = params[i]; a.g[k] = grads[i]; a.m[k] = exp_avg[i]; a.v[k] = exp_avg_sq[i]; a.n[k] = (uint32_t)numel[i]; a.lr[k] = lr[i];
+            a.blk0[k] = blocks;
+            blocks += (uint32_t)((numel[i] + 1023) / 1024);
+        }
+        a.blk0[a.nt] = blocks;
+        if (!blocks) continue;
+        hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                           (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), reinterpret_cast<const long long *>(step_device));
+        GOM_LAUNCH_CHECK();
+    }
+    if (step_device) {
+        hipLaunchKernelGGL(k_adam_multi_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<long long *>(step_device));
+        GOM_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -454,6 +549,7 @@ static int peer_adam_common(GomPeerReduce *h, const char *who, float *params, fl
     if (!peer_ready(h, who)) return -1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     if (int rc = adam_segments(segs, h->n, n_segments, seg_begin, seg_lr, bc1)) return rc;
+    segs.omb1 = one_minus_beta(beta1); segs.omb2 = one_minus_beta(beta2);
     isb2 = (float)(1.0 / sqrt(bc2));
     return 0;
 }

@@ -451,6 +451,16 @@ int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float 
                             const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
                             float beta2, float eps, float grad_scale, void *stream);
 
+/* The same Adam step over a LIST of separately allocated tensors -- torch.optim.Adam(Model.get_param_groups()) as the reference builds it
+ * (train.py:263-267) in one launch per GOM_ADAM_MULTI_MAX tensors instead of ~35 multi-tensor launches: host arrays of n_tensors device
+ * pointers / element counts / learning rates (one per tensor: its group's).  step counts from 1; with step_device != NULL the count lives in
+ * device memory (steps taken so far; advanced behind the update) and nothing changes between calls, so the launch can be graph-captured.
+ * Arithmetic of torch/optim/adam.py::_single_tensor_adam (no weight decay, no amsgrad, maximize = False); betas and eps arrive as DOUBLES, as
+ * torch holds them (1 - beta2 is formed in double and rounded once: 1.f - 0.999f would be 4.7e-5 away from torch's 0.001f). */
+#define GOM_ADAM_MULTI_MAX 16
+int gom_adam_multi(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel,
+                   const float *lr, int64_t step, int64_t *step_device, double beta1, double beta2, double eps, void *stream);
+
 /* Direct all-reduce of the flat gradient buffer over peer pointers ("for this latency-bound size use a direct one-/two-shot
  * algorithm, not a ring"): one process per GPU; every rank creates a region, the 64-byte IPC handles are exchanged once (any transport:
  * the process group), and `run` enqueues two kernels that leave scale x (sum over the ranks, in RANK ORDER) in `out` -- the same bits on
