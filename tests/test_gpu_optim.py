@@ -32,7 +32,7 @@ def test_gom_adam_follows_torch_adam_and_exchanges_checkpoints():
 
     def close():
         for a, b in zip(pa, pb):
-            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+            assert float((a - b).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max())
         for a, b in zip(pa, pb):
             if a in oa.state:
                 for k in ("exp_avg", "exp_avg_sq"):
@@ -49,7 +49,8 @@ def test_gom_adam_follows_torch_adam_and_exchanges_checkpoints():
         close()
     assert pb[10] not in ob.state or len(ob.state[pb[10]]) == 0     # no gradient, no state (as torch)
     # checkpoints both ways: torch's state into GomAdam, GomAdam's state into torch -- then three more steps together
-    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    import copy
+    sd_a, sd_b = copy.deepcopy(oa.state_dict()), copy.deepcopy(ob.state_dict())   # (as torch.save / torch.load would: load_state_dict itself does not copy tensors)
     assert sd_a["state"].keys() == sd_b["state"].keys() and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd_b["state"].values())
     pc, gc = _groups(0)
     pd, gd = _groups(0)
@@ -63,7 +64,7 @@ def test_gom_adam_follows_torch_adam_and_exchanges_checkpoints():
             _set_grads(ps, it)
             o.step()
     for a, c, d in zip(pa, pc, pd):
-        assert float((a - c).abs().max()) <= 2e-6 * float(a.abs().max()) and float((a - d).abs().max()) <= 4e-6 * float(a.abs().max())
+        assert float((a - c).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max()) and float((a - d).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max())
 
 
 def test_gom_adam_capturable_in_a_replayed_graph():
@@ -95,7 +96,7 @@ def test_gom_adam_capturable_in_a_replayed_graph():
     torch.cuda.synchronize()
     assert int(ob._step_dev.item()) == 4
     for a, b in zip(pa, pb):
-        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+        assert float((a - b).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max())
 
 
 def test_gom_adam_refuses_what_it_does_not_implement():
