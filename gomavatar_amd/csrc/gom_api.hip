@@ -65,7 +65,7 @@ extern "C" void gom_state_destroy(GomState *s) {
     void *ptrs[] = {s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->pair_off, s->tile_count, s->tile_base,
                     s->tile_cursor, s->tile_nmax, s->seg_base, s->keys, s->point_list, s->pair_pos, s->ent_slot, s->partial, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->seg_T,
                     s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, s->sub_T, s->sub_C, s->sub_Tend, s->final_T, s->n_contrib, s->scratch_img, s->status, s->task_ctr, s->batch_grads, s->mesh_face,
-                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count, s->vdepth_minmax, s->cull_masks, s->piece_ub, s->piece_rec, s->rec_ti, s->rec_acc};
+                    s->depth_minmax, s->bucket_count, s->bucket_base, s->bucket_cursor, s->bkeys, s->bkeys_scratch, s->rec_g, s->order, s->rank_of, s->keys32, s->tile_qlim, s->work_items, s->seg_cost, s->bwd_order, s->big_list, s->big_count, s->vdepth_minmax, s->cull_masks, s->piece_ub, s->piece_rec, s->piece_cnt, s->rec_ti, s->rec_acc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev)
@@ -221,7 +221,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const size_t n = (size_t)wantSegs;
         if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, GOM_BWD_ORDER_BASE + GOM_TQ_SHARDS * (size_t)gom_bwd_order_region((uint32_t)n)) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
             grow_s(s, &s->seg_Tend, n * GOM_TPX) || grow_s(s, &s->seg_Sbehind, n * 4 * GOM_TPX) || grow_s(s, &s->sub_T, n * 4 * GOM_TPX) || grow_s(s, &s->cull_masks, n * 16) ||
-            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX) || grow_s(s, &s->piece_ub, n * 16) || grow_s(s, &s->piece_rec, n * 16))
+            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX) || grow_s(s, &s->piece_ub, n * 16) || grow_s(s, &s->piece_rec, n * 16) || grow_s(s, &s->piece_cnt, n * 16 * 64))
             return -2;
         s->capSegs = wantSegs;
     }

@@ -161,6 +161,7 @@ struct GomState {
     // records mode of the render backward: per (segment, sub-range, quadrant) piece and per blending (pixel, entry) pair
     uint32_t *piece_ub = nullptr;     // [capSegs][4][4]  lanes x surviving entries with alpha > 0 (k_seg_T): upper bound of the piece's records
     uint2 *piece_rec = nullptr;       // [capSegs][4][4]  (first record, number of records) of a piece k_seg_fwd found alive
+    uint8_t *piece_cnt = nullptr;     // [capSegs][4][4][64]  records per entry of the piece (entry-major inside the region: a lane walks its entry's run)
     float2 *rec_ti = nullptr;         // [capRec] (T in front of the entry at the pixel, bits: entry of the sub-range << 6 | pixel of the quadrant)
     float4 *rec_acc = nullptr;        // [capRec] colour the piece had added to the pixel in front of the entry
     int64_t capRec = 0;

@@ -114,6 +114,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 struct GomRecArgs {
     uint32_t *piece_ub;      // null: records off
     uint2 *piece_rec;
+    uint8_t *piece_cnt;      // [piece][64] records per entry
     float2 *rec_ti;
     float4 *rec_acc;
     uint32_t *cursor;        // GOM_REC_SHARDS heads, 32 words apart
@@ -854,7 +855,7 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
 #endif
             // (REC) the piece's record region: upper bound from k_seg_T, one dequeue-like atomic per live piece
             const uint32_t piece = ((seg * GOM_NSUB + (uint32_t)sub) << 2) | (uint32_t)q;
-            uint32_t rbase = 0, rcur = 0, rub = 0;
+            uint32_t rbase = 0, rcur = 0, rub = 0, my_cnt = 0;   // my_cnt: records of entry `lane` of the sub-range (v_writelane, one per entry)
             bool rec_on = false;
             if (REC) {
                 rub = __builtin_amdgcn_readfirstlane(rec.piece_ub[piece]);
@@ -921,7 +922,9 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
                                 rec.rec_acc[idx] = make_float4(acc[0], C > 1 ? acc[1 % C] : 0.f, C > 2 ? acc[2 % C] : 0.f, C > 3 ? acc[3 % C] : 0.f);
                                 rec.rec_ti[idx] = make_float2(T, __uint_as_float(((uint32_t)kk[u] << 6) | (uint32_t)lane));
                             }
-                            rcur += (uint32_t)__popcll(bm);
+                            const uint32_t nb = (uint32_t)__popcll(bm);
+                            rcur += nb;
+                            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(my_cnt) : "s"(nb), "s"((uint32_t)kk[u]) : "m0");   // lane kk[u] <- nb (both wave-uniform; one SGPR per VALU operand set: the lane select goes through M0)
                         }
                     }
 #pragma unroll
@@ -932,7 +935,10 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
                 }
                 if (__ballot(wl != 0.f) == 0ull) break;
             }
-            if (REC && lane == 0) rec.piece_rec[piece] = make_uint2(rbase, rec_on ? rcur - rbase : (rub ? 0xffffffffu : 0u));
+            if (REC) {
+                rec.piece_cnt[(size_t)piece * 64 + lane] = (uint8_t)my_cnt;
+                if (lane == 0) rec.piece_rec[piece] = make_uint2(rbase, rec_on ? rcur - rbase : (rub ? 0xffffffffu : 0u));
+            }
         }
         // dead on arrival: T = 0.  stopped inside: -T.  still going: +T.
         s_t[sub][lane] = (T > 0.f && wl == 0.f) ? -T : T;
@@ -1613,7 +1619,7 @@ static int task_grid(int resident, int pct) {   // GOM_OPT_TASK_GRID_PCT of the 
 #endif
 
 static GomRecArgs rec_args(GomState *s) {
-    return GomRecArgs{s->piece_ub, s->piece_rec, s->rec_ti, s->rec_acc, &s->status->rec_cursor[0][0], &s->status->rec_overflow, (uint32_t)(s->capRec / GOM_REC_SHARDS)};
+    return GomRecArgs{s->piece_ub, s->piece_rec, s->piece_cnt, s->rec_ti, s->rec_acc, &s->status->rec_cursor[0][0], &s->status->rec_overflow, (uint32_t)(s->capRec / GOM_REC_SHARDS)};
 }
 // which render backward a forward prepares for: records only on request (GOM_OPT_BWD_MODE 3) -- measured slower than the replay on the
 // metric workload (profiles/r04_records_backward.txt), auto (-1) keeps the replay kernels
@@ -1681,7 +1687,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
 #define GOM_RB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_rec_bwd<CC>), dim3(GOM_RESIDENT(k_rec_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \
-                       s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, GOM_TASK_CTR, ra)
+                       s->sub_C, s->seg_Sbehind, s->ent_slot, s->partial, s->status, ra)
         if (C == 3) GOM_RB(3); else GOM_RB(4);
 #undef GOM_RB
         GOM_LAUNCH_CHECK();
