@@ -95,6 +95,7 @@ SIGNATURES = {
     "gom_lpips_layer_backward_nhwc_bf16": (c_int, [c_int] * 3 + [c_void_p] * 6),
     "gom_lpips_vgg_create": (c_void_p, [c_void_p] * 6),
     "gom_lpips_vgg_destroy": (None, [c_void_p]),
+    "gom_lpips_vgg_set_first_layer": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gom_lpips_vgg_set_precision": (c_int, [c_void_p, c_int32]),
     "gom_lpips_vgg_value_and_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint32, c_void_p]),
     "gom_mesh_raster_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -16,6 +16,7 @@ struct GomLpipsVgg {
     const void *w_fwd[13], *w_bwd[13];
     const float *bias[13], *lin[5];
     int cin[13], cout[13];
+    const void *w1_fwd = nullptr, *w1_bwd = nullptr;   // first layer as a 1 x 1 convolution over im2col rows (gom_lpips_vgg_set_first_layer; vgg_bf16.hip)
     int x3 = 0;                                  // GOM_LPIPS_PRECISION_BF16X3: two bf16 planes per tensor, three MFMA passes (vgg_bf16.hip)
     size_t lo_x = 0, lo_act[13] = {}, lo_pooled[13] = {}, lo_g = 0;   // element offsets of the lo planes (0 in the plain mode)
     // workspace for (B, H, W)
@@ -69,6 +70,13 @@ extern "C" int gom_lpips_vgg_set_precision(GomLpipsVgg *h, int32_t precision) {
     if (!h || (precision != GOM_LPIPS_PRECISION_BF16 && precision != GOM_LPIPS_PRECISION_BF16X3)) { gom_set_error("gom_lpips_vgg_set_precision: bad argument"); return -1; }
     if (h->x3 != (precision == GOM_LPIPS_PRECISION_BF16X3)) lp_free(h);   // other buffer sizes; the weights the handle points at must match
     h->x3 = precision == GOM_LPIPS_PRECISION_BF16X3;
+    return 0;
+}
+
+extern "C" int gom_lpips_vgg_set_first_layer(GomLpipsVgg *h, const void *w1x1_fwd, const void *w1x1_bwd) {
+    if (!h || (w1x1_fwd == nullptr) != (w1x1_bwd == nullptr)) { gom_set_error("gom_lpips_vgg_set_first_layer: both weight blocks or none"); return -1; }
+    if ((h->w1_fwd != nullptr) != (w1x1_fwd != nullptr)) lp_drop_graph(h);   // (a recorded sequence holds the other layer-0 launches)
+    h->w1_fwd = w1x1_fwd; h->w1_bwd = w1x1_bwd;
     return 0;
 }
 
@@ -164,8 +172,9 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
                       float *d_pred, void *stream) {
     int rc;
     const float *img[2] = {pred, gt};
+    const bool im2col = h->w1_fwd != nullptr;   // conv1_1 without its channel padding (vgg_bf16.hip: k_lpips_prepare_im2col)
     for (int k = 0; k < 2; k++)
-        if ((rc = gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
+        if ((rc = im2col ? gom_lpips_prepare_im2col_planes(B, H, W, img[k], h->x[k], h->lo_x, stream) : gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
     {
         int hh = H, ww = W;
         const void *cur = h->x[0];
@@ -176,7 +185,9 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
                 hh /= 2; ww /= 2;
                 cur = h->pooled[0][i]; cur_lo = h->lo_pooled[i];
             }
-            if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
+            if (i == 0 && im2col) {
+                if ((rc = gom_conv1x1_planes((size_t)2 * B * hh * ww, 32, h->cout[0], cur, h->w1_fwd, h->bias[0], h->act[0][0], 1, cur_lo, h->lo_act[0], stream))) return rc;
+            } else if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
             cur = h->act[0][i]; cur_lo = h->lo_act[i];
         }
     }
@@ -216,6 +227,10 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         const void *mask = (i > 0 && !kPoolBefore[i]) ? h->act[0][i - 1] : nullptr;
         void *dst = h->grad[pp];
         pp ^= 1;
+        if (i == 0 && im2col) {   // d(im2col rows) = W^T dY as a 1 x 1 convolution 64 -> 32; the col2im gather rides in the unprepare kernel
+            if ((rc = gom_conv1x1_planes((size_t)B * hh * ww, h->cout[0], 32, g, h->w1_bwd, nullptr, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
+            return gom_lpips_unprepare_col2im_planes(B, H, W, dst, d_pred, h->lo_g, stream);
+        }
         if ((rc = lp_conv(h, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
         g = dst;
     }

@@ -471,6 +471,116 @@ __global__ void __launch_bounds__(256) k_lpips_unprepare(size_t npix, int Cpad, 
     }
 }
 
+// ---- the trunk's FIRST layer without its channel padding (round 4) -----------------------------------------------------------------------
+// conv1_1 has 3 input channels; padded to the 32-channel chunk of k_conv3x3_bf16 it issues nine taps of 32 channels of which 29 are zero
+// (9.7 GFLOP per 512^2 image instead of 0.9), and its backward-data pass -- 64 -> 3 channels padded to 64 -- is a full 64 -> 64 convolution.
+// Here the input is laid out as IM2COL rows instead: channel k = 3 (3 ky + kx) + c of pixel p holds the scaled value of pixel p + (ky-1, kx-1),
+// zero outside the image (27 of 32 channels used), so that conv1_1 is a 1 x 1 convolution with K = 32 -- one MFMA k-step per plane pair --
+// and its backward-data pass a 1 x 1 convolution 64 -> 32 followed by the col2im gather inside the "unprepare" kernel.  Both are HBM-bound
+// streams (forward: 128 B in, 256 B out per pixel and plane pair) instead of MFMA-bound tiles.  Same products, same fp32 accumulation.
+__global__ void __launch_bounds__(256) k_lpips_prepare_im2col(int B, int H, int W, const float *__restrict__ rgb, bf16_t *__restrict__ out, size_t out_lo) {
+    const float shift[3] = {-0.030f, -0.088f, -0.188f}, scale[3] = {0.458f, 0.448f, 0.450f};
+    const size_t npix = (size_t)B * H * W;
+    // one thread per (pixel, group of 8 channels): a 16-byte store per plane
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix * 4; i += (size_t)gridDim.x * 256) {
+        const size_t p = i >> 2;
+        const int part = (int)(i & 3);
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const size_t img0 = p - (size_t)y * W - x;   // first pixel of the image
+        bf16_t hi[8], lo[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = part * 8 + r;
+            float v = 0.f;
+            if (k < 27) {
+                const int tap = k / 3, c = k % 3;
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = ((2.f * rgb[3 * (img0 + (size_t)yy * W + xx) + c] - 1.f) - shift[c]) / scale[c];
+            }
+            if (out_lo) split_bf(v, hi[r], lo[r]); else { hi[r] = f2bf(v); lo[r] = 0; }
+        }
+        auto pack = [](const bf16_t (&q)[8]) { return make_uint4((uint32_t)q[0] | ((uint32_t)q[1] << 16), (uint32_t)q[2] | ((uint32_t)q[3] << 16),
+                                                                   (uint32_t)q[4] | ((uint32_t)q[5] << 16), (uint32_t)q[6] | ((uint32_t)q[7] << 16)); };
+        *reinterpret_cast<uint4 *>(out + p * 32 + part * 8) = pack(hi);
+        if (out_lo) *reinterpret_cast<uint4 *>(out + out_lo + p * 32 + part * 8) = pack(lo);
+    }
+}
+// d rgb of the (B,H,W,3) image in [0,1] from the gradient w.r.t. the im2col rows: pixel p's channel c collects column 3 t + c of every pixel
+// q = p - offset(t) that has p as its tap t
+__global__ void __launch_bounds__(256) k_lpips_unprepare_col2im(int B, int H, int W, const bf16_t *__restrict__ d_col, float *__restrict__ d_rgb, size_t in_lo) {
+    const float scale[3] = {0.458f, 0.448f, 0.450f};
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        float g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int qy = y - (tap / 3 - 1), qx = x - (tap % 3 - 1);
+            if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+            const bf16_t *row = d_col + (p + (size_t)(qy - y) * W + (qx - x)) * 32 + 3 * tap;
+#pragma unroll
+            for (int c = 0; c < 3; c++) g[c] += load1(row + c, in_lo);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) d_rgb[3 * p + c] = g[c] * (2.f / scale[c]);
+    }
+}
+// 1 x 1 convolution on NHWC rows: out[p][co] = sum_k in[p][k] w[co][k] (+ bias, ReLU), Cin a multiple of 32, Cout = 16 NT.
+// wt [virtual chunk][Cout][32] bf16 (bf16x3: three virtual chunks per 32 input channels, (w_hi, w_hi, w_lo) for (x_hi, x_lo, x_hi), as the
+// 3 x 3 kernels).  A wave owns 32 pixels (two MFMA tiles) x all output channels; operands go straight from global memory into the MFMA
+// fragments (a lane reads the 16 bytes of k-group `kg` of its pixel / its output channel: the weights are a few KB and stay in L1).
+template <bool RELU, int NT>
+__global__ void __launch_bounds__(256) k_conv1x1_bf16(size_t npix, int Cin, const bf16_t *__restrict__ in, const bf16_t *__restrict__ wt, const float *__restrict__ bias,
+                                                      bf16_t *__restrict__ out, size_t in_lo, size_t out_lo) {
+    constexpr int Cout = 16 * NT;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwave = ((size_t)gridDim.x * 256) >> 6;
+    const int nsrc = Cin / 32, nchunk = in_lo ? 3 * nsrc : nsrc;
+    for (size_t p0 = wave * 32; p0 < npix; p0 += nwave * 32) {
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < nchunk; cc++) {
+            const int sc = in_lo ? cc / 3 : cc;
+            const bf16_t *plane = in + ((in_lo && cc % 3 == 1) ? in_lo : 0);
+            bf16x8 bfrag[2], afrag[NT];
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const size_t px = p0 + 16 * m + l15;
+                bfrag[m] = px < npix ? *reinterpret_cast<const bf16x8 *>(plane + px * Cin + sc * 32 + kg * 8) : bf16x8{};
+            }
+#pragma unroll
+            for (int n = 0; n < NT; n++) afrag[n] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)cc * Cout + n * 16 + l15) * 32 + kg * 8);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
+        }
+        // D[i = co][j = px]: the lane holds co = 16 n + 4 kg + r (r = 0..3) of pixel l15
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const size_t px = p0 + 16 * m + l15;
+            if (px >= npix) continue;
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int co = n * 16 + kg * 4;
+                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+                }
+                if (RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+                }
+                store4(out + px * Cout + co, out_lo, v);
+            }
+        }
+    }
+}
+
 // ---- LPIPS head on NHWC bf16 taps: 16 lanes per pixel, each lane strides over the channels 8 at a time ----------------
 constexpr float kEps = 1e-10f;
 __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a DPP row
@@ -697,6 +807,35 @@ int gom_lpips_prepare_planes(int B, int H, int W, const float *rgb, void *out32,
     if (!rgb || !out32 || npix == 0) { gom_set_error("gom_lpips_prepare_bf16: bad arguments"); return -1; }
     hipLaunchKernelGGL(k_lpips_prepare, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, npix, rgb,
                        (bf16_t *)out32, out_lo);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+// first layer as im2col rows + 1 x 1 convolutions (see k_lpips_prepare_im2col)
+int gom_lpips_prepare_im2col_planes(int B, int H, int W, const float *rgb, void *out32, size_t out_lo, void *stream) {
+    const size_t units = (size_t)B * H * W * 4;
+    if (!rgb || !out32 || units == 0) { gom_set_error("gom_lpips_prepare_im2col: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_lpips_prepare_im2col, dim3((unsigned)((units + 255) / 256 < 8192 ? (units + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, B, H, W, rgb,
+                       (bf16_t *)out32, out_lo);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+int gom_lpips_unprepare_col2im_planes(int B, int H, int W, const void *d_col, float *d_rgb, size_t in_lo, void *stream) {
+    const size_t npix = (size_t)B * H * W;
+    if (!d_col || !d_rgb || npix == 0) { gom_set_error("gom_lpips_unprepare_col2im: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_lpips_unprepare_col2im, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, B, H, W,
+                       (const bf16_t *)d_col, d_rgb, in_lo);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+int gom_conv1x1_planes(size_t npix, int Cin, int Cout, const void *in, const void *wt, const float *bias, void *out, int relu, size_t in_lo, size_t out_lo, void *stream) {
+    if (!in || !wt || !out || npix == 0 || Cin % 32 || (Cout != 32 && Cout != 64)) { gom_set_error("gom_conv1x1: Cin a multiple of 32, Cout 32 or 64"); return -1; }
+    const size_t waves = (npix + 31) / 32;
+    const unsigned grid = (unsigned)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);
+#define GOM_C1(RL, NT_) hipLaunchKernelGGL((k_conv1x1_bf16<RL, NT_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, npix, Cin, (const bf16_t *)in, (const bf16_t *)wt, bias, (bf16_t *)out, in_lo, out_lo)
+    if (Cout == 64) { if (relu) GOM_C1(true, 4); else GOM_C1(false, 4); }
+    else { if (relu) GOM_C1(true, 2); else GOM_C1(false, 2); }
+#undef GOM_C1
     GOM_LAUNCH_CHECK();
     return 0;
 }

@@ -171,6 +171,26 @@ def pack_conv_weight_backward(w: torch.Tensor) -> torch.Tensor:
     return pack_conv_weight(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
 
 
+def pack_first_layer(w: torch.Tensor, x3: bool):
+    """conv1_1 (Cout, 3, 3, 3) as 1 x 1 convolutions over im2col rows (csrc/vgg_bf16.hip: k_lpips_prepare_im2col): column
+    k = 3 (3 ky + kx) + c.  -> (forward [chunks][Cout][32], backward-data [chunks per 32 of Cout][32][32]) bf16; bf16x3: every chunk three
+    times (hi, hi, lo), the partners of (x_hi, x_lo, x_hi)."""
+    co = w.shape[0]
+    assert tuple(w.shape[1:]) == (3, 3, 3) and co % 32 == 0
+    w1 = torch.zeros(co, 32, dtype=torch.float32, device=w.device)
+    w1[:, :27] = w.permute(0, 2, 3, 1).reshape(co, 27)
+
+    def planes(t):          # t: [chunks][rows][32] fp32
+        hi = t.to(torch.bfloat16)
+        if not x3:
+            return hi.contiguous()
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return torch.stack([hi, hi, lo], 1).reshape(3 * t.shape[0], t.shape[1], 32).contiguous()
+    fwd = planes(w1[None])                                                   # one source chunk: the 32 im2col columns
+    bwd = planes(w1.T.reshape(32, co // 32, 32).permute(1, 0, 2))            # [co / 32][k = 32][co_local = 32]
+    return fwd, bwd
+
+
 class LPIPSMatrixCore:
     """LPIPS-VGG value AND gradient w.r.t. the predicted image in one pass (train.py:113-121 semantics:
     `mean_b LPIPS(2*pred-1, 2*gt-1)`), bf16 activations / fp32 accumulation on MFMA.
@@ -190,6 +210,7 @@ class LPIPSMatrixCore:
         lin = np.load(_DATA)
         self.lins = [torch.from_numpy(lin[f"lin{k}"].astype(np.float32).reshape(-1)).to(dev).contiguous() for k in range(5)]
         self._h = None
+        self.first_layer_im2col = os.environ.get("GOM_LPIPS_FIRST_LAYER_IM2COL", "1") != "0"   # (development switch: 0 = the padded 3 x 3 kernels for conv1_1 too)
         self.set_trunk([t.to(dev) for t in seeded_trunk(trunk_seed)])
 
     def set_trunk(self, wb: Sequence[torch.Tensor]) -> None:
@@ -206,6 +227,8 @@ class LPIPSMatrixCore:
                      for i in range(13)]
         self.cin = [_pad_to(wb[2 * i].shape[1], 32) for i in range(13)]
         self.cout = [_pad_to(wb[2 * i].shape[0], 64) for i in range(13)]
+        # the first layer without its channel padding (3 of 32 input channels are real): 1 x 1 convolutions over im2col rows
+        self.w1 = pack_first_layer(wb[0], self.precision == "bf16x3") if (self.first_layer_im2col and tuple(wb[0].shape) == (64, 3, 3, 3)) else None
 
     def load_trunk_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         wb = []
@@ -225,6 +248,8 @@ class LPIPSMatrixCore:
             if not self._h:
                 _lib.check(-1)
             _lib.check(self.lib.gom_lpips_vgg_set_precision(self._h, 1 if self.precision == "bf16x3" else 0))
+            if self.w1 is not None:
+                _lib.check(self.lib.gom_lpips_vgg_set_first_layer(self._h, _lib.ptr(self.w1[0]), _lib.ptr(self.w1[1])))
         return self._h
 
     def __del__(self):

@@ -314,6 +314,13 @@ void gom_lpips_vgg_destroy(GomLpipsVgg *h);
 #define GOM_LPIPS_PRECISION_BF16 0
 #define GOM_LPIPS_PRECISION_BF16X3 1
 int gom_lpips_vgg_set_precision(GomLpipsVgg *h, int32_t precision);
+/* The trunk's FIRST layer without its channel padding: conv1_1 (3 input channels) as a 1 x 1 convolution over im2col rows (channel
+ * 3 (3 ky + kx) + c of a pixel = its neighbour (ky-1, kx-1), zero outside the image) and its backward-data pass as a 1 x 1 convolution
+ * 64 -> 32 + a col2im gather -- 9x / 21x fewer MFMA than the padded 3 x 3 kernels, same products and accumulation
+ * (pretrained_networks.py:96-101: `slice1`'s first Conv2d(3, 64, 3, padding=1)).  w1x1_fwd: [chunks][64][32] bf16 with
+ * w[co][3 (3 ky + kx) + c] = W[co][c][ky][kx]; w1x1_bwd: [chunks][32][32] per 32 output channels of conv1_1, the transpose; chunks = 1
+ * (bf16) or 3 per 32 input channels (bf16x3: hi, hi, lo).  NULL, NULL: back to the padded 3 x 3 path. */
+int gom_lpips_vgg_set_first_layer(GomLpipsVgg *h, const void *w1x1_fwd, const void *w1x1_bwd);
 #define GOM_LPIPS_USE_GRAPH 1u   /* capture the ~75 launches once per (sizes, pointers) and replay them as one hipGraph */
 int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
                                  float grad_scale, float *d_pred, uint32_t flags, void *stream);
