@@ -154,7 +154,11 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         last_alpha = al.x;
         one_minus_last = oma.x;
         const v2f dLa = __builtin_elementwise_fma(U - Rv, Tv, (inv * v2f{ntf, ntf}) * v2f{bg_dot, bg_dot});
-        const v2f Q = (e.og * mm) * dLa;   // Q = opacity * G * dL/dalpha where the entry blends (the per-Gaussian backward no longer multiplies by the opacity)
+        // Q = opacity * G * dL/dalpha where the entry blends (the per-Gaussian backward no longer multiplies by the opacity).  An INDEFINITE conic (a
+        // caller's non-PSD covariance) can overflow the exponential where the entry is skipped (pw > 0, mm = 0): inf * 0 would poison the sums the
+        // reference never touches (`power > 0.f -> continue`), so og is capped at a finite stand-in first (tests: test_fuzz_indefinite_covariances)
+        const v2f og_f = {fminf(e.og.x, 3.0e38f), fminf(e.og.y, 3.0e38f)};
+        const v2f Q = (og_f * mm) * dLa;
         z[4] = Q;
         z[5] = Q * dx;
         z[6] = Q * dy;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + stats of the default bench command, then two separate PMC passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950), everything under gpurun_out/prof_$TAG.
-TAG=${1:-r03}
+TAG=${1:-r04}
 BENCH_ARGS=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG

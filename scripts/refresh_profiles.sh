@@ -3,7 +3,7 @@
 # copy them into profiles/ afterwards):   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
 # Runs TWICE the PMC-derived pieces feed bench.py: the bench line of the second pass carries roofline.traffic / roofline.valu read
 # from the json files the first pass produced (copy them to profiles/ in between, or simply run this script twice).
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1                       # default bench: one step in flight
 bash scripts/collect_profiles.sh ${TAG}_inflight3 "--inflight 3" > gpurun_out/collect_${TAG}_inflight3.log 2>&1
