@@ -14,7 +14,7 @@ constexpr int kRows = 32;   // rows staged per trip
 // one workgroup: row slice blockIdx.x of gridDim.x, the 64 x 64 block (o0, i0) of out x in; 256 threads = 16 x 16 sub-blocks of 4 x 4
 __device__ __forceinline__ void wgrad_partial_block(int64_t n, int in_dim, int out_dim, const float *__restrict__ X, const float *__restrict__ dY,
                                                     float *__restrict__ partial /* [slices][129][128]: row 128 = bias */, int o0, int i0) {
-    __shared__ __attribute__((aligned(16))) float s_x[kRows][64], s_y[kRows][64];
+    __shared__ __attribute__((aligned(16))) float s_x[kRows][64], s_y[kRows][64];   // (n may come from device memory: gom_shade_*, below)
     const int tid = threadIdx.x, to = tid >> 4, ti = tid & 15;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r_lo = (int64_t)blockIdx.x * per, r_hi = r_lo + per < n ? r_lo + per : n;
@@ -80,7 +80,8 @@ struct WgradLayers {
     float *dW[4], *db[4];
     int in_dim[4], out_dim[4];
 };
-__global__ void __launch_bounds__(256) k_mlp3_wgrad_partial(int64_t n, WgradLayers L, float *__restrict__ partial, int slices) {
+__global__ void __launch_bounds__(256) k_mlp3_wgrad_partial(int64_t n, WgradLayers L, float *__restrict__ partial, int slices, const int32_t *__restrict__ n_dev) {
+    if (n_dev) n = (int64_t)n_dev[0] + 1;   // rows under the mesh + the background row (gom_shade_*)
     const int layer = blockIdx.z >> 1, o0 = blockIdx.y * 64, i0 = (blockIdx.z & 1) * 64;
     if (o0 >= L.out_dim[layer] || i0 >= L.in_dim[layer]) return;
     wgrad_partial_block(n, L.in_dim[layer], L.out_dim[layer], L.X[layer], L.dY[layer], partial + (size_t)layer * slices * 129 * 128, o0, i0);
@@ -204,11 +205,12 @@ __global__ void __launch_bounds__(256) k_mlp3_fwd(int64_t n, int D0, int H, cons
                                                   const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
                                                   const float *__restrict__ W3, const float *__restrict__ b3, const float *__restrict__ w4,
                                                   const float *__restrict__ b4, float *__restrict__ h1, float *__restrict__ h2,
-                                                  float *__restrict__ h3, float *__restrict__ out) {
+                                                  float *__restrict__ h3, float *__restrict__ out, const int32_t *__restrict__ n_dev) {
     __shared__ __attribute__((aligned(16))) float s_a[kHW][kTRP];
     __shared__ __attribute__((aligned(16))) float s_w[32][kWP];
     const int tid = threadIdx.x, cg = tid & 31, rg = tid >> 5;
     const int64_t r0 = (int64_t)blockIdx.x * kTR;
+    if (n_dev) { n = (int64_t)n_dev[0] + 1; if (r0 >= n) return; }   // row count in device memory (gom_shade_*): the grid covers the capacity
     const int rows = (int)min<int64_t>(kTR, n - r0);
     for (int idx = tid; idx < kTR * D0; idx += 256) {   // the workgroup's rows are one contiguous piece of x
         const int rr = idx / D0, i = idx - rr * D0;
@@ -263,12 +265,13 @@ __global__ void __launch_bounds__(256) k_mlp3_bwd(int64_t n, int D0, int H, cons
                                                   const float *__restrict__ h1, const float *__restrict__ h2, const float *__restrict__ h3,
                                                   const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
                                                   const float *__restrict__ w4, float *__restrict__ dz4, float *__restrict__ dz3,
-                                                  float *__restrict__ dz2, float *__restrict__ dz1, float *__restrict__ dx) {
+                                                  float *__restrict__ dz2, float *__restrict__ dz1, float *__restrict__ dx, const int32_t *__restrict__ n_dev) {
     __shared__ __attribute__((aligned(16))) float s_a[kHW][kTRP];
     __shared__ __attribute__((aligned(16))) float s_w[32][kWP];
     __shared__ float s_d4[kTR];
     const int tid = threadIdx.x, cg = tid & 31, rg = tid >> 5;
     const int64_t r0 = (int64_t)blockIdx.x * kTR;
+    if (n_dev) { n = (int64_t)n_dev[0] + 1; if (r0 >= n) return; }
     const int rows = (int)min<int64_t>(kTR, n - r0);
     const bool cols = 4 * cg < H;
     if (tid < kTR) {
@@ -331,44 +334,257 @@ __global__ void __launch_bounds__(256) k_mlp3_bwd(int64_t n, int D0, int H, cons
 
 }  // namespace
 
-extern "C" int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
-                                const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out,
-                                void *stream) {
+static int mlp3_forward_impl(int64_t n, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out,
+                             const int32_t *n_dev, void *stream) {
     if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_forward: widths must be in 1..128"); return -1; }
     if (H % 4) { gom_set_error("gom_mlp3_forward: the hidden width must be a multiple of 4"); return -1; }
     if (n == 0) return 0;
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !w4 || !b4 || !h1 || !h2 || !h3 || !out) { gom_set_error("gom_mlp3_forward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_mlp3_fwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2,
-                       h3, out);
+                       h3, out, n_dev);
     GOM_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int gom_mlp3_forward(int64_t n, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                                const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out,
+                                void *stream) {
+    return mlp3_forward_impl(n, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2, h3, out, nullptr, stream);
+}
 
-extern "C" int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
-                                 const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
-                                 float *dx, void *stream) {
+static int mlp3_backward_impl(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
+                              const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
+                              float *dx, const int32_t *n_dev, void *stream) {
     if (n < 0 || D0 < 1 || D0 > kHW || H < 1 || H > kHW) { gom_set_error("gom_mlp3_backward: widths must be in 1..128"); return -1; }
     if (H % 4) { gom_set_error("gom_mlp3_backward: the hidden width must be a multiple of 4"); return -1; }
     if (n == 0) return 0;
     if (!g || !out || !h1 || !h2 || !h3 || !W1 || !W2 || !W3 || !w4 || !dz4 || !dz3 || !dz2 || !dz1 || !dx) { gom_set_error("gom_mlp3_backward: null pointer"); return -1; }
     hipLaunchKernelGGL(k_mlp3_bwd, dim3((unsigned)((n + kTR - 1) / kTR)), dim3(256), 0, (hipStream_t)stream, n, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4,
-                       dz3, dz2, dz1, dx);
+                       dz3, dz2, dz1, dx, n_dev);
     GOM_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int gom_mlp3_backward(int64_t n, int D0, int H, const float *g, const float *out, const float *h1, const float *h2, const float *h3,
+                                 const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1,
+                                 float *dx, void *stream) {
+    return mlp3_backward_impl(n, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4, dz3, dz2, dz1, dx, nullptr, stream);
+}
 
-extern "C" int gom_mlp3_wgrad(int64_t n, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3, const float *dz1, const float *dz2,
-                              const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3, float *dW4,
-                              float *db4, float *workspace, void *stream) {
+static int mlp3_wgrad_impl(int64_t n, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3, const float *dz1, const float *dz2,
+                           const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3, float *dW4,
+                           float *db4, float *workspace, const int32_t *n_dev, void *stream) {
     if (n <= 0 || D0 < 1 || D0 > 128 || H < 1 || H > 128) { gom_set_error("gom_mlp3_wgrad: widths must be in 1..128"); return -1; }
     if (!x || !h1 || !h2 || !h3 || !dz1 || !dz2 || !dz3 || !dz4 || !dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || !dW4 || !db4 || !workspace) {
         gom_set_error("gom_mlp3_wgrad: null pointer"); return -1;
     }
     WgradLayers L = {{x, h1, h2, h3}, {dz1, dz2, dz3, dz4}, {dW1, dW2, dW3, dW4}, {db1, db2, db3, db4}, {D0, H, H, H}, {H, H, H, 1}};
     const int slices = gom_linear_wgrad_slices();
-    hipLaunchKernelGGL(k_mlp3_wgrad_partial, dim3(slices, 2, 8), dim3(256), 0, (hipStream_t)stream, n, L, workspace, slices);
+    hipLaunchKernelGGL(k_mlp3_wgrad_partial, dim3(slices, 2, 8), dim3(256), 0, (hipStream_t)stream, n, L, workspace, slices, n_dev);
     GOM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mlp3_wgrad_reduce, dim3((129 * 128 + 255) / 256, 4), dim3(256), 0, (hipStream_t)stream, slices, L, workspace);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gom_mlp3_wgrad(int64_t n, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3, const float *dz1, const float *dz2,
+                              const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2, float *dW3, float *db3, float *dW4,
+                              float *db4, float *workspace, void *stream) {
+    return mlp3_wgrad_impl(n, D0, H, x, h1, h2, h3, dz1, dz2, dz3, dz4, dW1, db1, dW2, db2, dW3, db3, dW4, db4, workspace, nullptr, stream);
+}
+
+// =====================================================================================================================================
+// Shading of the pixels under the mesh, fused (round 4): models/model.py:279-283 evaluates shadow_module(normal) for every pixel; the
+// normal map is exactly zero outside the mesh (~85 % of a frame), where the MLP's output is one constant.  The host layer used to select
+// the pixels under the mesh with torch (ne / any / nonzero -- a host synchronisation --, index_select, cat, the embedding kernel,
+// index_put, split, clone ... ~35 launches forward + backward of the drop-in Model's iteration).  Here:
+//   gom_shade_select     ordered compaction of the pixels with a non-zero normal (two kernels: counts per 1 024 pixels, then positions),
+//                        their positional encoding written straight into the MLP's input rows, row n = the background's (the zero normal);
+//                        the row count stays in DEVICE memory -- no host synchronisation, static shapes (capacity = every pixel)
+//   gom_mlp3_*_rows      the MLP kernels above with the row count read from that word (blocks beyond it return at once)
+//   gom_shade_scatter    shading = scale * out[row of the pixel, or the background row]
+//   gom_shade_backward_gather   d out rows from the image gradient (background row: the sum over the pixels outside the mesh, block
+//                        partials added in block order by the last block to finish: one summation order)
+//   gom_shade_backward_scatter  d normal = the embedding's backward of the pixel's row, zero outside the mesh
+// Rows are in pixel order, as nonzero() returned them: the weight gradients sum the same rows in the same order as before.
+namespace {
+constexpr int kShadePx = 1024;   // pixels per workgroup of the selection kernels (4 per thread, consecutive)
+
+__device__ __forceinline__ bool shade_under(const float *normal, size_t p) { return normal[3 * p] != 0.f || normal[3 * p + 1] != 0.f || normal[3 * p + 2] != 0.f; }
+
+__global__ void __launch_bounds__(256) k_shade_count(size_t HW, const float *__restrict__ normal, int32_t *__restrict__ blk_cnt) {
+    __shared__ int s_w[4];
+    const size_t p0 = (size_t)blockIdx.x * kShadePx + 4 * threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) c += (p0 + k < HW && shade_under(normal, p0 + k)) ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__device__ __forceinline__ void posenc_row(const float *v, int L, float *o) {   // k_posenc_fwd's arithmetic (posenc.hip), one row
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    for (int l = 0; l < L; l++) {
+        const float f = (float)(1u << l);
+        float *q = o + 3 + 6 * l;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { q[c] = sinf(v[c] * f); q[3 + c] = cosf(v[c] * f); }
+    }
+}
+__global__ void __launch_bounds__(256) k_shade_place(size_t HW, int L, const float *__restrict__ normal, const int32_t *__restrict__ blk_cnt, int nblk,
+                                                     int32_t *__restrict__ pos, float *__restrict__ pe, int32_t *__restrict__ n_dev) {
+    __shared__ int s_w[4], s_base;
+    // rows in front of this workgroup's pixels: the counts of the workgroups before it (a few hundred words from L2)
+    int b = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) b += blk_cnt[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    const size_t p0 = (size_t)blockIdx.x * kShadePx + 4 * threadIdx.x;
+    bool u[4];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { u[k] = p0 + k < HW && shade_under(normal, p0 + k); c += u[k] ? 1 : 0; }
+    // exclusive scan of the per-thread counts over the workgroup
+    int incl = c;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); incl += lane >= d ? o : 0; }
+    __syncthreads();
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int off = s_base + incl - c;
+    for (int w = 0; w < wv; w++) off += s_w[w];
+    const int D = 3 + 6 * L;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (p0 + k >= HW) break;
+        pos[p0 + k] = u[k] ? off : -1;
+        if (u[k]) { posenc_row(normal + 3 * (p0 + k), L, pe + (size_t)off * D); off++; }
+    }
+    if (blockIdx.x == (unsigned)nblk - 1 && threadIdx.x == 255) {   // the last thread of the last workgroup knows the total
+        n_dev[0] = off;
+        const float z[3] = {0.f, 0.f, 0.f};
+        posenc_row(z, L, pe + (size_t)off * D);   // the background's row
+    }
+}
+__global__ void __launch_bounds__(256) k_shade_scatter(size_t HW, const int32_t *__restrict__ pos, const float *__restrict__ out, const int32_t *__restrict__ n_dev,
+                                                       float scale, float *__restrict__ shading) {
+    const int n = n_dev[0];
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+        const int r = pos[p];
+        shading[p] = scale * out[r >= 0 ? r : n];
+    }
+}
+// g_rows[row] = scale * g[p] under the mesh; g_rows[n] = scale * sum of g over the pixels outside it
+__global__ void __launch_bounds__(256) k_shade_bwd_gather(size_t HW, const int32_t *__restrict__ pos, const float *__restrict__ g, const int32_t *__restrict__ n_dev,
+                                                          float scale, float *__restrict__ g_rows, float *__restrict__ partial, uint32_t *__restrict__ done) {
+    __shared__ float s_w[4];
+    __shared__ bool s_last;
+    float acc = 0.f;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+        const int r = pos[p];
+        const float v = g[p];
+        if (r >= 0) g_rows[r] = scale * v; else acc += v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        __threadfence();
+        s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {   // block partials in block order: one summation order whatever block finishes last
+        __threadfence();
+        float t = 0.f;
+        for (unsigned i = 0; i < gridDim.x; i++) t += partial[i];
+        g_rows[n_dev[0]] = scale * t;
+        *done = 0;
+    }
+}
+// d normal [HW][3]: the embedding's backward (k_posenc_bwd's arithmetic) of the pixel's row of dpe, zero outside the mesh
+__global__ void __launch_bounds__(256) k_shade_bwd_scatter(size_t HW, int L, const int32_t *__restrict__ pos, const float *__restrict__ normal,
+                                                           const float *__restrict__ dpe, float *__restrict__ d_normal) {
+    const int D = 3 + 6 * L;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+        const int r = pos[p];
+        float o[3] = {0.f, 0.f, 0.f};
+        if (r >= 0) {
+            const float *gr = dpe + (size_t)r * D;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v = normal[3 * p + c];
+                float acc = gr[c];
+                for (int l = 0; l < L; l++) {
+                    const float f = (float)(1u << l);
+                    acc += f * (cosf(v * f) * gr[3 + 6 * l + c] - sinf(v * f) * gr[3 + 6 * l + 3 + c]);
+                }
+                o[c] = acc;
+            }
+        }
+        d_normal[3 * p] = o[0]; d_normal[3 * p + 1] = o[1]; d_normal[3 * p + 2] = o[2];
+    }
+}
+}  // namespace
+
+extern "C" int gom_shade_workspace_ints(int64_t HW) { return (int)((HW + kShadePx - 1) / kShadePx) + 1024 + 4; }   // block counts, 1 024 gather partials (as floats), the row count, a counter
+
+extern "C" int gom_shade_select(int64_t HW, int L, const float *normal, int32_t *pos, float *pe, int32_t *workspace, void *stream) {
+    if (HW <= 0 || L < 0 || L > 16 || !normal || !pos || !pe || !workspace) { gom_set_error("gom_shade_select: bad arguments"); return -1; }
+    const int nblk = (int)((HW + kShadePx - 1) / kShadePx);
+    int32_t *blk_cnt = workspace, *n_dev = workspace + nblk + 1024;
+    hipLaunchKernelGGL(k_shade_count, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (size_t)HW, normal, blk_cnt);
+    GOM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_shade_place, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (size_t)HW, L, normal, blk_cnt, nblk, pos, pe, n_dev);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+static const int32_t *shade_n_dev(int64_t HW, const int32_t *workspace) { return workspace + (HW + kShadePx - 1) / kShadePx + 1024; }
+
+extern "C" int gom_mlp3_forward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2,
+                                     const float *b2, const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3,
+                                     float *out, void *stream) {
+    if (!workspace) { gom_set_error("gom_mlp3_forward_rows: null workspace"); return -1; }
+    return mlp3_forward_impl(HW + 1, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2, h3, out, shade_n_dev(HW, workspace), stream);
+}
+extern "C" int gom_mlp3_backward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *g, const float *out, const float *h1, const float *h2,
+                                      const float *h3, const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2,
+                                      float *dz1, float *dx, void *stream) {
+    if (!workspace) { gom_set_error("gom_mlp3_backward_rows: null workspace"); return -1; }
+    return mlp3_backward_impl(HW + 1, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4, dz3, dz2, dz1, dx, shade_n_dev(HW, workspace), stream);
+}
+extern "C" int gom_mlp3_wgrad_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3,
+                                   const float *dz1, const float *dz2, const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2,
+                                   float *dW3, float *db3, float *dW4, float *db4, float *wgrad_workspace, void *stream) {
+    if (!workspace) { gom_set_error("gom_mlp3_wgrad_rows: null workspace"); return -1; }
+    return mlp3_wgrad_impl(HW + 1, D0, H, x, h1, h2, h3, dz1, dz2, dz3, dz4, dW1, db1, dW2, db2, dW3, db3, dW4, db4, wgrad_workspace, shade_n_dev(HW, workspace), stream);
+}
+extern "C" int gom_shade_scatter(int64_t HW, const int32_t *pos, const float *out, const int32_t *workspace, float scale, float *shading, void *stream) {
+    if (HW <= 0 || !pos || !out || !workspace || !shading) { gom_set_error("gom_shade_scatter: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_shade_scatter, dim3((unsigned)((HW + 255) / 256 < 2048 ? (HW + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, (size_t)HW, pos, out,
+                       shade_n_dev(HW, workspace), scale, shading);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gom_shade_backward_gather(int64_t HW, const int32_t *pos, const float *g, int32_t *workspace, float scale, float *g_rows, void *stream) {
+    if (HW <= 0 || !pos || !g || !workspace || !g_rows) { gom_set_error("gom_shade_backward_gather: bad arguments"); return -1; }
+    const int nblk = (int)((HW + kShadePx - 1) / kShadePx);
+    const unsigned grid = (unsigned)((HW + 255) / 256 < 1024 ? (HW + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_shade_bwd_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)HW, pos, g, shade_n_dev(HW, workspace), scale, g_rows,
+                       reinterpret_cast<float *>(workspace + nblk), reinterpret_cast<uint32_t *>(workspace + nblk + 1024 + 1));
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gom_shade_backward_scatter(int64_t HW, int L, const int32_t *pos, const float *normal, const float *dpe, float *d_normal, void *stream) {
+    if (HW <= 0 || L < 0 || L > 16 || !pos || !normal || !dpe || !d_normal) { gom_set_error("gom_shade_backward_scatter: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_shade_bwd_scatter, dim3((unsigned)((HW + 255) / 256 < 2048 ? (HW + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, (size_t)HW, L, pos,
+                       normal, dpe, d_normal);
     GOM_LAUNCH_CHECK();
     return 0;
 }

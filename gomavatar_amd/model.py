@@ -12,6 +12,8 @@ values of configs/default.yaml + exps/zju-mocap_377.yaml.  The optional non-rigi
 ready-made modules (the reference's own classes are plain torch and can be passed in unchanged)."""
 from __future__ import annotations
 
+import os
+
 import math
 from types import SimpleNamespace
 from typing import Optional
@@ -185,6 +187,62 @@ class _ShadowMLP3(torch.autograd.Function):
         return (dx.reshape(ctx.shape).to(ctx.dtype) if ctx.needs_input_grad[0] else None, *grads)
 
 
+class _ShadeUnderMesh(torch.autograd.Function):
+    """model.py:279-283 for the default shadow MLP, fused natively (csrc/mlp.hip, gom_shade_*): shading (HW, 1) = 2 * MLP(embed(normal)) with the MLP
+    evaluated on the pixels under the mesh only (normal != 0) and once for the background -- selection, embedding, scatter and their backward
+    without torch glue, without a host synchronisation (the row count stays on the device), ~10 launches instead of ~35."""
+    _ws = {}
+
+    @staticmethod
+    def forward(ctx, flat, L, W1, b1, W2, b2, W3, b3, W4, b4):
+        lib = _lib.load()
+        x = flat.detach().float().contiguous()
+        HW, dev = x.shape[0], x.device
+        D0, H = 3 + 6 * L, W1.shape[0]
+        key = (dev, HW)
+        ws = _ShadeUnderMesh._ws.get(key)
+        if ws is None:      # block counts / gather partials / the row count / a counter: zeroed once, the kernels leave it reusable
+            ws = _ShadeUnderMesh._ws[key] = torch.zeros(lib.gom_shade_workspace_ints(HW), dtype=torch.int32, device=dev)
+        ps = [t.detach().float().contiguous() for t in (W1, b1, W2, b2, W3, b3, W4, b4)]
+        pos = torch.empty(HW, dtype=torch.int32, device=dev)
+        pe = torch.empty(HW + 1, D0, dtype=torch.float32, device=dev)
+        hs = torch.empty(3, HW + 1, H, dtype=torch.float32, device=dev)
+        out = torch.empty(HW + 1, dtype=torch.float32, device=dev)
+        shading = torch.empty(HW, 1, dtype=torch.float32, device=dev)
+        st, P = _lib.stream_ptr(), _lib.ptr
+        _lib.check(lib.gom_shade_select(HW, L, P(x), P(pos), P(pe), P(ws), st))
+        _lib.check(lib.gom_mlp3_forward_rows(HW, P(ws), D0, H, P(pe), *[P(t) for t in ps], P(hs[0]), P(hs[1]), P(hs[2]), P(out), st))
+        _lib.check(lib.gom_shade_scatter(HW, P(pos), P(out), P(ws), 2.0, P(shading), st))
+        ctx.save_for_backward(x, pos, pe, hs, out, ws, *ps)
+        ctx.L, ctx.dtype = L, flat.dtype
+        return shading.to(flat.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, pos, pe, hs, out, ws, W1, b1, W2, b2, W3, b3, W4, b4 = ctx.saved_tensors
+        lib = _lib.load()
+        HW, dev, L = x.shape[0], x.device, ctx.L
+        D0, H = pe.shape[1], W1.shape[0]
+        st, P = _lib.stream_ptr(), _lib.ptr
+        g2 = g.reshape(-1).float().contiguous()
+        g_rows = torch.empty(HW + 1, dtype=torch.float32, device=dev)
+        dz = torch.empty(3, HW + 1, H, dtype=torch.float32, device=dev)
+        dz4 = torch.empty(HW + 1, dtype=torch.float32, device=dev)
+        dpe = torch.empty(HW + 1, D0, dtype=torch.float32, device=dev)
+        _lib.check(lib.gom_shade_backward_gather(HW, P(pos), P(g2), P(ws), 2.0, P(g_rows), st))
+        _lib.check(lib.gom_mlp3_backward_rows(HW, P(ws), D0, H, P(g_rows), P(out), P(hs[0]), P(hs[1]), P(hs[2]), P(W1), P(W2), P(W3), P(W4), P(dz4), P(dz[2]),
+                                              P(dz[1]), P(dz[0]), P(dpe), st))
+        wws = torch.empty(4 * lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(p) for p in (W1, b1, W2, b2, W3, b3, W4, b4)]
+        _lib.check(lib.gom_mlp3_wgrad_rows(HW, P(ws), D0, H, P(pe), P(hs[0]), P(hs[1]), P(hs[2]), P(dz[0]), P(dz[1]), P(dz[2]), P(dz4), *[P(t) for t in grads], P(wws), st))
+        d_flat = None
+        if ctx.needs_input_grad[0]:
+            d_flat = torch.empty_like(x)
+            _lib.check(lib.gom_shade_backward_scatter(HW, L, P(pos), P(x), P(dpe), P(d_flat), st))
+            d_flat = d_flat.to(ctx.dtype)
+        return (d_flat, None, *grads)
+
+
 class ShadowModule(nn.Module):
     """shadow_module.py:66-117: positional encoding of the normal (multires frequencies, sin/cos, input included) ->
     MLP (width, depth, optional skip) -> sigmoid.  The last layer starts at U(-1e-5, 1e-5) / zero bias."""
@@ -270,6 +328,8 @@ class Model(nn.Module):
         # captured graph (0.71 -> 0.62 ms at 55k faces, 1.39 -> 1.09 ms at 220k); costs host time when launched eagerly: off by default
         self.overlap_branches = False
         self._side_stream = None
+        # the shading of the pixels under the mesh as one native op (csrc/mlp.hip: gom_shade_*); False: the torch selection around the MLP kernels
+        self.fused_shading = os.environ.get("GOM_FUSED_SHADING", "1") != "0"
         self.non_rigid_module, self.pose_refinement_module = non_rigid_module, pose_refinement_module
         self.normal_renderer = MeshNormalRenderer(self.img_size, sigma=_get(model_cfg, "normal_renderer.sigma", None),
                                                   soft_mask=_get(model_cfg, "normal_renderer.soft_mask", True))
@@ -348,6 +408,12 @@ class Model(nn.Module):
             flat = normal.reshape(-1, 3)
             # The all-zero background normal rides along as one extra row of the same MLP call (a second call for that single
             # row would double the module's launches, forward and backward).
+            lin = [m for m in self.shadow_module.block_mlps if isinstance(m, nn.Linear)]
+            if (self.fused_shading and flat.is_cuda and flat.dtype == torch.float32 and len(lin) == 4 and not self.shadow_module.layers_to_cat_inputs
+                    and lin[0].out_features <= 128 and lin[0].out_features % 4 == 0 and lin[0].in_features <= 128 and lin[3].out_features == 1):
+                # the default module: selection, embedding, MLP, scatter and their backward natively, row count on the device (csrc/mlp.hip: gom_shade_*)
+                s_all = _ShadeUnderMesh.apply(flat, self.shadow_module.multires, *[p for m in lin for p in (m.weight, m.bias)])
+                return normal, normal_mask, s_all.reshape(Bn, H, W, 1)
             if self.capture_safe:
                 # same result with static shapes: the pixels under the mesh are compacted into a list of fixed capacity
                 # (prefix sum, no nonzero()); every unused slot points at its own dummy row (duplicate indices would send

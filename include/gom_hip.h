@@ -461,6 +461,28 @@ int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float 
                             const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
                             float beta2, float eps, float grad_scale, void *stream);
 
+/* Shading of the pixels under the mesh, fused (models/model.py:279-283: shadow = 2 * shadow_module(normal) for every pixel; the normal map is
+ * zero outside the mesh, where the MLP is one constant).  `normal`: (HW, 3); `pos`: (HW) int32 row of a pixel or -1; `pe`: (HW + 1, 3 + 6 L)
+ * rows of the positional encoding (shadow_module.py:96-97), row n = the background's; `workspace`: gom_shade_workspace_ints(HW) int32, ZEROED
+ * once by the caller, holds the row count n in device memory (no host synchronisation; the *_rows entry points read it and take HW + 1 as the
+ * capacity of every row-indexed buffer).  Forward: select -> gom_mlp3_forward_rows -> scatter (shading = scale * out[row | background]);
+ * backward: backward_gather (d out rows; the background row sums the pixels outside the mesh in a fixed order) -> gom_mlp3_backward_rows /
+ * gom_mlp3_wgrad_rows -> backward_scatter (d normal through the encoding's backward, zero outside the mesh). */
+int gom_shade_workspace_ints(int64_t HW);
+int gom_shade_select(int64_t HW, int L, const float *normal, int32_t *pos, float *pe, int32_t *workspace, void *stream);
+int gom_mlp3_forward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2,
+                          const float *b2, const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3,
+                          float *out, void *stream);
+int gom_mlp3_backward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *g, const float *out, const float *h1, const float *h2,
+                           const float *h3, const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2,
+                           float *dz1, float *dx, void *stream);
+int gom_mlp3_wgrad_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3,
+                        const float *dz1, const float *dz2, const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2,
+                        float *dW3, float *db3, float *dW4, float *db4, float *wgrad_workspace, void *stream);
+int gom_shade_scatter(int64_t HW, const int32_t *pos, const float *out, const int32_t *workspace, float scale, float *shading, void *stream);
+int gom_shade_backward_gather(int64_t HW, const int32_t *pos, const float *g, int32_t *workspace, float scale, float *g_rows, void *stream);
+int gom_shade_backward_scatter(int64_t HW, int L, const int32_t *pos, const float *normal, const float *dpe, float *d_normal, void *stream);
+
 /* The same Adam step over a LIST of separately allocated tensors -- torch.optim.Adam(Model.get_param_groups()) as the reference builds it
  * (train.py:263-267) in one launch per GOM_ADAM_MULTI_MAX tensors instead of ~35 multi-tensor launches: host arrays of n_tensors device
  * pointers / element counts / learning rates (one per tensor: its group's).  step counts from 1; with step_device != NULL the count lives in

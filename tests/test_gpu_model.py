@@ -127,6 +127,7 @@ def test_capture_safe_forward_equals_the_host_camera_path():
     """Device-resident camera (gom_raster_*_dcam) + fixed-capacity shadow pixel list = the regular forward, values and gradients."""
     img = 96
     m = _small_model(img)
+    m.fused_shading = False          # (the torch selection around the MLP: the fixed-capacity list is its capture-safe form; the fused op needs neither)
     dv = {k: v.cuda() for k, v in _frame(2, img).items() if torch.is_tensor(v)}
     res = []
     for safe in (False, True):
@@ -146,6 +147,29 @@ def test_capture_safe_forward_equals_the_host_camera_path():
     m.shadow_capacity = 16                                                                 # too few slots: loud, not silently wrong
     rgbs, _, _ = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"])
     assert torch.isnan(rgbs).all()
+
+
+def test_fused_shading_equals_the_torch_selection_around_the_mlp():
+    """Model.fused_shading (csrc/mlp.hip gom_shade_*: selection of the pixels under the mesh, embedding, MLP with the row count in device memory,
+    scatter -- and their backward -- natively) against the torch ops it replaces (nonzero / index_select / cat / index_put around the same MLP
+    kernels): same rows in the same order, so images are bitwise equal; the background row's gradient is a sum in another order (round-off)."""
+    img = 128
+    m = _small_model(img)
+    dv = {k: v.cuda() for k, v in _frame(3, img).items() if torch.is_tensor(v)}
+    res = []
+    for fused in (False, True, True):
+        m.fused_shading = fused
+        m.zero_grad(set_to_none=True)
+        rgbs, masks, out = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"])
+        w = torch.linspace(0.5, 1.5, img * img * 3, device="cuda").reshape(1, img, img, 3)
+        ((rgbs * w).sum() + 2.0 * masks.sum()).backward()
+        res.append((rgbs.detach().clone(), out["shadow"].detach().clone(),
+                    [p.grad.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)] + [p.grad.detach().clone() for p in m.shadow_module.parameters()]))
+    assert float(res[0][1].min()) != float(res[0][1].max())                      # the shading really varies under the mesh
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b, c in zip(res[0][2], res[1][2], res[2][2]):
+        assert torch.equal(b, c)                                                  # run to run: bitwise
+        assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-12, (tuple(a.shape), float((a - b).norm()), float(a.norm()))
 
 
 def test_graphed_train_step_matches_the_eager_iterations():
