@@ -500,12 +500,20 @@ __global__ void __launch_bounds__(256) k_shade_bwd_gather(size_t HW, const int32
         s_last = atomicAdd(done, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (s_last && threadIdx.x == 0) {   // block partials in block order: one summation order whatever block finishes last
+    if (s_last) {   // the block partials in ONE order whatever workgroup finishes last: thread t adds partials 4t .. 4t+3, then a fixed tree
         __threadfence();
         float t = 0.f;
-        for (unsigned i = 0; i < gridDim.x; i++) t += partial[i];
-        g_rows[n_dev[0]] = scale * t;
-        *done = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const unsigned i = 4u * threadIdx.x + (unsigned)k; t += i < gridDim.x ? partial[i] : 0.f; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        __syncthreads();   // (s_w is read by thread 0 above)
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            g_rows[n_dev[0]] = scale * ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+            *done = 0;
+        }
     }
 }
 // d normal [HW][3]: the embedding's backward (k_posenc_bwd's arithmetic) of the pixel's row of dpe, zero outside the mesh
@@ -575,7 +583,7 @@ extern "C" int gom_shade_scatter(int64_t HW, const int32_t *pos, const float *ou
 extern "C" int gom_shade_backward_gather(int64_t HW, const int32_t *pos, const float *g, int32_t *workspace, float scale, float *g_rows, void *stream) {
     if (HW <= 0 || !pos || !g || !workspace || !g_rows) { gom_set_error("gom_shade_backward_gather: bad arguments"); return -1; }
     const int nblk = (int)((HW + kShadePx - 1) / kShadePx);
-    const unsigned grid = (unsigned)((HW + 255) / 256 < 1024 ? (HW + 255) / 256 : 1024);
+    const unsigned grid = (unsigned)((HW + 255) / 256 < 256 ? (HW + 255) / 256 : 256);   // (every workgroup ends with one atomic on one word: few, long workgroups)
     hipLaunchKernelGGL(k_shade_bwd_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)HW, pos, g, shade_n_dev(HW, workspace), scale, g_rows,
                        reinterpret_cast<float *>(workspace + nblk), reinterpret_cast<uint32_t *>(workspace + nblk + 1024 + 1));
     GOM_LAUNCH_CHECK();
