@@ -74,6 +74,14 @@ class RasterState:
         _lib.check(_lib.load().gom_state_poll(self.handle, ctypes.byref(n), ctypes.byref(ov), _lib.stream_ptr()))
         return int(n.value), bool(ov.value)
 
+    def poll_flags(self) -> int:
+        """The raw overflow word of the last forward: bit 0 = pair buffers (image poisoned), bit 1 = the record buffer of GOM_OPT_BWD_MODE 3
+        (gradients poisoned); synchronises the stream."""
+        n = ctypes.c_int64(0)
+        ov = ctypes.c_int32(0)
+        _lib.check(_lib.load().gom_state_poll(self.handle, ctypes.byref(n), ctypes.byref(ov), _lib.stream_ptr()))
+        return int(ov.value)
+
     def kernel_times_ms(self) -> dict:
         """Per-kernel duration (ms) of the most recent launches; needs set_option(OPT_PROFILE, 1)."""
         arr = (ctypes.c_float * len(_lib.KERNEL_NAMES))()

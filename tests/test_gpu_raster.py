@@ -142,6 +142,36 @@ def test_pair_buffer_overflow_is_loud():
     assert torch.isnan(out).all()
 
 
+def test_record_buffer_overflow_poisons_the_gradients_loudly():
+    """GOM_OPT_BWD_MODE 3: the forward's per-(pixel, entry) records live in a buffer of 8 records per unit of pair capacity.  Forty Gaussians that
+    cover the whole 64 x 64 image need 164 k records where an 8 192-pair state has room for 65 k: the IMAGE is the usual one (the records are a
+    by-product), the overflow is reported (gom_state_poll bit 1) and every gradient is NaN -- loud, not silently short; the same state with
+    its capacity back to automatic works again."""
+    from gpu_util import hip_forward
+    from gomavatar_amd import _lib, rasterizer as R
+    cam, means, cov6, colors, op = small_scene(seed=61, P=40, H=64, W=64, opacity=(0.05, 0.2), spread=0.2, scale=0.6, C=4)
+    ref, _, _, _ = hip_forward(cam, means, cov6, colors, op)
+    st = R.RasterState()
+    st.set_option(_lib.OPT_BWD_MODE, 3)
+    st.set_option(_lib.OPT_PAIR_CAPACITY, 8192)      # (pairs: eight shards of 1 024, 640 needed; records: 32 shards of 2 048)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True, state=st)
+    D, overflow = st.poll()
+    assert overflow and 0 < D <= 1024
+    assert st.poll_flags() == 2                       # bit 1 = the records, bit 0 (pair buffers, poisoned image) clear
+    assert torch.isfinite(out).all() and float((out - ref).abs().max()) < 1e-5
+    out.sum().backward()
+    assert all(torch.isnan(x.grad).any() for x in t[:3])
+    st.set_option(_lib.OPT_PAIR_CAPACITY, 0)
+    out2, _, st, t2 = hip_forward(cam, means, cov6, colors, op, requires_grad=True, state=st)
+    out2.sum().backward()
+    assert not st.poll()[1] and all(torch.isfinite(x.grad).all() for x in t2)
+    # ... and they are the replay's gradients to round-off
+    o3, _, _, t3 = hip_forward(cam, means, cov6, colors, op, requires_grad=True)
+    o3.sum().backward()
+    for a, b in zip(t2, t3):
+        assert float((a.grad - b.grad).abs().max()) <= 1e-4 * float(b.grad.abs().max()) + 1e-12
+
+
 def test_overflow_with_long_lists_in_rank_mode_stays_inside_its_buffers():
     """The scan kernel lists one k_tile_rank work item per 2 048 list positions of a tile from counts that keep growing AFTER the pair
     buffer has overflowed: 5 000 Gaussians over all 16 tiles are 48 items for a 19-item buffer (capacity 4 096 pairs).  The store is
