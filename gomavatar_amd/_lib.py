@@ -122,8 +122,9 @@ SIGNATURES = {
                                         c_float, c_float, c_float, c_float, c_void_p]),
     "gom_shade_workspace_ints": (c_int, [c_int64]),
     "gom_shade_select": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gom_mlp3_forward_rows": (c_int, [c_int64, c_void_p, c_int, c_int] + [c_void_p] * 14),
-    "gom_mlp3_backward_rows": (c_int, [c_int64, c_void_p, c_int, c_int] + [c_void_p] * 15),
+    "gom_mlp3_pack_elems": (c_int, []),
+    "gom_mlp3_forward_rows": (c_int, [c_int64, c_void_p, c_int, c_int] + [c_void_p] * 15),
+    "gom_mlp3_backward_rows": (c_int, [c_int64, c_void_p, c_int, c_int] + [c_void_p] * 16),
     "gom_mlp3_wgrad_rows": (c_int, [c_int64, c_void_p, c_int, c_int] + [c_void_p] * 18),
     "gom_shade_scatter": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "gom_shade_backward_gather": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),

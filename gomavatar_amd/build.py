@@ -31,6 +31,7 @@ SOURCES = [
     ("mesh_losses.hip", []),
     ("posenc.hip", []),
     ("mlp.hip", []),
+    ("mlp_mc.hip", []),
     ("frame_parallel.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -555,16 +555,34 @@ extern "C" int gom_shade_select(int64_t HW, int L, const float *normal, int32_t 
 }
 static const int32_t *shade_n_dev(int64_t HW, const int32_t *workspace) { return workspace + (HW + kShadePx - 1) / kShadePx + 1024; }
 
+// csrc/mlp_mc.hip: the same layers on the bf16 matrix cores at fp32 precision (three passes over hi / lo planes)
+size_t gom_mlp3_mc_pack_elems(void);
+bool gom_mlp3_mc_supported(int D0, int H);
+int gom_mlp3_mc_forward(int64_t n, int D0, const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                        const float *w4, const float *b4, float *h1, float *h2, float *h3, float *out, const int32_t *n_dev, uint16_t *pack, void *stream);
+int gom_mlp3_mc_backward(int64_t n, int D0, const float *g, const float *out, const float *h1, const float *h2, const float *h3, const float *W1, const float *W2,
+                         const float *W3, const float *w4, float *dz4, float *dz3, float *dz2, float *dz1, float *dx, const int32_t *n_dev, uint16_t *pack,
+                         void *stream);
+extern "C" int gom_mlp3_pack_elems(void) { return (int)gom_mlp3_mc_pack_elems(); }
+
 extern "C" int gom_mlp3_forward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2,
                                      const float *b2, const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3,
-                                     float *out, void *stream) {
+                                     float *out, uint16_t *pack, void *stream) {
     if (!workspace) { gom_set_error("gom_mlp3_forward_rows: null workspace"); return -1; }
+    if (pack && gom_mlp3_mc_supported(D0, H)) {
+        if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !w4 || !b4 || !h1 || !h2 || !h3 || !out) { gom_set_error("gom_mlp3_forward_rows: null pointer"); return -1; }
+        return gom_mlp3_mc_forward(HW + 1, D0, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2, h3, out, shade_n_dev(HW, workspace), pack, stream);
+    }
     return mlp3_forward_impl(HW + 1, D0, H, x, W1, b1, W2, b2, W3, b3, w4, b4, h1, h2, h3, out, shade_n_dev(HW, workspace), stream);
 }
 extern "C" int gom_mlp3_backward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *g, const float *out, const float *h1, const float *h2,
                                       const float *h3, const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2,
-                                      float *dz1, float *dx, void *stream) {
+                                      float *dz1, float *dx, uint16_t *pack, void *stream) {
     if (!workspace) { gom_set_error("gom_mlp3_backward_rows: null workspace"); return -1; }
+    if (pack && gom_mlp3_mc_supported(D0, H)) {
+        if (!g || !out || !h1 || !h2 || !h3 || !W1 || !W2 || !W3 || !w4 || !dz4 || !dz3 || !dz2 || !dz1 || !dx) { gom_set_error("gom_mlp3_backward_rows: null pointer"); return -1; }
+        return gom_mlp3_mc_backward(HW + 1, D0, g, out, h1, h2, h3, W1, W2, W3, w4, dz4, dz3, dz2, dz1, dx, shade_n_dev(HW, workspace), pack, stream);
+    }
     return mlp3_backward_impl(HW + 1, D0, H, g, out, h1, h2, h3, W1, W2, W3, w4, dz4, dz3, dz2, dz1, dx, shade_n_dev(HW, workspace), stream);
 }
 extern "C" int gom_mlp3_wgrad_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3,

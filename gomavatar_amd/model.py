@@ -192,6 +192,10 @@ class _ShadeUnderMesh(torch.autograd.Function):
     evaluated on the pixels under the mesh only (normal != 0) and once for the background -- selection, embedding, scatter and their backward
     without torch glue, without a host synchronisation (the row count stays on the device), ~10 launches instead of ~35."""
     _ws = {}
+    # GOM_MLP_MATRIX_CORES=1: the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes).  Measured: forward 49 -> 22 us,
+    # backward 63 -> 37 us (+ 8 us of weight packing) per frame, and the shading moves by 6e-6 relative (three chained layers of dropped lo x lo
+    # terms) where the fp32 VALU layers are exact fp32: 45 us of a 3.3 ms iteration is not worth the digit -- opt-in.
+    matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "0") != "0"
 
     @staticmethod
     def forward(ctx, flat, L, W1, b1, W2, b2, W3, b3, W4, b4):
@@ -211,7 +215,8 @@ class _ShadeUnderMesh(torch.autograd.Function):
         shading = torch.empty(HW, 1, dtype=torch.float32, device=dev)
         st, P = _lib.stream_ptr(), _lib.ptr
         _lib.check(lib.gom_shade_select(HW, L, P(x), P(pos), P(pe), P(ws), st))
-        _lib.check(lib.gom_mlp3_forward_rows(HW, P(ws), D0, H, P(pe), *[P(t) for t in ps], P(hs[0]), P(hs[1]), P(hs[2]), P(out), st))
+        pack = torch.empty(lib.gom_mlp3_pack_elems(), dtype=torch.int16, device=dev) if _ShadeUnderMesh.matrix_cores else None
+        _lib.check(lib.gom_mlp3_forward_rows(HW, P(ws), D0, H, P(pe), *[P(t) for t in ps], P(hs[0]), P(hs[1]), P(hs[2]), P(out), P(pack), st))
         _lib.check(lib.gom_shade_scatter(HW, P(pos), P(out), P(ws), 2.0, P(shading), st))
         ctx.save_for_backward(x, pos, pe, hs, out, ws, *ps)
         ctx.L, ctx.dtype = L, flat.dtype
@@ -226,12 +231,13 @@ class _ShadeUnderMesh(torch.autograd.Function):
         st, P = _lib.stream_ptr(), _lib.ptr
         g2 = g.reshape(-1).float().contiguous()
         g_rows = torch.empty(HW + 1, dtype=torch.float32, device=dev)
+        pack = torch.empty(lib.gom_mlp3_pack_elems(), dtype=torch.int16, device=dev) if _ShadeUnderMesh.matrix_cores else None
         dz = torch.empty(3, HW + 1, H, dtype=torch.float32, device=dev)
         dz4 = torch.empty(HW + 1, dtype=torch.float32, device=dev)
         dpe = torch.empty(HW + 1, D0, dtype=torch.float32, device=dev)
         _lib.check(lib.gom_shade_backward_gather(HW, P(pos), P(g2), P(ws), 2.0, P(g_rows), st))
         _lib.check(lib.gom_mlp3_backward_rows(HW, P(ws), D0, H, P(g_rows), P(out), P(hs[0]), P(hs[1]), P(hs[2]), P(W1), P(W2), P(W3), P(W4), P(dz4), P(dz[2]),
-                                              P(dz[1]), P(dz[0]), P(dpe), st))
+                                              P(dz[1]), P(dz[0]), P(dpe), P(pack), st))
         wws = torch.empty(4 * lib.gom_linear_wgrad_slices() * 129 * 128, dtype=torch.float32, device=dev)
         grads = [torch.empty_like(p) for p in (W1, b1, W2, b2, W3, b3, W4, b4)]
         _lib.check(lib.gom_mlp3_wgrad_rows(HW, P(ws), D0, H, P(pe), P(hs[0]), P(hs[1]), P(hs[2]), P(dz[0]), P(dz[1]), P(dz[2]), P(dz4), *[P(t) for t in grads], P(wws), st))

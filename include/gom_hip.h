@@ -467,15 +467,18 @@ int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float 
  * once by the caller, holds the row count n in device memory (no host synchronisation; the *_rows entry points read it and take HW + 1 as the
  * capacity of every row-indexed buffer).  Forward: select -> gom_mlp3_forward_rows -> scatter (shading = scale * out[row | background]);
  * backward: backward_gather (d out rows; the background row sums the pixels outside the mesh in a fixed order) -> gom_mlp3_backward_rows /
- * gom_mlp3_wgrad_rows -> backward_scatter (d normal through the encoding's backward, zero outside the mesh). */
+ * gom_mlp3_wgrad_rows -> backward_scatter (d normal through the encoding's backward, zero outside the mesh).
+ * `pack`: NULL = the fp32 VALU layers of csrc/mlp.hip; a scratch buffer of gom_mlp3_pack_elems() uint16 = the layers on the bf16 matrix cores at
+ * fp32 precision (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes per product; D0 <= 64, H = 128 -- other shapes take the VALU kernels). */
+int gom_mlp3_pack_elems(void);
 int gom_shade_workspace_ints(int64_t HW);
 int gom_shade_select(int64_t HW, int L, const float *normal, int32_t *pos, float *pe, int32_t *workspace, void *stream);
 int gom_mlp3_forward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *W1, const float *b1, const float *W2,
                           const float *b2, const float *W3, const float *b3, const float *w4, const float *b4, float *h1, float *h2, float *h3,
-                          float *out, void *stream);
+                          float *out, uint16_t *pack, void *stream);
 int gom_mlp3_backward_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *g, const float *out, const float *h1, const float *h2,
                            const float *h3, const float *W1, const float *W2, const float *W3, const float *w4, float *dz4, float *dz3, float *dz2,
-                           float *dz1, float *dx, void *stream);
+                           float *dz1, float *dx, uint16_t *pack, void *stream);
 int gom_mlp3_wgrad_rows(int64_t HW, const int32_t *workspace, int D0, int H, const float *x, const float *h1, const float *h2, const float *h3,
                         const float *dz1, const float *dz2, const float *dz3, const float *dz4, float *dW1, float *db1, float *dW2, float *db2,
                         float *dW3, float *db3, float *dW4, float *db4, float *wgrad_workspace, void *stream);
