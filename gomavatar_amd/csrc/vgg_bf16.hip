@@ -67,6 +67,55 @@ constexpr int kPatchW = kTileW + 2;  // 18
 // group slot ^ 2 * bit2(row): the writers apply it to the source (LDS-DMA writes linearly), the readers to the address.
 __device__ __forceinline__ int swz_part(int part, int row) { return part ^ (((row >> 2) & 1) << 1); }
 
+// Epilogue shared by the convolution kernels: the wave's RPW x 4 accumulator tiles -> + bias, ReLU, ReLU mask -> bf16 plane(s).
+// D[i = co][j = px]: a lane holds co = 4 * kg + r (r = 0..3) of pixel column l15: one 8-byte NHWC store per plane.
+template <bool RELU, int RPW>
+__device__ __forceinline__ void conv_store(const f32x4 (&acc)[RPW][4], int H, int W, int Cout, size_t img, int ty0, int tx0, int row0, int co0, int l15, int kg,
+                                           const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, size_t out_lo) {
+#pragma unroll
+    for (int m = 0; m < RPW; m++) {
+        const int gy = ty0 + row0 + m, gx = tx0 + l15;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int co = co0 + n * 16 + kg * 4;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+            }
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (mask) {
+                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
+                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
+            }
+            store4(out + pix + co, out_lo, v);
+        }
+    }
+}
+
+// Split-K: raw fp32 partial sums of this workgroup's share of the input channels -> partial [splits][B][H][W][Cout]; k_splitk_epilogue
+// adds the shares up in split order and applies bias / ReLU / mask.  (Summing inside the convolution, in the tile's last workgroup, was
+// built in round 4 and is slower: LABBOOK R4.7.)
+template <int RPW>
+__device__ __forceinline__ void conv_store_partial(const f32x4 (&acc)[RPW][4], int H, int W, int Cout, size_t img, int nb, int zs, int ty0, int tx0, int row0, int co0,
+                                                   int l15, int kg, float *__restrict__ partial) {
+#pragma unroll
+    for (int m = 0; m < RPW; m++) {
+        const int gy = ty0 + row0 + m, gx = tx0 + l15;
+        if (gy >= H || gx >= W) continue;
+        float *dst = partial + (size_t)zs * nb * H * W * Cout + (img + (size_t)gy * W + gx) * Cout + co0 + kg * 4;
+#pragma unroll
+        for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + n * 16) = acc[m][n];
+    }
+}
+
 // in  [B][H][W][Cin]  bf16 (Cin multiple of 32);  wt [Cin/32][9][Cout][32] bf16 (Cout multiple of 64)
 // out [B][H][W][Cout] bf16;  bias fp32 [Cout] or null;  mask (same shape as out) or null: out *= (mask > 0)
 // SPLITK: blockIdx.z = image * splits + s; this block sums only its share of the input-channel chunks and stores raw fp32
@@ -136,39 +185,8 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
                 for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
         }
     }
-    // D[i = co][j = px]: lane holds co = 4*kg + r (r = 0..3) of pixel column l15
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int gy = ty0 + 2 * wave + m, gx = tx0 + l15;
-        if (gy >= H || gx >= W) continue;
-        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
-        if (SPLITK) {
-            float *dst = partial + (size_t)zs * (gridDim.z / splits) * H * W * Cout + pix;   // [splits][B][H][W][Cout]
-#pragma unroll
-            for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + co0 + n * 16 + kg * 4) = acc[m][n];
-            continue;
-        }
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const int co = co0 + n * 16 + kg * 4;
-            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            if (bias) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
-            }
-            if (RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (mask) {
-                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
-                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
-            }
-            store4(out + pix + co, out_lo, v);
-        }
-    }
+    if (SPLITK) conv_store_partial<2>(acc, H, W, Cout, img, (int)gridDim.z / splits, zs, ty0, tx0, 2 * wave, co0, l15, kg, partial);
+    else conv_store<RELU, 2>(acc, H, W, Cout, img, ty0, tx0, 2 * wave, co0, l15, kg, bias, mask, out, out_lo);
 }
 
 // ---- pipelined variant: global -> LDS by LDS-DMA (global_load_lds_dwordx4), three stages in flight ---------------------
@@ -192,8 +210,13 @@ constexpr int kV2PatchBytes = kV2PatchUnits * 16;     // 20 736
 constexpr int kV2WBytes = 3 * kBN * kKC * 2;          // 12 288: three taps
 constexpr int kV2Lds = 2 * kV2PatchBytes + 3 * kV2WBytes;   // 78 336
 
+// Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: the compiler's wait-count pass books the builtin as a FLAT
+// access that may touch LDS, and while one is pending every LDS wait it inserts is lgkmcnt(0) -- with DMA loads always in flight the
+// fragment reads of the next tap could never stay outstanding behind the MFMAs of the current one.  The loop's vmcnt waits are
+// written by hand anyway (counted, see below).
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory", "m0");
 }
 
 template <bool RELU, bool SPLITK, int RPW>
@@ -262,6 +285,9 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Every scalar argument the epilogue needs is pulled into SGPRs HERE: a scalar load left pending across the loop makes lgkmcnt count two
+    // kinds of events, and the wait-count pass then turns every LDS wait of the loop into lgkmcnt(0).
+    asm volatile("" ::"s"(bias), "s"(mask), "s"(out), "s"(partial), "s"(out_lo), "s"(Cout), "s"(splits));
     issue(0);
     if (NS > 1) issue(1);
     for (int s = 0; s < NS; s++) {
@@ -274,57 +300,34 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
         const int ky = s % 3;
         const bf16_t *pb = reinterpret_cast<const bf16_t *>(smem + ((s / 3) & 1) * kV2PatchBytes);
         const bf16_t *wb = reinterpret_cast<const bf16_t *>(smem + 2 * kV2PatchBytes + (s % 3) * kV2WBytes);
+        // Fragments of tap kx + 1 are requested BEFORE the MFMAs of tap kx issue (two register sets, counted lgkmcnt waits).  Measured
+        // neutral against one set re-filled behind the 5th MFMA (what hipcc schedules by itself): with four waves per SIMD another wave's
+        // MFMAs cover the read latency either way (LABBOOK R4.7); kept because it no longer depends on that occupancy.
+        bf16x8 bfrag[2][RPW], afrag[2][4];
+        auto fetch = [&](int set, int kx) {
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-            bf16x8 bfrag[RPW], afrag[4];
-#pragma unroll
-            for (int m = 0; m < RPW; m++)
-            {
+            for (int m = 0; m < RPW; m++) {
                 const int px = (RPW * wave + m + ky) * kPatchW + l15 + kx;
-                bfrag[m] = *reinterpret_cast<const bf16x8 *>(pb + px * kKC + swz_part(kg, px) * 8);
+                bfrag[set][m] = *reinterpret_cast<const bf16x8 *>(pb + px * kKC + swz_part(kg, px) * 8);
             }
 #pragma unroll
             for (int n = 0; n < 4; n++)
-                afrag[n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + swz_part(kg, l15) * 8);
+                afrag[set][n] = *reinterpret_cast<const bf16x8 *>(wb + (kx * kBN + n * 16 + l15) * kKC + swz_part(kg, l15) * 8);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            if (kx < 2) fetch((kx + 1) & 1, kx + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < RPW; m++)
 #pragma unroll
-                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[kx & 1][n], bfrag[kx & 1][m], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // epilogue: identical to k_conv3x3_bf16
-#pragma unroll
-    for (int m = 0; m < RPW; m++) {
-        const int gy = ty0 + RPW * wave + m, gx = tx0 + l15;
-        if (gy >= H || gx >= W) continue;
-        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
-        if (SPLITK) {
-            float *dst = partial + (size_t)zs * (gridDim.z / splits) * H * W * Cout + pix;   // [splits][B][H][W][Cout]
-#pragma unroll
-            for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + co0 + n * 16 + kg * 4) = acc[m][n];
-            continue;
-        }
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const int co = co0 + n * 16 + kg * 4;
-            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            if (bias) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
-            }
-            if (RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (mask) {
-                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
-                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
-            }
-            store4(out + pix + co, out_lo, v);
-        }
-    }
+    if (SPLITK) conv_store_partial<RPW>(acc, H, W, Cout, img, (int)gridDim.z / splits, zs, ty0, tx0, RPW * wave, co0, l15, kg, partial);
+    else conv_store<RELU, RPW>(acc, H, W, Cout, img, ty0, tx0, RPW * wave, co0, l15, kg, bias, mask, out, out_lo);
 }
 
 __device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
@@ -728,10 +731,13 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
 }
 
 extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
-    const long blocks = (long)((W + kTileW - 1) / kTileW) * ((H + 7) / 8) * (Cout / kBN) * B;
+    // 16 x 16-pixel tiles x 64 output channels: split the input channels until the launch has >= 2 workgroups per CU (equal shares of
+    // the chunks).  Measured (MI355X, bf16x3 trunk at 512^2, + 7-12 us of epilogue launch each): conv4 forward 122 -> 106 us, conv4 / conv3 backward 72 -> 58 / 71 -> 59,
+    // conv5 43 -> 34 + 8 (the second launch: k_splitk_epilogue).
+    static const int mode = getenv("GOM_CONV_SPLIT_MODE") ? atoi(getenv("GOM_CONV_SPLIT_MODE")) : 1;   // development switch: 0 = round-3 rule (8-row tiles)
+    const long blocks = (long)((W + kTileW - 1) / kTileW) * (mode ? (H + 15) / 16 : (H + 7) / 8) * (Cout / kBN) * B;
     int s = 1;
-    while (s < 16 && blocks * s < 512 && (Cin / kKC) % (2 * s) == 0) s *= 2;   // >= 2 workgroups per CU, equal shares of the chunks
-    // (measured on MI355X: 512 plain workgroups beat 2 x 512 split ones -- the fp32 partials and the second launch cost more)
+    while (s < 16 && blocks * s < 512 && (Cin / kKC) % (2 * s) == 0) s *= 2;
     return s;
 }
 
