@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 6
+GOM_ABI_VERSION = 7
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
@@ -98,6 +98,7 @@ SIGNATURES = {
     "gom_lpips_vgg_set_first_layer": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gom_lpips_vgg_set_precision": (c_int, [c_void_p, c_int32]),
     "gom_lpips_vgg_value_and_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint32, c_void_p]),
+    "gom_lpips_vgg_target_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gom_mesh_raster_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gom_mesh_raster_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
     "gom_mesh_pix_to_face": (c_int, [c_void_p, c_void_p, c_void_p]),

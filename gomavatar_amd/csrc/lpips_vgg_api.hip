@@ -26,7 +26,7 @@ struct GomLpipsVgg {
     void *pooled[2][13] = {};                    // pool outputs feeding conv i (i in kPoolBefore)
     void *grad[2] = {nullptr, nullptr};          // ping-pong gradient buffers (largest activation)
     void *gtap = nullptr;                        // head gradient of the current tap
-    float *splitk = nullptr;
+    float *splitk = nullptr, *splitk_target = nullptr;   // split-K partial sums; the target-only pass (its own stream) has its own
     float *go = nullptr;                         // [B] d value / d value_b
     size_t splitk_elems = 0;
     // captured launch sequence (GOM_LPIPS_USE_GRAPH), valid for exactly these arguments
@@ -35,6 +35,7 @@ struct GomLpipsVgg {
     const float *g_pred = nullptr, *g_gt = nullptr;
     float *g_partials = nullptr, *g_dpred = nullptr;
     float g_scale = 0.f;
+    uint32_t g_flags = 0;
 };
 
 static void lp_drop_graph(GomLpipsVgg *h) {
@@ -45,7 +46,7 @@ static void lp_drop_graph(GomLpipsVgg *h) {
 
 static void lp_free(GomLpipsVgg *h) {
     lp_drop_graph(h);
-    void *ptrs[] = {h->x[0], h->grad[0], h->grad[1], h->gtap, h->splitk, h->go};   // (x[1], act[1][], pooled[1][] are the second halves of [0])
+    void *ptrs[] = {h->x[0], h->grad[0], h->grad[1], h->gtap, h->splitk, h->splitk_target, h->go};   // (x[1], act[1][], pooled[1][] are the second halves of [0])
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 13; i++) {
         if (h->act[0][i]) (void)hipFree(h->act[0][i]);
@@ -53,7 +54,7 @@ static void lp_free(GomLpipsVgg *h) {
         for (int k = 0; k < 2; k++) h->act[k][i] = h->pooled[k][i] = nullptr;
     }
     h->x[0] = h->x[1] = h->grad[0] = h->grad[1] = h->gtap = nullptr;
-    h->splitk = nullptr; h->go = nullptr;
+    h->splitk = h->splitk_target = nullptr; h->go = nullptr;
     h->B = h->H = h->W = 0;
 }
 
@@ -117,22 +118,25 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
         const size_t sf = (size_t)gom_conv3x3_splits(2 * B, hh, ww, h->cin[i], h->cout[i]) * 2 * n;
         const size_t sb = (size_t)gom_conv3x3_splits(B, hh, ww, h->cout[i], h->cin[i] < 64 ? 64 : h->cin[i]) * nin;
         maxsplit = sf > maxsplit ? sf : maxsplit;
+        const size_t s1 = (size_t)gom_conv3x3_splits(B, hh, ww, h->cin[i], h->cout[i]) * n;   // (one image set alone: GOM_LPIPS_TARGET_READY / target_features)
+        maxsplit = s1 > maxsplit ? s1 : maxsplit;
         maxsplit = sb > maxsplit ? sb : maxsplit;
     }
     for (int k = 0; k < 2; k++) GOM_HIP_CHECK(hipMalloc(&h->grad[k], maxact * 2 * planes));
     GOM_HIP_CHECK(hipMalloc(&h->gtap, maxact * 2 * planes));
     h->lo_g = h->x3 ? maxact : 0;
     GOM_HIP_CHECK(hipMalloc((void **)&h->splitk, maxsplit * sizeof(float)));
+    GOM_HIP_CHECK(hipMalloc((void **)&h->splitk_target, maxsplit * sizeof(float)));
     GOM_HIP_CHECK(hipMalloc((void **)&h->go, (size_t)B * sizeof(float)));
     h->splitk_elems = maxsplit;
     h->B = B; h->H = H; h->W = W;
     return 0;
 }
 
-static int lp_conv(GomLpipsVgg *h, int B, int hh, int ww, int cin, int cout, const void *in, const void *wt, const float *bias, const void *mask,
+static int lp_conv(float *splitk, int B, int hh, int ww, int cin, int cout, const void *in, const void *wt, const float *bias, const void *mask,
                    void *out, uint32_t flags, size_t in_lo, size_t out_lo, void *stream) {
     const int s = gom_conv3x3_splits(B, hh, ww, cin, cout);
-    return gom_conv3x3_planes(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? h->splitk : nullptr, in_lo, out_lo, stream);
+    return gom_conv3x3_planes(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? splitk : nullptr, in_lo, out_lo, stream);
 }
 
 __global__ void k_fill(float *p, int n, float v) {
@@ -141,7 +145,17 @@ __global__ void k_fill(float *p, int n, float v) {
 }
 
 static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials, float grad_scale,
-                      float *d_pred, void *stream);
+                      float *d_pred, bool target_ready, void *stream);
+static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int W, const float *const *img, float *splitk, void *stream);
+
+extern "C" int gom_lpips_vgg_target_features(GomLpipsVgg *h, int B, int H, int W, const float *gt, void *stream) {
+    if (!h || !gt) { gom_set_error("gom_lpips_vgg_target_features: null argument"); return -1; }
+    if (B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) { gom_set_error("gom_lpips_vgg_target_features: H and W must be multiples of 16"); return -1; }
+    int rc;
+    if ((rc = lp_ensure(h, B, H, W))) return rc;
+    const float *img[2] = {nullptr, gt};
+    return lp_trunk_forward(h, 1, 1, B, H, W, img, h->splitk_target, stream);
+}
 
 extern "C" int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
                                             float grad_scale, float *d_pred, uint32_t flags, void *stream) {
@@ -150,47 +164,58 @@ extern "C" int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W,
     int rc;
     const bool same_size = h->B == B && h->H == H && h->W == W;
     if ((rc = lp_ensure(h, B, H, W))) return rc;
-    if (!(flags & GOM_LPIPS_USE_GRAPH) || stream == nullptr) return lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, stream);
+    const bool target_ready = (flags & GOM_LPIPS_TARGET_READY) != 0;
+    if (target_ready && !same_size) { gom_set_error("gom_lpips_vgg_value_and_grad: GOM_LPIPS_TARGET_READY without gom_lpips_vgg_target_features at this size"); return -1; }
+    if (!(flags & GOM_LPIPS_USE_GRAPH) || stream == nullptr) return lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, target_ready, stream);
     hipStream_t st = (hipStream_t)stream;
-    if (h->exec && same_size && h->g_pred == pred && h->g_gt == gt && h->g_partials == value_partials && h->g_dpred == d_pred && h->g_scale == grad_scale) {
+    if (h->exec && same_size && h->g_pred == pred && h->g_gt == gt && h->g_partials == value_partials && h->g_dpred == d_pred && h->g_scale == grad_scale && h->g_flags == flags) {
         GOM_HIP_CHECK(hipGraphLaunch(h->exec, st));
         return 0;
     }
     lp_drop_graph(h);
     GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    rc = lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, stream);
+    rc = lp_enqueue(h, B, H, W, pred, gt, value_partials, grad_scale, d_pred, target_ready, stream);
     hipError_t ce = hipStreamEndCapture(st, &h->graph);
     if (rc) { lp_drop_graph(h); return rc; }
     if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); h->graph = nullptr; return -2; }
     GOM_HIP_CHECK(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
-    h->g_pred = pred; h->g_gt = gt; h->g_partials = value_partials; h->g_dpred = d_pred; h->g_scale = grad_scale;
+    h->g_pred = pred; h->g_gt = gt; h->g_partials = value_partials; h->g_dpred = d_pred; h->g_scale = grad_scale; h->g_flags = flags;
     GOM_HIP_CHECK(hipGraphLaunch(h->exec, st));
     return 0;
 }
 
+// prepare + 13 convolutions + 4 pools of `nsets` image sets starting at set k0 (0 = prediction, 1 = target) as one batch of nsets * B images
+static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int W, const float *const *img, float *splitk, void *stream) {
+    int rc;
+    const bool im2col = h->w1_fwd != nullptr;   // conv1_1 without its channel padding (vgg_bf16.hip: k_lpips_prepare_im2col)
+    for (int k = k0; k < k0 + nsets; k++)
+        if ((rc = im2col ? gom_lpips_prepare_im2col_planes(B, H, W, img[k], h->x[k], h->lo_x, stream) : gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
+    const int nb = nsets * B;
+    int hh = H, ww = W;
+    const void *cur = h->x[k0];
+    size_t cur_lo = h->lo_x;
+    for (int i = 0; i < 13; i++) {
+        if (kPoolBefore[i]) {
+            if ((rc = gom_maxpool2x2_planes(nb, hh, ww, h->cin[i], cur, h->pooled[k0][i], cur_lo, h->lo_pooled[i], stream))) return rc;
+            hh /= 2; ww /= 2;
+            cur = h->pooled[k0][i]; cur_lo = h->lo_pooled[i];
+        }
+        if (i == 0 && im2col) {
+            if ((rc = gom_conv1x1_planes((size_t)nb * hh * ww, 32, h->cout[0], cur, h->w1_fwd, h->bias[0], h->act[k0][0], 1, cur_lo, h->lo_act[0], stream))) return rc;
+        } else if ((rc = lp_conv(splitk, nb, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
+        cur = h->act[k0][i]; cur_lo = h->lo_act[i];
+    }
+    return 0;
+}
+
 static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials, float grad_scale,
-                      float *d_pred, void *stream) {
+                      float *d_pred, bool target_ready, void *stream) {
     int rc;
     const float *img[2] = {pred, gt};
-    const bool im2col = h->w1_fwd != nullptr;   // conv1_1 without its channel padding (vgg_bf16.hip: k_lpips_prepare_im2col)
-    for (int k = 0; k < 2; k++)
-        if ((rc = im2col ? gom_lpips_prepare_im2col_planes(B, H, W, img[k], h->x[k], h->lo_x, stream) : gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
-    {
-        int hh = H, ww = W;
-        const void *cur = h->x[0];
-        size_t cur_lo = h->lo_x;
-        for (int i = 0; i < 13; i++) {
-            if (kPoolBefore[i]) {
-                if ((rc = gom_maxpool2x2_planes(2 * B, hh, ww, h->cin[i], cur, h->pooled[0][i], cur_lo, h->lo_pooled[i], stream))) return rc;
-                hh /= 2; ww /= 2;
-                cur = h->pooled[0][i]; cur_lo = h->lo_pooled[i];
-            }
-            if (i == 0 && im2col) {
-                if ((rc = gom_conv1x1_planes((size_t)2 * B * hh * ww, 32, h->cout[0], cur, h->w1_fwd, h->bias[0], h->act[0][0], 1, cur_lo, h->lo_act[0], stream))) return rc;
-            } else if ((rc = lp_conv(h, 2 * B, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
-            cur = h->act[0][i]; cur_lo = h->lo_act[i];
-        }
-    }
+    const bool im2col = h->w1_fwd != nullptr;
+    // prediction and target as ONE batch of 2B images -- or, when the caller ran the target's trunk beforehand
+    // (gom_lpips_vgg_target_features, typically on another stream under the frame's forward), the prediction alone
+    if ((rc = lp_trunk_forward(h, 0, target_ready ? 1 : 2, B, H, W, img, h->splitk, stream))) return rc;
     {   // heads
         int hh = H, ww = W;
         for (int i = 0; i < 13; i++) {
@@ -231,7 +256,7 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
             if ((rc = gom_conv1x1_planes((size_t)B * hh * ww, h->cout[0], 32, g, h->w1_bwd, nullptr, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
             return gom_lpips_unprepare_col2im_planes(B, H, W, dst, d_pred, h->lo_g, stream);
         }
-        if ((rc = lp_conv(h, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
+        if ((rc = lp_conv(h->splitk, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
         g = dst;
     }
     return gom_lpips_unprepare_planes(B, H, W, 64, g, d_pred, h->lo_g, stream);

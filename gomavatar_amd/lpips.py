@@ -210,6 +210,7 @@ class LPIPSMatrixCore:
         lin = np.load(_DATA)
         self.lins = [torch.from_numpy(lin[f"lin{k}"].astype(np.float32).reshape(-1)).to(dev).contiguous() for k in range(5)]
         self._h = None
+        self._side, self._target = None, None          # prefetch_target: its stream, (key, event, the fp32 copy kept alive)
         self.first_layer_im2col = os.environ.get("GOM_LPIPS_FIRST_LAYER_IM2COL", "1") != "0"   # (development switch: 0 = the padded 3 x 3 kernels for conv1_1 too)
         self.set_trunk([t.to(dev) for t in seeded_trunk(trunk_seed)])
 
@@ -257,6 +258,32 @@ class LPIPSMatrixCore:
             self.lib.gom_lpips_vgg_destroy(self._h)
             self._h = None
 
+    def prefetch_target(self, gt: torch.Tensor) -> None:
+        """The target image's half of the trunk forward on a second stream, to be called BEFORE the frame's forward is enqueued: it depends
+        on nothing the model computes, and the geometry / raster launches of a frame leave most of the chip idle (train_util.train_iteration
+        does this).  The next `value_and_grad` / `loss` with the same `gt` tensor then walks the trunk with the prediction alone."""
+        assert gt.is_cuda and gt.dim() == 4 and gt.shape[-1] == 3
+        B, H, W, _ = gt.shape
+        g32 = gt.detach().float().contiguous()
+        main = torch.cuda.current_stream(gt.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=gt.device)
+        self._side.wait_stream(main)           # after the target tensor is written AND after the previous value_and_grad read the handle's buffers
+        with torch.cuda.stream(self._side):
+            _lib.check(self.lib.gom_lpips_vgg_target_features(self._handle(), B, H, W, _lib.ptr(g32), _lib.stream_ptr()))
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._target = ((gt.data_ptr(), gt._version, tuple(gt.shape)), ev, g32)
+
+    def _target_ready(self, gt: torch.Tensor) -> bool:
+        t, self._target = self._target, None
+        if t is None or t[0] != (gt.data_ptr(), gt._version, tuple(gt.shape)):
+            if t is not None:   # another target after all: the side stream's writes must still land before this call's
+                torch.cuda.current_stream(gt.device).wait_event(t[1])
+            return False
+        torch.cuda.current_stream(gt.device).wait_event(t[1])
+        return True
+
     def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True, out=None):
         """(mean_b LPIPS_b, d/d pred of it): ~75 kernel launches from one `gom_lpips_vgg_value_and_grad` call.
         `out=(partials, d_pred)` persistent buffers + contiguous fp32 `pred`/`gt` at stable addresses on a non-default
@@ -269,7 +296,7 @@ class LPIPSMatrixCore:
             d_pred = torch.empty((B, H, W, 3), dtype=torch.float32, device=pred.device) if want_grad else None
         else:
             partials, d_pred = out
-        flags = 1 if (out is not None and _lib.stream_ptr() != 0) else 0
+        flags = (1 if (out is not None and _lib.stream_ptr() != 0) else 0) | (2 if self._target_ready(gt) else 0)
         _lib.check(self.lib.gom_lpips_vgg_value_and_grad(self._handle(), B, H, W, _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(partials), 1.0 / B,
                                                          _lib.ptr(d_pred), flags, _lib.stream_ptr()))
         return partials.sum(2).sum(0).mean(), d_pred

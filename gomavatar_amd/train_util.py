@@ -132,6 +132,8 @@ def train_iteration(model, optimizer, data, train_cfg, n_iters, lpips_func=None,
     """One iteration of the reference's loop, train.py:313-348 (without logging / checkpoints / subdivision, which the caller owns):
     zero_grad -> forward -> unpack -> compute_loss -> backward -> optimizer step -> update_lr.  Returns (loss, loss_items, rgb, mask)."""
     optimizer.zero_grad()
+    if hasattr(lpips_func, "prefetch_target") and _get(train_cfg.losses, "lpips.coeff", 1.0) > 0:
+        lpips_func.prefetch_target(data["target_rgbs"])       # (the target's half of the LPIPS trunk, on a second stream under the frame's forward)
     rgb, mask, outputs = model(data["K"], data["E"], data["cnl_gtfms"], data["dst_Rs"], data["dst_Ts"], dst_posevec=data.get("dst_posevec"),
                                canonical_joints=data.get("dst_tpose_joints"), i_iter=n_iters, bgcolor=data.get("bgcolor"))
     if random_bgcolor:
@@ -182,6 +184,8 @@ class GraphedTrainStep:
     def _iteration(self):
         fr = self.static
         self.opt.zero_grad(set_to_none=True)
+        if hasattr(self.lpips, "prefetch_target") and _get(self.loss_cfg, "lpips.coeff", 1.0) > 0:
+            self.lpips.prefetch_target(fr["target_rgbs"])     # (a second stream inside the capture: a parallel branch of the graph)
         rgbs, masks, out = self.model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], dst_posevec=fr.get("dst_posevec"),
                                       i_iter=self.i_iter)
         total, _ = compute_loss(unpack(rgbs, masks, fr["bgcolor"]), masks, out, fr["target_rgbs"], fr["target_masks"], self.loss_cfg,

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 6
+#define GOM_ABI_VERSION 7
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -325,6 +325,13 @@ int gom_lpips_vgg_set_precision(GomLpipsVgg *h, int32_t precision);
  * (bf16) or 3 per 32 input channels (bf16x3: hi, hi, lo).  NULL, NULL: back to the padded 3 x 3 path. */
 int gom_lpips_vgg_set_first_layer(GomLpipsVgg *h, const void *w1x1_fwd, const void *w1x1_bwd);
 #define GOM_LPIPS_USE_GRAPH 1u   /* capture the ~75 launches once per (sizes, pointers) and replay them as one hipGraph */
+#define GOM_LPIPS_TARGET_READY 2u /* the target's trunk features are already in the handle (gom_lpips_vgg_target_features at this size, ordered
+                                    before this call by the caller): walk the trunk with the prediction alone */
+/* The target image's half of the trunk forward on its own: it depends on nothing the frame's forward computes, so a caller can
+ * enqueue it on a second stream under the geometry / raster launches of the same iteration (train.py:113-121 evaluates both images
+ * where the loss is computed; same arithmetic, earlier).  The features stay in the handle until the next call of either function;
+ * the caller orders the two streams (event) both ways: target_features after the previous value_and_grad, value_and_grad after it. */
+int gom_lpips_vgg_target_features(GomLpipsVgg *h, int B, int H, int W, const float *gt, void *stream);
 int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W, const float *pred, const float *gt, float *value_partials,
                                  float grad_scale, float *d_pred, uint32_t flags, void *stream);
 

@@ -186,11 +186,15 @@ def test_fused_shading_equals_the_torch_selection_around_the_mlp():
         assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-12, (tuple(a.shape), float((a - b).norm()), float(a.norm()))
 
 
-def test_graphed_train_step_matches_the_eager_iterations():
-    """One HIP graph per training iteration (train_util.GraphedTrainStep) = the same iterations launched one by one."""
+@pytest.mark.parametrize("with_lpips", [False, True])
+def test_graphed_train_step_matches_the_eager_iterations(with_lpips):
+    """One HIP graph per training iteration (train_util.GraphedTrainStep) = the same iterations launched one by one; with the LPIPS term the
+    graph holds a parallel branch (the target's trunk features on a second stream: LPIPSMatrixCore.prefetch_target)."""
     from gomavatar_amd.train_util import GraphedTrainStep, compute_loss, unpack
+    from gomavatar_amd.lpips import LPIPSMatrixCore
     img = 96
-    loss_cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+    lp = LPIPSMatrixCore(trunk_seed=0, precision="bf16x3") if with_lpips else None
+    loss_cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=1.0 if with_lpips else 0.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
                   normal=NS(coeff_mask=1.0, kernel_size=5, coeff_consist=0.1), color_consist=NS(coeff=0.05))
     lr = NS(lr=NS(appearance=5e-3, canonical_geometry=5e-4, canonical_geometry_xyz=5e-5, shadow=5e-4))
     teacher = _small_model(img)
@@ -207,7 +211,7 @@ def test_graphed_train_step_matches_the_eager_iterations():
         m = Model(_cfg(img), syn.icosphere_body(3)).train()
         m.capture_safe = True
         opt = torch.optim.Adam(m.get_param_groups(lr), capturable=True)
-        step = GraphedTrainStep(m, opt, loss_cfg, None, warmup=2) if graphed else None
+        step = GraphedTrainStep(m, opt, loss_cfg, lp, warmup=2) if graphed else None
         if graphed:   # the first call runs its 2 warm-up iterations on its frame (the capture itself executes nothing)
             for it in range(8):
                 total = step(frames[it % 4])
@@ -215,16 +219,25 @@ def test_graphed_train_step_matches_the_eager_iterations():
             for fi in [0, 0] + [it % 4 for it in range(1, 8)]:
                 f2 = frames[fi]
                 opt.zero_grad(set_to_none=True)
+                if lp is not None:
+                    lp.prefetch_target(f2["target_rgbs"])      # (as train_util.train_iteration and the graphed step do)
                 rgbs, masks, out = m(f2["K"], f2["E"], f2["cnl_gtfms"], f2["dst_Rs"], f2["dst_Ts"])
-                total, _ = compute_loss(unpack(rgbs, masks, f2["bgcolor"]), masks, out, f2["target_rgbs"], f2["target_masks"], loss_cfg)
+                total, _ = compute_loss(unpack(rgbs, masks, f2["bgcolor"]), masks, out, f2["target_rgbs"], f2["target_masks"], loss_cfg, lpips_func=lp)
                 total.backward(); opt.step()
         torch.cuda.synchronize()
         finals.append((float(total.detach()), [p.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)]))
     assert abs(finals[0][0] - finals[1][0]) <= 1e-3 * max(1.0, abs(finals[0][0])), (finals[0][0], finals[1][0])   # (two eager runs differ by ~1e-4 too)
     # Two eager runs differ by as much: the torch ops around the kernels (index_put backward) sum with atomics, and Adam turns a
     # last-bit gradient difference on a near-zero gradient into a +-lr step.  So: within a few steps of each parameter's lr.
+    # With the LPIPS term a last-bit difference of the image moves its gradient by 5e-3 of its norm (ReLU masks and pool argmaxes flip at isolated
+    # pixels: tests/test_gpu_vgg_bf16.py), i.e. more signs of near-zero gradients differ: measured up to 4.6 steps at single elements after these
+    # 8 iterations (8 is the most two runs can differ by): the bulk is held instead -- mean deviation half a step (measured 0.28), 99 % within three steps (measured 2.1).
     for (a, b), step_size in zip(zip(finals[0][1], finals[1][1]), (5e-5, 5e-4, 5e-4, 5e-3)):
-        assert float((a - b).abs().max()) <= 4 * step_size, (tuple(a.shape), float((a - b).abs().max()))
+        d = (a - b).abs()
+        if with_lpips:
+            assert float(d.mean()) <= 0.5 * step_size and float(torch.quantile(d.flatten()[:1_000_000], 0.99)) <= 3 * step_size, (tuple(a.shape), float(d.mean()), float(d.max()))
+        else:
+            assert float(d.max()) <= 4 * step_size, (tuple(a.shape), float(d.max()))
 
 
 def test_fused_positional_encoding_matches_the_torch_formula():

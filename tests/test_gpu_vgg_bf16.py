@@ -157,6 +157,42 @@ def test_lpips_bf16x3_trunk_has_the_precision_of_the_fp32_path(shape):
     assert float(val2) == float(val) and torch.equal(grad, grad2)          # reproducible
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_target_features_on_a_second_stream_give_the_same_lpips(precision):
+    """LPIPSMatrixCore.prefetch_target: the target image's half of the trunk on another stream before the prediction exists
+    (gom_lpips_vgg_target_features + GOM_LPIPS_TARGET_READY).  Same arithmetic per image; the batch of one image set picks other split-K
+    counts than the batch of two, i.e. fp32 sums in another order: value to 2e-6 relative (measured 8e-8); the gradient moves by 4.6e-3 of
+    its norm -- exactly what ANY change of the split-K summation order does to it (scripts/lpips_split_sensitivity.py: the batched path
+    with the round-3 split rule against today's: 4.5e-3; last-bit differences of activations flip ReLU masks and pool argmaxes at isolated
+    pixels), inside the 3e-3 .. 6e-3 this trunk keeps to the float64 one (test above).  Bound 1.4e-2.  Bitwise equal from prefetch to
+    prefetch over 12 rounds with other work on both streams in between.  A prefetch for ANOTHER target tensor is ignored (the batched path runs)."""
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    B, H, W = 1, 256, 256
+    g = torch.Generator().manual_seed(21)
+    pred = torch.rand(B, H, W, 3, generator=g).cuda()
+    gts = [(pred.cpu() + 0.2 * torch.randn(B, H, W, 3, generator=g)).clamp(0, 1).cuda() for _ in range(2)]
+    mc = LPIPSMatrixCore(trunk_seed=5, precision=precision)
+    base = [mc.value_and_grad(pred, gt) for gt in gts]
+    junk = torch.empty(1 << 22, device="cuda")
+    first = {}
+    for rnd in range(12):
+        k = rnd % 2
+        mc.prefetch_target(gts[k])
+        junk.normal_()                                     # (the frame's forward would be enqueued here)
+        val, grad = mc.value_and_grad(pred, gts[k])
+        assert mc._target is None
+        if k not in first:
+            first[k] = (float(val), grad.clone())
+            assert abs(float(val) - float(base[k][0])) <= (2e-6 if precision == "bf16x3" else 2e-4) * float(base[k][0]), (float(val), float(base[k][0]))   # (bf16: 1.7e-5)
+            tol = 1.4e-2 if precision == "bf16x3" else 0.3   # (one-pass bf16: a rounding of an activation is 2^-9; its distance to float64 is 0.2)
+            assert float((grad - base[k][1]).norm()) <= tol * float(base[k][1].norm()), float((grad - base[k][1]).norm() / base[k][1].norm())
+        else:
+            assert float(val) == first[k][0] and torch.equal(grad, first[k][1]), rnd
+    mc.prefetch_target(gts[0])
+    val, grad = mc.value_and_grad(pred, gts[1])            # not the prefetched tensor: both images walk the trunk together
+    assert float(val) == float(base[1][0]) and torch.equal(grad, base[1][1])
+
+
 def test_pipelined_conv_is_race_free_over_many_launches():
     """The 16-row kernel orders its LDS-DMA staging by counted vmcnt waits and one barrier per stage: a misplaced wait would show
     up as rare, timing-dependent wrong tiles.  300 back-to-back launches (other launches in between to perturb timing) must
