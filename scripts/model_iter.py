@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE configs[1] as the reference runs it, alone: N iterations of train.py:309-349 through the drop-in Model (55 104 Gaussians, 512^2, every
 loss term incl. LPIPS on the bf16x3 trunk) -- for rocprofv3 kernel traces of the iteration (scripts/model_iter_prof.sh) and quick timings.
-usage: python scripts/model_iter.py [iters] [torch|gom] [bf16x3|bf16]"""
+usage: python scripts/model_iter.py [iters] [torch|gom|graph] [bf16x3|bf16]"""
 import os, sys, time
 from types import SimpleNamespace as NS
 import torch
@@ -27,18 +27,24 @@ tcfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, c
 model = Model(cfg, wl.body).train()
 mcl = LPIPSMatrixCore(trunk_seed=0, device=dev, precision=prec)
 groups = model.get_param_groups(tcfg)
-opt = GomAdam(groups, betas=(0.9, 0.999)) if which == "gom" else torch.optim.Adam(groups, betas=(0.9, 0.999))
+opt = torch.optim.Adam(groups, betas=(0.9, 0.999)) if which == "torch" else GomAdam(groups, betas=(0.9, 0.999))
 frames = []
 for i in range(4):
     fr = {k: torch.from_numpy(v).to(dev) for k, v in wl.frames_np[i].items()}
     fr["target_rgbs"], fr["target_masks"] = wl.frames[i]["gt_rgb"][None], wl.frames[i]["gt_mask"][None]
     frames.append(fr)
+if which == "graph":          # the same iteration as ONE HIP graph (train_util.GraphedTrainStep: Adam capturable, lr frozen at capture)
+    opt = GomAdam(groups, betas=(0.9, 0.999), capturable=True)
+    gstep = tu.GraphedTrainStep(model, opt, tcfg.losses, mcl)
+    step = lambda it: gstep(frames[it % 4], i_iter=1)
+else:
+    step = lambda it: tu.train_iteration(model, opt, frames[it % 4], tcfg, it + 1, lpips_func=mcl)
 for it in range(10):
-    tu.train_iteration(model, opt, frames[it % 4], tcfg, it + 1, lpips_func=mcl)
+    step(it)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for it in range(iters):
-    tu.train_iteration(model, opt, frames[it % 4], tcfg, it + 11, lpips_func=mcl)
+    step(10 + it)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
 print(f"model train iteration ({which} Adam, {prec}): {dt * 1e3:.3f} ms = {1 / dt:.1f} it/s")
