@@ -299,7 +299,7 @@ class LPIPSMatrixCore:
         flags = (1 if (out is not None and _lib.stream_ptr() != 0) else 0) | (2 if self._target_ready(gt) else 0)
         _lib.check(self.lib.gom_lpips_vgg_value_and_grad(self._handle(), B, H, W, _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(partials), 1.0 / B,
                                                          _lib.ptr(d_pred), flags, _lib.stream_ptr()))
-        return partials.sum(2).sum(0).mean(), d_pred
+        return (partials.sum() if B == 1 else partials.sum() * (1.0 / B)), d_pred      # mean_b of (sum over layers and blocks): one reduction
 
     def loss(self, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:
         """Differentiable `lpips_loss` (train.py:113-117) for autograd callers."""

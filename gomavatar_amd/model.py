@@ -44,6 +44,7 @@ class SimpleMesh:
 
     def __init__(self, verts: torch.Tensor, faces: torch.Tensor, edges: torch.Tensor, topo=None, loss_topo=None, normal_pairs=None):
         self._v, self._f, self._e = verts, faces, edges
+        self._vc = None
         self.topo, self.loss_topo = topo, loss_topo          # device CSR adjacency for the HIP regularisers
         self._normal_pairs = normal_pairs                     # every pair of edge-adjacent faces (mesh_normal_consistency)
 
@@ -54,10 +55,14 @@ class SimpleMesh:
             self._normal_pairs = edge_adjacent_face_pairs(f2e).to(self._f.device)
         return self._normal_pairs
 
-    def verts_packed(self): return self._v
+    def verts_packed(self):
+        # ONE contiguous (N, 3) copy of the (3, N) parameter view for all the regularisers that read it (each made its own)
+        if self._vc is None:
+            self._vc = self._v.contiguous()
+        return self._vc
     def faces_packed(self): return self._f
     def edges_packed(self): return self._e
-    def verts_padded(self): return self._v[None]
+    def verts_padded(self): return self.verts_packed()[None]
     def faces_padded(self): return self._f[None]
 
 

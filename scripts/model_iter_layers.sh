@@ -8,7 +8,7 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o it -- python scripts/model_iter.py "$@" > $OUT/run.log 2>&1
 tail -1 $OUT/run.log
 python - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
@@ -23,7 +23,7 @@ keys = ("conv", "pool", "lpips", "splitk")
 for j in range(n0):
     nm = seqs[0][j]["Kernel_Name"]
     d = sum(int(s[j]["End_Timestamp"]) - int(s[j]["Start_Timestamp"]) for s in seqs) / len(seqs) / 1e3
-    if any(k in nm for k in keys):
+    if os.environ.get("ALL") or any(k in nm for k in keys):
         tot += d
         r = seqs[0][j]
         short = nm.replace("(anonymous namespace)::", "").replace("void ", "")[:64]
