@@ -394,14 +394,14 @@ def extra_figures(torch, wl):
             def train_it():
                 tu.train_iteration(model, optm, frames[it_[0] % 4], tcfg, it_[0] + 1, lpips_func=mcl)
                 it_[0] += 1
-            out[f"model_train_iteration_lpips_{prec}_torch_adam_b1_ips"] = round(timeit(torch, train_it, warm=5, chunk=5), 1)
+            out[f"model_train_iteration_lpips_{prec}_torch_adam_b1_ips"] = round(timeit(torch, train_it, warm=20, chunk=5), 1)   # (warm: torch builds its foreach optimizer state and the library its LPIPS buffers in the first iterations)
             # the same iteration with the reference's optimizer as one native launch (gomavatar_amd.optim.GomAdam: a torch.optim.Optimizer over the
             # same param groups, update_lr and checkpoints unchanged) -- the default the drop-in train loop is meant to run with
             from gomavatar_amd.optim import GomAdam
             model = Model(cfg, wl.body).train()
             optm = GomAdam(model.get_param_groups(tcfg), betas=(0.9, 0.999))
             it_[0] = 0
-            out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=5, chunk=5), 1)
+            out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=10, chunk=5), 1)
             if prec == "bf16x3":   # the same iteration captured once in a HIP graph and replayed per frame (train_util.GraphedTrainStep; Adam capturable, lr frozen at capture)
                 model_g = Model(cfg, wl.body).train()
                 opt_g = GomAdam(model_g.get_param_groups(tcfg), betas=(0.9, 0.999), capturable=True)

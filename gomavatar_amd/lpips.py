@@ -211,6 +211,7 @@ class LPIPSMatrixCore:
         self.lins = [torch.from_numpy(lin[f"lin{k}"].astype(np.float32).reshape(-1)).to(dev).contiguous() for k in range(5)]
         self._h = None
         self._side, self._target = None, None          # prefetch_target: its stream, (key, event, the fp32 copy kept alive)
+        self.prefetch_enabled = os.environ.get("GOM_LPIPS_PREFETCH", "1") != "0"   # (development switch: 0 = both images as one batch at the loss)
         self.first_layer_im2col = os.environ.get("GOM_LPIPS_FIRST_LAYER_IM2COL", "1") != "0"   # (development switch: 0 = the padded 3 x 3 kernels for conv1_1 too)
         self.set_trunk([t.to(dev) for t in seeded_trunk(trunk_seed)])
 
@@ -263,6 +264,8 @@ class LPIPSMatrixCore:
         on nothing the model computes, and the geometry / raster launches of a frame leave most of the chip idle (train_util.train_iteration
         does this).  The next `value_and_grad` / `loss` with the same `gt` tensor then walks the trunk with the prediction alone."""
         assert gt.is_cuda and gt.dim() == 4 and gt.shape[-1] == 3
+        if not self.prefetch_enabled:
+            return
         B, H, W, _ = gt.shape
         g32 = gt.detach().float().contiguous()
         main = torch.cuda.current_stream(gt.device)
