@@ -3,6 +3,7 @@
 // 13 backward-data convolutions + the image gradient -- ~75 launches enqueued back to back on the caller's stream
 // (hipGraph-capturable: no allocation after the first call of a given size, no host sync).
 // Replaces train.py:113-121 (LPIPS(2*pred-1, 2*gt-1).mean() and its autograd backward).
+#include <stdlib.h>
 #include <string.h>
 
 #include "gom_internal.h"
@@ -188,7 +189,11 @@ extern "C" int gom_lpips_vgg_value_and_grad(GomLpipsVgg *h, int B, int H, int W,
 static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int W, const float *const *img, float *splitk, void *stream) {
     int rc;
     const bool im2col = h->w1_fwd != nullptr;   // conv1_1 without its channel padding (vgg_bf16.hip: k_lpips_prepare_im2col)
-    for (int k = k0; k < k0 + nsets; k++)
+    // conv1_1 reads the image itself (k_conv1_1_image) unless GOM_LPIPS_FIRST_LAYER_FUSED=0 asks for the two-kernel form (im2col rows, then a 1 x 1
+    // convolution: the same bits, 33 MB more traffic per image and plane) -- read per call so that a test can compare the two in one process
+    const char *fenv = getenv("GOM_LPIPS_FIRST_LAYER_FUSED");
+    const bool fused1 = im2col && W % 32 == 0 && !(fenv && fenv[0] == '0');
+    for (int k = k0; k < k0 + nsets && !fused1; k++)
         if ((rc = im2col ? gom_lpips_prepare_im2col_planes(B, H, W, img[k], h->x[k], h->lo_x, stream) : gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
     const int nb = nsets * B;
     int hh = H, ww = W;
@@ -200,7 +205,10 @@ static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int
             hh /= 2; ww /= 2;
             cur = h->pooled[k0][i]; cur_lo = h->lo_pooled[i];
         }
-        if (i == 0 && im2col) {
+        if (i == 0 && fused1) {
+            for (int k = k0; k < k0 + nsets; k++)   // (one launch per image set: the sets' images are separate tensors)
+                if ((rc = gom_conv1_1_image_planes(B, hh, ww, img[k], h->w1_fwd, h->bias[0], h->act[k][0], h->lo_act[0], stream))) return rc;
+        } else if (i == 0 && im2col) {
             if ((rc = gom_conv1x1_planes((size_t)nb * hh * ww, 32, h->cout[0], cur, h->w1_fwd, h->bias[0], h->act[k0][0], 1, cur_lo, h->lo_act[0], stream))) return rc;
         } else if ((rc = lp_conv(splitk, nb, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
         cur = h->act[k0][i]; cur_lo = h->lo_act[i];

@@ -53,6 +53,31 @@ __device__ __forceinline__ void store4(bf16_t *p, size_t lo, const float (&v)[4]
     *reinterpret_cast<uint2 *>(p + lo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
+// Which output channel an MFMA tile row stands for.  D[i][j] of tile n leaves lane (kg, l15) with rows 4 kg .. 4 kg + 3: with the natural order
+// (row i of tile n = channel 16 n + i) a lane ends with NT separate groups of 4 channels -- NT 8-byte stores per pixel and plane, a quarter of a
+// 32-byte sector each.  With row i of tile n = channel 4 NT (i / 4) + 4 n + i % 4 the same lane holds the 4 NT CONSECUTIVE channels
+// 4 NT kg .. 4 NT kg + 4 NT - 1: one 32-byte store (NT = 4), and the four lanes of a pixel write its 128-byte line.  Only the row a weight fragment
+// is fetched from changes (the staging kernels apply it to the SOURCE row, LDS rows stay consecutive: the swizzle's proof holds); the sums are the same.
+template <int NT>
+__device__ __forceinline__ int tile_row_channel(int i) { return 4 * NT * ((i & 15) >> 2) + 4 * (i >> 4) + (i & 3); }   // i = 16 n + row
+// 4 NT consecutive channels of one pixel: 8 NT bytes per plane in 16-byte stores
+template <int NT>
+__device__ __forceinline__ void store_row(bf16_t *p, size_t lo, const float (&v)[4 * NT]) {
+    uint32_t h[2 * NT], l[2 * NT];
+#pragma unroll
+    for (int k = 0; k < 2 * NT; k++) {
+        bf16_t h0, h1, l0 = 0, l1 = 0;
+        if (lo) { split_bf(v[2 * k], h0, l0); split_bf(v[2 * k + 1], h1, l1); } else { h0 = f2bf(v[2 * k]); h1 = f2bf(v[2 * k + 1]); }
+        h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[k] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+#pragma unroll
+    for (int q = 0; q < NT / 2; q++) {
+        *reinterpret_cast<uint4 *>(p + 8 * q) = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+        if (lo) *reinterpret_cast<uint4 *>(p + lo + 8 * q) = make_uint4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+    }
+}
+
 constexpr int kTileW = 16, kBN = 64, kKC = 32;
 constexpr int kPatchW = kTileW + 2;  // 18
 // TH = pixel rows per workgroup (2 per wave): 8 rows / 4 waves for the small deep layers, 16 rows / 8 waves for the large
@@ -72,31 +97,35 @@ __device__ __forceinline__ int swz_part(int part, int row) { return part ^ (((ro
 template <bool RELU, int RPW>
 __device__ __forceinline__ void conv_store(const f32x4 (&acc)[RPW][4], int H, int W, int Cout, size_t img, int ty0, int tx0, int row0, int co0, int l15, int kg,
                                            const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, size_t out_lo) {
+    const int co = co0 + 16 * kg;   // this lane's 16 consecutive channels (tile_row_channel<4>): 4 n + r <- acc[m][n][r]
 #pragma unroll
     for (int m = 0; m < RPW; m++) {
         const int gy = ty0 + row0 + m, gx = tx0 + l15;
         if (gy >= H || gx >= W) continue;
         const size_t pix = (img + (size_t)gy * W + gx) * Cout;
+        float v[16];
 #pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const int co = co0 + n * 16 + kg * 4;
-            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            if (bias) {
+        for (int n = 0; n < 4; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] += bias[co + r];
-            }
-            if (RELU) {
+            for (int r = 0; r < 4; r++) v[4 * n + r] = acc[m][n][r];
+        if (bias) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (mask) {
-                const uint2 mk = *reinterpret_cast<const uint2 *>(mask + pix + co);
-                const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
-            }
-            store4(out + pix + co, out_lo, v);
+            for (int k = 0; k < 16; k++) v[k] += bias[co + k];
         }
+        if (RELU) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (mask) {
+            const uint4 m0 = *reinterpret_cast<const uint4 *>(mask + pix + co), m1 = *reinterpret_cast<const uint4 *>(mask + pix + co + 8);
+            const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                v[2 * k] = bf2f((bf16_t)(mw[k] & 0xffff)) > 0.f ? v[2 * k] : 0.f;
+                v[2 * k + 1] = bf2f((bf16_t)(mw[k] >> 16)) > 0.f ? v[2 * k + 1] : 0.f;
+            }
+        }
+        store_row<4>(out + pix + co, out_lo, v);
     }
 }
 
@@ -110,9 +139,9 @@ __device__ __forceinline__ void conv_store_partial(const f32x4 (&acc)[RPW][4], i
     for (int m = 0; m < RPW; m++) {
         const int gy = ty0 + row0 + m, gx = tx0 + l15;
         if (gy >= H || gx >= W) continue;
-        float *dst = partial + (size_t)zs * nb * H * W * Cout + (img + (size_t)gy * W + gx) * Cout + co0 + kg * 4;
+        float *dst = partial + (size_t)zs * nb * H * W * Cout + (img + (size_t)gy * W + gx) * Cout + co0 + 16 * kg;   // 16 consecutive channels (tile_row_channel<4>)
 #pragma unroll
-        for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + n * 16) = acc[m][n];
+        for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4 *>(dst + 4 * n) = acc[m][n];
     }
 }
 
@@ -163,7 +192,7 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
             for (int idx = tid; idx < 9 * kBN * 4; idx += NT) {
                 const int tap = idx >> 8, r = idx & 255;  // 256 16-byte units per tap (64 co x 32 ci)
                 *reinterpret_cast<uint4 *>(s_w + tap * kBN * kKC + (r >> 2) * kKC + swz_part(r & 3, r >> 2) * 8) =
-                    *reinterpret_cast<const uint4 *>(wsrc + (size_t)tap * Cout * kKC + r * 8);
+                    *reinterpret_cast<const uint4 *>(wsrc + (size_t)tap * Cout * kKC + tile_row_channel<4>(r >> 2) * kKC + (r & 3) * 8);   // LDS row r >> 2 <- its channel's weights
             }
         }
         __syncthreads();
@@ -259,7 +288,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
     for (int j = 0; j < WI; j++) {
         const int v = min(WU * wave + 64 * j + lane, 3 * kBN * 4 - 1);
         const int row = (v & 255) >> 2;                                           // output channel of the unit
-        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)row * kKC + (size_t)swz_part(v & 3, row) * 8) * 2;   // bytes inside the (chunk, ky) row block
+        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)tile_row_channel<4>(row) * kKC + (size_t)swz_part(v & 3, row) * 8) * 2;   // bytes inside the (chunk, ky) row block: LDS row <- its channel (tile_row_channel)
     }
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wt + (size_t)co0 * kKC);
 
@@ -555,31 +584,102 @@ __global__ void __launch_bounds__(256) k_conv1x1_bf16(size_t npix, int Cin, cons
                 bfrag[m] = px < npix ? *reinterpret_cast<const bf16x8 *>(plane + px * Cin + sc * 32 + kg * 8) : bf16x8{};
             }
 #pragma unroll
-            for (int n = 0; n < NT; n++) afrag[n] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)cc * Cout + n * 16 + l15) * 32 + kg * 8);
+            for (int n = 0; n < NT; n++) afrag[n] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)cc * Cout + tile_row_channel<NT>(n * 16 + l15)) * 32 + kg * 8);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < NT; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], bfrag[m], acc[m][n], 0, 0, 0);
         }
-        // D[i = co][j = px]: the lane holds co = 16 n + 4 kg + r (r = 0..3) of pixel l15
+        // the lane holds the 4 NT consecutive channels 4 NT kg + 4 n + r of pixel l15 (tile_row_channel)
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             const size_t px = p0 + 16 * m + l15;
             if (px >= npix) continue;
+            const int co = 4 * NT * kg;
+            float v[4 * NT];
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                const int co = n * 16 + kg * 4;
-                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-                if (bias) {
+            for (int n = 0; n < NT; n++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] += bias[co + r];
-                }
-                if (RELU) {
+                for (int r = 0; r < 4; r++) v[4 * n + r] = acc[m][n][r];
+            if (bias) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-                }
-                store4(out + px * Cout + co, out_lo, v);
+                for (int k = 0; k < 4 * NT; k++) v[k] += bias[co + k];
             }
+            if (RELU) {
+#pragma unroll
+                for (int k = 0; k < 4 * NT; k++) v[k] = fmaxf(v[k], 0.f);
+            }
+            store_row<NT>(out + px * Cout + co, out_lo, v);
+        }
+    }
+}
+
+// conv1_1 straight from the image: k_lpips_prepare_im2col + k_conv1x1_bf16<true, 4> in one kernel.  The im2col row of a pixel (3 x 3 taps x 3
+// channels of ScalingLayer(2x - 1), zero-padded to 32) is built in registers by exactly the lanes that need it as a B fragment (pixel l15, channel
+// group kg: the unit one thread of the prepare kernel writes), so the same values go through the same MFMA sequence -- bitwise the two-kernel
+// result -- without 33 MB of rows written and read back per image and plane.  wt: [chunks][64][32], chunks = 1 (bf16) or 3 (bf16x3: hi, hi, lo).
+template <bool X3>
+__global__ void __launch_bounds__(256) k_conv1_1_image(int B, int H, int W, const float *__restrict__ rgb, const bf16_t *__restrict__ wt, const float *__restrict__ bias,
+                                                       bf16_t *__restrict__ out, size_t out_lo) {
+    constexpr int NT = 4, Cout = 64;
+    const float shift[3] = {-0.030f, -0.088f, -0.188f}, scale[3] = {0.458f, 0.448f, 0.450f};
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
+    // a wave owns 32 consecutive pixels of ONE image row (W is a multiple of 32 here: the launcher checks): 32-bit index arithmetic, once per wave
+    const uint32_t wpr = (uint32_t)W / 32u, nrow = (uint32_t)B * (uint32_t)H;
+    const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwave = (gridDim.x * 256u) >> 6;
+    for (uint32_t wv = wave0; wv < nrow * wpr; wv += nwave) {
+        const uint32_t row = wv / wpr, x0 = (wv - row * wpr) * 32u;
+        const int y = (int)(row % (uint32_t)H);
+        const size_t p0 = (size_t)row * W + x0;
+        const float *img_row = rgb + 3 * ((size_t)row * W);   // pixel (row, 0) of this image row; the rows above / below are +- 3 W floats
+        bf16x8 bhi[2], blo[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int x = (int)x0 + 16 * m + l15;
+            bf16_t hi[8], lo[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = kg * 8 + r;
+                float v = 0.f;
+                if (k < 27) {
+                    const int tap = k / 3, c = k % 3;
+                    const int dy = tap / 3 - 1, xx = x + tap % 3 - 1;
+                    if (y + dy >= 0 && y + dy < H && xx >= 0 && xx < W) v = ((2.f * img_row[3 * ((ptrdiff_t)dy * W + xx) + c] - 1.f) - shift[c]) / scale[c];
+                }
+                if (X3) split_bf(v, hi[r], lo[r]); else { hi[r] = f2bf(v); lo[r] = 0; }
+            }
+            const uint4 qh = make_uint4((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16), (uint32_t)hi[4] | ((uint32_t)hi[5] << 16),
+                                        (uint32_t)hi[6] | ((uint32_t)hi[7] << 16));
+            const uint4 ql = make_uint4((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16), (uint32_t)lo[4] | ((uint32_t)lo[5] << 16),
+                                        (uint32_t)lo[6] | ((uint32_t)lo[7] << 16));
+            bhi[m] = __builtin_bit_cast(bf16x8, qh);
+            blo[m] = __builtin_bit_cast(bf16x8, ql);
+        }
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < (X3 ? 3 : 1); cc++) {   // (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo): the order of k_conv1x1_bf16's chunk loop
+            bf16x8 afrag[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) afrag[n] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)cc * Cout + tile_row_channel<NT>(n * 16 + l15)) * 32 + kg * 8);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[n], cc == 1 ? blo[m] : bhi[m], acc[m][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const size_t px = p0 + 16 * m + l15;
+            const int co = 16 * kg;   // 16 consecutive channels (tile_row_channel<4>)
+            float v[16];
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[4 * n + r] = fmaxf(acc[m][n][r] + bias[co + 4 * n + r], 0.f);
+            store_row<4>(out + px * Cout + co, out_lo, v);
         }
     }
 }
@@ -842,6 +942,17 @@ int gom_conv1x1_planes(size_t npix, int Cin, int Cout, const void *in, const voi
     if (Cout == 64) { if (relu) GOM_C1(true, 4); else GOM_C1(false, 4); }
     else { if (relu) GOM_C1(true, 2); else GOM_C1(false, 2); }
 #undef GOM_C1
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_conv1_1_image_planes(int B, int H, int W, const float *rgb, const void *wt, const float *bias, void *out, size_t out_lo, void *stream) {
+    const size_t npix = (size_t)B * H * W;
+    if (!rgb || !wt || !bias || !out || npix == 0 || W % 32) { gom_set_error("gom_conv1_1_image: bad arguments (W must be a multiple of 32)"); return -1; }
+    const size_t waves = (npix + 31) / 32;
+    const unsigned grid = (unsigned)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);
+    if (out_lo) hipLaunchKernelGGL((k_conv1_1_image<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, W, rgb, (const bf16_t *)wt, bias, (bf16_t *)out, out_lo);
+    else hipLaunchKernelGGL((k_conv1_1_image<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, W, rgb, (const bf16_t *)wt, bias, (bf16_t *)out, out_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }

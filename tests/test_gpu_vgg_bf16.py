@@ -193,6 +193,32 @@ def test_target_features_on_a_second_stream_give_the_same_lpips(precision):
     assert float(val) == float(base[1][0]) and torch.equal(grad, base[1][1])
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_first_layer_from_the_image_is_bitwise_the_two_kernel_form(precision):
+    """k_conv1_1_image builds conv1_1's im2col rows in registers; GOM_LPIPS_FIRST_LAYER_FUSED=0 writes them out and runs the 1 x 1 convolution
+    over them (round 4's first form).  Same values through the same MFMA sequence: LPIPS value and gradient equal bit for bit, with and
+    without the target prefetch (one image set alone / both as a batch)."""
+    import os
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    g = torch.Generator().manual_seed(31)
+    pred = torch.rand(2, 64, 96, 3, generator=g).cuda()
+    gt = (pred.cpu() + 0.2 * torch.randn(2, 64, 96, 3, generator=g)).clamp(0, 1).cuda()
+    mc = LPIPSMatrixCore(trunk_seed=7, precision=precision)
+    res = {}
+    try:
+        for fused in ("1", "0"):
+            os.environ["GOM_LPIPS_FIRST_LAYER_FUSED"] = fused
+            v, gr = mc.value_and_grad(pred, gt)
+            mc.prefetch_target(gt)
+            v2, gr2 = mc.value_and_grad(pred, gt)
+            res[fused] = (float(v), gr.clone(), float(v2), gr2.clone())
+    finally:
+        os.environ.pop("GOM_LPIPS_FIRST_LAYER_FUSED", None)
+    assert res["1"][0] == res["0"][0] and torch.equal(res["1"][1], res["0"][1])
+    assert res["1"][2] == res["0"][2] and torch.equal(res["1"][3], res["0"][3])
+    assert res["1"][0] > 0 and float(res["1"][1].abs().max()) > 0
+
+
 def test_pipelined_conv_is_race_free_over_many_launches():
     """The 16-row kernel orders its LDS-DMA staging by counted vmcnt waits and one barrier per stage: a misplaced wait would show
     up as rare, timing-dependent wrong tiles.  300 back-to-back launches (other launches in between to perturb timing) must
