@@ -378,40 +378,37 @@ __device__ __forceinline__ float load1(const bf16_t *p, size_t lo) { return lo ?
 __device__ __forceinline__ void store1(bf16_t *p, size_t lo, float v) {
     if (lo) { bf16_t h, l; split_bf(v, h, l); p[0] = h; p[lo] = l; } else p[0] = f2bf(v);
 }
-__device__ __forceinline__ void store8(bf16_t *p, size_t lo, const float (&v)[8]) {
-    const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
-    store4(p, lo, a);
-    store4(p + 4, lo, b);
-}
+__device__ __forceinline__ void store8(bf16_t *p, size_t lo, const float (&v)[8]) { store_row<2>(p, lo, v); }   // 8 consecutive channels: one 16-byte store per plane
 
-// sum of the split-K partials + bias, ReLU, mask -> bf16; 4 channels per thread
-__global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n4, int Cout, int splits, const float *__restrict__ partial,
+// sum of the split-K partials + bias, ReLU, mask -> bf16; 8 channels per thread (16-byte stores per plane)
+__global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n8, int Cout, int splits, const float *__restrict__ partial,
                                                          const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out,
                                                          int relu, size_t out_lo) {
-    const size_t stride = n4 * 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 a = *reinterpret_cast<const f32x4 *>(partial + 4 * i);
+    const size_t stride = n8 * 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(partial + 8 * i), a1 = *reinterpret_cast<const f32x4 *>(partial + 8 * i + 4);
         for (int s = 1; s < splits; s++) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 4 * i);
-            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 8 * i), b1 = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 8 * i + 4);
+            a0[0] += b0[0]; a0[1] += b0[1]; a0[2] += b0[2]; a0[3] += b0[3];
+            a1[0] += b1[0]; a1[1] += b1[1]; a1[2] += b1[2]; a1[3] += b1[3];
         }
-        const int co = (int)((4 * i) % Cout);
-        float v[4] = {a[0], a[1], a[2], a[3]};
+        const int co = (int)((8 * i) % Cout);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         if (bias) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] += bias[co + r];
+            for (int r = 0; r < 8; r++) v[r] += bias[co + r];
         }
         if (relu) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], 0.f);
         }
         if (mask) {
-            const uint2 mk = *reinterpret_cast<const uint2 *>(mask + 4 * i);
-            const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16), (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
+            float mk[8];
+            unpack8(*reinterpret_cast<const uint4 *>(mask + 8 * i), mk);
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = bf2f(mm[r]) > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 8; r++) v[r] = mk[r] > 0.f ? v[r] : 0.f;
         }
-        store4(out + 4 * i, out_lo, v);
+        store8(out + 8 * i, out_lo, v);
     }
 }
 
@@ -440,9 +437,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C
             for (int k = 0; k < 8; k++) m[k] = w4 == 0 ? f[k] : fmaxf(m[k], f[k]);
         }
         bf16_t *dst = y + (((size_t)b * Ho + yo) * Wo + xo) * C + c8 * 8;
-        const float lo4[4] = {m[0], m[1], m[2], m[3]}, hi4[4] = {m[4], m[5], m[6], m[7]};
-        store4(dst, y_lo, lo4);   // (a maximum is one of the inputs: hi + lo represents it exactly again)
-        store4(dst + 4, y_lo, hi4);
+        store8(dst, y_lo, m);   // (a maximum is one of the inputs: hi + lo represents it exactly again)
     }
 }
 
@@ -451,26 +446,39 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(int B, int H, int W, int C
 // accumulate: dx already holds another gradient (the LPIPS head's) for this activation
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(int B, int H, int W, int C, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                       bf16_t *__restrict__ dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo) {
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)B * Ho * Wo * C;
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;   // 8 channels per thread: 16-byte loads and stores (the kernel is HBM-bound: x, dy, dx twice when it accumulates)
+    const size_t total = (size_t)B * Ho * Wo * C8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const size_t p = i / C;
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
         const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
-        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c8 * 8;
         const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
-        float v[4];
+        float v[4][8], g[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = load1(x + base + off[k], x_lo);
-        int am = 0;
+        for (int k = 0; k < 4; k++) load8(x + base + off[k], x_lo, v[k]);
+        load8(dy + p * C + c8 * 8, dy_lo, g);
+        int am[8];      // first maximum of each channel's window in row-major order, like the reference framework
+        bool pos[8];    // ... and the ReLU derivative of the layer that produced it
 #pragma unroll
-        for (int k = 1; k < 4; k++)
-            if (v[k] > v[am]) am = k;
-        const float g = load1(dy + i, dy_lo);
+        for (int ch = 0; ch < 8; ch++) {
+            float best = v[0][ch];
+            am[ch] = 0;
+#pragma unroll
+            for (int q = 1; q < 4; q++)
+                if (v[q][ch] > best) { best = v[q][ch]; am[ch] = q; }
+            pos[ch] = best > 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float add = (k == am && v[am] > 0.f) ? g : 0.f;
-            store1(dx + base + off[k], dx_lo, accumulate ? load1(dx + base + off[k], dx_lo) + add : add);
+            float o[8];
+            if (accumulate) load8(dx + base + off[k], dx_lo, o);
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) {
+                const float add = (k == am[ch] && pos[ch]) ? g[ch] : 0.f;
+                o[ch] = accumulate ? o[ch] + add : add;
+            }
+            store8(dx + base + off[k], dx_lo, o);
         }
     }
 }
@@ -872,8 +880,8 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
     if (splits > 1) {
         GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace, in_lo, out_lo);
         GOM_LAUNCH_CHECK();
-        const size_t n4 = (size_t)B * H * W * Cout / 4;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, n4, Cout, splits, workspace,
+        const size_t n8 = (size_t)B * H * W * Cout / 8;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096)), dim3(256), 0, st, n8, Cout, splits, workspace,
                            bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0, out_lo);
     } else if (flags & GOM_CONV_RELU) {
         GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo);
@@ -899,8 +907,8 @@ extern "C" int gom_maxpool2x2_backward_bf16(int B, int H, int W, int C, const vo
     return gom_maxpool2x2_backward_planes(B, H, W, C, x, dy, dx, accumulate, 0, 0, 0, stream);
 }
 int gom_maxpool2x2_backward_planes(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo, void *stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) { gom_set_error("gom_maxpool2x2_backward_bf16: bad sizes"); return -1; }
-    const size_t total = (size_t)B * (H / 2) * (W / 2) * C;
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) { gom_set_error("gom_maxpool2x2_backward_bf16: bad sizes (even H, W; C a multiple of 8)"); return -1; }
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(k_maxpool2_bwd, dim3((unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384)), dim3(256), 0, (hipStream_t)stream, B, H, W, C,
                        (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, accumulate, x_lo, dy_lo, dx_lo);
     GOM_LAUNCH_CHECK();
