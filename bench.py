@@ -257,19 +257,24 @@ class Runner:
         return {k: acc[k] / n for k in _lib.KERNEL_NAMES if acc.get(k, -1.0) >= 0.0}, D / n
 
 
-def timeit(torch, fn, min_s=MIN_TIMED_S, warm=5, chunk=10):
+def timeit(torch, fn, min_s=MIN_TIMED_S, warm=5, chunk=10, windows=1):
+    """Calls per second over `windows` timed windows of >= min_s each (the median window: a launch-bound Python loop is exposed to host jitter)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        for _ in range(chunk):
-            fn()
-        torch.cuda.synchronize()
-        n += chunk
-        el = time.perf_counter() - t0
-        if el >= min_s:
-            return n / el
+    rates = []
+    for _ in range(windows):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(chunk):
+                fn()
+            torch.cuda.synchronize()
+            n += chunk
+            el = time.perf_counter() - t0
+            if el >= min_s:
+                rates.append(n / el)
+                break
+    return sorted(rates)[len(rates) // 2]
 
 
 def extra_figures(torch, wl):
@@ -394,14 +399,14 @@ def extra_figures(torch, wl):
             def train_it():
                 tu.train_iteration(model, optm, frames[it_[0] % 4], tcfg, it_[0] + 1, lpips_func=mcl)
                 it_[0] += 1
-            out[f"model_train_iteration_lpips_{prec}_torch_adam_b1_ips"] = round(timeit(torch, train_it, warm=20, chunk=5), 1)   # (warm: torch builds its foreach optimizer state and the library its LPIPS buffers in the first iterations)
+            out[f"model_train_iteration_lpips_{prec}_torch_adam_b1_ips"] = round(timeit(torch, train_it, warm=20, chunk=5, windows=3), 1)   # (warm: torch builds its foreach optimizer state and the library its LPIPS buffers in the first iterations)
             # the same iteration with the reference's optimizer as one native launch (gomavatar_amd.optim.GomAdam: a torch.optim.Optimizer over the
             # same param groups, update_lr and checkpoints unchanged) -- the default the drop-in train loop is meant to run with
             from gomavatar_amd.optim import GomAdam
             model = Model(cfg, wl.body).train()
             optm = GomAdam(model.get_param_groups(tcfg), betas=(0.9, 0.999))
             it_[0] = 0
-            out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=10, chunk=5), 1)
+            out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=10, chunk=5, windows=3), 1)
             if prec == "bf16x3":   # the same iteration captured once in a HIP graph and replayed per frame (train_util.GraphedTrainStep; Adam capturable, lr frozen at capture)
                 model_g = Model(cfg, wl.body).train()
                 opt_g = GomAdam(model_g.get_param_groups(tcfg), betas=(0.9, 0.999), capturable=True)
@@ -411,7 +416,7 @@ def extra_figures(torch, wl):
                 def train_graphed():
                     gstep(frames[jt[0] % 4], i_iter=1)
                     jt[0] += 1
-                out["model_train_iteration_lpips_bf16x3_b1_graphed_ips"] = round(timeit(torch, train_graphed, warm=6, chunk=5), 1)
+                out["model_train_iteration_lpips_bf16x3_b1_graphed_ips"] = round(timeit(torch, train_graphed, warm=6, chunk=5, windows=3), 1)
                 del model_g, opt_g, gstep
             del model, mcl, optm
     except Exception as e:  # report, do not hide
