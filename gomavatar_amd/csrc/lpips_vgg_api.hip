@@ -29,6 +29,7 @@ struct GomLpipsVgg {
     void *gtap = nullptr;                        // head gradient of the current tap
     float *splitk = nullptr, *splitk_target = nullptr;   // split-K partial sums; the target-only pass (its own stream) has its own
     float *go = nullptr;                         // [B] d value / d value_b
+    float *head_sums = nullptr;                  // [5][B][GOM_LPIPS_HEAD_BLOCKS]: per-workgroup value sums of the taps when the backward kernels produce them
     size_t splitk_elems = 0;
     // captured launch sequence (GOM_LPIPS_USE_GRAPH), valid for exactly these arguments
     hipGraph_t graph = nullptr;
@@ -47,7 +48,7 @@ static void lp_drop_graph(GomLpipsVgg *h) {
 
 static void lp_free(GomLpipsVgg *h) {
     lp_drop_graph(h);
-    void *ptrs[] = {h->x[0], h->grad[0], h->grad[1], h->gtap, h->splitk, h->splitk_target, h->go};   // (x[1], act[1][], pooled[1][] are the second halves of [0])
+    void *ptrs[] = {h->x[0], h->grad[0], h->grad[1], h->gtap, h->splitk, h->splitk_target, h->go, h->head_sums};   // (x[1], act[1][], pooled[1][] are the second halves of [0])
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 13; i++) {
         if (h->act[0][i]) (void)hipFree(h->act[0][i]);
@@ -55,7 +56,7 @@ static void lp_free(GomLpipsVgg *h) {
         for (int k = 0; k < 2; k++) h->act[k][i] = h->pooled[k][i] = nullptr;
     }
     h->x[0] = h->x[1] = h->grad[0] = h->grad[1] = h->gtap = nullptr;
-    h->splitk = h->splitk_target = nullptr; h->go = nullptr;
+    h->splitk = h->splitk_target = nullptr; h->go = h->head_sums = nullptr;
     h->B = h->H = h->W = 0;
 }
 
@@ -129,6 +130,7 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
     GOM_HIP_CHECK(hipMalloc((void **)&h->splitk, maxsplit * sizeof(float)));
     GOM_HIP_CHECK(hipMalloc((void **)&h->splitk_target, maxsplit * sizeof(float)));
     GOM_HIP_CHECK(hipMalloc((void **)&h->go, (size_t)B * sizeof(float)));
+    GOM_HIP_CHECK(hipMalloc((void **)&h->head_sums, (size_t)5 * B * GOM_LPIPS_HEAD_BLOCKS * sizeof(float)));
     h->splitk_elems = maxsplit;
     h->B = B; h->H = H; h->W = W;
     return 0;
@@ -224,7 +226,7 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
     // prediction and target as ONE batch of 2B images -- or, when the caller ran the target's trunk beforehand
     // (gom_lpips_vgg_target_features, typically on another stream under the frame's forward), the prediction alone
     if ((rc = lp_trunk_forward(h, 0, target_ready ? 1 : 2, B, H, W, img, h->splitk, stream))) return rc;
-    {   // heads
+    if (!d_pred) {   // value only: the head forwards (with a gradient wanted, each tap's backward kernel leaves its value too: one read of the feature maps)
         int hh = H, ww = W;
         for (int i = 0; i < 13; i++) {
             if (kPoolBefore[i]) { hh /= 2; ww /= 2; }
@@ -245,12 +247,13 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         for (int i = 0; i < 13; i++) { if (kPoolBefore[i]) { hh /= 2; ww /= 2; } hs[i] = hh; wsz[i] = ww; }
     }
     const void *g = nullptr;
-    int pp = 0;
+    int pp = 0, head_blocks[5] = {0, 0, 0, 0, 0};
     for (int i = 12; i >= 0; i--) {
         const int hh = hs[i], ww = wsz[i], t = kTapIndex[i];
         if (t >= 0) {
             void *gh = h->gtap;
-            if ((rc = gom_lpips_layer_backward_planes(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh, h->lo_act[i], h->lo_g, stream))) return rc;
+            if ((rc = gom_lpips_layer_backward_value_planes(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh,
+                                                            h->head_sums + (size_t)t * B * GOM_LPIPS_HEAD_BLOCKS, &head_blocks[t], h->lo_act[i], h->lo_g, stream))) return rc;
             if (g) {  // g = gradient w.r.t. the pooled activation feeding conv i+1
                 if ((rc = gom_maxpool2x2_backward_planes(B, hh, ww, h->cout[i], h->act[0][i], g, gh, 1, h->lo_act[i], h->lo_g, h->lo_g, stream))) return rc;
             }
@@ -262,10 +265,12 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         pp ^= 1;
         if (i == 0 && im2col) {   // d(im2col rows) = W^T dY as a 1 x 1 convolution 64 -> 32; the col2im gather rides in the unprepare kernel
             if ((rc = gom_conv1x1_planes((size_t)B * hh * ww, h->cout[0], 32, g, h->w1_bwd, nullptr, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
+            if ((rc = gom_lpips_fold_values(B, h->head_sums, head_blocks, value_partials, stream))) return rc;
             return gom_lpips_unprepare_col2im_planes(B, H, W, dst, d_pred, h->lo_g, stream);
         }
         if ((rc = lp_conv(h->splitk, B, hh, ww, h->cout[i], co, g, h->w_bwd[i], nullptr, mask, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
         g = dst;
     }
+    if ((rc = gom_lpips_fold_values(B, h->head_sums, head_blocks, value_partials, stream))) return rc;
     return gom_lpips_unprepare_planes(B, H, W, 64, g, d_pred, h->lo_g, stream);
 }

@@ -767,7 +767,9 @@ __global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const
 // Single-pass variant for the tap widths of VGG16 (C = 64 .. 512): LPP = C / 8 lanes per pixel, every lane keeps its 8 channels
 // of both feature maps in registers across the three phases (norms, weighted difference, gradient), so each feature is read
 // from memory once (the generic kernel above reads it two / three times and idles half its lanes at C = 64).
-template <bool BWD, int LPP>
+// VAL (with BWD): the backward pass also leaves the tap's VALUE (per-block sums in `partials`, one per workgroup of ITS grid): a training step reads the
+// two feature maps once instead of twice (gom_lpips_layer_backward_value_planes; the forward launch is skipped).
+template <bool BWD, int LPP, bool VAL = false>
 __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
                                                                         const float *__restrict__ w, const float *__restrict__ grad_out,
                                                                         float *__restrict__ partials, bf16_t *__restrict__ d_f0, size_t f_lo, size_t d_lo) {
@@ -794,14 +796,20 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
         for (int d = LPP / 2; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
         const float n0 = sqrtf(s0 + kEps);
         const float i0 = 1.f / (n0 + kEps), i1 = 1.f / (sqrtf(s1 + kEps) + kEps);
-        float v = 0.f;   // forward: sum w d^2 ; backward: sum w d f0
+        float v = 0.f, v2 = 0.f;   // forward: sum w d^2 ; backward: sum w d f0 (v2: the forward's sum beside it)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float d = x[k] * i0 - y[k] * i1;
             v += BWD ? wl[k] * d * x[k] : wl[k] * d * d;
+            if (BWD && VAL) v2 += wl[k] * d * d;
         }
 #pragma unroll
         for (int d = LPP / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (BWD && VAL) {
+#pragma unroll
+            for (int d = LPP / 2; d >= 1; d >>= 1) v2 += __shfl_xor(v2, d, 64);
+            acc += (sub == 0) ? v2 : 0.f;
+        }
         if (!BWD) {
             acc += (sub == 0) ? v : 0.f;
         } else {
@@ -813,7 +821,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
             store8(d_f0 + p * C + sub * 8, d_lo, gq);
         }
     }
-    if (!BWD) {
+    if (!BWD || VAL) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
@@ -821,9 +829,29 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
         if (threadIdx.x == 0) {
             float t = 0.f;
             for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += s_red[k];
-            partials[b * gridDim.x + blockIdx.x] = t / (float)HW;
+            partials[b * (VAL ? (size_t)GOM_LPIPS_HEAD_BLOCKS : (size_t)gridDim.x) + blockIdx.x] = t / (float)HW;
         }
     }
+}
+
+// values of the taps whose per-block sums came out of the backward kernels (k_lpips_head_nhwc_1p<true, .., true>): one workgroup per (tap, image) adds
+// its nblk[tap] sums in a fixed order and leaves the total in slot 0 of the caller's [5][B][GOM_LOSS_BLOCKS] rows (the other slots: zero)
+__global__ void __launch_bounds__(256) k_lpips_fold_values(int B, const float *__restrict__ scratch, int scratch_stride, int n0, int n1, int n2, int n3, int n4,
+                                                           float *__restrict__ partials) {
+    __shared__ float s_red[256];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int n = t == 0 ? n0 : (t == 1 ? n1 : (t == 2 ? n2 : (t == 3 ? n3 : n4)));
+    const float *src = scratch + ((size_t)t * B + b) * scratch_stride;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += src[i];
+    s_red[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) s_red[threadIdx.x] += s_red[threadIdx.x + d];
+        __syncthreads();
+    }
+    float *dst = partials + ((size_t)t * B + b) * GOM_LOSS_BLOCKS;
+    for (int i = threadIdx.x; i < GOM_LOSS_BLOCKS; i += 256) dst[i] = i == 0 ? s_red[0] : 0.f;
 }
 
 }  // namespace
@@ -997,6 +1025,28 @@ int gom_lpips_layer_forward_planes(int B, int C, int HW, const void *f0, const v
 extern "C" int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0,
                                                   void *stream) {
     return gom_lpips_layer_backward_planes(B, C, HW, f0, f1, w, grad_out, d_f0, 0, 0, stream);
+}
+// backward of a tap that also leaves the tap's value: `block_sums` gets one sum per workgroup (the return value = how many; <= GOM_LPIPS_HEAD_BLOCKS per image,
+// image b's at block_sums + b * stride); gom_lpips_fold_values turns the five taps' sums into the caller's value rows.  C = 64, 128, 256 or 512.
+int gom_lpips_layer_backward_value_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, float *block_sums,
+                                          int *n_blocks, size_t f_lo, size_t d_lo, void *stream) {
+    if (C != 64 && C != 128 && C != 256 && C != 512) { gom_set_error("LPIPS head (backward + value): C must be 64, 128, 256 or 512"); return -1; }
+    if (B <= 0 || HW <= 0 || !block_sums || !n_blocks) { gom_set_error("LPIPS head (backward + value): bad arguments"); return -1; }
+    const size_t groups = ((size_t)HW + 15) / 16;
+    const dim3 gridb((unsigned)(groups < GOM_LPIPS_HEAD_BLOCKS ? groups : GOM_LPIPS_HEAD_BLOCKS), B);
+    *n_blocks = (int)gridb.x;
+#define GOM_HEADV(LPP_) hipLaunchKernelGGL((k_lpips_head_nhwc_1p<true, LPP_, true>), gridb, dim3(256), 0, (hipStream_t)stream, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, \
+                                           block_sums, (bf16_t *)d_f0, f_lo, d_lo)
+    if (C == 64) GOM_HEADV(8); else if (C == 128) GOM_HEADV(16); else if (C == 256) GOM_HEADV(32); else GOM_HEADV(64);
+#undef GOM_HEADV
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+int gom_lpips_fold_values(int B, const float *block_sums, const int *n_blocks5, float *partials, void *stream) {
+    hipLaunchKernelGGL(k_lpips_fold_values, dim3(5, B), dim3(256), 0, (hipStream_t)stream, B, block_sums, GOM_LPIPS_HEAD_BLOCKS, n_blocks5[0], n_blocks5[1], n_blocks5[2], n_blocks5[3],
+                       n_blocks5[4], partials);
+    GOM_LAUNCH_CHECK();
+    return 0;
 }
 int gom_lpips_layer_backward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, size_t f_lo, size_t d_lo,
                                     void *stream) {

@@ -217,6 +217,10 @@ def test_first_layer_from_the_image_is_bitwise_the_two_kernel_form(precision):
     assert res["1"][0] == res["0"][0] and torch.equal(res["1"][1], res["0"][1])
     assert res["1"][2] == res["0"][2] and torch.equal(res["1"][3], res["0"][3])
     assert res["1"][0] > 0 and float(res["1"][1].abs().max()) > 0
+    # with a gradient wanted the taps' values come out of the head BACKWARD kernels (one read of the feature maps); without, out of the forward ones:
+    # the same per-pixel terms summed in another order
+    v_only, none = mc.value_and_grad(pred, gt, want_grad=False)
+    assert none is None and abs(float(v_only) - res["1"][0]) <= 2e-6 * res["1"][0], (float(v_only), res["1"][0])
 
 
 def test_pipelined_conv_is_race_free_over_many_launches():
