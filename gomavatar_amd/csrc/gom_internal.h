@@ -371,7 +371,7 @@ int gom_lpips_unprepare_planes(int B, int H, int W, int Cpad, const void *d_in, 
 int gom_lpips_layer_forward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, size_t f_lo, void *stream);
 #define GOM_LPIPS_HEAD_BLOCKS 4096   // workgroups per image of a head backward launch = per-block value sums of a tap (lpips_vgg_api.hip: head_sums)
 int gom_lpips_layer_backward_value_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, float *block_sums,
-                                          int *n_blocks, size_t f_lo, size_t d_lo, void *stream);
+                                          int *n_blocks, size_t f_lo, size_t d_lo, const void *pool_dy, size_t pool_dy_lo, int W, void *stream);
 int gom_lpips_fold_values(int B, const float *block_sums, const int *n_blocks5, float *partials, void *stream);
 int gom_lpips_layer_backward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, size_t f_lo, size_t d_lo,
                                     void *stream);

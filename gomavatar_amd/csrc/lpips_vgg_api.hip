@@ -252,11 +252,9 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         const int hh = hs[i], ww = wsz[i], t = kTapIndex[i];
         if (t >= 0) {
             void *gh = h->gtap;
+            // (the gradient of the pool this activation feeds -- g, from the layers above -- is routed inside the same kernel: k_lpips_head_nhwc_1p POOL)
             if ((rc = gom_lpips_layer_backward_value_planes(B, h->cout[i], hh * ww, h->act[0][i], h->act[1][i], h->lin[t], h->go, gh,
-                                                            h->head_sums + (size_t)t * B * GOM_LPIPS_HEAD_BLOCKS, &head_blocks[t], h->lo_act[i], h->lo_g, stream))) return rc;
-            if (g) {  // g = gradient w.r.t. the pooled activation feeding conv i+1
-                if ((rc = gom_maxpool2x2_backward_planes(B, hh, ww, h->cout[i], h->act[0][i], g, gh, 1, h->lo_act[i], h->lo_g, h->lo_g, stream))) return rc;
-            }
+                                                            h->head_sums + (size_t)t * B * GOM_LPIPS_HEAD_BLOCKS, &head_blocks[t], h->lo_act[i], h->lo_g, g, h->lo_g, ww, stream))) return rc;
             g = gh;
         }
         const int co = h->cin[i] < 64 ? 64 : h->cin[i];

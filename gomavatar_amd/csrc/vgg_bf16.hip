@@ -769,15 +769,20 @@ __global__ void __launch_bounds__(256) k_lpips_head_nhwc(int C, size_t HW, const
 // from memory once (the generic kernel above reads it two / three times and idles half its lanes at C = 64).
 // VAL (with BWD): the backward pass also leaves the tap's VALUE (per-block sums in `partials`, one per workgroup of ITS grid): a training step reads the
 // two feature maps once instead of twice (gom_lpips_layer_backward_value_planes; the forward launch is skipped).
-template <bool BWD, int LPP, bool VAL = false>
+// POOL (with BWD): f0 is also the input of a 2 x 2 max-pool whose output gradient `dy` [HW / 4][C] exists already (the layers above were walked first):
+// the pixel that is the FIRST maximum of its window (row-major order, like the reference framework) and positive receives it here, added in fp32 before
+// the one rounding to the gradient's planes -- k_maxpool2_bwd's accumulate form without its read-modify-write of the whole gradient tensor.
+template <bool BWD, int LPP, bool VAL = false, bool POOL = false>
 __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t HW, const bf16_t *__restrict__ f0, const bf16_t *__restrict__ f1,
                                                                         const float *__restrict__ w, const float *__restrict__ grad_out,
-                                                                        float *__restrict__ partials, bf16_t *__restrict__ d_f0, size_t f_lo, size_t d_lo) {
+                                                                        float *__restrict__ partials, bf16_t *__restrict__ d_f0, size_t f_lo, size_t d_lo,
+                                                                        const bf16_t *__restrict__ dy = nullptr, size_t dy_lo = 0, int W = 0) {
     constexpr int C = 8 * LPP;
     __shared__ float s_red[16];
     const size_t b = blockIdx.y;
     f0 += b * HW * C; f1 += b * HW * C;
     if (BWD) d_f0 += b * HW * C;
+    if (POOL) dy += b * (HW / 4) * C;
     const int sub = threadIdx.x & (LPP - 1);
     const size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LPP, ngrp = ((size_t)gridDim.x * blockDim.x) / LPP;
     const float go = BWD ? grad_out[b] * (2.0f / (float)HW) : 0.f;
@@ -785,9 +790,9 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
 #pragma unroll
     for (int k = 0; k < 8; k++) wl[k] = w[sub * 8 + k];
     float acc = 0.f;
-    for (size_t p = grp; p < HW; p += ngrp) {
-        float x[8], y[8];
-        load8(f0 + p * C + sub * 8, f_lo, x);
+    // one pixel: x = its 8 channels of f0 (already loaded), add = what else its gradient receives (the pool's routing, or zeros)
+    auto pixel = [&](size_t p, const float (&x)[8], const float (&add)[8]) {
+        float y[8];
         load8(f1 + p * C + sub * 8, f_lo, y);
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -817,8 +822,47 @@ __global__ void __launch_bounds__(BWD ? 256 : 1024) k_lpips_head_nhwc_1p(size_t 
             float gq[8];
 #pragma unroll
             for (int k = 0; k < 8; k++)   // times the ReLU derivative of the tap's own layer (x = 0 <=> the pre-activation was clipped)
-                gq[k] = x[k] > 0.f ? go * (wl[k] * (x[k] * i0 - y[k] * i1) * i0 - x[k] * kk) : 0.f;
+                gq[k] = (x[k] > 0.f ? go * (wl[k] * (x[k] * i0 - y[k] * i1) * i0 - x[k] * kk) : 0.f) + add[k];
             store8(d_f0 + p * C + sub * 8, d_lo, gq);
+        }
+    };
+    if constexpr (POOL) {
+        // a group of LPP lanes owns a 2 x 2 WINDOW: its four pixels' f0 rows are read once, the window's maximum is found per channel, then the four
+        // pixels are walked like everywhere else
+        const size_t NW = HW / 4;
+        const int W2 = W >> 1;
+        for (size_t wi = grp; wi < NW; wi += ngrp) {
+            const size_t wy = wi / (size_t)W2, wx = wi - wy * W2;
+            const size_t p0 = 2 * wy * W + 2 * wx;
+            const size_t pq[4] = {p0, p0 + 1, p0 + W, p0 + W + 1};
+            float xs[4][8], g8[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) load8(f0 + pq[q] * C + sub * 8, f_lo, xs[q]);
+            load8(dy + wi * C + sub * 8, dy_lo, g8);
+            int am[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {   // first maximum in row-major order; nothing passes a non-positive one (the ReLU derivative)
+                float best = xs[0][k];
+                am[k] = 0;
+#pragma unroll
+                for (int q = 1; q < 4; q++)
+                    if (xs[q][k] > best) { best = xs[q][k]; am[k] = q; }
+                if (!(best > 0.f)) am[k] = -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float add[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) add[k] = am[k] == q ? g8[k] : 0.f;
+                pixel(pq[q], xs[q], add);
+            }
+        }
+    } else {
+        const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (size_t p = grp; p < HW; p += ngrp) {
+            float x[8];
+            load8(f0 + p * C + sub * 8, f_lo, x);
+            pixel(p, x, zero);
         }
     }
     if (!BWD || VAL) {
@@ -1029,15 +1073,17 @@ extern "C" int gom_lpips_layer_backward_nhwc_bf16(int B, int C, int HW, const vo
 // backward of a tap that also leaves the tap's value: `block_sums` gets one sum per workgroup (the return value = how many; <= GOM_LPIPS_HEAD_BLOCKS per image,
 // image b's at block_sums + b * stride); gom_lpips_fold_values turns the five taps' sums into the caller's value rows.  C = 64, 128, 256 or 512.
 int gom_lpips_layer_backward_value_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, const float *grad_out, void *d_f0, float *block_sums,
-                                          int *n_blocks, size_t f_lo, size_t d_lo, void *stream) {
+                                          int *n_blocks, size_t f_lo, size_t d_lo, const void *pool_dy, size_t pool_dy_lo, int W, void *stream) {
     if (C != 64 && C != 128 && C != 256 && C != 512) { gom_set_error("LPIPS head (backward + value): C must be 64, 128, 256 or 512"); return -1; }
     if (B <= 0 || HW <= 0 || !block_sums || !n_blocks) { gom_set_error("LPIPS head (backward + value): bad arguments"); return -1; }
     const size_t groups = ((size_t)HW + 15) / 16;
     const dim3 gridb((unsigned)(groups < GOM_LPIPS_HEAD_BLOCKS ? groups : GOM_LPIPS_HEAD_BLOCKS), B);
     *n_blocks = (int)gridb.x;
-#define GOM_HEADV(LPP_) hipLaunchKernelGGL((k_lpips_head_nhwc_1p<true, LPP_, true>), gridb, dim3(256), 0, (hipStream_t)stream, (size_t)HW, (const bf16_t *)f0, (const bf16_t *)f1, w, grad_out, \
-                                           block_sums, (bf16_t *)d_f0, f_lo, d_lo)
-    if (C == 64) GOM_HEADV(8); else if (C == 128) GOM_HEADV(16); else if (C == 256) GOM_HEADV(32); else GOM_HEADV(64);
+    if (pool_dy && (W <= 0 || (W & 1) || HW % W || ((HW / W) & 1))) { gom_set_error("LPIPS head (backward + value + pool): even image sides"); return -1; }
+#define GOM_HEADV(LPP_, POOL_) hipLaunchKernelGGL((k_lpips_head_nhwc_1p<true, LPP_, true, POOL_>), gridb, dim3(256), 0, (hipStream_t)stream, (size_t)HW, (const bf16_t *)f0, \
+                                                  (const bf16_t *)f1, w, grad_out, block_sums, (bf16_t *)d_f0, f_lo, d_lo, (const bf16_t *)pool_dy, pool_dy_lo, W)
+    if (pool_dy) { if (C == 64) GOM_HEADV(8, true); else if (C == 128) GOM_HEADV(16, true); else if (C == 256) GOM_HEADV(32, true); else GOM_HEADV(64, true); }
+    else { if (C == 64) GOM_HEADV(8, false); else if (C == 128) GOM_HEADV(16, false); else if (C == 256) GOM_HEADV(32, false); else GOM_HEADV(64, false); }
 #undef GOM_HEADV
     GOM_LAUNCH_CHECK();
     return 0;
