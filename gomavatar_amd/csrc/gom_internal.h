@@ -359,7 +359,7 @@ int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int
 
 // ---- LPIPS trunk with one or two bf16 planes per tensor (vgg_bf16.hip; `*_lo` = element offset of the lo plane, 0 = plain bf16) ----
 int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
-                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *stream);
+                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *pooled, size_t pooled_lo, void *stream);
 int gom_maxpool2x2_planes(int B, int H, int W, int C, const void *x, void *y, size_t x_lo, size_t y_lo, void *stream);
 int gom_maxpool2x2_backward_planes(int B, int H, int W, int C, const void *x, const void *dy, void *dx, int accumulate, size_t x_lo, size_t dy_lo, size_t dx_lo, void *stream);
 int gom_lpips_prepare_planes(int B, int H, int W, const float *rgb, void *out32, size_t out_lo, void *stream);

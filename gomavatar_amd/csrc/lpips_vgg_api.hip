@@ -137,9 +137,9 @@ static int lp_ensure(GomLpipsVgg *h, int B, int H, int W) {
 }
 
 static int lp_conv(float *splitk, int B, int hh, int ww, int cin, int cout, const void *in, const void *wt, const float *bias, const void *mask,
-                   void *out, uint32_t flags, size_t in_lo, size_t out_lo, void *stream) {
+                   void *out, uint32_t flags, size_t in_lo, size_t out_lo, void *stream, void *pooled = nullptr, size_t pooled_lo = 0) {
     const int s = gom_conv3x3_splits(B, hh, ww, cin, cout);
-    return gom_conv3x3_planes(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? splitk : nullptr, in_lo, out_lo, stream);
+    return gom_conv3x3_planes(B, hh, ww, cin, cout, in, wt, bias, mask, out, flags, s, s > 1 ? splitk : nullptr, in_lo, out_lo, pooled, pooled_lo, stream);
 }
 
 __global__ void k_fill(float *p, int n, float v) {
@@ -195,6 +195,8 @@ static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int
     // convolution: the same bits, 33 MB more traffic per image and plane) -- read per call so that a test can compare the two in one process
     const char *fenv = getenv("GOM_LPIPS_FIRST_LAYER_FUSED");
     const bool fused1 = im2col && W % 32 == 0 && !(fenv && fenv[0] == '0');
+    const char *penv = getenv("GOM_LPIPS_FUSED_POOL");                 // (development switch: 0 = the pools as launches of their own)
+    const bool fused_pool = !(penv && penv[0] == '0');
     for (int k = k0; k < k0 + nsets && !fused1; k++)
         if ((rc = im2col ? gom_lpips_prepare_im2col_planes(B, H, W, img[k], h->x[k], h->lo_x, stream) : gom_lpips_prepare_planes(B, H, W, img[k], h->x[k], h->lo_x, stream))) return rc;
     const int nb = nsets * B;
@@ -202,17 +204,19 @@ static int lp_trunk_forward(GomLpipsVgg *h, int k0, int nsets, int B, int H, int
     const void *cur = h->x[k0];
     size_t cur_lo = h->lo_x;
     for (int i = 0; i < 13; i++) {
-        if (kPoolBefore[i]) {
-            if ((rc = gom_maxpool2x2_planes(nb, hh, ww, h->cin[i], cur, h->pooled[k0][i], cur_lo, h->lo_pooled[i], stream))) return rc;
+        if (kPoolBefore[i]) {   // (written by the convolution in front of it: conv_store / k_splitk_epilogue with `pooled`)
+            if (!fused_pool && (rc = gom_maxpool2x2_planes(nb, hh, ww, h->cin[i], cur, h->pooled[k0][i], cur_lo, h->lo_pooled[i], stream))) return rc;
             hh /= 2; ww /= 2;
             cur = h->pooled[k0][i]; cur_lo = h->lo_pooled[i];
         }
+        const bool pool_next = fused_pool && i + 1 < 13 && kPoolBefore[i + 1];
         if (i == 0 && fused1) {
             for (int k = k0; k < k0 + nsets; k++)   // (one launch per image set: the sets' images are separate tensors)
                 if ((rc = gom_conv1_1_image_planes(B, hh, ww, img[k], h->w1_fwd, h->bias[0], h->act[k][0], h->lo_act[0], stream))) return rc;
         } else if (i == 0 && im2col) {
             if ((rc = gom_conv1x1_planes((size_t)nb * hh * ww, 32, h->cout[0], cur, h->w1_fwd, h->bias[0], h->act[k0][0], 1, cur_lo, h->lo_act[0], stream))) return rc;
-        } else if ((rc = lp_conv(splitk, nb, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream))) return rc;
+        } else if ((rc = lp_conv(splitk, nb, hh, ww, h->cin[i], h->cout[i], cur, h->w_fwd[i], h->bias[i], nullptr, h->act[k0][i], GOM_CONV_RELU, cur_lo, h->lo_act[i], stream,
+                                 pool_next ? h->pooled[k0][i + 1] : nullptr, pool_next ? h->lo_pooled[i + 1] : 0))) return rc;
         cur = h->act[k0][i]; cur_lo = h->lo_act[i];
     }
     return 0;

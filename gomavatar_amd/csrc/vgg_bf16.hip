@@ -94,15 +94,28 @@ __device__ __forceinline__ int swz_part(int part, int row) { return part ^ (((ro
 
 // Epilogue shared by the convolution kernels: the wave's RPW x 4 accumulator tiles -> + bias, ReLU, ReLU mask -> bf16 plane(s).
 // D[i = co][j = px]: a lane holds co = 4 * kg + r (r = 0..3) of pixel column l15: one 8-byte NHWC store per plane.
+// what a value reads back as from its stored plane(s): hi + lo (exact in fp32), or the one bf16
+__device__ __forceinline__ float stored_value(float v, bool two_planes) {
+    bf16_t h, l;
+    if (!two_planes) return bf2f(f2bf(v));
+    split_bf(v, h, l);
+    return bf2f(h) + bf2f(l);
+}
+
+// `pooled` (forward layers in front of a 2 x 2 max-pool): the pooled tensor [B][H/2][W/2][Cout] is written here as well -- the maximum of the four STORED
+// values (what k_maxpool2_fwd would read back; a wave's rows 2 w, 2 w + 1 are a lane's own, the neighbour column is lane ^ 1), so the pool's launch and its
+// read of the full-resolution tensor disappear.  H, W even; tiles start at even coordinates.
 template <bool RELU, int RPW>
 __device__ __forceinline__ void conv_store(const f32x4 (&acc)[RPW][4], int H, int W, int Cout, size_t img, int ty0, int tx0, int row0, int co0, int l15, int kg,
-                                           const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, size_t out_lo) {
+                                           const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, size_t out_lo,
+                                           bf16_t *__restrict__ pooled, size_t pooled_lo) {
     const int co = co0 + 16 * kg;   // this lane's 16 consecutive channels (tile_row_channel<4>): 4 n + r <- acc[m][n][r]
+    float keep[RPW][16];            // (read again only when pooled != null)
 #pragma unroll
     for (int m = 0; m < RPW; m++) {
         const int gy = ty0 + row0 + m, gx = tx0 + l15;
-        if (gy >= H || gx >= W) continue;
-        const size_t pix = (img + (size_t)gy * W + gx) * Cout;
+        const bool in = gy < H && gx < W;
+        const size_t pix = in ? (img + (size_t)gy * W + gx) * Cout : 0;
         float v[16];
 #pragma unroll
         for (int n = 0; n < 4; n++)
@@ -116,7 +129,7 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[RPW][4], int H, in
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = fmaxf(v[k], 0.f);
         }
-        if (mask) {
+        if (mask && in) {
             const uint4 m0 = *reinterpret_cast<const uint4 *>(mask + pix + co), m1 = *reinterpret_cast<const uint4 *>(mask + pix + co + 8);
             const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
@@ -125,7 +138,22 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[RPW][4], int H, in
                 v[2 * k + 1] = bf2f((bf16_t)(mw[k] >> 16)) > 0.f ? v[2 * k + 1] : 0.f;
             }
         }
-        store_row<4>(out + pix + co, out_lo, v);
+        if (in) store_row<4>(out + pix + co, out_lo, v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) keep[m][k] = v[k];
+    }
+    if (pooled) {
+#pragma unroll
+        for (int m = 0; m + 1 < RPW; m += 2) {
+            const int gy = ty0 + row0 + m, gx = tx0 + l15;
+            float mx[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float a = fmaxf(stored_value(keep[m][k], out_lo != 0), stored_value(keep[m + 1][k], out_lo != 0));
+                mx[k] = fmaxf(a, __shfl_xor(a, 1, 64));   // (every lane takes part; the stores below are the conditional part)
+            }
+            if (!(l15 & 1) && gy < H && gx < W) store_row<4>(pooled + (img / 4 + (size_t)(gy >> 1) * (W >> 1) + (size_t)(gx >> 1)) * Cout + co, pooled_lo, mx);
+        }
     }
 }
 
@@ -154,7 +182,7 @@ template <bool RELU, bool SPLITK, int TH>
 __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
                                                       const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                       const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
-                                                      float *__restrict__ partial, size_t in_lo, size_t out_lo) {
+                                                      float *__restrict__ partial, size_t in_lo, size_t out_lo, bf16_t *__restrict__ pooled, size_t pooled_lo) {
     constexpr int kTileH = TH, kPatchPx = (TH + 2) * kPatchW, NT = TH * 32;
     __shared__ __attribute__((aligned(16))) bf16_t s_in[kPatchPx * kKC];   // 11 520 B (TH = 8) / 20 736 B (TH = 16)
     __shared__ __attribute__((aligned(16))) bf16_t s_w[9 * kBN * kKC];      // 36 864 B
@@ -215,7 +243,7 @@ __global__ void __launch_bounds__(TH * 32) k_conv3x3_bf16(int H, int W, int Cin,
         }
     }
     if (SPLITK) conv_store_partial<2>(acc, H, W, Cout, img, (int)gridDim.z / splits, zs, ty0, tx0, 2 * wave, co0, l15, kg, partial);
-    else conv_store<RELU, 2>(acc, H, W, Cout, img, ty0, tx0, 2 * wave, co0, l15, kg, bias, mask, out, out_lo);
+    else conv_store<RELU, 2>(acc, H, W, Cout, img, ty0, tx0, 2 * wave, co0, l15, kg, bias, mask, out, out_lo, pooled, pooled_lo);
 }
 
 // ---- pipelined variant: global -> LDS by LDS-DMA (global_load_lds_dwordx4), three stages in flight ---------------------
@@ -252,7 +280,7 @@ template <bool RELU, bool SPLITK, int RPW>
 __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in,
                                                                 const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                                 const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
-                                                                float *__restrict__ partial, size_t in_lo, size_t out_lo) {
+                                                                float *__restrict__ partial, size_t in_lo, size_t out_lo, bf16_t *__restrict__ pooled, size_t pooled_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 16, NW = TH / RPW;                                  // RPW pixel rows per wave, NW waves
     constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: patch (162 / 324), weights (96 / 192)
@@ -316,7 +344,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 
     // Every scalar argument the epilogue needs is pulled into SGPRs HERE: a scalar load left pending across the loop makes lgkmcnt count two
     // kinds of events, and the wait-count pass then turns every LDS wait of the loop into lgkmcnt(0).
-    asm volatile("" ::"s"(bias), "s"(mask), "s"(out), "s"(partial), "s"(out_lo), "s"(Cout), "s"(splits));
+    asm volatile("" ::"s"(bias), "s"(mask), "s"(out), "s"(partial), "s"(out_lo), "s"(Cout), "s"(splits), "s"(pooled), "s"(pooled_lo));
     issue(0);
     if (NS > 1) issue(1);
     for (int s = 0; s < NS; s++) {
@@ -356,7 +384,7 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
         }
     }
     if (SPLITK) conv_store_partial<RPW>(acc, H, W, Cout, img, (int)gridDim.z / splits, zs, ty0, tx0, RPW * wave, co0, l15, kg, partial);
-    else conv_store<RELU, RPW>(acc, H, W, Cout, img, ty0, tx0, RPW * wave, co0, l15, kg, bias, mask, out, out_lo);
+    else conv_store<RELU, RPW>(acc, H, W, Cout, img, ty0, tx0, RPW * wave, co0, l15, kg, bias, mask, out, out_lo, pooled, pooled_lo);
 }
 
 __device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
@@ -380,12 +408,15 @@ __device__ __forceinline__ void store1(bf16_t *p, size_t lo, float v) {
 }
 __device__ __forceinline__ void store8(bf16_t *p, size_t lo, const float (&v)[8]) { store_row<2>(p, lo, v); }   // 8 consecutive channels: one 16-byte store per plane
 
-// sum of the split-K partials + bias, ReLU, mask -> bf16; 8 channels per thread (16-byte stores per plane)
-__global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n8, int Cout, int splits, const float *__restrict__ partial,
+// sum of the split-K partials + bias, ReLU, mask -> bf16; 8 channels per thread (16-byte stores per plane).  POOL: a thread owns a 2 x 2 window's four
+// pixels and writes their maximum (of the stored values) to `pooled` as well, like conv_store.
+template <bool POOL>
+__global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n8, int H, int W, int Cout, int splits, const float *__restrict__ partial,
                                                          const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out,
-                                                         int relu, size_t out_lo) {
+                                                         int relu, size_t out_lo, bf16_t *__restrict__ pooled, size_t pooled_lo) {
     const size_t stride = n8 * 8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const int C8 = Cout / 8;
+    auto one = [&](size_t i, float (&v)[8]) {   // i: (pixel, group of 8 channels)
         f32x4 a0 = *reinterpret_cast<const f32x4 *>(partial + 8 * i), a1 = *reinterpret_cast<const f32x4 *>(partial + 8 * i + 4);
         for (int s = 1; s < splits; s++) {
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 8 * i), b1 = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * stride + 8 * i + 4);
@@ -393,7 +424,7 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n8, int Cout, in
             a1[0] += b1[0]; a1[1] += b1[1]; a1[2] += b1[2]; a1[3] += b1[3];
         }
         const int co = (int)((8 * i) % Cout);
-        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3]; v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
         if (bias) {
 #pragma unroll
             for (int r = 0; r < 8; r++) v[r] += bias[co + r];
@@ -409,6 +440,34 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(size_t n8, int Cout, in
             for (int r = 0; r < 8; r++) v[r] = mk[r] > 0.f ? v[r] : 0.f;
         }
         store8(out + 8 * i, out_lo, v);
+    };
+    if constexpr (POOL) {
+        const int Ho = H / 2, Wo = W / 2;
+        const size_t nwin = n8 / 4;   // (image, window, group of 8 channels)
+        for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < nwin; j += (size_t)gridDim.x * 256) {
+            const int c8 = (int)(j % C8);
+            const size_t wv = j / C8;
+            const int xo = (int)(wv % Wo), yo = (int)((wv / Wo) % Ho);
+            const size_t b = wv / ((size_t)Wo * Ho);
+            const size_t p0 = ((size_t)b * H + 2 * yo) * W + 2 * xo;
+            float mx[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v[8];
+                one((p0 + (size_t)(q >> 1) * W + (q & 1)) * C8 + c8, v);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float sv = stored_value(v[r], out_lo != 0);
+                    mx[r] = q == 0 ? sv : fmaxf(mx[r], sv);
+                }
+            }
+            store8(pooled + (wv * C8 + c8) * 8, pooled_lo, mx);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+            float v[8];
+            one(i, v);
+        }
     }
 }
 
@@ -907,7 +966,7 @@ extern "C" int gom_conv3x3_bf16(int B, int H, int W, int Cin, int Cout, const vo
 
 extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
                                        void *out, uint32_t flags, int splits, float *workspace, void *stream) {
-    return gom_conv3x3_planes(B, H, W, Cin, Cout, in, wt, bias, mask, out, flags, splits, workspace, 0, 0, stream);
+    return gom_conv3x3_planes(B, H, W, Cin, Cout, in, wt, bias, mask, out, flags, splits, workspace, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
@@ -924,10 +983,12 @@ extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
 // in_lo / out_lo: element offsets of the lo planes of input and output (0: plain bf16); bf16x3 takes `wt` with 3 x Cin/32 chunks
 // (w_hi, w_hi, w_lo per 32 input channels: lpips.pack_conv_weight_x3)
 int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, const void *wt, const float *bias, const void *mask,
-                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *stream) {
+                       void *out, uint32_t flags, int splits, float *workspace, size_t in_lo, size_t out_lo, void *pooled, size_t pooled_lo, void *stream) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kKC || Cout % kBN) { gom_set_error("gom_conv3x3_bf16: Cin %% 32 / Cout %% 64 / sizes"); return -1; }
     if (!in || !wt || !out) { gom_set_error("gom_conv3x3_bf16: null pointer"); return -1; }
     if (splits < 1 || (splits > 1 && (!workspace || (Cin / kKC) % splits))) { gom_set_error("gom_conv3x3_bf16: bad split-K arguments"); return -1; }
+    if (pooled && ((H & 1) || (W & 1) || mask)) { gom_set_error("gom_conv3x3_bf16: fused 2 x 2 pooling needs even H, W and no mask"); return -1; }
+    bf16_t *p_ = (bf16_t *)pooled;
     hipStream_t st = (hipStream_t)stream;
     // 16 pixel rows per workgroup when that still leaves >= 2 workgroups per CU
     const long blocks16 = (long)((W + kTileW - 1) / kTileW) * ((H + 15) / 16) * (Cout / kBN) * B * splits;
@@ -950,15 +1011,17 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
         else hipLaunchKernelGGL((k_conv3x3_bf16<RELU_, SPLIT_, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                            \
     } while (0)
     if (splits > 1) {
-        GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace, in_lo, out_lo);
+        GOM_CONV_LAUNCH(false, true, H, W, Cin, Cout, i_, w_, nullptr, nullptr, nullptr, splits, workspace, in_lo, out_lo, nullptr, (size_t)0);
         GOM_LAUNCH_CHECK();
         const size_t n8 = (size_t)B * H * W * Cout / 8;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096)), dim3(256), 0, st, n8, Cout, splits, workspace,
-                           bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0, out_lo);
+        if (p_) hipLaunchKernelGGL(k_splitk_epilogue<true>, dim3((unsigned)((n8 / 4 + 255) / 256 < 4096 ? (n8 / 4 + 255) / 256 : 4096)), dim3(256), 0, st, n8, H, W, Cout, splits,
+                                   workspace, bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0, out_lo, p_, pooled_lo);
+        else hipLaunchKernelGGL(k_splitk_epilogue<false>, dim3((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096)), dim3(256), 0, st, n8, H, W, Cout, splits,
+                                workspace, bias, m_, (bf16_t *)out, (flags & GOM_CONV_RELU) ? 1 : 0, out_lo, p_, pooled_lo);
     } else if (flags & GOM_CONV_RELU) {
-        GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo);
+        GOM_CONV_LAUNCH(true, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo, p_, pooled_lo);
     } else {
-        GOM_CONV_LAUNCH(false, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo);
+        GOM_CONV_LAUNCH(false, false, H, W, Cin, Cout, i_, w_, bias, m_, (bf16_t *)out, 1, nullptr, in_lo, out_lo, p_, pooled_lo);
     }
 #undef GOM_CONV_LAUNCH
     GOM_LAUNCH_CHECK();

@@ -223,6 +223,33 @@ def test_first_layer_from_the_image_is_bitwise_the_two_kernel_form(precision):
     assert none is None and abs(float(v_only) - res["1"][0]) <= 2e-6 * res["1"][0], (float(v_only), res["1"][0])
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512)])
+def test_pooling_inside_the_convolutions_is_bitwise_the_pool_kernel(shape):
+    """The four max-pools of the trunk ride in the epilogue of the convolution in front of them (conv_store: a lane's two rows and its neighbour lane;
+    k_splitk_epilogue<true>: a thread per window) -- the maximum of the STORED values, i.e. what k_maxpool2_fwd (GOM_LPIPS_FUSED_POOL=0) reads back.
+    LPIPS value and gradient equal bit for bit; (2, 64, 96) takes the split-K epilogue everywhere, 512^2 the plain epilogue on the first two pools."""
+    import os
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    B, H, W = shape
+    g = torch.Generator().manual_seed(41)
+    pred = torch.rand(B, H, W, 3, generator=g).cuda()
+    gt = (pred.cpu() + 0.2 * torch.randn(B, H, W, 3, generator=g)).clamp(0, 1).cuda()
+    for precision in ("bf16x3", "bf16"):
+        mc = LPIPSMatrixCore(trunk_seed=3, precision=precision)
+        res = {}
+        try:
+            for fused in ("1", "0"):
+                os.environ["GOM_LPIPS_FUSED_POOL"] = fused
+                v, gr = mc.value_and_grad(pred, gt)
+                mc.prefetch_target(gt)
+                v2, gr2 = mc.value_and_grad(pred, gt)
+                res[fused] = (float(v), gr.clone(), float(v2), gr2.clone())
+        finally:
+            os.environ.pop("GOM_LPIPS_FUSED_POOL", None)
+        assert res["1"][0] == res["0"][0] and torch.equal(res["1"][1], res["0"][1]), precision
+        assert res["1"][2] == res["0"][2] and torch.equal(res["1"][3], res["0"][3]), precision
+
+
 def test_pipelined_conv_is_race_free_over_many_launches():
     """The 16-row kernel orders its LDS-DMA staging by counted vmcnt waits and one barrier per stage: a misplaced wait would show
     up as rare, timing-dependent wrong tiles.  300 back-to-back launches (other launches in between to perturb timing) must
