@@ -29,6 +29,7 @@ struct GomLpipsVgg {
     void *gtap = nullptr;                        // head gradient of the current tap
     float *splitk = nullptr, *splitk_target = nullptr;   // split-K partial sums; the target-only pass (its own stream) has its own
     float *go = nullptr;                         // [B] d value / d value_b
+    float go_scale = -1.f;                       // what `go` holds (a value no caller passes: filled at the first call)
     float *head_sums = nullptr;                  // [5][B][GOM_LPIPS_HEAD_BLOCKS]: per-workgroup value sums of the taps when the backward kernels produce them
     size_t splitk_elems = 0;
     // captured launch sequence (GOM_LPIPS_USE_GRAPH), valid for exactly these arguments
@@ -56,7 +57,7 @@ static void lp_free(GomLpipsVgg *h) {
         for (int k = 0; k < 2; k++) h->act[k][i] = h->pooled[k][i] = nullptr;
     }
     h->x[0] = h->x[1] = h->grad[0] = h->grad[1] = h->gtap = nullptr;
-    h->splitk = h->splitk_target = nullptr; h->go = h->head_sums = nullptr;
+    h->splitk = h->splitk_target = nullptr; h->go = h->head_sums = nullptr; h->go_scale = -1.f;
     h->B = h->H = h->W = 0;
 }
 
@@ -242,8 +243,11 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         }
     }
     if (!d_pred) return 0;
-    hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->go, B, grad_scale);
-    GOM_LAUNCH_CHECK();
+    if (h->go_scale != grad_scale) {   // d value / d value_b, the same number for every image: rewritten only when it changes (not a launch per call)
+        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->go, B, grad_scale);
+        GOM_LAUNCH_CHECK();
+        h->go_scale = grad_scale;
+    }
     // backward: g = gradient w.r.t. the pre-ReLU output of conv i, walking the trunk of image 0 in reverse
     int hs[13], wsz[13];
     {
