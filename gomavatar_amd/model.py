@@ -338,6 +338,7 @@ class Model(nn.Module):
         # rendering (no autograd) only: mesh branch and splat rasterizer on two streams.  Shortens a frame's latency inside a
         # captured graph (0.71 -> 0.62 ms at 55k faces, 1.39 -> 1.09 ms at 220k); costs host time when launched eagerly: off by default
         self.overlap_branches = False
+        self._ones = None
         self._side_stream = None
         # the shading of the pixels under the mesh as one native op (csrc/mlp.hip: gom_shade_*); False: the torch selection around the MLP kernels
         self.fused_shading = os.environ.get("GOM_FUSED_SHADING", "1") != "0"
@@ -477,8 +478,10 @@ class Model(nn.Module):
             vertices_observation = Rg @ vertices_observation + global_T[:, None]
             xyz, cov6 = face_gaussians(vertices_observation, self.so3, self.scale, self.topo, self.sigma)
         # pseudo albedo + mask: one 4-channel pass (the reference pads to 6 channels and rasterizes twice)
-        feat = torch.cat([self.appearance.T, torch.ones(F, 1, device=xyz.device)], 1)
-        opacity = torch.ones(F, device=xyz.device)
+        if self._ones is None or self._ones.shape[0] != F or self._ones.device != xyz.device:
+            self._ones = torch.ones(F, 1, device=xyz.device)          # (constants of the topology: not two fill launches per frame)
+        feat = torch.cat([self.appearance.T, self._ones], 1)
+        opacity = self._ones[:, 0]
         if self.capture_safe:
             if self._dcam is None or (self._dcam.H, self._dcam.W) != (self.img_size[1], self.img_size[0]):
                 self._dcam = DeviceCamera(self.img_size[1], self.img_size[0], xyz.device)

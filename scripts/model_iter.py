@@ -25,6 +25,8 @@ tcfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, c
           losses=NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=1.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
                     normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05)))
 model = Model(cfg, wl.body).train()
+if os.environ.get("CAPTURE_SAFE"):
+    model.capture_safe = True   # (device-resident camera: no host read of K / E per iteration)
 mcl = LPIPSMatrixCore(trunk_seed=0, device=dev, precision=prec)
 groups = model.get_param_groups(tcfg)
 opt = torch.optim.Adam(groups, betas=(0.9, 0.999)) if which == "torch" else GomAdam(groups, betas=(0.9, 0.999))
