@@ -160,7 +160,8 @@ class MeshNormalRenderer(torch.nn.Module):
         topo = self.topology(faces, xyzs_ndc.shape[1])
         lease = _StateLease(_MESH_POOL.acquire(xyzs_ndc.device), pool=_MESH_POOL)      # goes back when the backward has run (or the graph is dropped)
         self.state = lease.st      # scratch of the MOST RECENT forward (pix_to_face export in the tests); may be re-leased once released
-        normal, alpha = _MeshRaster.apply(xyzs_ndc[0], vertex_normals_[0], topo, lease, H, W, self.blur_radius, self.BLEND_SIGMA, self.training)
+        # (squeeze, not [0]: the backward of a select is a zero fill + a copy, two launches per operand; a view's is a view)
+        normal, alpha = _MeshRaster.apply(xyzs_ndc.squeeze(0), vertex_normals_.squeeze(0), topo, lease, H, W, self.blur_radius, self.BLEND_SIGMA, self.training)
         if not normal.requires_grad:   # no autograd graph was recorded: nothing will call backward
             lease.finish()
         if not self.training:
