@@ -970,13 +970,15 @@ extern "C" int gom_conv3x3_bf16_splitk(int B, int H, int W, int Cin, int Cout, c
 }
 
 extern "C" int gom_conv3x3_splits(int B, int H, int W, int Cin, int Cout) {
-    // 16 x 16-pixel tiles x 64 output channels: split the input channels until the launch has >= 2 workgroups per CU (equal shares of
-    // the chunks).  Measured (MI355X, bf16x3 trunk at 512^2, + 7-12 us of epilogue launch each): conv4 forward 122 -> 106 us, conv4 / conv3 backward 72 -> 58 / 71 -> 59,
-    // conv5 43 -> 34 + 8 (the second launch: k_splitk_epilogue).
-    static const int mode = getenv("GOM_CONV_SPLIT_MODE") ? atoi(getenv("GOM_CONV_SPLIT_MODE")) : 1;   // development switch: 0 = round-3 rule (8-row tiles)
+    // 16 x 16-pixel tiles x 64 output channels: split the input channels until the launch has >= 256 workgroups (one per CU; equal shares of the
+    // chunks).  Every split layer pays a second launch (k_splitk_epilogue, 8-14 us).  Measured on the Model iteration (MI355X, bf16x3, target trunk
+    // prefetched = one image per pass): a target of 256 workgroups 2.84 ms, 384 / 512 (two per CU) 2.95-2.98, the round-3 rule (512 on 8-row tiles) 2.87-2.92;
+    // below 256 the launcher falls back to 8-row tiles through the unpipelined kernel: 4.4 ms.
+    static const int mode = getenv("GOM_CONV_SPLIT_MODE") ? atoi(getenv("GOM_CONV_SPLIT_MODE")) : 2;   // development switch: 0 = round-3 rule, 1 = 512 on 16-row tiles
     const long blocks = (long)((W + kTileW - 1) / kTileW) * (mode ? (H + 15) / 16 : (H + 7) / 8) * (Cout / kBN) * B;
+    const long want = mode == 2 ? 256 : 512;
     int s = 1;
-    while (s < 16 && blocks * s < 512 && (Cin / kKC) % (2 * s) == 0) s *= 2;
+    while (s < 16 && blocks * s < want && (Cin / kKC) % (2 * s) == 0) s *= 2;
     return s;
 }
 

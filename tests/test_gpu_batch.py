@@ -203,8 +203,9 @@ def test_split_call_with_lpips_hook_matches_the_autograd_composition(B):
         # Without the hook the two paths agree bitwise; with it the image gradients agree to 2e-8 (the order of three additions)
         # and the geometry gradients -- sums of large cancelling terms under a noise-like LPIPS image gradient -- to 3e-3.
         # (B = 2: the trunk picks other split-K factors for a 4-image batch, and bf16 activations turn a last-bit difference of a
-        #  partial sum into a flipped rounding somewhere downstream: 1e-3 on every gradient)
-        assert d < (1e-5 if k == "appearance" and B == 1 else 1e-2), (k, d)
+        #  partial sum into a flipped rounding somewhere downstream: 1e-3 .. 1e-2 on every gradient, depending on which layers split --
+        #  this is the ONE-PASS bf16 trunk, whose own distance to the float64 gradient is 0.2: tests/test_gpu_vgg_bf16.py)
+        assert d < (1e-5 if k == "appearance" and B == 1 else 3e-2), (k, d)
 
 
 def test_batch_with_small_segments_equals_single_frames_bitwise():

@@ -96,7 +96,7 @@ def test_lpips_matrix_core_matches_fp32_path():
     (3.0 * mc.loss(q, gt)).backward()
     assert torch.allclose(q.grad, 3.0 * grad, rtol=1e-6, atol=0)
     v2, none = mc.value_and_grad(pred, gt, want_grad=False)
-    assert none is None and float(v2) == float(val)
+    assert none is None and abs(float(v2) - float(val)) <= 2e-6 * float(val)      # (value-only: the head FORWARD kernels; with a gradient: out of the backward ones, another summation order)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 256)])
