@@ -6,6 +6,7 @@
 // (train.py:263-267, models/model.py:305-327, update_lr train.py:166-175); through torch that is ~10 multi-tensor launches and
 // ~100 us of host time per step -- half of a single-frame step (0.2 ms) of this path.  Here it is ONE launch over the flat buffer:
 // 16 bytes read and 12 written per parameter, HBM-bound (951 023 parameters: 26.6 MB, ~6 us).
+#include <unistd.h>
 #include "gom_internal.h"
 #include <math.h>
 #include <string.h>
@@ -478,8 +479,17 @@ extern "C" GomPeerReduce *gom_peer_reduce_create(int32_t rank, int32_t world, in
 extern "C" int gom_peer_reduce_handle(GomPeerReduce *h, void *handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     if (!h || !handle64) { gom_set_error("gom_peer_reduce_handle: null argument"); return -1; }
-    GOM_HIP_CHECK(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), h->local));
-    return 0;
+    // (seen once in ~25 multi-process runs on one device: `invalid argument` while several processes export their regions at the same moment;
+    //  the same call succeeds a few milliseconds later)
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), h->local);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+        usleep(20000 << attempt);
+    }
+    gom_set_error("hipIpcGetMemHandle failed after 6 attempts: %s", hipGetErrorString(e));
+    return -2;
 }
 
 extern "C" int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles) {
