@@ -498,7 +498,14 @@ extern "C" int gom_peer_reduce_connect(GomPeerReduce *h, const void *handles) {
         if (p == h->rank || h->opened[p]) continue;
         hipIpcMemHandle_t hd;
         memcpy(&hd, (const unsigned char *)handles + 64 * (size_t)p, 64);
-        GOM_HIP_CHECK(hipIpcOpenMemHandle((void **)&h->peer[p], hd, hipIpcMemLazyEnablePeerAccess));
+        hipError_t e = hipSuccess;
+        for (int attempt = 0; attempt < 6; attempt++) {   // (same transient as in gom_peer_reduce_handle)
+            e = hipIpcOpenMemHandle((void **)&h->peer[p], hd, hipIpcMemLazyEnablePeerAccess);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            usleep(20000 << attempt);
+        }
+        if (e != hipSuccess) { gom_set_error("hipIpcOpenMemHandle (rank %d) failed after 6 attempts: %s", p, hipGetErrorString(e)); return -2; }
         h->opened[p] = true;
     }
     return 0;
