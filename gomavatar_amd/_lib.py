@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 7
+GOM_ABI_VERSION = 8
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
@@ -117,9 +117,9 @@ SIGNATURES = {
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_frame_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_uint32, c_void_p]),
     "gom_batch_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_int32, c_void_p, c_uint32, c_void_p]),
-    "gom_adam_flat": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
+    "gom_adam_flat": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_float, c_float,
                               c_float, c_float, c_void_p]),
-    "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_void_p, c_float,
+    "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_void_p, c_float,
                                         c_float, c_float, c_float, c_float, c_void_p]),
     "gom_shade_workspace_ints": (c_int, [c_int64]),
     "gom_shade_select": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -137,9 +137,9 @@ SIGNATURES = {
     "gom_peer_reduce_connect": (c_int, [c_void_p, c_void_p]),
     "gom_peer_reduce_buffer": (c_void_p, [c_void_p]),
     "gom_peer_reduce_run": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
-    "gom_peer_reduce_run_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
+    "gom_peer_reduce_run_adam": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_float, c_float,
                                          c_float, c_void_p]),
-    "gom_peer_reduce_run_zero1": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), c_int64, c_float, c_float,
+    "gom_peer_reduce_run_zero1": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_float, c_float,
                                           c_float, c_void_p]),
     "gom_peer_reduce_set_timeout": (c_int, [c_void_p, ctypes.c_double]),
     "gom_peer_reduce_poll": (c_int, [c_void_p]),

@@ -15,7 +15,10 @@ namespace {
 
 struct AdamSegs {
     uint32_t begin[GOM_ADAM_MAX_SEGMENTS + 1];   // segment i = [begin[i], begin[i + 1]) of the flat buffer
-    float step_size[GOM_ADAM_MAX_SEGMENTS];      // lr_i / (1 - beta1^t); with a device step counter: lr_i, corrected in the kernel
+    float step_size[GOM_ADAM_MAX_SEGMENTS];      // lr_i / (1 - beta1^t_i); with a device step counter: lr_i, corrected in the kernel
+    float isb2[GOM_ADAM_MAX_SEGMENTS];           // 1 / sqrt(1 - beta2^t_i); t_i = the segment's OWN step count (a module that joined late, seg_start)
+    int32_t start[GOM_ADAM_MAX_SEGMENTS];        // device step counter only: steps that had passed when the segment joined (t_i = t - start_i)
+    uint32_t inactive;                           // bit i: segment i has not joined yet -> its elements are left alone, like padding
     int n;
     float omb1, omb2;                            // 1 - beta as torch forms it: in DOUBLE from the decimal the caller wrote, rounded once (one_minus_beta below)
 };
@@ -28,13 +31,12 @@ static float one_minus_beta(float beta) { return (float)(1.0 - round((double)bet
 // torch.optim.Adam (no weight decay, no amsgrad, maximize = False), the arithmetic of torch/optim/adam.py::_single_tensor_adam:
 //   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g g;  p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
 // -> false when element e lies outside every segment (padding of the payload: not a parameter, untouched)
-__device__ __forceinline__ bool adam_element(const AdamSegs &segs, uint32_t e, float gr, float &pp, float &mm, float &vv, float beta1, float beta2, float eps,
-                                             float inv_sqrt_bc2) {
-    float ss = 0.f;
+__device__ __forceinline__ bool adam_element(const AdamSegs &segs, uint32_t e, float gr, float &pp, float &mm, float &vv, float beta1, float beta2, float eps) {
+    float ss = 0.f, inv_sqrt_bc2 = 0.f;
     bool in = false;
 #pragma unroll
     for (int s = 0; s < GOM_ADAM_MAX_SEGMENTS; s++)
-        if (s < segs.n && e >= segs.begin[s] && e < segs.begin[s + 1]) { ss = segs.step_size[s]; in = true; }
+        if (s < segs.n && e >= segs.begin[s] && e < segs.begin[s + 1]) { ss = segs.step_size[s]; inv_sqrt_bc2 = segs.isb2[s]; in = !((segs.inactive >> s) & 1u); }
     if (!in) return false;
     mm = __fmaf_rn(beta1, mm, __fmul_rn(segs.omb1, gr));              // exp_avg.lerp_(grad, 1 - beta1) up to rounding
     vv = __fmaf_rn(beta2, vv, __fmul_rn(__fmul_rn(segs.omb2, gr), gr));
@@ -43,7 +45,7 @@ __device__ __forceinline__ bool adam_element(const AdamSegs &segs, uint32_t e, f
     return true;
 }
 __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps, float inv_sqrt_bc2,
+                                                   float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
                                                    float grad_scale, long long *__restrict__ step_dev, float lr_decay_steps) {
     // Device-resident step count (step_dev[0] = steps taken so far, step_dev[1] = workgroups of this launch that are done): nothing of
     // the step number is baked into the launch, so the optimizer can sit inside a captured graph.  Every workgroup reads the count
@@ -51,24 +53,28 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
     if (step_dev) {
         // Once per workgroup: threads 0 .. GOM_ADAM_MAX_SEGMENTS-1 derive one segment's step size each (three double-precision pow() per
         // THREAD of the launch used to be most of this ~6 us kernel's arithmetic), LDS hands the results to everyone.  Same expressions, same bits.
-        __shared__ float s_step[GOM_ADAM_MAX_SEGMENTS], s_isb2;
+        __shared__ float s_step[GOM_ADAM_MAX_SEGMENTS], s_isb2[GOM_ADAM_MAX_SEGMENTS];
         if (threadIdx.x < GOM_ADAM_MAX_SEGMENTS) {
             // (the only writer of step_dev[0] is the last workgroup of a launch, behind every workgroup's read: the atomic load states that)
             const double t = (double)(__hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
-            const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-            // update_lr (train.py:166-175) runs after the step of iteration n_iters (which counts from 1, train.py:268) with n_iters as its
-            // argument: step t uses base * 0.1^((t - 1) / D)
-            const double decay = lr_decay_steps > 0.f ? pow(0.1, (t - 1.0) / (double)lr_decay_steps) : 1.0;
             float base = 0.f;
+            int start = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) base = (int)threadIdx.x == s2 ? segs.step_size[s2] : base;   // (no dynamic index into the kernel arguments)
+            for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) {   // (no dynamic index into the kernel arguments)
+                base = (int)threadIdx.x == s2 ? segs.step_size[s2] : base;
+                start = (int)threadIdx.x == s2 ? segs.start[s2] : start;
+            }
+            const double ti = fmax(t - (double)start, 1.0);   // the segment's own step count (bias corrections)
+            const double bc1 = 1.0 - pow((double)beta1, ti), bc2 = 1.0 - pow((double)beta2, ti);
+            // update_lr (train.py:166-175) runs after the step of iteration n_iters (which counts from 1, train.py:268) with n_iters as its
+            // argument: step t uses base * 0.1^((t - 1) / D) -- the ITERATION, not the segment's own count
+            const double decay = lr_decay_steps > 0.f ? pow(0.1, (t - 1.0) / (double)lr_decay_steps) : 1.0;
             s_step[threadIdx.x] = (float)((double)base * decay / bc1);
-            if (threadIdx.x == 0) s_isb2 = (float)(1.0 / sqrt(bc2));
+            s_isb2[threadIdx.x] = (float)(1.0 / sqrt(bc2));
         }
         __syncthreads();
 #pragma unroll
-        for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) segs.step_size[s2] = s_step[s2];
-        inv_sqrt_bc2 = s_isb2;
+        for (int s2 = 0; s2 < GOM_ADAM_MAX_SEGMENTS; s2++) { segs.step_size[s2] = s_step[s2]; segs.isb2[s2] = s_isb2[s2]; }
     }
     // 4 consecutive parameters per thread and trip (the buffers come from hipMalloc / torch: 16-byte aligned); the ragged end one by one
     const uint32_t n4 = n >> 2;
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (u >= cnt) break;
-            adam_element(segs, e0 + (uint32_t)u, gg[u] * grad_scale, pp[u], mm[u], vv[u], beta1, beta2, eps, inv_sqrt_bc2);
+            adam_element(segs, e0 + (uint32_t)u, gg[u] * grad_scale, pp[u], mm[u], vv[u], beta1, beta2, eps);
         }
         if (vec) {
             reinterpret_cast<float4 *>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -109,26 +115,41 @@ __global__ void __launch_bounds__(256) k_adam_flat(uint32_t n, float *__restrict
 
 }  // namespace
 
-static int adam_segments(AdamSegs &segs, int64_t n, int32_t n_segments, const int64_t *seg_begin, const float *seg_lr, double bc1) {
+// seg_start (may be NULL: every segment has stepped from the beginning): seg_start[i] = optimizer steps that had been taken when segment i joined
+// (torch.optim.Adam skips a parameter whose .grad is None and counts ITS steps from its first gradient: the non-rigid and pose-refinement
+// MLPs, which Model.forward leaves out until their kick_in_iter, models/model.py:193,200); seg_start[i] < 0 = not joined yet: left alone.
+// device_count: the step count lives on the device -- bias corrections are formed in the kernel, step_size carries the bare learning rate.
+static int adam_segments(AdamSegs &segs, int64_t n, int32_t n_segments, const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step,
+                         double beta1, double beta2, bool device_count) {
     if (n_segments < 1 || n_segments > GOM_ADAM_MAX_SEGMENTS || !seg_begin || !seg_lr) { gom_set_error("Adam: 1..%d segments", GOM_ADAM_MAX_SEGMENTS); return -1; }
     segs.n = n_segments;
+    segs.inactive = 0u;
     for (int i = 0; i <= n_segments; i++) {
         if (seg_begin[i] < 0 || seg_begin[i] > n || (i > 0 && seg_begin[i] < seg_begin[i - 1])) { gom_set_error("Adam: segment bounds must ascend inside [0, n]"); return -1; }
         segs.begin[i] = (uint32_t)seg_begin[i];
     }
-    for (int i = 0; i < n_segments; i++) segs.step_size[i] = (float)((double)seg_lr[i] / bc1);
+    for (int i = 0; i < n_segments; i++) {
+        const int64_t st = seg_start ? seg_start[i] : 0;
+        if (st < 0 || (!device_count && st >= step)) { segs.inactive |= 1u << i; segs.step_size[i] = 0.f; segs.isb2[i] = 0.f; segs.start[i] = 0; continue; }
+        if (st > 0x7fffffffLL) { gom_set_error("Adam: seg_start out of range"); return -1; }
+        segs.start[i] = (int32_t)st;
+        const double ti = (double)(step - st);
+        segs.step_size[i] = device_count ? seg_lr[i] : (float)((double)seg_lr[i] / (1.0 - pow(beta1, ti)));
+        segs.isb2[i] = device_count ? 0.f : (float)(1.0 / sqrt(1.0 - pow(beta2, ti)));
+    }
     return 0;
 }
 
 extern "C" int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                             const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
-                             void *stream) {
-    return gom_adam_flat_graphable(n, params, grads, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, nullptr, 0.f, beta1, beta2, eps, grad_scale, stream);
+                             const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps,
+                             float grad_scale, void *stream) {
+    return gom_adam_flat_graphable(n, params, grads, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, seg_start, step, nullptr, 0.f, beta1, beta2, eps, grad_scale,
+                                   stream);
 }
 
 extern "C" int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                                       const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
-                                       float beta2, float eps, float grad_scale, void *stream) {
+                                       const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, int64_t *step_device,
+                                       float lr_decay_steps, float beta1, float beta2, float eps, float grad_scale, void *stream) {
     if (n < 0 || n > 0xffffffffLL) { gom_set_error("gom_adam_flat: bad size"); return -1; }
     if (n_segments < 1 || n_segments > GOM_ADAM_MAX_SEGMENTS || !seg_begin || !seg_lr) { gom_set_error("gom_adam_flat: 1..%d segments", GOM_ADAM_MAX_SEGMENTS); return -1; }
     if (!step_device && step < 1) { gom_set_error("gom_adam_flat: step counts from 1"); return -1; }
@@ -136,13 +157,12 @@ extern "C" int gom_adam_flat_graphable(int64_t n, float *params, const float *gr
     if (n == 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq) { gom_set_error("gom_adam_flat: null pointer"); return -1; }
     AdamSegs segs{};
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    if (int rc = adam_segments(segs, n, n_segments, seg_begin, seg_lr, step_device ? 1.0 : bc1)) return rc;
+    if (int rc = adam_segments(segs, n, n_segments, seg_begin, seg_lr, seg_start, step, beta1, beta2, step_device != nullptr)) return rc;
     segs.omb1 = one_minus_beta(beta1); segs.omb2 = one_minus_beta(beta2);
     const uint32_t work = (uint32_t)(n >> 2) + (uint32_t)(n & 3);
     const unsigned blocks = (unsigned)((work + 255) / 256);
     hipLaunchKernelGGL(k_adam_flat, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, params, grads, exp_avg, exp_avg_sq, segs,
-                       beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, reinterpret_cast<long long *>(step_device), lr_decay_steps);
+                       beta1, beta2, eps, grad_scale, reinterpret_cast<long long *>(step_device), lr_decay_steps);
     GOM_LAUNCH_CHECK();
     return 0;
 }
@@ -346,16 +366,16 @@ __global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int ra
                 if (4 * i + 3 < pend) {
                     float4 c = reinterpret_cast<float4 *>(m)[i], d = reinterpret_cast<float4 *>(v)[i];
                     q = reinterpret_cast<float4 *>(prm)[i];
-                    adam_element(segs, e, a.x, q.x, c.x, d.x, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 1, a.y, q.y, c.y, d.y, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 2, a.z, q.z, c.z, d.z, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 3, a.w, q.w, c.w, d.w, beta1, beta2, eps, inv_sqrt_bc2);
+                    adam_element(segs, e, a.x, q.x, c.x, d.x, beta1, beta2, eps);
+                    adam_element(segs, e + 1, a.y, q.y, c.y, d.y, beta1, beta2, eps);
+                    adam_element(segs, e + 2, a.z, q.z, c.z, d.z, beta1, beta2, eps);
+                    adam_element(segs, e + 3, a.w, q.w, c.w, d.w, beta1, beta2, eps);
                     reinterpret_cast<float4 *>(prm)[i] = q; reinterpret_cast<float4 *>(m)[i] = c; reinterpret_cast<float4 *>(v)[i] = d;
                 } else {
                     const float gq[4] = {a.x, a.y, a.z, a.w};
                     float qq[4] = {0.f, 0.f, 0.f, 0.f};
                     for (int u = 0; u < 4; u++)
-                        if (4 * i + u < pend) { adam_element(segs, e + (uint32_t)u, gq[u], prm[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps, inv_sqrt_bc2); qq[u] = prm[4 * i + u]; }
+                        if (4 * i + u < pend) { adam_element(segs, e + (uint32_t)u, gq[u], prm[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps); qq[u] = prm[4 * i + u]; }
                     q = make_float4(qq[0], qq[1], qq[2], qq[3]);
                 }
                 a = q;
@@ -368,7 +388,7 @@ __global__ void __launch_bounds__(256) k_peer_reduce_scatter(PeerPtrs pp, int ra
                 for (int p = 1; p < world; p++) a += reinterpret_cast<const float *>(pp.p[p])[i];
                 a *= scale;
                 if (ZERO1) {
-                    if (i < pend) { adam_element(segs, (uint32_t)i, a, prm[i], m[i], v[i], beta1, beta2, eps, inv_sqrt_bc2); a = prm[i]; }
+                    if (i < pend) { adam_element(segs, (uint32_t)i, a, prm[i], m[i], v[i], beta1, beta2, eps); a = prm[i]; }
                     else a = 0.f;
                 }
                 reinterpret_cast<float *>(pp.p[rank] + (size_t)n * sizeof(float))[i] = a;
@@ -416,17 +436,17 @@ __global__ void __launch_bounds__(256) k_peer_all_gather(PeerPtrs pp, int rank, 
                 if (4 * i + 3 < pend) {
                     if (MODE == 2) { reinterpret_cast<float4 *>(p)[i] = g4; continue; }
                     float4 a = reinterpret_cast<float4 *>(p)[i], c = reinterpret_cast<float4 *>(m)[i], d = reinterpret_cast<float4 *>(v)[i];
-                    adam_element(segs, e, g4.x, a.x, c.x, d.x, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 1, g4.y, a.y, c.y, d.y, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 2, g4.z, a.z, c.z, d.z, beta1, beta2, eps, inv_sqrt_bc2);
-                    adam_element(segs, e + 3, g4.w, a.w, c.w, d.w, beta1, beta2, eps, inv_sqrt_bc2);
+                    adam_element(segs, e, g4.x, a.x, c.x, d.x, beta1, beta2, eps);
+                    adam_element(segs, e + 1, g4.y, a.y, c.y, d.y, beta1, beta2, eps);
+                    adam_element(segs, e + 2, g4.z, a.z, c.z, d.z, beta1, beta2, eps);
+                    adam_element(segs, e + 3, g4.w, a.w, c.w, d.w, beta1, beta2, eps);
                     reinterpret_cast<float4 *>(p)[i] = a; reinterpret_cast<float4 *>(m)[i] = c; reinterpret_cast<float4 *>(v)[i] = d;
                 } else {
                     const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
                     for (int u = 0; u < 4; u++)
                         if (4 * i + u < pend) {
                             if (MODE == 2) p[4 * i + u] = gq[u];
-                            else adam_element(segs, e + (uint32_t)u, gq[u], p[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps, inv_sqrt_bc2);
+                            else adam_element(segs, e + (uint32_t)u, gq[u], p[4 * i + u], m[4 * i + u], v[4 * i + u], beta1, beta2, eps);
                         }
                 }
             }
@@ -437,7 +457,7 @@ __global__ void __launch_bounds__(256) k_peer_all_gather(PeerPtrs pp, int rank, 
                     if (MODE == 1 && out) out[i] = g1;
                     if (i < pend) {
                         if (MODE == 2) p[i] = g1;
-                        else adam_element(segs, (uint32_t)i, g1, p[i], m[i], v[i], beta1, beta2, eps, inv_sqrt_bc2);
+                        else adam_element(segs, (uint32_t)i, g1, p[i], m[i], v[i], beta1, beta2, eps);
                     }
                 }
         }
@@ -560,22 +580,20 @@ extern "C" int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, vo
 }
 
 static int peer_adam_common(GomPeerReduce *h, const char *who, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments, const int64_t *seg_begin,
-                            const float *seg_lr, int64_t step, float beta1, float beta2, AdamSegs &segs, float &isb2) {
+                            const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, AdamSegs &segs) {
     if (!params || !exp_avg || !exp_avg_sq) { gom_set_error("%s: null argument", who); return -1; }
     if (step < 1) { gom_set_error("%s: step counts from 1", who); return -1; }
     if (!peer_ready(h, who)) return -1;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    if (int rc = adam_segments(segs, h->n, n_segments, seg_begin, seg_lr, bc1)) return rc;
+    if (int rc = adam_segments(segs, h->n, n_segments, seg_begin, seg_lr, seg_start, step, beta1, beta2, false)) return rc;
     segs.omb1 = one_minus_beta(beta1); segs.omb2 = one_minus_beta(beta2);
-    isb2 = (float)(1.0 / sqrt(bc2));
     return 0;
 }
 
 extern "C" int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *out, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                                        const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream) {
+                                        const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps, void *stream) {
     AdamSegs segs{};
-    float isb2 = 0.f;
-    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_adam", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, beta1, beta2, segs, isb2)) return rc;
+    const float isb2 = 0.f;   // (per segment, inside `segs`)
+    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_adam", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, seg_start, step, beta1, beta2, segs)) return rc;
     h->epoch++;
     PeerPtrs pp{};
     for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];
@@ -589,10 +607,10 @@ extern "C" int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *ou
 }
 
 extern "C" int gom_peer_reduce_run_zero1(GomPeerReduce *h, float scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                                         const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream) {
+                                         const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps, void *stream) {
     AdamSegs segs{};
-    float isb2 = 0.f;
-    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_zero1", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, step, beta1, beta2, segs, isb2)) return rc;
+    const float isb2 = 0.f;   // (per segment, inside `segs`)
+    if (int rc = peer_adam_common(h, "gom_peer_reduce_run_zero1", params, exp_avg, exp_avg_sq, n_segments, seg_begin, seg_lr, seg_start, step, beta1, beta2, segs)) return rc;
     h->epoch++;
     PeerPtrs pp{};
     for (int p = 0; p < h->world; p++) pp.p[p] = h->peer[p];

@@ -576,7 +576,7 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     }
     if (s->adam.on) {   // the optimizer step behind the gradients, inside the same (recordable) launch sequence
         if ((rc = gom_adam_flat_graphable(s->adam.n, s->adam.params, s->adam.grads, s->adam.exp_avg, s->adam.exp_avg_sq, s->adam.n_segments, s->adam.seg_begin,
-                                          s->adam.seg_lr, 1, s->adam.step_device, s->adam.lr_decay_steps, s->adam.beta1, s->adam.beta2, s->adam.eps, s->adam.grad_scale,
+                                          s->adam.seg_lr, nullptr, 1, s->adam.step_device, s->adam.lr_decay_steps, s->adam.beta1, s->adam.beta2, s->adam.eps, s->adam.grad_scale,
                                           stream)))
             return rc;
     }

@@ -19,13 +19,15 @@ import torch.distributed as dist
 class FlatBuffer:
     """Named tensors as views into one contiguous fp32 buffer."""
 
-    def __init__(self, shapes: Sequence[Tuple[str, Tuple[int, ...]]], device, pad_to: int = 0):
+    def __init__(self, shapes: Sequence[Tuple[str, Tuple[int, ...]]], device, pad_to: int = 0, align: int = 1):
+        """align: every tensor starts at a multiple of `align` floats (4 = 16 bytes: what kernels with vector loads expect of a base pointer)."""
         self.layout = []
         off = 0
         for name, shape in shapes:
             n = 1
             for d in shape:
                 n *= int(d)
+            off = -(-off // align) * align
             self.layout.append((name, tuple(int(d) for d in shape), off, n))
             off += n
         self.numel = max(off, int(pad_to))
@@ -97,8 +99,10 @@ class PeerAllReduce:
         """Every step, before the exchange is enqueued: raises if a wait of an EARLIER exchange gave up (the kernel that times out writes a
         pinned host word; reading it costs no synchronisation).  The native run calls refuse to enqueue on a failed handle as well."""
         if self.lib.gom_peer_reduce_poll(self._h):
-            raise RuntimeError("peer all-reduce: a peer did not answer within the wait limit -- the gradients of that step were NOT reduced "
-                               "(reset() on every rank, or rebuild the exchange, before stepping again)")
+            raise RuntimeError("peer all-reduce: a peer did not answer within the wait limit -- that step's exchange is INCOMPLETE: with the optimizer inside the "
+                               "exchange (run_adam / run_zero1) some slices of the parameters and moments were stepped and others were not, differently on every "
+                               "rank.  Before stepping again, on EVERY rank: FrameParallel.recover(opt) (= reset() + re-broadcast of parameters, moments and "
+                               "step count from one rank), or restore a checkpoint and rebuild the exchange")
 
     def run(self, out: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
         out = self.buffer if out is None else out
@@ -118,10 +122,11 @@ class PeerAllReduce:
         if zero1:
             assert out is None, "the ZeRO-1 exchange gathers parameters: there is no reduced gradient to hand out"
             self._lib.check(self.lib.gom_peer_reduce_run_zero1(self._h, float(scale), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
-                                                               opt._begin, lr, opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+                                                               opt._begin, lr, opt._seg_start(), opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+            opt.moments_sharded = True
         else:
             self._lib.check(self.lib.gom_peer_reduce_run_adam(self._h, float(scale), P(out), P(opt.fp.params.flat), P(opt.exp_avg), P(opt.exp_avg_sq), len(opt.lr),
-                                                              opt._begin, lr, opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
+                                                              opt._begin, lr, opt._seg_start(), opt.t + 1, opt.betas[0], opt.betas[1], opt.eps, self._lib.stream_ptr()))
         opt.t += 1   # (only a step that was enqueued counts)
 
     def check(self) -> None:
@@ -129,7 +134,9 @@ class PeerAllReduce:
         self._lib.check(-self.lib.gom_peer_reduce_status(self._h))
 
     def reset(self) -> None:
-        """After a timeout, on EVERY rank: clears the condition between two barriers of the group and moves all ranks to a common epoch."""
+        """After a timeout, on EVERY rank: clears the condition between two barriers of the group and moves all ranks to a common epoch.
+        This restores the EXCHANGE only.  A timed-out run_adam / run_zero1 has stepped some slices of the parameters and moments and not others,
+        differently per rank: the replicas must be re-synchronised as well (FrameParallel.recover does both)."""
         torch.cuda.synchronize()
         dist.barrier(group=self.group)
         ep = torch.tensor([int(self.lib.gom_peer_reduce_epoch(self._h))], dtype=torch.int64)
@@ -164,7 +171,7 @@ class FrameParallel:
     """
 
     def __init__(self, shapes: Sequence[Tuple[str, Tuple[int, ...]]], device, group: Optional[dist.ProcessGroup] = None,
-                 average: bool = True, pad_to: int = 0, impl: str = "collective"):
+                 average: bool = True, pad_to: int = 0, impl: str = "collective", align: int = 1):
         """impl: "collective" = torch.distributed all_reduce (RCCL on GPUs, gloo on the host); "peer" = the direct two-shot all-reduce
         over IPC-mapped peer buffers (`PeerAllReduce`; the gradient buffer then lives in the peer-mapped region); "peer-zero1" = the same
         exchange with the optimizer sharded over the ranks (`all_reduce_and_step` only: each rank steps its slice, parameters are gathered)."""
@@ -175,8 +182,8 @@ class FrameParallel:
         self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._native_avg = self._nccl
         self._host = None
-        self.params = FlatBuffer(shapes, device)
-        self.grads = FlatBuffer(shapes, device, pad_to=pad_to)
+        self.params = FlatBuffer(shapes, device, align=align)
+        self.grads = FlatBuffer(shapes, device, pad_to=pad_to, align=align)
         self.impl, self.peer = impl, None
         if impl not in ("collective", "peer", "peer-zero1"):
             raise ValueError(f"unknown all-reduce implementation {impl!r}")
@@ -189,9 +196,63 @@ class FrameParallel:
         """Global index of the frame this rank renders at `step`."""
         return step * self.world + self.rank
 
+    def _staged(self, t: torch.Tensor, fn) -> None:
+        """`fn(tensor)` = a torch.distributed call.  gloo with DEVICE tensors (ranks sharing one GPU on a development lease): staged through pinned
+        host memory -- gloo's plain host path -- rather than through its device-tensor path."""
+        if t.is_cuda and not self._nccl:
+            if self._host is None or self._host.numel() < t.numel():
+                self._host = torch.empty(t.numel(), dtype=torch.float32).pin_memory()
+            h = self._host[:t.numel()].view(t.shape)
+            h.copy_(t, non_blocking=False)
+            fn(h)
+            t.copy_(h, non_blocking=False)
+        else:
+            fn(t)
+
     def broadcast_params(self, src: int = 0) -> None:
         if self.world > 1:
-            dist.broadcast(self.params.flat, src=src, group=self.group)
+            self._staged(self.params.flat, lambda x: dist.broadcast(x, src=src, group=self.group))
+
+    def zero1_slice(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        """[lo, hi) of the flat buffers that `rank` owns under impl="peer-zero1" (csrc/frame_parallel.hip: float4 units dealt in rank order,
+        the ragged end to the last rank)."""
+        r = self.rank if rank is None else rank
+        n = self.grads.numel
+        n4 = n // 4
+        per = -(-n4 // self.world)
+        lo, hi = 4 * min(per * r, n4), 4 * min(per * (r + 1), n4)
+        return lo, (n if r == self.world - 1 else hi)
+
+    def gather_optimizer_state(self, opt: "FlatAdam") -> None:
+        """Collective.  Under impl="peer-zero1" every rank's FlatAdam holds CURRENT moments for its own slice only (the other slices are stale):
+        before a checkpoint is written from one rank, or before the implementation is switched, this makes every rank's exp_avg / exp_avg_sq
+        complete again (own slice kept, the rest zeroed, one sum over the ranks)."""
+        if self.world <= 1 or not getattr(opt, "moments_sharded", False):
+            return
+        lo, hi = self.zero1_slice()
+        hi = min(hi, opt.exp_avg.numel())
+        for m in (opt.exp_avg, opt.exp_avg_sq):
+            m[:min(lo, m.numel())].zero_()
+            m[hi:].zero_()
+            self._staged(m, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
+        opt.moments_sharded = False
+
+    def recover(self, opt: Optional["FlatAdam"] = None, src: int = 0) -> None:
+        """Collective, on EVERY rank after a timed-out peer exchange (PeerAllReduce.poll / check raised): resets the exchange and re-broadcasts the
+        parameters -- and `opt`'s moments and step count -- from rank `src`, because a timed-out exchange with the optimizer inside it leaves the
+        replicas stepped slice by slice, differently per rank.  (Under ZeRO-1 the moments of `src` are complete only for its own slice: restore a
+        checkpoint instead if the step that timed out matters.)"""
+        if self.peer is not None:
+            self.peer.reset()
+        if self.world <= 1:
+            return
+        self.broadcast_params(src)
+        if opt is not None:
+            for m in (opt.exp_avg, opt.exp_avg_sq):
+                self._staged(m, lambda x: dist.broadcast(x, src=src, group=self.group))
+            got = [opt.t]
+            dist.broadcast_object_list(got, src=src, group=self.group)
+            opt.t = int(got[0])
 
     def all_reduce_grads(self) -> None:
         """ONE collective on the flat buffer (enqueued on the current stream).  RCCL averages inside the collective
@@ -212,18 +273,8 @@ class FrameParallel:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 flat.mul_(1.0 / self.world)
-        elif flat.is_cuda:
-            # gloo with device tensors (ranks sharing one GPU on a development lease): staged through one pinned host buffer --
-            # gloo's plain host path -- rather than through its device-tensor path
-            if self._host is None:
-                self._host = torch.empty(flat.shape, dtype=torch.float32).pin_memory()
-            self._host.copy_(flat, non_blocking=False)
-            dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                self._host.mul_(1.0 / self.world)
-            flat.copy_(self._host, non_blocking=False)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        else:   # gloo: host tensors (CPU tests), or device tensors staged through pinned host memory
+            self._staged(flat, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
             if self.average:
                 flat.mul_(1.0 / self.world)
 
@@ -274,9 +325,12 @@ class FlatAdam:
     in two more flat buffers, the step count on the host.  Device buffers only: there is no CPU path (the gloo tests use `make_adam`)."""
 
     def __init__(self, fp: "FrameParallel", lrs: Dict[str, float], betas=(0.9, 0.999), eps: float = 1e-8, graphable: bool = False,
-                 lr_decay_steps: float = 0.0):
+                 lr_decay_steps: float = 0.0, segments: Optional[Sequence[Tuple[str, int, int]]] = None):
         """graphable: the step count lives in device memory and the learning-rate decay (update_lr) is derived from it in the kernel
-        (`gom_adam_flat_graphable`), so `step()` can be captured into a graph behind the frame step and replayed."""
+        (`gom_adam_flat_graphable`), so `step()` can be captured into a graph behind the frame step and replayed.
+        segments: (name, begin, end) runs of the flat buffer that share a learning rate `lrs[name]` (the reference's PARAMETER GROUPS:
+        a group's tensors laid out next to each other are one segment; at most GOM_ADAM_MAX_SEGMENTS = 12); default: one per tensor.
+        See `join`: a segment that has not joined is left alone, one that joined late counts its own steps."""
         import ctypes
         from . import _lib
         if not fp.params.flat.is_cuda:
@@ -286,9 +340,17 @@ class FlatAdam:
         n = fp.params.numel
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=fp.params.flat.device)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
-        self.names = [name for name, _, _, _ in fp.params.layout]
-        bounds = [off for _, _, off, _ in fp.params.layout] + [fp.params.layout[-1][2] + fp.params.layout[-1][3]]
+        if segments is None:
+            segments = [(name, off, off + cnt) for name, _, off, cnt in fp.params.layout]
+        segments = [(str(nm), int(b), int(e)) for nm, b, e in segments]
+        assert all(a[2] <= b[1] for a, b in zip(segments[:-1], segments[1:])), "segments must ascend without overlap"
+        # the native call takes n + 1 ascending bounds: a gap between two runs (alignment padding) is given to the run in front of it --
+        # its gradient, moments and parameters are zero and stay zero
+        self.names = [nm for nm, _, _ in segments]
+        bounds = [b for _, b, _ in segments] + [segments[-1][2]]
         self._begin = (ctypes.c_int64 * len(bounds))(*bounds)
+        self.start = [0] * len(segments)       # optimizer steps taken when the segment joined; -1: not yet (torch Adam skips .grad is None)
+        self.moments_sharded = False           # set by a ZeRO-1 exchange: only the own slice of the moments is current (gather_optimizer_state)
         self.base_lr = [float(lrs.get(name, lrs.get("default", 1e-3))) for name in self.names]
         self.lr = list(self.base_lr)
         self.graphable, self.lr_decay_steps = bool(graphable), float(lr_decay_steps)
@@ -311,19 +373,34 @@ class FlatAdam:
         """update_lr (train.py:166-175)."""
         self.lr = [b * 0.1 ** (iter_step / lr_decay_steps) for b in self.base_lr]
 
+    def join(self, name: str, active: bool = True) -> None:
+        """A segment whose parameters receive no gradient yet (the reference's non-rigid / pose-refinement MLPs before their kick_in_iter:
+        `.grad is None`, torch.optim.Adam skips them and counts their steps from the first gradient): join(name, False) before the first step
+        keeps it out, join(name) lets it in from the NEXT step on, with its own step count.  Same call on every rank."""
+        for i, nm in enumerate(self.names):
+            if nm == name:
+                if not active:
+                    assert self.start[i] < 0 or self.start[i] >= self.t, f"segment {name!r} has stepped already"
+                    self.start[i] = -1
+                elif self.start[i] < 0:
+                    self.start[i] = self.t
+
+    def _seg_start(self):
+        return (self._ct.c_int64 * len(self.start))(*self.start)
+
     def step(self, grad_scale: float = 1.0) -> None:
         """One Adam step on the current stream, reading `fp.grads.flat` (as the all-reduce left it)."""
         fp, P = self.fp, self._lib.ptr
         if self.graphable:
             lr = (self._ct.c_float * len(self.base_lr))(*self.base_lr)
             self._lib.check(self._lib.load().gom_adam_flat_graphable(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq),
-                                                                     len(self.base_lr), self._begin, lr, 1, P(self.step_dev), self.lr_decay_steps, self.betas[0],
+                                                                     len(self.base_lr), self._begin, lr, self._seg_start(), 1, P(self.step_dev), self.lr_decay_steps, self.betas[0],
                                                                      self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
             self.t += 1
             return
         lr = (self._ct.c_float * len(self.lr))(*self.lr)
         self._lib.check(self._lib.load().gom_adam_flat(fp.params.numel, P(fp.params.flat), P(fp.grads.flat), P(self.exp_avg), P(self.exp_avg_sq), len(self.lr),
-                                                       self._begin, lr, self.t + 1, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
+                                                       self._begin, lr, self._seg_start(), self.t + 1, self.betas[0], self.betas[1], self.eps, float(grad_scale), self._lib.stream_ptr()))
         self.t += 1   # (only a step that was enqueued counts)
 
 
@@ -331,3 +408,228 @@ def shapes_for_model(n_verts: int, n_faces: int, extra: Iterable[Tuple[str, Tupl
     """The hot path's trainables in the reference's layouts (models/model.py:74-85,
     appearance_module.py:14) followed by any extra tensors (MLP weights...)."""
     return [("vertices", (3, n_verts)), ("so3", (3, n_faces)), ("scale", (3, n_faces)), ("appearance", (3, n_faces))] + list(extra)
+
+
+class ModelFrameParallel:
+    """Frame-parallel training of the thing the reference trains: `model.Model` (vertices, so3, scale, appearance, shadow MLP and the
+    optional non-rigid / pose-refinement MLPs) through `train_util.train_iteration(..., frame_parallel=this)` -- BASELINE configs[3]
+    in the reference's own step shape (train.py:309-349: zero_grad -> Model.forward -> unpack -> compute_loss incl. LPIPS -> backward
+    -> Adam over Model.get_param_groups -> update_lr), one frame per rank per step, ONE exchange of the mean gradient per step.
+
+    * Every trainable tensor of `model.get_param_groups(train_cfg)` is RE-SEATED as a view of one flat fp32 buffer (SURVEY.md 8(e)'s
+      layout: vertices | so3 / scale | appearance | non-rigid MLP | pose MLP | shadow MLP; 951 023 floats at 55 104 Gaussians with
+      both MLPs, every tensor on a 16-byte boundary), and its `.grad` as the same view of the flat GRADIENT buffer: autograd accumulates
+      straight into the exchange region (`impl="peer"`: the hipIpc-mapped region the other ranks read).  `model.parameters()`,
+      `state_dict()` and checkpoints keep working -- the parameters are the same objects with other storage.
+    * The optimizer is the reference's (`torch.optim.Adam(param_groups, betas=(0.9, 0.999))`, per-group learning rates decayed by
+      update_lr) as `FlatAdam` segments, one per parameter group; a group whose module has not kicked in (`i_iter < kick_in_iter`,
+      models/model.py:193,200) is left alone and counts its own steps once it joins, as torch does for `.grad is None`.
+    * `impl`: "collective" (RCCL / gloo all-reduce, then one Adam launch), "peer" (two-shot exchange over peer pointers, Adam inside
+      the all-gather) or "peer-zero1" (the owner of a slice steps it, parameters are gathered).
+    * `overlap`: the exchange runs on its own stream; the next iteration's LPIPS target trunk (`prefetch_target`, 0.45 ms at 512^2)
+      is enqueued before the main stream waits for it, so it runs UNDER the exchange.
+    * Host tensors (the gloo CPU tests): the same re-seating, `torch.optim.Adam` over the re-seated parameters.
+
+    `model.subdivide()` creates new parameters: call `reseat()` afterwards on every rank (collective for the peer implementations; the
+    optimizer restarts, as the reference rebuilds it at a subdivision, train.py:330-340)."""
+
+    GROUP_ORDER = ("canonical_geometry_xyz", "canonical_geometry", "appearance", "non_rigid", "pose_refinement", "shadow")
+
+    def __init__(self, model, train_cfg, group: Optional[dist.ProcessGroup] = None, impl: str = "collective", betas=(0.9, 0.999), eps: float = 1e-8,
+                 average: bool = True, overlap: bool = True):
+        self.model, self.train_cfg, self.group, self.impl = model, train_cfg, group, impl
+        self.betas, self.eps, self.average, self.overlap = betas, eps, average, overlap
+        self.fp, self.opt, self.torch_opt = None, None, None
+        self._stream, self._done = None, None
+        self.reseat(first=True)
+
+    # -- layout ------------------------------------------------------------------------------------------------------------------
+    def _entries(self):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        out = []
+        for g in self.model.get_param_groups(self.train_cfg):
+            for p in list(g["params"]):
+                if isinstance(p, torch.nn.Parameter) and p.requires_grad:        # (group 0, the skinning weights, is a buffer: no gradient)
+                    rank = self.GROUP_ORDER.index(g["name"]) if g["name"] in self.GROUP_ORDER else len(self.GROUP_ORDER)
+                    out.append((rank, g["name"], names.get(id(p), f"{g['name']}.{len(out)}"), p, float(g["lr"])))
+        out.sort(key=lambda e: e[0])                                             # (stable: the order inside a group is the reference's)
+        return out
+
+    def reseat(self, first: bool = False) -> None:
+        ent = self._entries()
+        dev = ent[0][3].device
+        if self.fp is not None:
+            self.finish()
+            self.fp.close()
+        self.fp = FrameParallel([(nm, tuple(p.shape)) for _, _, nm, p, _ in ent], dev, group=self.group, average=self.average, impl=self.impl, align=4)
+        self.world, self.rank = self.fp.world, self.fp.rank
+        with torch.no_grad():
+            for _, _, nm, p, _ in ent:
+                self.fp.params[nm].copy_(p.detach())
+                p.data = self.fp.params[nm]
+                p.grad = self.fp.grads[nm]
+            self.fp.grads.flat.zero_()
+        # one optimizer segment per run of tensors of one parameter group
+        lay = {nm: (off, cnt) for nm, _, off, cnt in self.fp.params.layout}
+        segs, self.group_lr = [], {}
+        for _, gname, nm, _, lr in ent:
+            off, cnt = lay[nm]
+            if segs and segs[-1][0] == gname:
+                segs[-1] = (gname, segs[-1][1], off + cnt)
+            else:
+                assert all(sg[0] != gname for sg in segs), f"parameter group {gname!r} appears twice with other groups in between"
+                segs.append((gname, off, off + cnt))
+            self.group_lr[gname] = lr
+        self.segments = segs
+        self.param_floats = sum(cnt for _, _, _, cnt in self.fp.params.layout)
+        self.payload_floats = int(self.fp.grads.numel)
+        self._entries_cache = ent
+        if dev.type == "cuda":
+            self.opt = FlatAdam(self.fp, dict(self.group_lr), betas=self.betas, eps=self.eps, segments=segs)
+            self.torch_opt = None
+        else:
+            groups = {}
+            for _, gname, _, p, lr in ent:
+                groups.setdefault(gname, {"name": gname, "params": [], "lr": lr})["params"].append(p)
+            self.torch_opt = torch.optim.Adam(list(groups.values()), betas=self.betas, eps=self.eps)
+            self.opt = None
+        self._joined = {sg[0]: True for sg in segs}
+        if self.fp.world > 1:
+            self.fp.broadcast_params(0)          # replicas start from rank 0's initialisation
+        self.steps = 0
+
+    @property
+    def param_groups(self):
+        """[{name, lr}] of the groups this object steps (update_lr-compatible view; writing `lr` here has no effect: use `decay`)."""
+        return [{"name": nm, "lr": (self.opt.lr[i] if self.opt is not None else self.torch_opt.param_groups[i]["lr"])} for i, (nm, _, _) in enumerate(self.segments)]
+
+    # -- the step -----------------------------------------------------------------------------------------------------------------
+    def frame_index(self, step: int) -> int:
+        return self.fp.frame_index(step)
+
+    def finish(self) -> None:
+        """The main stream waits for the exchange + optimizer step enqueued by the last `step()` (no host synchronisation)."""
+        if self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+            self._done = None
+
+    def zero_grad(self) -> None:
+        """`.grad` stays seated on the flat gradient buffer; one fill (behind the previous exchange)."""
+        self.finish()
+        self.fp.grads.flat.zero_()
+
+    def _module_active(self, gname: str, i_iter) -> bool:
+        from .model import _get
+        key = {"non_rigid": "non_rigid.kick_in_iter", "pose_refinement": "pose_refinement.kick_in_iter"}.get(gname)
+        return True if key is None else bool(i_iter >= _get(self.model.cfg, key, 0))
+
+    def step(self, i_iter) -> None:
+        """Mean of the gradients over the ranks, Adam, update_lr(i_iter) -- train.py:339-341 with the exchange in front."""
+        lr_decay_steps = getattr(self.train_cfg, "lr_decay_steps", None)
+        active = {nm: self._module_active(nm, i_iter) for nm, _, _ in self.segments}
+        if self.opt is None:                                   # host tensors: gloo all-reduce + torch Adam over the re-seated parameters
+            self.fp.all_reduce_grads()
+            held = []
+            for _, gname, _, p, _ in self._entries_cache:
+                if not active[gname]:                          # torch skips `.grad is None` (and does not count the step)
+                    held.append((p, p.grad)); p.grad = None
+            self.torch_opt.step()
+            for p, g in held:
+                p.grad = g
+            if lr_decay_steps:
+                for grp in self.torch_opt.param_groups:
+                    grp["lr"] = self.group_lr[grp["name"]] * 0.1 ** (i_iter / lr_decay_steps)
+            self.steps += 1
+            return
+        for nm, a in active.items():
+            self.opt.join(nm, a)
+        cur = torch.cuda.current_stream()
+        if self.overlap:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(cur)                      # behind the backward
+        with torch.cuda.stream(self._stream if self.overlap else cur):
+            self.fp.all_reduce_and_step(self.opt)
+            if self.overlap:
+                self._done = torch.cuda.Event()
+                self._done.record()
+        if lr_decay_steps:
+            self.opt.decay(i_iter, lr_decay_steps)
+        self.steps += 1
+
+    # -- checkpoints (torch.optim.Adam's layout over Model.get_param_groups: formats.save_checkpoint / the reference's train.py:370-377) --------
+    def optimizer_state_dict(self) -> dict:
+        """Collective under ZeRO-1 (the moments are gathered first).  -> what `torch.optim.Adam(model.get_param_groups(cfg)).state_dict()` holds."""
+        self.finish()
+        if self.torch_opt is not None:
+            return self.torch_opt.state_dict()
+        torch.cuda.current_stream().synchronize()
+        self.fp.gather_optimizer_state(self.opt)
+        lay = {nm: (off, cnt, shape) for nm, shape, off, cnt in self.fp.params.layout}
+        by_id = {id(p): (gname, nm) for _, gname, nm, p, _ in self._entries_cache}
+        seg_i = {nm: i for i, (nm, _, _) in enumerate(self.segments)}
+        groups, state, idx = [], {}, 0
+        for g in self.model.get_param_groups(self.train_cfg):
+            ids = []
+            for p in list(g["params"]):
+                if id(p) in by_id:
+                    gname, nm = by_id[id(p)]
+                    off, cnt, shape = lay[nm]
+                    st = self.opt.start[seg_i[gname]]
+                    if st >= 0 and self.opt.t > st:
+                        state[idx] = {"step": torch.tensor(float(self.opt.t - st)), "exp_avg": self.opt.exp_avg[off:off + cnt].view(shape).clone(),
+                                      "exp_avg_sq": self.opt.exp_avg_sq[off:off + cnt].view(shape).clone()}
+                ids.append(idx); idx += 1
+            i = seg_i.get(g["name"])
+            groups.append({"name": g["name"], "lr": self.opt.lr[i] if i is not None else float(g["lr"]), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                           "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        if self.torch_opt is not None:
+            self.torch_opt.load_state_dict(sd)
+            return
+        self.finish()
+        lay = {nm: (off, cnt, shape) for nm, shape, off, cnt in self.fp.params.layout}
+        by_id = {id(p): (gname, nm) for _, gname, nm, p, _ in self._entries_cache}
+        seg_i = {nm: i for i, (nm, _, _) in enumerate(self.segments)}
+        steps, idx = {}, 0
+        for g in self.model.get_param_groups(self.train_cfg):
+            for p in list(g["params"]):
+                if id(p) in by_id:
+                    gname, nm = by_id[id(p)]
+                    off, cnt, shape = lay[nm]
+                    st = sd["state"].get(idx)
+                    if st is not None:
+                        self.opt.exp_avg[off:off + cnt].view(shape).copy_(st["exp_avg"])
+                        self.opt.exp_avg_sq[off:off + cnt].view(shape).copy_(st["exp_avg_sq"])
+                        steps.setdefault(gname, set()).add(int(float(st["step"])))
+                    else:
+                        steps.setdefault(gname, set()).add(0)
+                idx += 1
+        for gname, ss in steps.items():
+            if len(ss) != 1:
+                raise ValueError(f"parameter group {gname!r}: tensors with different step counts {sorted(ss)} cannot share one optimizer segment")
+        self.opt.t = max(next(iter(ss)) for ss in steps.values())
+        for gname, ss in steps.items():
+            k = next(iter(ss))
+            self.opt.start[seg_i[gname]] = -1 if k == 0 and self.opt.t > 0 else self.opt.t - k
+        self.opt.moments_sharded = False
+        for grp in sd.get("param_groups", []):
+            i = seg_i.get(grp.get("name"))
+            if i is not None:
+                self.opt.lr[i] = float(grp["lr"])
+
+    def recover(self) -> None:
+        """Collective, after a timed-out peer exchange: FrameParallel.recover with this object's optimizer."""
+        self.finish()
+        self.fp.recover(self.opt)
+
+    def close(self) -> None:
+        if self.fp is not None:
+            if self._entries_cache and self.fp.peer is not None:
+                torch.cuda.synchronize()
+                with torch.no_grad():      # the parameters outlive the peer region only as views of `params` (own allocation); the gradients move out of it
+                    for _, _, nm, p, _ in self._entries_cache:
+                        p.grad = None
+            self.fp.close()

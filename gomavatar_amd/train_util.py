@@ -128,21 +128,38 @@ def update_lr(optimizer, iter_step, train_cfg) -> None:
         param_group["lr"] = getattr(train_cfg.lr, param_group["name"]) * decay_value
 
 
-def train_iteration(model, optimizer, data, train_cfg, n_iters, lpips_func=None, random_bgcolor: bool = True):
-    """One iteration of the reference's loop, train.py:313-348 (without logging / checkpoints / subdivision, which the caller owns):
-    zero_grad -> forward -> unpack -> compute_loss -> backward -> optimizer step -> update_lr.  Returns (loss, loss_items, rgb, mask)."""
-    optimizer.zero_grad()
-    if hasattr(lpips_func, "prefetch_target") and _get(train_cfg.losses, "lpips.coeff", 1.0) > 0:
-        lpips_func.prefetch_target(data["target_rgbs"])       # (the target's half of the LPIPS trunk, on a second stream under the frame's forward)
+def forward_backward(model, data, train_cfg, n_iters, lpips_func=None, random_bgcolor: bool = True):
+    """train.py:317-338: forward -> unpack -> compute_loss -> backward (gradients accumulate into `.grad`).  Returns (loss, loss_items, rgb, mask)."""
     rgb, mask, outputs = model(data["K"], data["E"], data["cnl_gtfms"], data["dst_Rs"], data["dst_Ts"], dst_posevec=data.get("dst_posevec"),
                                canonical_joints=data.get("dst_tpose_joints"), i_iter=n_iters, bgcolor=data.get("bgcolor"))
     if random_bgcolor:
         rgb = unpack(rgb, mask, data["bgcolor"])
     loss, loss_items = compute_loss(rgb, mask, outputs, data["target_rgbs"], data["target_masks"], train_cfg.losses, data, n_iters, lpips_func=lpips_func)
     loss.backward()
-    optimizer.step()
-    update_lr(optimizer, n_iters, train_cfg)
     return loss, loss_items, rgb, mask
+
+
+def train_iteration(model, optimizer, data, train_cfg, n_iters, lpips_func=None, random_bgcolor: bool = True, frame_parallel=None):
+    """One iteration of the reference's loop, train.py:313-348 (without logging / checkpoints / subdivision, which the caller owns):
+    zero_grad -> forward -> unpack -> compute_loss -> backward -> optimizer step -> update_lr.  Returns (loss, loss_items, rgb, mask).
+
+    frame_parallel (parallel.ModelFrameParallel, `optimizer` may be None): the same iteration as ONE of N frame-parallel ranks
+    (BASELINE configs[3]; `data` = this rank's frame, `frame_parallel.frame_index(step)`): gradients accumulate straight into the
+    flat exchange buffer, ONE exchange forms their mean over the ranks with the reference's Adam + update_lr inside / behind it, on
+    its own stream -- the next iteration's LPIPS target trunk is enqueued before the main stream waits for the exchange and runs under it."""
+    if hasattr(lpips_func, "prefetch_target") and _get(train_cfg.losses, "lpips.coeff", 1.0) > 0:
+        lpips_func.prefetch_target(data["target_rgbs"])       # (the target's half of the LPIPS trunk, on a second stream under the frame's forward)
+    if frame_parallel is not None:
+        frame_parallel.zero_grad()                            # (waits for the previous step's exchange: the parameters it leaves are this forward's)
+    else:
+        optimizer.zero_grad()
+    out = forward_backward(model, data, train_cfg, n_iters, lpips_func, random_bgcolor)
+    if frame_parallel is not None:
+        frame_parallel.step(n_iters)
+    else:
+        optimizer.step()
+        update_lr(optimizer, n_iters, train_cfg)
+    return out
 
 
 def eval_frame(model, data, bgcolor255=(255.0, 255.0, 255.0)):

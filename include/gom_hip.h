@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 7
+#define GOM_ABI_VERSION 8
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -454,19 +454,23 @@ int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_t B, const 
  * per-group learning rates models/model.py:305-327, decayed by update_lr train.py:166-175) as one launch over the buffer the
  * gradient all-reduce leaves behind.  Segment i = elements [seg_begin[i], seg_begin[i + 1]) with learning rate seg_lr[i] (host
  * arrays, n_segments + 1 bounds); elements outside every segment (padding) are left alone.  `step` counts from 1 (bias correction);
- * the gradient is multiplied by grad_scale first (1 / world size when the collective summed).  No weight decay, no amsgrad. */
+ * the gradient is multiplied by grad_scale first (1 / world size when the collective summed).  No weight decay, no amsgrad.
+ * `seg_start` (host array of n_segments, or NULL = all zero): optimizer steps that had been taken when segment i JOINED -- torch.optim.Adam
+ * skips a parameter whose .grad is None and counts that parameter's steps from its first gradient, which is how the reference's non-rigid /
+ * pose-refinement MLPs behave before their kick_in_iter (models/model.py:193,200; exps/zju-mocap_377.yaml:73,85): segment i's bias
+ * corrections use step - seg_start[i]; seg_start[i] < 0 (or >= step) = not joined yet, its elements are left alone like padding. */
 #define GOM_ADAM_MAX_SEGMENTS 12
 int gom_adam_flat(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                  const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, float grad_scale,
-                  void *stream);
+                  const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps,
+                  float grad_scale, void *stream);
 
 /* The same step with the step COUNT in device memory -- step_device[0] = steps taken so far, step_device[1] = 0 (scratch), advanced by the
  * kernel -- and the reference's learning-rate schedule (update_lr: base * 0.1^(iteration / lr_decay_steps); 0 = constant) derived from it
  * on the device: no argument changes from step to step, so the launch can be captured into a hipGraph with the frame step in front of it.
  * step_device == NULL: exactly gom_adam_flat. */
 int gom_adam_flat_graphable(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                            const int64_t *seg_begin, const float *seg_lr, int64_t step, int64_t *step_device, float lr_decay_steps, float beta1,
-                            float beta2, float eps, float grad_scale, void *stream);
+                            const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, int64_t *step_device,
+                            float lr_decay_steps, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
 /* Shading of the pixels under the mesh, fused (models/model.py:279-283: shadow = 2 * shadow_module(normal) for every pixel; the normal map is
  * zero outside the mesh, where the MLP is one constant).  `normal`: (HW, 3); `pos`: (HW) int32 row of a pixel or -1; `pe`: (HW + 1, 3 + 6 L)
@@ -522,11 +526,13 @@ int gom_peer_reduce_run(GomPeerReduce *h, float *out, float scale, void *stream)
 /* The same exchange with the optimizer inside its second kernel: every rank applies gom_adam_flat's step of ITS parameter replica straight from
  * the reduced slices as it reads them (n_floats = the flat parameter count; out may be NULL: the reduced gradient is then not materialised). */
 int gom_peer_reduce_run_adam(GomPeerReduce *h, float scale, float *out, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                             const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream);
+                             const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps,
+                             void *stream);
 /* ZeRO-1: the rank that reduced a slice applies THAT slice's Adam step (moments are touched for the own slice only) and
  * publishes the updated parameters; the second kernel gathers parameters.  Replicas end with the bits gom_peer_reduce_run_adam gives. */
 int gom_peer_reduce_run_zero1(GomPeerReduce *h, float scale, float *params, float *exp_avg, float *exp_avg_sq, int32_t n_segments,
-                              const int64_t *seg_begin, const float *seg_lr, int64_t step, float beta1, float beta2, float eps, void *stream);
+                              const int64_t *seg_begin, const float *seg_lr, const int64_t *seg_start, int64_t step, float beta1, float beta2, float eps,
+                              void *stream);
 int gom_peer_reduce_set_timeout(GomPeerReduce *h, double seconds);
 int gom_peer_reduce_poll(GomPeerReduce *h);     /* 0 / 1, non-blocking (one step late at most) */
 int gom_peer_reduce_status(GomPeerReduce *h);   /* 0 / 1, synchronises the device */

@@ -1,0 +1,119 @@
+"""parallel.ModelFrameParallel on the host, 2 ranks over gloo: the re-seating of a model's parameter groups onto one flat buffer (`.grad`
+seated on the flat gradient buffer, autograd accumulating into it), the single exchange per step, torch.optim.Adam over the re-seated
+parameters with update_lr's decay, and a parameter group that JOINS late (the reference's pose-refinement MLP before its kick_in_iter:
+`.grad is None`, skipped by Adam) -- against one process that steps `torch.optim.Adam(model.get_param_groups())` on the mean gradient of the
+same frames.  The HIP kernels cannot run here: the stand-in model has the reference's group structure and real `modules.*` MLPs, its "render"
+is a differentiable function of (parameters, frame)."""
+import os
+import socket
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from gomavatar_amd.modules import PoseRefinementModule
+from gomavatar_amd.parallel import ModelFrameParallel
+
+STEPS, KICK = 5, 3
+TCFG = NS(lr=NS(lbs_weights=0.0, appearance=5e-3, canonical_geometry=5e-4, canonical_geometry_xyz=5e-5, pose_refinement=1e-3, shadow=2e-3), lr_decay_steps=20)
+
+
+class StandIn(nn.Module):
+    """Model's parameter groups (models/model.py:305-327) without the renderer."""
+
+    def __init__(self, n=37, f=70):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.cfg = NS(pose_refinement=NS(kick_in_iter=KICK))
+        self.register_buffer("lbs_weights", torch.rand(25, n, generator=g))
+        self.vertices = nn.Parameter(torch.randn(3, n, generator=g))
+        self.so3 = nn.Parameter(torch.zeros(3, f))
+        self.scale = nn.Parameter(torch.ones(3, f))
+        self.appearance = nn.Parameter(torch.full((3, f), 0.5))
+        torch.manual_seed(1)
+        self.pose_refinement_module = PoseRefinementModule(NS(embedding_size=69, total_bones=24, mlp_width=16, mlp_depth=2, refine_root=False, refine_t=False))
+        self.shadow_module = nn.Sequential(nn.Linear(3, 8), nn.ReLU(), nn.Linear(8, 1))
+
+    def get_param_groups(self, cfg):
+        lr = cfg.lr
+        return [{"name": "lbs_weights", "params": [self.lbs_weights], "lr": lr.lbs_weights},
+                {"name": "appearance", "params": [self.appearance], "lr": lr.appearance},
+                {"name": "canonical_geometry_xyz", "params": [self.vertices], "lr": lr.canonical_geometry_xyz},
+                {"name": "canonical_geometry", "params": [self.scale], "lr": lr.canonical_geometry},
+                {"name": "canonical_geometry", "params": [self.so3], "lr": lr.canonical_geometry},
+                {"name": "pose_refinement", "params": self.pose_refinement_module.parameters(), "lr": lr.pose_refinement},
+                {"name": "shadow", "params": self.shadow_module.parameters(), "lr": lr.shadow}]
+
+    def loss(self, frame, i_iter):
+        g = torch.Generator().manual_seed(100 + frame)
+        pose = torch.randn(1, 69, generator=g) * 0.3
+        tgt = torch.randn(3, self.vertices.shape[1], generator=g)
+        v = self.vertices
+        if i_iter >= self.cfg.pose_refinement.kick_in_iter:       # model.py:193: the module is not even called before
+            v = (self.pose_refinement_module(pose)[0, 1:4].sum(0) * 0.1 + torch.eye(3)) @ v
+        shade = self.shadow_module(v.T).mean()
+        col = (self.appearance * self.scale + self.so3.sin()).mean(1)
+        return ((v - tgt) ** 2).mean() + shade + (col - torch.rand(3, generator=g)).abs().sum()
+
+
+def _flat_of(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = StandIn()
+        mfp = ModelFrameParallel(model, TCFG)
+        assert mfp.world == world and [s[0] for s in mfp.segments] == ["canonical_geometry_xyz", "canonical_geometry", "appearance", "pose_refinement", "shadow"]
+        assert all(p.grad is not None and p.grad.data_ptr() == mfp.fp.grads[nm].data_ptr() for _, _, nm, p, _ in mfp._entries_cache)
+        assert all(off % 4 == 0 for _, _, off, _ in mfp.fp.params.layout)
+        for step in range(STEPS):
+            mfp.zero_grad()
+            model.loss(mfp.frame_index(step), step + 1).backward()
+            # autograd accumulated into the seated views (no new .grad tensors): what the exchange reads is what the backward wrote
+            assert all(p.grad.data_ptr() == mfp.fp.grads[nm].data_ptr() for _, _, nm, p, _ in mfp._entries_cache)
+            mfp.step(step + 1)
+        res = _flat_of(model)
+        gathered = [torch.zeros_like(res) for _ in range(world)]
+        dist.all_gather(gathered, res)
+        sd = mfp.optimizer_state_dict()
+        if rank == 0:
+            assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+            torch.save({"params": gathered[0], "opt": sd}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_match_torch_adam_on_the_mean_gradient(tmp_path):
+    out = str(tmp_path / "mfp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    # one process, the reference's own optimizer construction (train.py:263-267) and loop shape, mean gradient of the same two frames per step
+    model = StandIn()
+    opt = torch.optim.Adam(model.get_param_groups(TCFG), betas=(0.9, 0.999))
+    for step in range(STEPS):
+        opt.zero_grad()
+        (0.5 * (model.loss(2 * step, step + 1) + model.loss(2 * step + 1, step + 1))).backward()
+        opt.step()
+        for g in opt.param_groups:                                      # update_lr (train.py:166-175)
+            g["lr"] = getattr(TCFG.lr, g["name"]) * 0.1 ** ((step + 1) / TCFG.lr_decay_steps)
+    ref = _flat_of(model)
+    assert torch.allclose(got["params"], ref, rtol=2e-6, atol=2e-7), float((got["params"] - ref).abs().max())
+    # the late group stepped STEPS - KICK + 1 times, the others STEPS times -- in the reference's optimizer and in ours
+    steps = lambda sd, name: {int(sd["state"][i]["step"]) for g in sd["param_groups"] if g["name"] == name for i in g["params"] if i in sd["state"]}
+    ref_sd = opt.state_dict()
+    for name in ("appearance", "canonical_geometry", "pose_refinement", "shadow"):
+        assert steps(got["opt"], name) == steps(ref_sd, name), name
+    assert steps(ref_sd, "pose_refinement") == {STEPS - KICK + 1}
