@@ -135,8 +135,7 @@ class Runner:
         from gomavatar_amd import _lib
         from gomavatar_amd.parallel import FrameParallel, shapes_for_model
         self.torch, self.wl, self.B, self.S, self.graph, self.world = torch, wl, B, S, graph, world
-        n_own = 3 * wl.N + 9 * wl.F
-        pad = MODEL_PARAMS_M if wl.subdiv == 1 else n_own   # padded to the reference model's full parameter count: the collective moves what a real step moves
+        pad = 0   # the native step exchanges what it trains (vertices / so3 / scale / appearance); the reference model's full 951 023 floats are exchanged by `modes.model_parallel` (ModelFrameParallel: real weights)
         self.slots = []
         self.adam = not args.no_adam
         from gomavatar_amd.parallel import FlatAdam
@@ -421,6 +420,176 @@ def extra_figures(torch, wl):
             del model, mcl, optm
     except Exception as e:  # report, do not hide
         out["model_train_iteration_b1_ips"] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+VGG_LAYERS = ((3, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 256, 4), (256, 512, 8), (512, 512, 8), (512, 512, 8),
+              (512, 512, 16), (512, 512, 16), (512, 512, 16))   # (Cin, Cout, downscale) of the 13 3x3 convolutions (pretrained_networks.py:96-134)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 (MI355X_MICROARCH.md); scripts/ubench/mfma_rate.hip reaches 2 031 with random operands on this part
+
+
+def lpips_roofline(torch, wl):
+    """The kernel family that owns the wall clock of cfg 2's iteration: the LPIPS-VGG trunk on the bf16 matrix cores (csrc/vgg_bf16.hip).  One
+    training evaluation = trunk forward of the prediction and of the target + backward-data of the prediction = 3 walks over the 13
+    convolutions; bf16x3 (the reference's fp32 precision) issues every product three times.  `us` = HIP events in this run around
+    `LPIPSMatrixCore.value_and_grad` (both images as one batch, one stream: heads, pools, split-K epilogues and the first layer's im2col are
+    INSIDE the bracket), `flops` = 2 * MACs * 3 walks * 3 passes, `frac` = flops / us / the dense bf16 peak."""
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    img = wl.img
+    macs = sum(ci * co * 9 * (img // d) ** 2 for ci, co, d in VGG_LAYERS)
+    out = {}
+    for prec, passes in (("bf16x3", 3), ("bf16", 1)):
+        mc = LPIPSMatrixCore(trunk_seed=0, device=wl.device, precision=prec)
+        gt = wl.frames[0]["gt_rgb"][None].contiguous()
+        pred = (gt * 0.9 + 0.05).contiguous()
+        stream = torch.cuda.Stream(device=wl.device)
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                mc.value_and_grad(pred, gt)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 30
+            e0.record()
+            for _ in range(n):
+                v, _ = mc.value_and_grad(pred, gt)
+            e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        flops = 2.0 * macs * 3 * passes
+        out[prec] = {"us": round(us, 1), "flops": int(flops), "achieved": round(flops / (us * 1e-6) / 1e12, 1), "frac": round(flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "fp32_grade_tflops": round(2.0 * macs * 3 / (us * 1e-6) / 1e12, 1), "value": round(float(v), 6)}
+        del mc
+    lp, src = read_profile_json("lpips_launches")
+    r = out["bf16x3"]
+    return {"kernel": "k_conv3x3_bf16_v2 family (LPIPS-VGG trunk, bf16x3 = fp32-grade)", "bound": "mfma", "achieved": r["achieved"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["frac"], "us": r["us"], "flops": r["flops"], "walks": "prediction forward + target forward + prediction backward-data, x 3 bf16 passes",
+            "timing": "HIP events in this run around value_and_grad (heads, pools, epilogues, im2col inside the bracket)", "fp32_grade_tflops": r["fp32_grade_tflops"],
+            "one_pass_bf16": out["bf16"], "launches": (lp or {}).get("launches_per_evaluation"), "conv_only": (lp or {}).get("conv_only"), "launches_source": src,
+            "measured_peak_random_operands_tflops": 2031.0}
+
+
+def render_only_modes(torch, wl):
+    """The comparator for the paper's 43 FPS (eval.py:336-361): frames/s of RENDERING alone.  (i) the drop-in `Model` in
+    eval mode under no_grad -- mesh branch + shadow MLP included, unpack on the background -- frame by frame, eager and as one replayed HIP graph
+    with the two-stream overlap of the mesh branch and the splat rasterizer; (ii) the native forward half of the frame step (FK -> LBS -> face
+    Gaussians -> splat forward -> loss values), one frame and 8 per launch sequence."""
+    from gomavatar_amd.workload import zju_cfg, model_frames, build_model
+    from gomavatar_amd.train_util import GraphedRender, unpack
+    out = {}
+    mcfg, _ = zju_cfg(wl.img)
+    model = build_model(wl, mcfg, with_mlps=False).eval()
+    with torch.no_grad():
+        for k in ("so3", "scale", "appearance"):
+            getattr(model, k).copy_(wl.params[k])
+    frames = model_frames(wl, range(min(8, len(wl.frames))))
+    it = [0]
+
+    def eager():
+        fr = frames[it[0] % len(frames)]; it[0] += 1
+        with torch.no_grad():
+            rgbs, masks, _ = model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            return unpack(rgbs, masks, fr["bgcolor"])
+    try:
+        out["render_only_eval_eager_b1_fps"] = round(timeit(torch, eager, warm=10, chunk=10, windows=3), 1)
+        model.overlap_branches = True
+        with torch.no_grad():
+            model.shadow_capacity = int(1.3 * max(int((model(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])[1] > 0).sum()) for fr in frames))
+        render = GraphedRender(model)
+
+        def graphed():
+            fr = frames[it[0] % len(frames)]; it[0] += 1
+            return render(fr)
+        out["render_only_eval_b1_fps"] = round(timeit(torch, graphed, warm=10, chunk=10, windows=3), 1)
+    except Exception as e:  # report, do not hide
+        out["render_only_eval_b1_fps"] = f"failed: {type(e).__name__}: {e}"
+    for b_ in (1, 8):
+        try:
+            st = wl.step(b_)
+            bts = wl.batches(st)
+            stream = torch.cuda.Stream(device=wl.device)
+            j = [0]
+
+            def native():
+                bt = bts[j[0] % len(bts)]; j[0] += 1
+                with torch.cuda.stream(stream):
+                    st.cam = bt["cam"]
+                    if b_ > 1:
+                        st.cams_dev = bt["cams_dev"]
+                    st.forward_backward(wl.params, bt, bt["gt_rgb"], bt["gt_mask"], bt["bg"], backward=False, graph=True)
+            out[f"render_only_native_forward_b{b_}_fps"] = round(b_ * timeit(torch, native, warm=10, chunk=20, windows=3), 1)
+            del st
+        except Exception as e:
+            out[f"render_only_native_forward_b{b_}_fps"] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+def model_parallel_modes(torch, wl, world, rank, impls, iters=40, warm=8):
+    """BASELINE configs[3] in the reference's step shape: `Model` + compute_loss (every term, LPIPS bf16x3) + the reference's Adam, one frame per
+    rank per step through parallel.ModelFrameParallel (flat parameter / gradient buffers, ONE exchange per step, next iteration's target trunk
+    under it).  -> {impl: iterations/s of the whole job (= frames/s: world frames per step)}, `local_only` = the same iteration with GomAdam and no
+    exchange (what N independent GPUs do), and the exchanged float count.  Same iteration counts on every rank; MAX over ranks."""
+    import torch.distributed as dist
+    from gomavatar_amd.workload import zju_cfg, model_frames, build_model
+    from gomavatar_amd.parallel import ModelFrameParallel
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    from gomavatar_amd.optim import GomAdam
+    from gomavatar_amd import train_util as tu
+    mcfg, tcfg = zju_cfg(wl.img)
+    frames = model_frames(wl, range(min(8, len(wl.frames))))
+    mcl = LPIPSMatrixCore(trunk_seed=0, device=wl.device, precision="bf16x3")
+    out = {"unit": "iterations/s x ranks = frames/s (whole job)", "what": "Model iteration (mesh branch, shadow MLP, all loss terms, LPIPS bf16x3, Adam + update_lr), one frame per rank per step"}
+
+    def timed(fn):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            fn(warm + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=wl.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return round(world * iters / el, 1)
+
+    model = build_model(wl, mcfg)
+    opt = GomAdam(model.get_param_groups(tcfg), betas=(0.9, 0.999))
+    out["local_only_ips"] = timed(lambda i: tu.train_iteration(model, opt, frames[i % len(frames)], tcfg, i + 1, lpips_func=mcl))
+    del model, opt
+    for impl in impls:
+        key = f"model_train_iteration_lpips_bf16x3_{impl.replace('-', '_')}_ips"
+        ok = torch.ones(1, dtype=torch.int32)
+        mfp, err = None, None
+        try:
+            model = build_model(wl, mcfg)
+            mfp = ModelFrameParallel(model, tcfg, impl=impl)
+        except Exception as e:   # report, do not hide (e.g. IPC not permitted between these devices)
+            err, _ = f"{type(e).__name__}: {e}", ok.zero_()
+        if world > 1:
+            okd = ok.to(wl.device) if dist.get_backend() == "nccl" else ok
+            dist.all_reduce(okd, op=dist.ReduceOp.MIN)
+            ok = okd.cpu()
+        if int(ok.item()) != 1:
+            out[key] = f"not available on some rank ({err})"
+            continue
+        try:
+            out[key] = timed(lambda i: tu.train_iteration(model, None, frames[i % len(frames)], tcfg, i + 1, lpips_func=mcl, frame_parallel=mfp))
+            mfp.finish()
+            if mfp.fp.peer is not None:
+                mfp.fp.peer.check()
+            out["param_floats"], out["allreduce_floats"] = mfp.param_floats, mfp.payload_floats
+            mfp.overlap = False
+            out[key.replace("_ips", "_no_overlap_ips")] = timed(lambda i: tu.train_iteration(model, None, frames[i % len(frames)], tcfg, i + 1, lpips_func=mcl, frame_parallel=mfp))
+            mfp.finish()
+        except Exception as e:
+            out[key] = f"failed: {type(e).__name__}: {e}"
+        mfp.close()
+        del model, mfp
     return out
 
 

@@ -45,6 +45,9 @@ extern "C" GomState *gom_state_create(void) {
     if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // the cost-ordered backward queue of the batched frame step
     if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // the frame step's loss kernel leaving the pixels of empty tiles alone
     if (const char *e = getenv("GOM_BWD_MODE")) s->bwdMode = atoi(e);          // initial GOM_OPT_BWD_MODE (A / B runs of the whole test suite)
+#ifndef GOM_LAB
+    if (s->bwdMode >= 2) s->bwdMode = -1;                                      // (modes 2 and 3 exist in -DGOM_LAB builds only)
+#endif
     if (hipGetDevice(&s->device) != hipSuccess) {
         gom_set_error("hipGetDevice failed (no HIP device?)");
         delete s;
@@ -104,6 +107,7 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value < -1 || value > 3) { gom_set_error("backward mode must be -1 (auto), 0 (paired sub-ranges), 1 (one sub-range per barrier), 2 (4x4-block items per DPP row, GOM_LAB builds) or 3 (lane per (pixel, entry) record)"); return -1; }
 #ifndef GOM_LAB
             if (value == 2) { gom_set_error("backward mode 2 (4x4-block items) exists in -DGOM_LAB builds only (include/gom_hip_lab.h)"); return -1; }
+            if (value == 3) { gom_set_error("backward mode 3 (records) exists in -DGOM_LAB builds only (include/gom_hip_lab.h): measured slower than the replay"); return -1; }
 #endif
             s->bwdMode = (int)value;
             s->allocGen++;   // (a recorded launch sequence was made under the old setting: dropped at its next use)
@@ -200,14 +204,6 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         s->capPairs = want;
         s->capSegs = 0;
     }
-    {   // records of the render backward: one per blending (pixel, entry) pair, GOM_REC_SHARDS equal regions
-        int64_t wantRec = s->capPairs * GOM_REC_PER_PAIR / GOM_REC_SHARDS * GOM_REC_SHARDS;
-        if (wantRec > 0xf0000000LL) wantRec = 0xf0000000LL / GOM_REC_SHARDS * GOM_REC_SHARDS;
-        if (wantRec != s->capRec) {
-            if (grow_s(s, &s->rec_ti, (size_t)wantRec) || grow_s(s, &s->rec_acc, (size_t)wantRec)) return -2;
-            s->capRec = wantRec;
-        }
-    }
     {
         const int64_t wantItems = s->capTiles + s->capPairs / GOM_RANK_WIN + 1;
         if (wantItems > s->capItems) {
@@ -221,10 +217,26 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const size_t n = (size_t)wantSegs;
         if (grow_s(s, &s->seg_desc, n) || grow_s(s, &s->seg_cost, 16 * n) || grow_s(s, &s->bwd_order, GOM_BWD_ORDER_BASE + GOM_TQ_SHARDS * (size_t)gom_bwd_order_region((uint32_t)n)) || grow_s(s, &s->seg_qmax, n) || grow_s(s, &s->seg_T, n * GOM_TPX) || grow_s(s, &s->seg_C, n * 4 * GOM_TPX) || grow_s(s, &s->seg_last, n * GOM_TPX) ||
             grow_s(s, &s->seg_Tend, n * GOM_TPX) || grow_s(s, &s->seg_Sbehind, n * 4 * GOM_TPX) || grow_s(s, &s->sub_T, n * 4 * GOM_TPX) || grow_s(s, &s->cull_masks, n * 16) ||
-            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX) || grow_s(s, &s->piece_ub, n * 16) || grow_s(s, &s->piece_rec, n * 16) || grow_s(s, &s->piece_cnt, n * 16 * 64))
+            grow_s(s, &s->sub_C, n * 16 * GOM_TPX) || grow_s(s, &s->sub_Tend, n * 4 * GOM_TPX))
             return -2;
         s->capSegs = wantSegs;
     }
+#ifdef GOM_LAB
+    if (s->bwdMode == 3) {   // records of the laboratory render backward (rec_bwd.hpp), only for a state that uses it: one per blending (pixel, entry) pair in
+                             // GOM_REC_SHARDS equal regions (24 bytes x 8 per unit of pair capacity), and the per-piece bookkeeping
+        int64_t wantRec = s->capPairs * GOM_REC_PER_PAIR / GOM_REC_SHARDS * GOM_REC_SHARDS;
+        if (wantRec > 0xf0000000LL) wantRec = 0xf0000000LL / GOM_REC_SHARDS * GOM_REC_SHARDS;
+        if (wantRec != s->capRec) {
+            if (grow_s(s, &s->rec_ti, (size_t)wantRec) || grow_s(s, &s->rec_acc, (size_t)wantRec)) return -2;
+            s->capRec = wantRec;
+        }
+        if (s->capSegs > s->capPieceSegs) {
+            const size_t n = (size_t)s->capSegs;
+            if (grow_s(s, &s->piece_ub, n * 16) || grow_s(s, &s->piece_rec, n * 16) || grow_s(s, &s->piece_cnt, n * 16 * 64)) return -2;
+            s->capPieceSegs = s->capSegs;
+        }
+    }
+#endif
     s->gx = gx;
     s->gy = gy;
     s->B = B;

@@ -164,7 +164,7 @@ struct GomState {
     uint8_t *piece_cnt = nullptr;     // [capSegs][4][4][64]  records per entry of the piece (entry-major inside the region: a lane walks its entry's run)
     float2 *rec_ti = nullptr;         // [capRec] (T in front of the entry at the pixel, bits: entry of the sub-range << 6 | pixel of the quadrant)
     float4 *rec_acc = nullptr;        // [capRec] colour the piece had added to the pixel in front of the entry
-    int64_t capRec = 0;
+    int64_t capRec = 0, capPieceSegs = 0;   // (allocated for a state in records mode only: -DGOM_LAB builds)
     // per pixel
     // depth ranking of the splat path (raster_rank.hip)
     bool rankSort = false;            // this binning used it (decided per forward: GOM_OPT_SORT_MODE, P small enough for the LDS bitmap)

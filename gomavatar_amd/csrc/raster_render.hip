@@ -1559,8 +1559,8 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
 
 #ifdef GOM_LAB   // (include/gom_hip_lab.h: built, measured, not adopted)
 #include "seg_bwd_blk.hpp"
-#endif
 #include "rec_bwd.hpp"
+#endif
 
 }  // namespace
 
@@ -1621,9 +1621,14 @@ static int task_grid(int resident, int pct) {   // GOM_OPT_TASK_GRID_PCT of the 
 static GomRecArgs rec_args(GomState *s) {
     return GomRecArgs{s->piece_ub, s->piece_rec, s->piece_cnt, s->rec_ti, s->rec_acc, &s->status->rec_cursor[0][0], &s->status->rec_overflow, (uint32_t)(s->capRec / GOM_REC_SHARDS)};
 }
-// which render backward a forward prepares for: records only on request (GOM_OPT_BWD_MODE 3) -- measured slower than the replay on the
-// metric workload (profiles/r04_records_backward.txt), auto (-1) keeps the replay kernels
+// which render backward a forward prepares for: records (GOM_OPT_BWD_MODE 3) exist in -DGOM_LAB builds only -- measured slower than the replay on
+// the metric workload (298 us + 55 us of forward overhead against 153: profiles/r04_records_backward.txt), closed in round 5;
+// the product library neither instantiates the REC = true kernels nor allocates their buffers
+#ifdef GOM_LAB
 static bool records_mode(const GomState *s) { return s->bwdMode == 3; }
+#else
+static bool records_mode(const GomState *) { return false; }
+#endif
 
 int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const float *colors, float *out_color, bool reuse_T,
                               hipStream_t st) {
@@ -1639,8 +1644,10 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 #define GOM_ST(CC, RR)                                                                                                    \
     hipLaunchKernelGGL((k_seg_T<CC, RR>), dim3(GOM_RESIDENT((k_seg_T<CC, RR>))), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->point_list, s->ent_geo, colors, \
                        s->ent_col, s->seg_T, s->sub_T, s->status, GOM_STATIC_T ? nullptr : GOM_TASK_CTR, s->cull_masks, ra)
-            if (rec) { if (C == 3) GOM_ST(3, true); else GOM_ST(4, true); }
-            else { if (C == 3) GOM_ST(3, false); else GOM_ST(4, false); }
+#ifdef GOM_LAB
+            if (rec) { if (C == 3) GOM_ST(3, true); else GOM_ST(4, true); } else
+#endif
+            { if (C == 3) GOM_ST(3, false); else GOM_ST(4, false); }
 #undef GOM_ST
             s->recCounts = rec;
         } else {  // only the colours changed: bring them into list order
@@ -1654,8 +1661,10 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
 #define GOM_SF(CC, RR)                                                                                                    \
     hipLaunchKernelGGL((k_seg_fwd<CC, RR>), dim3(GOM_RESIDENT((k_seg_fwd<CC, RR>))), dim3(256), 0, st, (uint32_t)s->segShift, s->gx, s->gy, s->seg_desc, s->ent_geo, s->ent_col, s->seg_T,  \
                        s->sub_T, s->seg_C, s->seg_Tend, s->seg_last, s->sub_C, s->sub_Tend, s->status, GOM_STATIC_FWD ? nullptr : GOM_TASK_CTR, s->B > 1 && s->rankSort && s->bwdOrder ? s->seg_cost : nullptr, s->cull_masks, ra)
-        if (rec) { if (C == 3) GOM_SF(3, true); else GOM_SF(4, true); }
-        else { if (C == 3) GOM_SF(3, false); else GOM_SF(4, false); }
+#ifdef GOM_LAB
+        if (rec) { if (C == 3) GOM_SF(3, true); else GOM_SF(4, true); } else
+#endif
+        { if (C == 3) GOM_SF(3, false); else GOM_SF(4, false); }
 #undef GOM_SF
         s->recForward = rec;
     }
@@ -1682,6 +1691,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     const int n_tiles = s->gx * s->gy * s->B;
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
+#ifdef GOM_LAB
     if (s->recForward) {   // the forward left records: a lane per blending (pixel, entry) pair (rec_bwd.hpp)
         const GomRecArgs ra = rec_args(s);
 #define GOM_RB(CC)                                                                                                        \
@@ -1693,7 +1703,6 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
         GOM_LAUNCH_CHECK();
         return 0;
     }
-#ifdef GOM_LAB
     if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (seg_bwd_blk.hpp)
 #define GOM_SBB(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_blk<CC>), dim3(GOM_RESIDENT(k_seg_bwd_blk<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \

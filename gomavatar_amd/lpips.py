@@ -5,10 +5,13 @@ train.py:113-121 as `LPIPS(net='vgg')(2*pred-1, 2*gt-1)`).
     (relu1_2, relu2_2, relu3_3, relu4_3, relu5_3) -> per tap: channel-normalise,
     squared difference, 1x1 "lin" layer, spatial mean -> sum over taps -> (B,1,1,1)
 
-Split for MI355X: the trunk is 13 plain 3x3 convolutions (GEMM-shaped, library
-territory: torch -> MIOpen / hipBLASLt, fp32 like the reference or bf16); the
-LPIPS-specific head is a fused HIP kernel pair per tap (`csrc/lpips.hip`) instead
-of ~12 element-wise/reduction launches with full-size temporaries.
+Two trunks for MI355X.  `LPIPSMatrixCore` (the training path): the 13 3x3 convolutions, pools, heads and their
+backward as hand-written implicit-GEMM kernels on the bf16 matrix cores (`csrc/vgg_bf16.hip`, `lpips_vgg_api.hip`;
+`v_mfma_f32_16x16x32_bf16`, NHWC, LDS-DMA staging) -- precision "bf16x3" (DEFAULT: hi / lo bf16 planes, three MFMA
+passes = the reference's fp32 precision, value within 1.4e-6 of fp64) or "bf16" (one pass, 3 % on the value, opt-in).
+`LPIPS` (the fp32 yardstick of the tests and of bench.py's `full_step_lpips_fp32` row): the trunk through the library
+convolutions (torch -> MIOpen), the LPIPS-specific head as a fused HIP kernel pair per tap (`csrc/lpips.hip`) instead
+of ~12 element-wise / reduction launches with full-size temporaries.
 
 Weights: the five `lin` vectors are the LPIPS v0.1 VGG weights
 (`data/lpips_vgg_lin_v0.1.npz`, 1 472 floats, BSD-licensed, converted by
@@ -199,9 +202,9 @@ class LPIPSMatrixCore:
 
     H and W must be multiples of 16 (four 2x2 pools)."""
 
-    def __init__(self, trunk_seed: int = 0, device=None, precision: str = "bf16"):
-        """precision: "bf16" (bf16 activations, 3 % on the value) or "bf16x3" (two bf16 planes per tensor, three MFMA passes:
-        the reference's fp32 precision on the matrix cores)."""
+    def __init__(self, trunk_seed: int = 0, device=None, precision: str = "bf16x3"):
+        """precision: "bf16x3" (default: two bf16 planes per tensor, three MFMA passes = the reference's fp32 precision on the matrix cores)
+        or "bf16" (one pass, bf16 activations: 3 % on the value -- BELOW the reference's precision, hence opt-in)."""
         assert precision in ("bf16", "bf16x3")
         self.precision = precision
         self.lib = _lib.load()

@@ -195,8 +195,10 @@ class _ShadowMLP3(torch.autograd.Function):
 class _ShadeUnderMesh(torch.autograd.Function):
     """model.py:279-283 for the default shadow MLP, fused natively (csrc/mlp.hip, gom_shade_*): shading (HW, 1) = 2 * MLP(embed(normal)) with the MLP
     evaluated on the pixels under the mesh only (normal != 0) and once for the background -- selection, embedding, scatter and their backward
-    without torch glue, without a host synchronisation (the row count stays on the device), ~10 launches instead of ~35."""
-    _ws = {}
+    without torch glue, without a host synchronisation (the row count stays on the device), ~10 launches instead of ~35.
+    The workspace (block counts, gather partials, the ROW COUNT, a counter) is allocated per forward call and saved for that call's backward:
+    a second forward before the first backward (gradient accumulation over frames, a second Model, a render in between, another stream)
+    must not overwrite the row count the first backward reads."""
     # GOM_MLP_MATRIX_CORES=1: the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes).  Measured: forward 49 -> 22 us,
     # backward 63 -> 37 us (+ 8 us of weight packing) per frame, and the shading moves by 6e-6 relative (three chained layers of dropped lo x lo
     # terms) where the fp32 VALU layers are exact fp32: 45 us of a 3.3 ms iteration is not worth the digit -- opt-in.
@@ -208,10 +210,7 @@ class _ShadeUnderMesh(torch.autograd.Function):
         x = flat.detach().float().contiguous()
         HW, dev = x.shape[0], x.device
         D0, H = 3 + 6 * L, W1.shape[0]
-        key = (dev, HW)
-        ws = _ShadeUnderMesh._ws.get(key)
-        if ws is None:      # block counts / gather partials / the row count / a counter: zeroed once, the kernels leave it reusable
-            ws = _ShadeUnderMesh._ws[key] = torch.zeros(lib.gom_shade_workspace_ints(HW), dtype=torch.int32, device=dev)
+        ws = torch.zeros(lib.gom_shade_workspace_ints(HW), dtype=torch.int32, device=dev)      # (per call: see the class docstring)
         ps = [t.detach().float().contiguous() for t in (W1, b1, W2, b2, W3, b3, W4, b4)]
         pos = torch.empty(HW, dtype=torch.int32, device=dev)
         pe = torch.empty(HW + 1, D0, dtype=torch.float32, device=dev)

@@ -57,6 +57,11 @@ class GomAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 key = (group["betas"], group["eps"], float(st["step"]), bool(group.get("capturable", False)))
                 calls.setdefault(key, []).append((p, g, st, float(group["lr"])))
+        if any(k[3] for k in calls) and len(calls) > 1:
+            # ONE device counter serves a captured step: parameters with different step counts (a module that received its first gradient later) or
+            # different betas / eps would each need their own -- and each native call would advance the shared one
+            raise RuntimeError("GomAdam(capturable=True): all parameters must share betas, eps and step count (got %d different settings); "
+                               "step the late parameters with a second optimizer, or use capturable=False" % len(calls))
         for (betas, eps, t, capt), items in calls.items():
             n = len(items)
             P = (ctypes.c_void_p * n)(*[i[0].data_ptr() for i in items])
@@ -71,6 +76,28 @@ class GomAdam(torch.optim.Optimizer):
                     self._step_dev = torch.full((1,), int(t), dtype=torch.int64, device=items[0][0].device)
                 sd = self._step_dev.data_ptr()
             self._lib.check(lib.gom_adam_multi(n, P, G, M, V, N, LR, int(t) + 1, sd, float(betas[0]), float(betas[1]), float(eps), self._lib.stream_ptr()))
-            for i in items:          # (only a step that was enqueued counts)
+            for i in items:          # (only a step that was enqueued counts; under graph REPLAY the device counter runs ahead of these: state_dict() reads it back)
                 i[2]["step"] += 1
         return loss
+
+    def _sync_steps(self) -> None:
+        """capturable: the authoritative step count is the device counter (a graph replay advances it without running this Python); copy it into
+        every state entry.  Synchronises the device: never call during capture."""
+        if self._step_dev is not None:
+            t = float(int(self._step_dev.item()))
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = torch.tensor(t, dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        """torch.optim.Adam checkpoints load unchanged; a capturable torch checkpoint holds `step` as DEVICE tensors -- moved to the host here (reading
+        them inside step() would synchronise, which a capture forbids) -- and the device counter is re-seeded from the loaded count at the next step."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                st["step"] = st["step"].detach().float().cpu()
+        self._step_dev = None

@@ -77,3 +77,41 @@ class MetricWorkload:
     def oracle_frame(self, i: int) -> Dict[str, torch.Tensor]:
         """Frame i as the CPU oracle's `render_path` takes it (batch dimension 1, host tensors)."""
         return {k: torch.from_numpy(v) for k, v in self.frames_np[i].items()}
+
+
+# ---- BASELINE configs[1] / configs[3] as the reference runs them: the `Model` iteration on the metric workload ------------------------------
+def zju_cfg(img: int = 512, non_rigid_kick_in: int = 150000, pose_kick_in: int = 100000, lr_decay_steps: float = 100000):
+    """(model cfg, train cfg) with the values of configs/default.yaml + exps/zju-mocap_377.yaml that the hot path reads, as attribute nodes."""
+    from types import SimpleNamespace as NS
+    mcfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
+              normal_renderer=NS(sigma=1e-5, soft_mask=True), shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)),
+              lbs_weights=NS(refine=False),
+              non_rigid=NS(name="basic", condition_code_size=69, mlp_width=128, mlp_depth=6, skips=[4], multires=6, i_embed=0, kick_in_iter=non_rigid_kick_in,
+                           full_band_iter=non_rigid_kick_in + 50000),
+              pose_refinement=NS(name="basic", embedding_size=69, total_bones=24, mlp_width=256, mlp_depth=4, refine_root=False, refine_t=False, kick_in_iter=pose_kick_in))
+    tcfg = NS(lr=NS(lbs_weights=0.0, appearance=0.0005, canonical_geometry=0.0005, canonical_geometry_xyz=0.0005, non_rigid=0.0005, pose_refinement=0.00005, shadow=0.0005),
+              lr_decay_steps=lr_decay_steps,
+              losses=NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=1.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
+                        normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05)))
+    return mcfg, tcfg
+
+
+def model_frames(wl: "MetricWorkload", ids=None):
+    """The workload's frames as the reference's data dicts (dataset/train.py:209-287: batch dimension 1, `target_rgbs` / `target_masks`)."""
+    out = []
+    for i in (range(len(wl.frames)) if ids is None else ids):
+        fr = {k: torch.from_numpy(v).to(wl.device) for k, v in wl.frames_np[i].items()}
+        fr["target_rgbs"], fr["target_masks"] = wl.frames[i]["gt_rgb"][None], wl.frames[i]["gt_mask"][None]
+        out.append(fr)
+    return out
+
+
+def build_model(wl: "MetricWorkload", mcfg, with_mlps: bool = True, seed: int = 0):
+    """The drop-in `Model` on the workload's body, with the reference's two optional MLPs (modules.NonRigidModule / PoseRefinementModule:
+    334 152 of the 951 023 parameters of SURVEY.md 8(e)) when `with_mlps`.  Seeded: every rank builds the same weights."""
+    from .model import Model
+    from .modules import NonRigidModule, PoseRefinementModule
+    torch.manual_seed(seed)
+    nr = NonRigidModule(mcfg.non_rigid).to(wl.device) if with_mlps else None
+    pr = PoseRefinementModule(mcfg.pose_refinement).to(wl.device) if with_mlps else None
+    return Model(mcfg, wl.body, non_rigid_module=nr, pose_refinement_module=pr, device=wl.device).train()

@@ -96,12 +96,9 @@ enum {
                                   slot until it ends).  Results do not depend on it. */
     GOM_OPT_BWD_MODE = 6,      /* render backward: 0 = a workgroup replays two consecutive sub-ranges between barriers, every wave taking
                                   diagonally opposite 8x8 quadrants in the two (evens out the quadrant imbalance of a tile); 1 = one
-                                  sub-range per barrier (round 1); 3 (round 4, opt-in) = records: the forward leaves one record per blending
-                                  (pixel, entry) pair, the backward walks a lane per entry over its records instead of replaying the list
-                                  (parity-green, measured slower: profiles/r04_records_backward.txt; set it BEFORE the forward);
-                                  -1 (default) = auto (0 for a batch, 1 for one frame).  0 and 1 give bitwise the same gradients; 3 sums
-                                  in another order (fp32 round-off apart), reproducible run to run.  2 = the (sub-range, 4x4 block) kernel
-                                  of round 3: -DGOM_LAB builds only (gom_hip_lab.h). */
+                                  sub-range per barrier (round 1); -1 (default) = auto (0 for a batch, 1 for one frame).  0 and 1 give
+                                  bitwise the same gradients.  2 (the (sub-range, 4x4 block) kernel of round 3) and 3 (the records backward
+                                  of round 4) were measured slower and exist in -DGOM_LAB builds only (gom_hip_lab.h): refused here. */
     GOM_OPT_SORT_MODE = 5,     /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
                                   frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
                                   bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */

@@ -15,7 +15,7 @@ def timeit(fn, n=20, warm=3):
 
 H = W = int(os.environ.get("IMG", 512))
 pred = torch.rand(1, H, W, 3, device="cuda"); gt = torch.rand(1, H, W, 3, device="cuda")
-mc = LPIPSMatrixCore(trunk_seed=0)
+mc = LPIPSMatrixCore(trunk_seed=0, precision="bf16")
 bufs = (torch.empty((5, 1, _lib.GOM_LOSS_BLOCKS), device="cuda"), torch.empty((1, H, W, 3), device="cuda"))
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):

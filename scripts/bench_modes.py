@@ -97,7 +97,7 @@ def main():
         topo = MeshTopology(faces, N, device=dev)
         from gomavatar_amd.lpips import LPIPSMatrixCore
         for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16), ("bf16_matrix_core", None)):
-            lp = LPIPS(trunk_seed=0, trunk_dtype=dt, device=dev) if dt is not None else LPIPSMatrixCore(trunk_seed=0, device=dev)
+            lp = LPIPS(trunk_seed=0, trunk_dtype=dt, device=dev) if dt is not None else LPIPSMatrixCore(trunk_seed=0, device=dev, precision="bf16")
             P = {k: v.clone().requires_grad_() for k, v in params.items()}
             opt = torch.optim.Adam(list(P.values()), lr=1e-4)
 
@@ -119,7 +119,7 @@ def main():
                 out[f"full_step_lpips_{name}_adam_fps"] = f"failed: {type(e).__name__}: {e}"
         # (iii) at batch 8 through the native path: forward half -> LPIPS on 8 unpacked images -> backward half -> Adam on the summed
         # gradients (RenderStep.lpips_hook); the same "one optimizer step on 8 frames" the 8-GPU frame-parallel run takes.
-        lp8 = LPIPSMatrixCore(trunk_seed=0, device=dev)
+        lp8 = LPIPSMatrixCore(trunk_seed=0, device=dev, precision="bf16")
         P8 = {k: v.clone() for k, v in params.items()}
         for k, v in P8.items():
             v.grad = stepB.grads[k]

@@ -164,7 +164,7 @@ def test_split_call_with_lpips_hook_matches_the_autograd_composition(B):
     stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
     fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
     bg_b = stack("bgcolor")
-    lp = LPIPSMatrixCore(trunk_seed=0)
+    lp = LPIPSMatrixCore(trunk_seed=0, precision="bf16")
     step = RenderStep(faces, N, (img, img), w25, batch=B)
     sq = (lambda t: t) if B > 1 else (lambda t: t[0].contiguous())
     if B > 1:

@@ -186,6 +186,37 @@ def test_fused_shading_equals_the_torch_selection_around_the_mlp():
         assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-12, (tuple(a.shape), float((a - b).norm()), float(a.norm()))
 
 
+def test_two_forwards_before_the_first_backward_keep_their_own_row_counts():
+    """Gradient accumulation over two frames (forward A, forward B, then both backwards) and a no-grad render between a forward and its backward: the
+    fused shading keeps the number of pixels under the mesh in device memory PER CALL (round-4 advisor finding: it lived in a workspace shared by
+    every call at that resolution, so backward A ran with B's count).  Held: bitwise the gradients of the two frames run one after the other."""
+    img = 128
+    torch.manual_seed(12)
+    m = _small_model(img)
+    assert m.fused_shading
+    fa, fb = ({k: v.cuda() for k, v in _frame(i, img).items() if torch.is_tensor(v)} for i in (3, 6))
+    w = torch.linspace(0.5, 1.5, img * img * 3, device="cuda").reshape(1, img, img, 3)
+    run = lambda d: m(d["K"], d["E"], d["cnl_gtfms"], d["dst_Rs"], d["dst_Ts"])
+    loss = lambda r: (r[0] * w).sum() + 2.0 * r[1].sum()
+    params = [m.vertices, m.so3, m.scale, m.appearance] + list(m.shadow_module.parameters())
+    grads = []
+    for d in (fa, fb):                      # one after the other
+        m.zero_grad(set_to_none=True)
+        loss(run(d)).backward()
+        grads.append([p.grad.detach().clone() for p in params])
+    n_under = [int((run(d)[2]["normal"].detach() != 0).any(-1).sum()) for d in (fa, fb)]
+    assert n_under[0] != n_under[1]         # (otherwise the shared count would have been right by accident)
+    m.zero_grad(set_to_none=True)
+    ra, rb = run(fa), run(fb)               # A, B, then the backwards -- and a render of a third pose in between
+    with torch.no_grad():
+        run({k: v.cuda() for k, v in _frame(9, img).items() if torch.is_tensor(v)})
+    la, lb = loss(ra), loss(rb)
+    ga = torch.autograd.grad(la, params, retain_graph=False)
+    gb = torch.autograd.grad(lb, params)
+    for a, b, x, y in zip(grads[0], grads[1], ga, gb):
+        assert torch.equal(a, x) and torch.equal(b, y), tuple(a.shape)
+
+
 @pytest.mark.parametrize("with_lpips", [False, True])
 def test_graphed_train_step_matches_the_eager_iterations(with_lpips):
     """One HIP graph per training iteration (train_util.GraphedTrainStep) = the same iterations launched one by one; with the LPIPS term the

@@ -97,6 +97,38 @@ def test_gom_adam_capturable_in_a_replayed_graph():
     assert int(ob._step_dev.item()) == 4
     for a, b in zip(pa, pb):
         assert float((a - b).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max())
+    # a checkpoint written after REPLAYS carries the device count (4), not the capture-time Python count (2) -- round-4 advisor finding -- and a fresh
+    # optimizer loaded from it continues with step 5's bias corrections, like the eager optimizer that has really stepped four times
+    sd = ob.state_dict()
+    assert {int(float(st["step"])) for st in sd["state"].values()} == {4}
+    pc, gc = _groups(1)
+    with torch.no_grad():
+        for c, b in zip(pc, pb):
+            c.copy_(b)
+    oc = GomAdam(gc, capturable=True)
+    oc.load_state_dict(sd)
+    _set_grads(pa, 4); _set_grads(pc, 4)
+    oa.step(); oc.step()
+    assert int(oc._step_dev.item()) == 5
+    for a, c in zip(pa, pc):
+        assert float((a - c).detach().abs().max()) <= 2e-6 * float(a.detach().abs().max())
+    # a torch CAPTURABLE checkpoint holds `step` on the device: loaded onto the host, no synchronising read inside step()
+    sd2 = oa.state_dict()
+    for st in sd2["state"].values():
+        st["step"] = st["step"].cuda()
+    od = GomAdam(_groups(1)[1], capturable=True)
+    od.load_state_dict(sd2)
+    assert all(not st["step"].is_cuda for st in od.state.values())
+    # parameters with different step counts cannot share the one device counter: refused, not silently mis-stepped
+    pe, ge = _groups(1)
+    oe = GomAdam(ge, capturable=True)
+    _set_grads(pe, 0)
+    held = pe[0].grad
+    pe[0].grad = None
+    oe.step()
+    pe[0].grad = held
+    with pytest.raises(RuntimeError):
+        oe.step()
 
 
 def test_gom_adam_refuses_what_it_does_not_implement():

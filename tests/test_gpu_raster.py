@@ -149,6 +149,10 @@ def test_record_buffer_overflow_poisons_the_gradients_loudly():
     its capacity back to automatic works again."""
     from gpu_util import hip_forward
     from gomavatar_amd import _lib, rasterizer as R
+    if not _lib.has_lab():      # round 5: the records backward (measured slower than the replay) left the product library; the product build REFUSES the mode
+        with pytest.raises(RuntimeError):
+            R.RasterState().set_option(_lib.OPT_BWD_MODE, 3)
+        pytest.skip("records backward: -DGOM_LAB builds only (include/gom_hip_lab.h)")
     cam, means, cov6, colors, op = small_scene(seed=61, P=40, H=64, W=64, opacity=(0.05, 0.2), spread=0.2, scale=0.6, C=4)
     ref, _, _, _ = hip_forward(cam, means, cov6, colors, op)
     st = R.RasterState()
@@ -498,8 +502,8 @@ def test_backward_task_shapes_agree(seg_shift):
     g = orast.backward(f, wimg.astype(np.float64))
     assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 600          # several segments per tile
     got = []
-    lab = _lib.has_lab()   # mode 2 lives in -DGOM_LAB builds only (include/gom_hip_lab.h); without it modes 0 / 1 stand in (then trivially equal)
-    for mode in (0, 1, 2 if lab else 0, 2 if lab else 0, 3, 3):
+    lab = _lib.has_lab()   # modes 2 and 3 live in -DGOM_LAB builds only (include/gom_hip_lab.h); without it modes 0 / 1 stand in (then trivially equal)
+    for mode in (0, 1, 2 if lab else 0, 2 if lab else 0, 3 if lab else 1, 3 if lab else 1):
         st = R.RasterState()
         st.set_option(_lib.OPT_BWD_MODE, mode)
         st.set_option(_lib.OPT_SEG_SHIFT, seg_shift)

@@ -83,7 +83,7 @@ def test_lpips_matrix_core_matches_fp32_path():
     p = pred.clone().requires_grad_()
     ref = lpips_loss(ref_model, p, gt)
     ref.backward()
-    mc = LPIPSMatrixCore(trunk_seed=5)
+    mc = LPIPSMatrixCore(trunk_seed=5, precision="bf16")
     val, grad = mc.value_and_grad(pred, gt)
     torch.cuda.synchronize()
     assert abs(float(val) - float(ref.detach())) <= 0.03 * float(ref.detach()), (float(val), float(ref.detach()))      # bf16 activations
@@ -148,7 +148,7 @@ def test_lpips_bf16x3_trunk_has_the_precision_of_the_fp32_path(shape):
           f"bf16x3 {sx[0]:.2e} {sx[1]:.2e} {sx[2]:.2e}   fp32 library {s32[0]:.2e} {s32[1]:.2e} {s32[2]:.2e}")
     assert abs(float(val) - v32) <= 1e-5 * v32 and rel <= 1e-5, (float(val), v32, v64)
     assert sx[0] <= 1.8e-2 and sx[1] <= 4e-2 and sx[2] <= 0.2, (sx, s32)
-    plain = LPIPSMatrixCore(trunk_seed=5)                                  # the one-pass bf16 trunk on the same inputs
+    plain = LPIPSMatrixCore(trunk_seed=5, precision="bf16")                                  # the one-pass bf16 trunk on the same inputs
     vp, gp = plain.value_and_grad(pred, gt)
     sp = stats(gp)
     print(f"[bf16   {shape}] value vs float64 {abs(float(vp) - v64) / v64:.2e}; gradient rel L2 {sp[0]:.2e}")
