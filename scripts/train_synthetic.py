@@ -1,81 +1,115 @@
 #!/usr/bin/env python
-"""The reference's training iteration (train.py:309-349: zero_grad -> forward -> unpack -> compute_loss -> backward ->
-Adam step) on synthetic data, through `gomavatar_amd.model.Model` + `train_util.compute_loss` (+ LPIPS on the matrix
-cores).  A teacher avatar renders the targets; the student starts from the reference's initialisation (grey colours,
-unit scales).  Prints PSNR of the student's renders against the targets while it trains, and iterations/s.
+"""BASELINE configs[1] at its stated shape ("3 000-iteration loop S -> (subdivide at iteration 1 000) -> M @ 512^2"), on synthetic
+data, as the reference runs it: train.py:309-349 per iteration (zero_grad -> Model.forward -> unpack -> compute_loss with EVERY term of
+exps/zju-mocap_377.yaml incl. LPIPS on the bf16x3 trunk -> backward -> Adam over Model.get_param_groups -> update_lr) through the drop-in
+`Model`, `train_util.train_iteration` and `GomAdam`; the subdivision rebuilds the optimizer like train.py:330-346.  A teacher avatar renders the
+8 target views; the student starts from the reference's initial state (scripts/train_curve_common.py -- the state scripts/train_curve_oracle.py
+trains from on the CPU oracle).  Writes profiles/<tag>_train_curve.json: loss terms + 8-bit PSNR per iteration for the first --dense
+iterations and every --every afterwards, mean PSNR over the 8 views at the checkpoints, iterations/s before and after the subdivision, peak memory.
 
-    python scripts/train_synthetic.py --iters 300 --img 256 --subdivide-at 150"""
+    python scripts/train_synthetic.py --iters 3000 --subdivide-at 1000 [--tag r05] [--no-lpips] [--precision bf16x3]"""
 import argparse, json, os, sys, time
-from types import SimpleNamespace as NS
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from gomavatar_amd import synthetic as syn
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import train_curve_common as C
+from gomavatar_amd.workload import zju_cfg
 from gomavatar_amd.model import Model
-from gomavatar_amd.train_util import GraphedTrainStep, compute_loss, unpack
+from gomavatar_amd import train_util as tu, metrics as M
 from gomavatar_amd.lpips import LPIPSMatrixCore
-from gomavatar_amd import metrics as M
+from gomavatar_amd.optim import GomAdam
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--iters", type=int, default=300); ap.add_argument("--img", type=int, default=256)
-ap.add_argument("--level", type=int, default=0, help="SMPL-like body subdivisions (0: 13 776 faces)")
-ap.add_argument("--subdivide-at", type=int, default=-1); ap.add_argument("--no-lpips", action="store_true")
-ap.add_argument("--graph", action="store_true", help="capture the whole iteration in one HIP graph (train_util.GraphedTrainStep)")
-ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one kernel per step instead of ~40")
-ap.add_argument("--no-host-sync", action="store_true", help="Model.capture_safe without a graph: no device->host read per iteration, the host runs ahead")
+ap.add_argument("--iters", type=int, default=3000); ap.add_argument("--subdivide-at", type=int, default=1000)
+ap.add_argument("--dense", type=int, default=200, help="log every iteration up to here (the span the oracle-trained curve covers)")
+ap.add_argument("--every", type=int, default=50); ap.add_argument("--tag", default="r05"); ap.add_argument("--no-lpips", action="store_true")
+ap.add_argument("--precision", default="bf16x3"); ap.add_argument("--out", default=None)
 a = ap.parse_args()
-img = a.img
-cfg = NS(img_size=(img, img), canonical_geometry=NS(sigma=1e-3, radius_scale=1.0, deform_so3=True, deform_scale=True), appearance=NS(color_init=0.5),
-         normal_renderer=NS(sigma=1e-5, soft_mask=True), shadow_module=NS(name="basic", multires=6, mlp_width=128, mlp_depth=3, skips=(4,)),
-         lbs_weights=NS(refine=False))
-loss_cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=0.0 if a.no_lpips else 1.0), laplacian=NS(coeff_canonical=0.0, coeff_observation=10.0),
-              normal=NS(coeff_mask=1.0, kernel_size=7, coeff_consist=0.1), color_consist=NS(coeff=0.05))
-lr = NS(lr=NS(appearance=5e-3, canonical_geometry=5e-4, canonical_geometry_xyz=5e-5, shadow=5e-4))
-body = syn.make_body(a.level)
-teacher, student = Model(cfg, body).train(), Model(cfg, body).train()
-with torch.no_grad():
-    g = torch.Generator(device="cuda").manual_seed(0)
-    teacher.appearance.copy_(torch.rand(teacher.appearance.shape, device="cuda", generator=g))
+dev = "cuda"
+mcfg, tcfg = zju_cfg(C.IMG, lr_decay_steps=C.LR_DECAY_STEPS)
+if a.no_lpips:
+    tcfg.losses.lpips.coeff = 0.0
+body, tp, sp, twb, swb = C.setup(0)
+
+
+def make(params, wb):
+    m = Model(mcfg, body, device=dev)
+    lin = [l for l in m.shadow_module.block_mlps if isinstance(l, torch.nn.Linear)]
+    with torch.no_grad():
+        for k in ("vertices", "so3", "scale", "appearance"):
+            getattr(m, k).copy_(params[k])
+        for i, l in enumerate(lin):
+            l.weight.copy_(wb[2 * i].float()); l.bias.copy_(wb[2 * i + 1].float())
+    return m
+
+
+teacher, student = make(tp, twb).eval(), make(sp, swb).train()
 frames = []
-for i in range(8):
-    fr = {k: torch.from_numpy(v).cuda() for k, v in syn.make_frame(i, img).items()}
+for i in range(C.N_VIEWS):
+    fr = {k: torch.from_numpy(v).to(dev) for k, v in C.frame(i).items()}
     with torch.no_grad():
         rgbs, masks, _ = teacher(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
-        fr["gt_rgb"], fr["gt_mask"] = unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()
+        fr["target_rgbs"], fr["target_masks"] = tu.unpack(rgbs, masks, fr["bgcolor"]).clamp(0, 1), masks.clone()   # the reference's key names (dataset/train.py:272-275)
     frames.append(fr)
-lp = None if a.no_lpips else LPIPSMatrixCore(trunk_seed=0)
-adam_kw = dict(fused=True, capturable=a.graph) if a.fused_adam else dict(capturable=a.graph)
-opt = torch.optim.Adam(student.get_param_groups(lr), **adam_kw)
-for fr in frames:
-    fr["target_rgbs"], fr["target_masks"] = fr["gt_rgb"], fr["gt_mask"]                  # the reference's key names (dataset/train.py:272-275)
-student.capture_safe = a.no_host_sync or a.graph
-gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None
-log, t0, t_warm, n_warm = [], time.perf_counter(), None, min(20, a.iters // 2)
+lp = None if a.no_lpips else LPIPSMatrixCore(trunk_seed=0, device=dev, precision=a.precision)
+opt = GomAdam(student.get_param_groups(tcfg), betas=(0.9, 0.999))
+
+
+def psnr8(pred, gt):
+    return float(M.psnr(M.from_8b(M.to_8b(pred)), M.from_8b(M.to_8b(gt))))
+
+
+def all_views_psnr():
+    was = student.training
+    student.eval()
+    vals = []
+    with torch.no_grad():
+        for fr in frames:
+            rgbs, masks, _ = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"])
+            vals.append(psnr8(tu.unpack(rgbs, masks, fr["bgcolor"])[0], fr["target_rgbs"][0]))
+    student.train(was)
+    return sum(vals) / len(vals)
+
+
+log, marks, rates = [], {}, {}
+torch.cuda.reset_peak_memory_stats()
+torch.cuda.synchronize(); t_start = time.perf_counter()
+t_seg, n_seg, seg_name = None, 0, "before_subdivision"
 for it in range(a.iters):
-    if it == n_warm:                      # steady state: lazy kernel loading, graph capture and allocator growth are behind us
-        torch.cuda.synchronize(); t_warm = time.perf_counter()
-    if it == a.subdivide_at:
-        student.subdivide(); opt = torch.optim.Adam(student.get_param_groups(lr), **adam_kw)   # train.py:330-340 rebuilds the optimizer
-        gstep = GraphedTrainStep(student, opt, loss_cfg, lp) if a.graph else None        # new topology: new capture
-    fr = frames[it % 8]
-    if gstep is not None:
-        total = gstep(fr, i_iter=it)
-        if it % 50 == 0 or it == a.iters - 1:
-            with torch.no_grad():
-                rgbs, masks, _ = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
-                pred = unpack(rgbs, masks, fr["bgcolor"])
-    else:
-        opt.zero_grad(set_to_none=True)
-        rgbs, masks, out = student(fr["K"], fr["E"], fr["cnl_gtfms"], fr["dst_Rs"], fr["dst_Ts"], i_iter=it)
-        pred = unpack(rgbs, masks, fr["bgcolor"])
-        total, losses = compute_loss(pred, masks, out, fr["gt_rgb"], fr["gt_mask"], loss_cfg, lpips_func=lp)
-        total.backward(); opt.step()
-    if it % 50 == 0 or it == a.iters - 1:
-        with torch.no_grad():
-            p8, g8 = M.from_8b(M.to_8b(pred[0])), M.from_8b(M.to_8b(fr["gt_rgb"][0]))
-            log.append({"iter": it, "loss": round(float(total), 5), "psnr": round(M.psnr(p8, g8), 2), "faces": int(student.faces.shape[0])})
-            print(log[-1], flush=True)
+    n_iters = it + 1                                               # train.py:268: n_iters counts from 1
+    if it == a.subdivide_at:                                       # train.py:330-346: subdivide, rebuild the optimizer
+        torch.cuda.synchronize()
+        rates[seg_name] = round(n_seg / (time.perf_counter() - t_seg), 1)
+        student.subdivide()
+        opt = GomAdam(student.get_param_groups(tcfg), betas=(0.9, 0.999))
+        seg_name, t_seg, n_seg = "after_subdivision", None, 0
+    if t_seg is None and (it >= 20 if seg_name == "before_subdivision" else it >= a.subdivide_at + 20):   # steady state: lazy loading, allocator growth behind us
+        torch.cuda.synchronize(); t_seg, n_seg = time.perf_counter(), 0
+    fr = frames[it % C.N_VIEWS]
+    loss, items, rgb, mask = tu.train_iteration(student, opt, fr, tcfg, n_iters, lpips_func=lp)
+    n_seg += 1
+    if n_iters <= a.dense or n_iters % a.every == 0 or n_iters == a.iters:
+        t_log = time.perf_counter()
+        row = {"iter": n_iters, "total": float(loss), "psnr": round(psnr8(rgb.detach()[0], fr["target_rgbs"][0]), 4), "faces": int(student.faces.shape[0]),
+               **{k: float(v["unscaled"]) for k, v in items.items()}}
+        if n_iters % (4 * a.every) == 0 or n_iters == a.iters or n_iters == a.subdivide_at:
+            row["psnr_mean_8_views"] = round(all_views_psnr(), 4)
+        log.append(row)
+        if n_iters % a.every == 0 or n_iters == a.iters:
+            print(row, flush=True)
+        torch.cuda.synchronize()
+        if t_seg is not None:
+            t_seg += time.perf_counter() - t_log                   # (logging is not training time)
 torch.cuda.synchronize()
-t1 = time.perf_counter()
-print(json.dumps({"iters_per_s": round((a.iters - n_warm) / (t1 - t_warm), 1), "iters_per_s_including_first_%d" % n_warm: round(a.iters / (t1 - t0), 1),
-                  "img": img, "log": log}))
+rates[seg_name] = round(n_seg / (time.perf_counter() - t_seg), 1)
+wall = time.perf_counter() - t_start
+out = {"what": "BASELINE configs[1] on synthetic data through gomavatar_amd (Model + train_util.train_iteration + GomAdam + update_lr), one MI355X: "
+               f"13 776 Gaussians -> subdivide at iteration {a.subdivide_at} -> 55 104, 512 x 512, 8 views, every loss term of exps/zju-mocap_377.yaml"
+               + ("" if a.no_lpips else f" incl. LPIPS on the {a.precision} matrix-core trunk (seeded VGG16)"),
+       "iterations": a.iters, "subdivide_at": a.subdivide_at, "wall_seconds_including_logging": round(wall, 2), "iterations_per_s": rates,
+       "peak_memory_MB": round(torch.cuda.max_memory_allocated() / 2 ** 20, 1), "final_psnr_mean_8_views": log[-1].get("psnr_mean_8_views"),
+       "final_psnr_last_frame": log[-1]["psnr"], "log": log}
+path = a.out or os.path.join(ROOT, "profiles", f"{a.tag}_train_curve.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=0)
+print(json.dumps({k: v for k, v in out.items() if k != "log"}))
