@@ -45,7 +45,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
 MIN_TIMED_S = 0.25
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 ADAM_LR = 1e-9   # the reference's Adam arithmetic and traffic at a rate that leaves the synthetic workload the parity tests check unchanged over 10^4 timed steps
 
 

@@ -387,6 +387,142 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
     else conv_store<RELU, RPW>(acc, H, W, Cout, img, ty0, tx0, RPW * wave, co0, l15, kg, bias, mask, out, out_lo, pooled, pooled_lo);
 }
 
+// ---- bf16x3 with SHARED stages (round 5): one stage = one kernel row of one 32-channel GROUP, all three products ----------------
+// k_conv3x3_bf16_v2 walks bf16x3 as three virtual chunks per 32 input channels -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) -- each with its
+// own patch and its own weight stages: x_hi and w_hi cross the LDS twice, and every MFMA pays 0.75 fragment reads (RPW + 4 ds_read_b128 per
+// 4 RPW MFMAs).  The LDS pipe is what the K loop of that kernel runs against: per stage and CU 288 fragment reads x 1 KB + 38 KB of DMA
+// writes against 1 536 MFMA cycles per SIMD (LABBOOK R5.3).  Here a stage carries w_hi AND w_lo of a kernel row (24 KB) and both patches of
+// the group stay resident (x_hi, x_lo: 41 KB, double-buffered per group): per tap 4 A_hi + 4 A_lo + RPW B_hi + RPW B_lo fragment reads feed
+// 12 RPW MFMAs -- 0.5 reads per MFMA -- and a third less DMA.  157 KB of LDS: ONE workgroup of 8 waves per CU (the loop no longer leans on a
+// second workgroup: 72 MFMAs per wave between barriers, fragments of the next tap in flight behind the current tap's).
+// Same weights buffer as v2 (chunks 3g and 3g + 2 of lpips.pack_conv_weight_x3; chunk 3g + 1, the duplicate of w_hi, is not read).
+// The accumulation order differs from v2's (per tap hi.hi, lo.hi, hi.lo instead of three passes over the taps): fp32 round-off apart.
+constexpr int kX3WBytes = 2 * kV2WBytes;                              // 24 576: three taps of w_hi, then three taps of w_lo
+constexpr int kX3Lds = 4 * kV2PatchBytes + 3 * kX3WBytes;             // 156 672
+
+template <bool RELU, bool SPLITK>
+__global__ void __launch_bounds__(512, 1) k_conv3x3_x3s(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in, const bf16_t *__restrict__ wt,
+                                                          const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
+                                                          float *__restrict__ partial, size_t in_lo, size_t out_lo, bf16_t *__restrict__ pooled, size_t pooled_lo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPW = 2, TH = 16, NW = 8;
+    constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: a patch plane (162), a weight plane of a stage (96)
+    constexpr int PI = (PU + 63) / 64, WI = (WU + 63) / 64;                // load instructions per wave and plane (3, 2)
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int co0 = blockIdx.y * kBN;
+    const int zb = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, zs = SPLITK ? (int)blockIdx.z % splits : 0;
+    const size_t img = (size_t)zb * H * W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int G = Cin / kKC;                                               // 32-channel groups
+    const int g_lo = SPLITK ? zs * G / splits : 0, g_hi = SPLITK ? (zs + 1) * G / splits : G;
+    const int NS = 3 * (g_hi - g_lo);   // stages: (group, ky)
+
+    const unsigned char *zero = reinterpret_cast<const unsigned char *>(g_zero16);
+    const unsigned char *psrc[PI];
+    bool pin[PI];
+#pragma unroll
+    for (int j = 0; j < PI; j++) {
+        const int u = min(PU * wave + 64 * j + lane, kV2PatchUnits - 1);
+        const int px = u >> 2, part = swz_part(u & 3, px);
+        const int gy = ty0 + px / kPatchW - 1, gx = tx0 + px % kPatchW - 1;
+        pin[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        psrc[j] = pin[j] ? reinterpret_cast<const unsigned char *>(in + (img + (size_t)gy * W + gx) * Cin + part * 8) : zero;
+    }
+    size_t woff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+        const int v = min(WU * wave + 64 * j + lane, 3 * kBN * 4 - 1);
+        const int row = (v & 255) >> 2;
+        woff[j] = ((size_t)(v >> 8) * Cout * kKC + (size_t)tile_row_channel<4>(row) * kKC + (size_t)swz_part(v & 3, row) * 8) * 2;
+    }
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wt + (size_t)co0 * kKC);
+
+    auto issue = [&](int s) {   // loads of stage s: 2 WI weight instructions (w_hi, w_lo), + 2 PI patch instructions (x_hi, x_lo) when ky == 0
+        const int g = g_lo + s / 3, ky = s % 3;
+        unsigned char *wb = smem + 4 * kV2PatchBytes + (s % 3) * kX3WBytes + (WU * wave) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {   // virtual chunks 3 g (w_hi) and 3 g + 2 (w_lo) of the packed weights
+            const unsigned char *wsrc = wbase + ((size_t)((3 * g + 2 * pl) * 9 + ky * 3) * Cout * kKC) * 2;
+#pragma unroll
+            for (int j = 0; j < WI; j++)
+                if (64 * j + lane < WU) glds16(wsrc + woff[j], wb + pl * kV2WBytes + 64 * j * 16);
+        }
+        if (ky == 0) {
+            unsigned char *pb = smem + ((s / 3) & 1) * 2 * kV2PatchBytes + (PU * wave) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) {
+                const size_t coff = (size_t)g * kKC * 2 + (pl ? in_lo * 2 : 0);
+#pragma unroll
+                for (int j = 0; j < PI; j++)
+                    if (64 * j + lane < PU) glds16(pin[j] ? psrc[j] + coff : psrc[j], pb + pl * kV2PatchBytes + 64 * j * 16);
+            }
+        }
+    };
+
+    f32x4 acc[RPW][4];
+#pragma unroll
+    for (int m = 0; m < RPW; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("" ::"s"(bias), "s"(mask), "s"(out), "s"(partial), "s"(out_lo), "s"(Cout), "s"(splits), "s"(pooled), "s"(pooled_lo));   // (see k_conv3x3_bf16_v2)
+    issue(0);
+    if (NS > 1) issue(1);
+    for (int s = 0; s < NS; s++) {
+        if (s + 1 >= NS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if ((s + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WI + 2 * PI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < NS) issue(s + 2);
+        const int ky = s % 3;
+        const bf16_t *pbh = reinterpret_cast<const bf16_t *>(smem + ((s / 3) & 1) * 2 * kV2PatchBytes);
+        const bf16_t *pbl = reinterpret_cast<const bf16_t *>(smem + ((s / 3) & 1) * 2 * kV2PatchBytes + kV2PatchBytes);
+        const bf16_t *wbh = reinterpret_cast<const bf16_t *>(smem + 4 * kV2PatchBytes + (s % 3) * kX3WBytes);
+        const bf16_t *wbl = reinterpret_cast<const bf16_t *>(smem + 4 * kV2PatchBytes + (s % 3) * kX3WBytes + kV2WBytes);
+        bf16x8 bh[2][RPW], bl[2][RPW], ah[2][4], al[2][4];
+        auto fetch = [&](int set, int kx) {
+#pragma unroll
+            for (int m = 0; m < RPW; m++) {
+                const int px = (RPW * wave + m + ky) * kPatchW + l15 + kx;
+                const int o = px * kKC + swz_part(kg, px) * 8;
+                bh[set][m] = *reinterpret_cast<const bf16x8 *>(pbh + o);
+                bl[set][m] = *reinterpret_cast<const bf16x8 *>(pbl + o);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const int o = (kx * kBN + n * 16 + l15) * kKC + swz_part(kg, l15) * 8;
+                ah[set][n] = *reinterpret_cast<const bf16x8 *>(wbh + o);
+                al[set][n] = *reinterpret_cast<const bf16x8 *>(wbl + o);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            if (kx < 2) fetch((kx + 1) & 1, kx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int c = kx & 1;
+#pragma unroll
+            for (int m = 0; m < RPW; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][n], bh[c][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < RPW; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][n], bl[c][m], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < RPW; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[c][n], bh[c][m], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (SPLITK) conv_store_partial<RPW>(acc, H, W, Cout, img, (int)gridDim.z / splits, zs, ty0, tx0, RPW * wave, co0, l15, kg, partial);
+    else conv_store<RELU, RPW>(acc, H, W, Cout, img, ty0, tx0, RPW * wave, co0, l15, kg, bias, mask, out, out_lo, pooled, pooled_lo);
+}
+
 __device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -999,9 +1135,15 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
     static const bool use_v2 = !(getenv("GOM_CONV_V2") && atoi(getenv("GOM_CONV_V2")) == 0);   // development switches
     static const int v2_rpw = getenv("GOM_CONV_RPW") ? atoi(getenv("GOM_CONV_RPW")) : 2;
+    static const bool use_x3s = !(getenv("GOM_CONV_X3S") && atoi(getenv("GOM_CONV_X3S")) == 0);   // bf16x3 with shared stages (k_conv3x3_x3s); 0: the three virtual chunks of k_conv3x3_bf16_v2
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \
-        if (TH == 16 && use_v2) {                                                                                                     \
+        if (TH == 16 && use_v2 && use_x3s && in_lo) {                                                                                 \
+            static const hipError_t attrx_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_x3s<RELU_, SPLIT_>),       \
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kX3Lds);                  \
+            if (attrx_ != hipSuccess) { gom_set_error("hipFuncSetAttribute(k_conv3x3_x3s) failed"); return -1; }                      \
+            hipLaunchKernelGGL((k_conv3x3_x3s<RELU_, SPLIT_>), grid, dim3(512), kX3Lds, st, __VA_ARGS__);                             \
+        } else if (TH == 16 && use_v2) {                                                                                                     \
             static const hipError_t attr2_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_, 2>),   \
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                  \
             static const hipError_t attr4_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_, 4>),   \

@@ -3,7 +3,7 @@
 # copy them into profiles/ afterwards):   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
 # Runs TWICE the PMC-derived pieces feed bench.py: the bench line of the second pass carries roofline.traffic / roofline.valu read
 # from the json files the first pass produced (copy them to profiles/ in between, or simply run this script twice).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 bash scripts/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1                       # default bench: one step in flight
 bash scripts/collect_profiles.sh ${TAG}_inflight3 "--inflight 3" > gpurun_out/collect_${TAG}_inflight3.log 2>&1
@@ -48,6 +48,23 @@ for r in csv.DictReader(open(f"{out}/{tag}_pmc_sq_busy_per_kernel.csv")):
 json.dump(res, open(f"{out}/{tag}_valu.json", "w"), indent=1)
 print(json.dumps(res.get("k_seg_bwd"), indent=1))
 PY
+# the rocprofv3 averages of the GRAPH-REPLAYED launches of the metric workload alone, under bench.py's kernel ids (roofline.avg_us_rocprof)
+python - "$OUT" "$TAG" <<'PY'
+import csv, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {"batch": json.load(open(f"{out}/{tag}_metric_only_bench_line.json"))["config"]["frames_per_gpu_per_step"],
+       "what": "rocprofv3 --kernel-trace --stats of `python bench.py --no-modes --no-configs --no-cpu-baseline`: AverageNs per kernel (graph-replayed launches of the timed loop + the event-bracketed pass)"}
+for r in csv.DictReader(open(f"{out}/{tag}_metric_only_kernel_stats.csv")):
+    k = r["Name"]
+    if "anonymous namespace" not in k: continue
+    name = k.split("::")[1].split("(")[0].split("<")[0]
+    name = {"k_tile_rank": "k_sort", "k_seg_bwd_pair": "k_seg_bwd"}.get(name, name)
+    res.setdefault(name, round(float(r["AverageNs"]) / 1e3, 2))
+json.dump(res, open(f"{out}/{tag}_kernel_avg.json", "w"), indent=1)
+PY
+# the LPIPS launches of one Model iteration in order (both images as one batch at the loss: positions are stable) -> <tag>_lpips_conv.txt + <tag>_lpips_launches.json
+GOM_LPIPS_PREFETCH=0 bash scripts/model_iter_layers.sh lpips_layers_$TAG 60 gom bf16x3 > $OUT/${TAG}_lpips_conv.txt 2>&1
+cp gpurun_out/lpips_layers_$TAG/lpips_launches.json $OUT/${TAG}_lpips_launches.json
 ls -la $OUT; cat $OUT/${TAG}_bench_line.json | cut -c1-600
 # gpurun merges at most 64 MiB back: drop the raw traces / counter dumps, the summaries above are what is kept
 rm -rf gpurun_out/prof_${TAG}_pure/trace gpurun_out/prof_${TAG}/trace gpurun_out/prof_${TAG}/pmc_fetch gpurun_out/prof_${TAG}/pmc_write gpurun_out/prof_${TAG}_inflight3/trace \
