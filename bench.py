@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--task-grid-pct", type=int, default=0, help="GOM_OPT_TASK_GRID_PCT, 10..100 (0 = library default, 100)")
     ap.add_argument("--bwd-mode", type=int, default=-1, help="GOM_OPT_BWD_MODE (-1 = library default)")
     ap.add_argument("--sort-mode", type=int, default=-1, help="GOM_OPT_SORT_MODE (-1 = library default)")
+    ap.add_argument("--train-curve", action="store_true", help="run BASELINE configs[1] at its stated shape now (scripts/train_synthetic.py: 3 000 iterations through a "
+                                                               "subdivision, ~10 s) and report it under modes.cfg2_train_curve; default: cite the committed profiles/ curve")
     ap.add_argument("--backend", default="auto", help="auto: nccl (= RCCL) with one device per rank, gloo when ranks share a device")
     return ap.parse_args()
 
@@ -954,6 +956,33 @@ def main():
             out["roofline_lpips"] = lpips_roofline(torch, wl)
         except Exception as e:
             out["roofline_lpips"] = f"failed: {type(e).__name__}: {e}"
+
+    # ---------------- BASELINE configs[1] at its stated shape: S -> subdivide at 1 000 -> M, 3 000 iterations, every loss term + LPIPS bf16x3 + GomAdam ----------------
+    if world == 1 and not args.no_modes:
+        curve, src = None, None
+        if args.train_curve:
+            note("training curve (scripts/train_synthetic.py)")
+            tmp = os.path.join(ROOT, "gpurun_out", "bench_train_curve.json")
+            os.makedirs(os.path.dirname(tmp), exist_ok=True)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_synthetic.py"), "--iters", "3000", "--subdivide-at", "1000", "--out", tmp],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode == 0:
+                curve, src = json.load(open(tmp)), {"measured_in_this_run": True}
+            else:
+                out["modes"]["cfg2_train_curve"] = "failed: " + r.stdout[-300:]
+        else:
+            curve, src = read_profile_json("train_curve")
+        if curve:
+            orc, osrc = read_profile_json("train_curve_oracle")
+            row = {k: curve.get(k) for k in ("iterations", "subdivide_at", "wall_seconds_including_logging", "iterations_per_s", "peak_memory_MB", "final_psnr_mean_8_views")}
+            row["psnr_at"] = {str(r_["iter"]): r_["psnr"] for r_ in curve["log"] if r_["iter"] in (1, 50, 100, 150, 500, 1000, 2000, 3000)}
+            if orc:   # the CPU oracle trained from the same initialisation (scripts/train_curve_oracle.py): PSNR of the same iterations, side by side
+                hip = {r_["iter"]: r_["psnr"] for r_ in curve["log"]}
+                both = [(r_["iter"], hip[r_["iter"]], r_["psnr"]) for r_ in orc["log"] if r_["iter"] in hip]
+                row["vs_oracle_trained"] = {"iterations_compared": len(both), "max_abs_psnr_difference_db": round(max(abs(a - b) for _, a, b in both), 3) if both else None,
+                                            "mean_abs_psnr_difference_db": round(sum(abs(a - b) for _, a, b in both) / max(len(both), 1), 4), "source": osrc}
+            row["source"] = src
+            out["modes"]["cfg2_train_curve"] = row
 
     # ---------------- the other BASELINE configs (N = 1) ----------------
     if world == 1 and not args.no_configs and not args.no_modes:

@@ -1135,7 +1135,12 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
     const bf16_t *i_ = (const bf16_t *)in, *w_ = (const bf16_t *)wt, *m_ = (const bf16_t *)mask;
     static const bool use_v2 = !(getenv("GOM_CONV_V2") && atoi(getenv("GOM_CONV_V2")) == 0);   // development switches
     static const int v2_rpw = getenv("GOM_CONV_RPW") ? atoi(getenv("GOM_CONV_RPW")) : 2;
-    static const bool use_x3s = !(getenv("GOM_CONV_X3S") && atoi(getenv("GOM_CONV_X3S")) == 0);   // bf16x3 with shared stages (k_conv3x3_x3s); 0: the three virtual chunks of k_conv3x3_bf16_v2
+    // bf16x3 with shared stages (k_conv3x3_x3s: one workgroup per CU) for launches of FEWER than two workgroups per CU -- the deep layers and every split-K
+    // launch: conv4 forward 130 -> 102 us, conv5 41 -> 34, conv3 / conv4 backward 72 -> 57; launches of >= 512 workgroups keep k_conv3x3_bf16_v2, whose second
+    // co-resident workgroup hides the prologue and the store tail of the first (conv1_2: 130 us against 161, conv2_2 112 against 131: LABBOOK R5.3).
+    // GOM_CONV_X3S: 0 = never, 2 = always (development)
+    static const int x3s_mode = getenv("GOM_CONV_X3S") ? atoi(getenv("GOM_CONV_X3S")) : 1;
+    const bool use_x3s = x3s_mode == 2 || (x3s_mode == 1 && (long)grid.x * grid.y * grid.z < 512);
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \
         if (TH == 16 && use_v2 && use_x3s && in_lo) {                                                                                 \
