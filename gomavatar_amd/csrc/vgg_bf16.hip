@@ -400,14 +400,14 @@ __global__ void __launch_bounds__(1024 / RPW, 2) k_conv3x3_bf16_v2(int H, int W,
 constexpr int kX3WBytes = 2 * kV2WBytes;                              // 24 576: three taps of w_hi, then three taps of w_lo
 constexpr int kX3Lds = 4 * kV2PatchBytes + 3 * kX3WBytes;             // 156 672
 
-template <bool RELU, bool SPLITK>
-__global__ void __launch_bounds__(512, 1) k_conv3x3_x3s(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in, const bf16_t *__restrict__ wt,
+template <bool RELU, bool SPLITK, int RPW>
+__global__ void __launch_bounds__(1024 / RPW, 1) k_conv3x3_x3s(int H, int W, int Cin, int Cout, const bf16_t *__restrict__ in, const bf16_t *__restrict__ wt,
                                                           const float *__restrict__ bias, const bf16_t *__restrict__ mask, bf16_t *__restrict__ out, int splits,
                                                           float *__restrict__ partial, size_t in_lo, size_t out_lo, bf16_t *__restrict__ pooled, size_t pooled_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RPW = 2, TH = 16, NW = 8;
-    constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: a patch plane (162), a weight plane of a stage (96)
-    constexpr int PI = (PU + 63) / 64, WI = (WU + 63) / 64;                // load instructions per wave and plane (3, 2)
+    constexpr int TH = 16, NW = TH / RPW;                                  // RPW pixel rows per wave (2: 8 waves; 4: 4 waves with 0.33 fragment reads per MFMA)
+    constexpr int PU = kV2PatchUnits / NW, WU = 3 * kBN * 4 / NW;          // 16-byte units per wave: a patch plane (162 / 324), a weight plane of a stage (96 / 192)
+    constexpr int PI = (PU + 63) / 64, WI = (WU + 63) / 64;                // load instructions per wave and plane (3, 2 / 6, 3)
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int tx0 = (blockIdx.x % tiles_x) * kTileW, ty0 = (blockIdx.x / tiles_x) * TH;
     const int co0 = blockIdx.y * kBN;
@@ -1140,14 +1140,15 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
     // co-resident workgroup hides the prologue and the store tail of the first (conv1_2: 130 us against 161, conv2_2 112 against 131: LABBOOK R5.3).
     // GOM_CONV_X3S: 0 = never, 2 = always (development)
     static const int x3s_mode = getenv("GOM_CONV_X3S") ? atoi(getenv("GOM_CONV_X3S")) : 1;
+    // (RPW = 4 -- four waves of four rows, 0.33 fragment reads per MFMA, 232 registers, one wave per SIMD -- measured slower: Model iteration 2.85 against 2.78 ms)
     const bool use_x3s = x3s_mode == 2 || (x3s_mode == 1 && (long)grid.x * grid.y * grid.z < 512);
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \
         if (TH == 16 && use_v2 && use_x3s && in_lo) {                                                                                 \
-            static const hipError_t attrx_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_x3s<RELU_, SPLIT_>),       \
+            static const hipError_t attrx_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_x3s<RELU_, SPLIT_, 2>),    \
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kX3Lds);                  \
             if (attrx_ != hipSuccess) { gom_set_error("hipFuncSetAttribute(k_conv3x3_x3s) failed"); return -1; }                      \
-            hipLaunchKernelGGL((k_conv3x3_x3s<RELU_, SPLIT_>), grid, dim3(512), kX3Lds, st, __VA_ARGS__);                             \
+            hipLaunchKernelGGL((k_conv3x3_x3s<RELU_, SPLIT_, 2>), grid, dim3(512), kX3Lds, st, __VA_ARGS__);                          \
         } else if (TH == 16 && use_v2) {                                                                                                     \
             static const hipError_t attr2_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_bf16_v2<RELU_, SPLIT_, 2>),   \
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds);                  \
