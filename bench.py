@@ -115,6 +115,52 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+PEER_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from gomavatar_amd.parallel import PeerAllReduce
+dev = int(sys.argv[2]); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ar = PeerAllReduce(65536 + 3, f"cuda:{dev}", timeout_s=20.0)
+ok = True
+for epoch in range(3):
+    g = torch.Generator().manual_seed(10 * epoch)
+    parts = [torch.randn(65536 + 3, generator=g) for _ in range(world)]
+    ar.buffer.copy_(parts[rank].cuda())
+    out = ar.run(scale=1.0); ar.check()
+    ref = parts[0].clone()
+    for r in range(1, world):
+        ref = ref + parts[r]
+    ok = ok and bool(torch.equal(out.cpu(), ref))
+ar.close(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def peer_probe(world, rank, dev_idx):
+    """The direct peer exchange touches other processes' device memory from inside running kernels: where that is not possible (IPC mapping refused, no
+    peer access between two devices, ...) the failure mode can be a GPU memory fault that takes the PROCESS down -- and the bench line with it.  So the
+    exchange is tried first in CHILD processes (one per rank, their own gloo group on another port, the same devices, a small buffer, bitwise check): only
+    when every child exits 0 do the parents run the peer phases.  -> (ok on every rank, note)"""
+    import torch
+    import torch.distributed as dist
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 733)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    err = None
+    try:
+        r = subprocess.run([sys.executable, "-c", PEER_PROBE, ROOT, str(dev_idx)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        if r.returncode != 0:
+            err = f"probe exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    got = [None] * world
+    dist.all_gather_object(got, err)
+    bad = [f"rank {i}: {e}" for i, e in enumerate(got) if e]
+    return (not bad), (bad[0] if bad else None)
+
+
 def algorithmic_bytes(P, D, HW, C):
     """SURVEY.md section 8(d) byte model, per kernel, per launch (P Gaussians, D pairs, HW pixels of the whole launch)."""
     return {
@@ -783,12 +829,18 @@ def main():
 
     # ---------------- N > 1: the same job over the direct peer-pointer all-reduce (csrc/frame_parallel.hip), when it comes up ----------------
     peer_info, use_peer, collective_fps = None, False, None
+    peer_ok = False
     if world > 1:
-        note("peer exchange")
-        peer_info = {"impl": "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum, Adam inside the all-gather kernel (gom_peer_reduce_run_adam)"}
+        note("peer exchange: probe in child processes")
+        peer_ok, probe_err = peer_probe(world, rank, dev_idx)
+        note(f"peer exchange: probe {'ok' if peer_ok else 'FAILED: ' + str(probe_err)}")
+        peer_info = {"impl": "two-shot reduce-scatter / all-gather over hipIpc-mapped peer buffers, rank-order sum, Adam inside the all-gather kernel (gom_peer_reduce_run_adam)",
+                     "probe": "ok" if peer_ok else probe_err}
         ok_t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         peer_run, err = None, None
         try:
+            if not peer_ok:
+                raise RuntimeError("the peer exchange failed its probe in child processes: " + str(probe_err))
             peer_run = Runner(wl, B, 1, not args.no_graph, world, args, impl="peer")
         except Exception as e:   # report, do not hide (e.g. IPC not permitted between these devices)
             err = f"{type(e).__name__}: {e}"
@@ -916,7 +968,7 @@ def main():
     if world > 1 and not args.no_modes:
         note("Model frame-parallel modes")
         torch.cuda.empty_cache()
-        mp_ = model_parallel_modes(torch, wl, world, rank, ("collective", "peer", "peer-zero1"))
+        mp_ = model_parallel_modes(torch, wl, world, rank, ("collective", "peer", "peer-zero1") if peer_ok else ("collective",))
         out.setdefault("modes", {})["model_parallel"] = mp_
         out["config"]["model_allreduce_floats"] = mp_.get("allreduce_floats")
         out["config"]["model_param_floats"] = mp_.get("param_floats")

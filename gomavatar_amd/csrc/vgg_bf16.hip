@@ -1140,7 +1140,9 @@ int gom_conv3x3_planes(int B, int H, int W, int Cin, int Cout, const void *in, c
     // co-resident workgroup hides the prologue and the store tail of the first (conv1_2: 130 us against 161, conv2_2 112 against 131: LABBOOK R5.3).
     // GOM_CONV_X3S: 0 = never, 2 = always (development)
     static const int x3s_mode = getenv("GOM_CONV_X3S") ? atoi(getenv("GOM_CONV_X3S")) : 1;
-    // (RPW = 4 -- four waves of four rows, 0.33 fragment reads per MFMA, 232 registers, one wave per SIMD -- measured slower: Model iteration 2.85 against 2.78 ms)
+    // (Measured and dropped: RPW = 4 -- four waves of four rows, 0.33 fragment reads per MFMA, 232 registers, one wave per SIMD: Model iteration 2.85 against
+    //  2.78 ms; the same products with ONE-TAP weight stages and single-buffered patches in 66 KB, two workgroups per CU, for the launches of >= 512
+    //  workgroups (k_conv3x3_x3l): 2.93-2.96 against 2.93-3.05 ms on the same box -- no gain over k_conv3x3_bf16_v2 there: LABBOOK R5.3.)
     const bool use_x3s = x3s_mode == 2 || (x3s_mode == 1 && (long)grid.x * grid.y * grid.z < 512);
 #define GOM_CONV_LAUNCH(RELU_, SPLIT_, ...)                                                                                          \
     do {                                                                                                                              \

@@ -54,12 +54,18 @@ def test_bench_launches_itself_for_two_ranks():
             raise
         d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
     # N > 1 defaults to BASELINE configs[3]'s literal operating point: ONE frame per GPU per step, all-reduce + Adam inside the timed loop
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["frames_per_gpu_per_step"] == 1 and d["config"]["allreduce_floats"] == 951023
+    # (the native render step exchanges what it trains -- vertices / so3 / scale / appearance of the metric workload, no padding: 3 * 27 554 + 9 * 55 104)
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["frames_per_gpu_per_step"] == 1 and d["config"]["allreduce_floats"] == 578598
     assert d["config"]["allreduce_us"] > 0 and d["config"]["parallelism"] == "frame-dp2" and d["value"] > 0
     assert d["config"]["optimizer"] and d["config"]["local_only_fps"] >= d["value"] * 0.5 and d["modes"]["b8_per_gpu"] > 0
     # the direct peer-pointer all-reduce comes up between two processes on the one device and carries the same loop
     pr = d["config"]["allreduce_peer"]
-    assert pr["status"] == "ok" and pr["us"] > 0 and pr["fps"] > 0, pr
+    assert pr["probe"] == "ok" and pr["status"] == "ok" and pr["us"] > 0 and pr["fps"] > 0, pr      # (probe: the exchange tried in child processes first)
+    # BASELINE configs[3] in the reference's step shape: the Model iteration frame-parallel (parallel.ModelFrameParallel), the reference model's REAL parameter count
+    mp = d["modes"]["model_parallel"]
+    assert d["config"]["model_param_floats"] == 951023 and d["config"]["model_allreduce_floats"] == 951029
+    for k in ("local_only_ips", "model_train_iteration_lpips_bf16x3_collective_ips", "model_train_iteration_lpips_bf16x3_peer_ips", "model_train_iteration_lpips_bf16x3_peer_zero1_ips"):
+        assert isinstance(mp[k], float) and mp[k] > 0, (k, mp[k])
     assert "cpu_baseline" not in d     # rank 0 at N = 1 only
 
 
