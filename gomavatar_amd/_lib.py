@@ -15,13 +15,13 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 8
+GOM_ABI_VERSION = 9
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
 (BUF_DEPTH, BUF_XY, BUF_CONIC_OPACITY, BUF_TILES_TOUCHED, BUF_RECT, BUF_TILE_BASE, BUF_KEYS, BUF_POINT_LIST, BUF_FINAL_T,
  BUF_N_CONTRIB, BUF_STATUS) = range(11)
-OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE, OPT_SEG_SHIFT, OPT_TASK_GRID_PCT, OPT_SORT_MODE, OPT_BWD_MODE, OPT_FUSE_FACE = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_SORT_CAP, OPT_PAIR_CAPACITY, OPT_PROFILE, OPT_SEG_SHIFT, OPT_TASK_GRID_PCT, OPT_SORT_MODE, OPT_BWD_MODE, OPT_FUSE_FACE, OPT_FUSE_LOSS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 SORT_AUTO, SORT_TILE_MERGE, SORT_DEPTH_RANK = 0, 1, 2
 KERNEL_NAMES = ("preprocess", "scan_tiles", "emit", "sort", "seg_T", "seg_fwd", "combine", "seg_bwd", "preprocess_bwd", "depth_hist", "depth_rank")
 
@@ -115,6 +115,7 @@ SIGNATURES = {
     "gom_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "gom_lpips_layer_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gom_lpips_layer_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gom_frame_loss_slots": (c_int, [c_int, c_int]),
     "gom_frame_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_uint32, c_void_p]),
     "gom_batch_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_int32, c_void_p, c_uint32, c_void_p]),
     "gom_adam_flat": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_float, c_float,

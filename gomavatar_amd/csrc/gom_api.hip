@@ -44,6 +44,7 @@ extern "C" GomState *gom_state_create(void) {
     // development switches (A / B measurements; both default on)
     if (const char *e = getenv("GOM_BWD_ORDER")) s->bwdOrder = atoi(e) != 0;   // the cost-ordered backward queue of the batched frame step
     if (const char *e = getenv("GOM_LOSS_SKIP")) s->lossSkip = atoi(e) != 0;   // the frame step's loss kernel leaving the pixels of empty tiles alone
+    if (const char *e = getenv("GOM_FUSE_LOSS")) s->fuseLoss = atoi(e) != 0;   // initial GOM_OPT_FUSE_LOSS
     if (const char *e = getenv("GOM_BWD_MODE")) s->bwdMode = atoi(e);          // initial GOM_OPT_BWD_MODE (A / B runs of the whole test suite)
 #ifndef GOM_LAB
     if (s->bwdMode >= 2) s->bwdMode = -1;                                      // (modes 2 and 3 exist in -DGOM_LAB builds only)
@@ -116,6 +117,11 @@ extern "C" int gom_state_set_option(GomState *s, int option, int64_t value) {
             if (value != 0 && value != 1) { gom_set_error("GOM_OPT_FUSE_FACE is 0 or 1"); return -1; }
             if ((value != 0) != s->fuseFace) s->allocGen++;   // recorded graphs hold the other launch sequence
             s->fuseFace = value != 0;
+            return 0;
+        case GOM_OPT_FUSE_LOSS:
+            if (value != 0 && value != 1) { gom_set_error("GOM_OPT_FUSE_LOSS is 0 or 1"); return -1; }
+            if ((value != 0) != s->fuseLoss) s->allocGen++;   // recorded graphs hold the other launch sequence
+            s->fuseLoss = value != 0;
             return 0;
         case GOM_OPT_SORT_MODE:
             if (value < 0 || value > 2) { gom_set_error("sort mode must be 0 (auto), 1 (per-tile merge sort) or 2 (depth ranking)"); return -1; }
@@ -517,6 +523,11 @@ extern "C" int gom_state_set_frame_optimizer(GomState *s, int64_t n, float *para
 }
 #endif
 
+extern "C" int gom_frame_loss_slots(int H, int W) {
+    const int tiles = ((W + GOM_TILE - 1) / GOM_TILE) * ((H + GOM_TILE - 1) / GOM_TILE);
+    return tiles > GOM_LOSS_BLOCKS ? tiles : GOM_LOSS_BLOCKS;
+}
+
 extern "C" int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream) {
     return frame_call(s, f, 1, nullptr, flags, stream);
 }
@@ -559,14 +570,24 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
         // batched launches: the assembly pass of the forward carries the riders that order the backward's task queue by the cost the forward counted
         const bool ride = B > 1 && s->bwdOrder;   // (and the depth ranking, decided inside the forward: its tile pass zeroes the cost words)
         s->rideBwdOrder = ride;
+        // GOM_OPT_FUSE_LOSS: the loss rides in the forward's emit and assembly launches (GomLossRider) -- when there is an emit launch (F > 0)
+        const bool fuse_loss = s->fuseLoss && s->lossSkip && F > 0 && f->gt_rgb && f->gt_mask && f->bgcolor && f->work_dimage && f->loss_partials;
+        if (fuse_loss) {
+            const int HW = H * W;
+            s->lossRider = GomLossRider{f->gt_rgb, f->gt_mask, f->bgcolor, 1.0f * f->c_rgb / (3.0f * (float)HW), 1.0f * f->c_mask / (float)HW, f->work_dimage, f->loss_partials,
+                                        gom_frame_loss_slots(H, W), (flags & GOM_FRAME_FORWARD_ONLY) ? 1 : 0};
+        }
         rc = raster_forward_impl(s, &f->cam, cams, B, F, 4, f->work_xyz, f->work_cov6, f->work_feat, f->work_opacity, f->image, f->work_radii, 0, stream, face);
         s->rideBwdOrder = false;
+        s->lossRider = GomLossRider{};
         if (rc) return rc;
 
-        GomLossSkip skip{s->tile_base, cams, {f->cam.bg[0], f->cam.bg[1], f->cam.bg[2], f->cam.bg[3]}, s->gx, s->gy, W, (flags & GOM_FRAME_FORWARD_ONLY) ? 1 : 0};
-        if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
-                                    nullptr, f->loss_partials, stream, s->lossSkip ? &skip : nullptr)))
-            return rc;
+        if (!fuse_loss) {
+            GomLossSkip skip{s->tile_base, cams, {f->cam.bg[0], f->cam.bg[1], f->cam.bg[2], f->cam.bg[3]}, s->gx, s->gy, W, (flags & GOM_FRAME_FORWARD_ONLY) ? 1 : 0};
+            if ((rc = gom_l1_loss_batch(B, H, W, f->image, nullptr, f->gt_rgb, f->gt_mask, f->bgcolor, f->c_rgb, f->c_mask, 1.0f, f->work_dimage,
+                                        nullptr, f->loss_partials, stream, s->lossSkip ? &skip : nullptr, gom_frame_loss_slots(H, W))))
+                return rc;
+        }
         s->bwdOrderReady = ride && s->rankSort;
     }
     if (flags & GOM_FRAME_FORWARD_ONLY) return 0;

@@ -60,6 +60,25 @@ struct GomDevStatus {
     uint32_t rec_cursor[GOM_REC_SHARDS][32];   // [shard][0] used: allocator of the record regions of the live (segment, sub-range, quadrant) pieces (k_seg_fwd)
 };
 
+// The frame step's loss INSIDE the rasterizer's forward (GOM_OPT_FUSE_LOSS, default on): the pixels of a non-empty tile are in the registers of
+// the k_combine_fwd workgroup that assembles them -- it writes dL/d(image) next to the image -- and the empty tiles' loss (a function of the
+// target and the background alone: 16 bytes per pixel, bandwidth) is summed by rider workgroups of the same launch, dispatched in front of the
+// tiles' latency chains and done long before them (in k_emit's painters the same work made that launch 8 us longer at B = 8: its tail is a
+// queue for workgroup slots).  Tile t of a frame leaves (sum |rgb|, sum |mask|) in slot t
+// of the frame's row of `partials` (gom_frame_loss_slots(H, W) = max(GOM_LOSS_BLOCKS, tiles) slots per frame: the caller sums them, as it sums
+// the stand-alone kernel's per-block slots).  One launch (7 us at B = 1, 14 at B = 8) and one read of the image less; no hand-off between
+// workgroups (a ticket per workgroup with its device-scope release cost k_combine_fwd 100 us: measured, dropped).
+struct GomLossRider {
+    const float *gt_rgb;        // [B][HW][3]; null: no rider (the caller launches k_l1_loss)
+    const float *gt_mask;       // [B][HW]
+    const float *bgcolor;       // [B][3] background of the unpack (train.py:53-55)
+    float k_rgb, k_mask;
+    float *dpred;               // [B][4][HW]
+    float *partials;            // [B][slots][2] (caller)
+    int slots;
+    int zero_empty;             // GomLossSkip::zero_empty
+};
+
 struct GomGraphEntry {
     GomFrame key;
     uint32_t flags;
@@ -88,6 +107,8 @@ struct GomState {
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
     bool lossSkip = true;             // the frame step's loss kernel skips loads and stores of empty tiles (GomLossSkip)
+    bool fuseLoss = true;             // GOM_OPT_FUSE_LOSS: the frame step's loss rides in k_emit (empty tiles) and k_combine_fwd (the others): GomLossRider
+    GomLossRider lossRider{};         // set by the frame step around its forward
     bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write
     bool bwdOrder = true;             // development switch: cost-ordered backward queue in the frame step
     bool fuseFace = true;             // GOM_OPT_FUSE_FACE: the frame step builds / differentiates the per-face frame inside k_preprocess / k_preprocess_bwd
@@ -350,7 +371,7 @@ struct GomLossSkip {
 };
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream, const GomLossSkip *skip = nullptr);
+                      float *loss_partials, void *stream, const GomLossSkip *skip = nullptr, int slots = GOM_LOSS_BLOCKS);
 int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
                     float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,

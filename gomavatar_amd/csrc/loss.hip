@@ -8,20 +8,21 @@
 // partial sums and nobody waits on a same-address atomic (11-13 ns each on
 // MI355X); the gradient does not depend on the value.
 #include "gom_internal.h"
+#include "l1_pixel.hpp"
 
 namespace {
 
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float sgn(float x) { return gom_sgn(x); }
 
 __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict__ pred, const float *__restrict__ shade,
                                                  const float *__restrict__ gt_rgb, const float *__restrict__ gt_mask,
                                                  const float *__restrict__ bg, float k_rgb, float k_mask,
-                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials, GomLossSkip skip) {
+                                                 float *__restrict__ dpred, float *__restrict__ dshade, float *__restrict__ partials, GomLossSkip skip, int slots) {
     __shared__ float s_red[2][4];
     {  // blockIdx.y = frame of a batched launch: [B][4][HW] images, [B][HW][3] targets, [B][3] backgrounds
         const size_t fr = blockIdx.y;
         pred += fr * 4 * HW; gt_rgb += fr * 3 * HW; gt_mask += fr * HW; bg += fr * 3; dpred += fr * 4 * HW;
-        partials += fr * 2 * GOM_LOSS_BLOCKS;
+        partials += fr * 2 * slots;
         if (shade) shade += fr * HW;
         if (dshade) dshade += fr * HW;
     }
@@ -44,22 +45,18 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
         const float s = shade ? shade[p] : 1.f;
         const float a0 = empty ? e0 : pred[p], a1 = empty ? e1 : pred[(size_t)HW + p], a2 = empty ? e2 : pred[2 * (size_t)HW + p];
         const float3 g = *reinterpret_cast<const float3 *>(gt_rgb + 3 * (size_t)p);   // one 12-byte load per lane (three strided 4-byte loads cost the texture path three passes)
-        const float r0 = a0 * s * m + b0 * (1.f - m) - g.x;
-        const float r1 = a1 * s * m + b1 * (1.f - m) - g.y;
-        const float r2 = a2 * s * m + b2 * (1.f - m) - g.z;
-        const float rm = m - gt_mask[p];
-        sum_rgb += fabsf(r0) + fabsf(r1) + fabsf(r2);
-        sum_mask += fabsf(rm);
-        const float s0 = sgn(r0) * k_rgb, s1 = sgn(r1) * k_rgb, s2 = sgn(r2) * k_rgb;
+        const GomL1Px o = gom_l1_pixel(a0, a1, a2, m, s, b0, b1, b2, g.x, g.y, g.z, gt_mask[p], k_rgb, k_mask);
+        sum_rgb += o.abs_rgb;
+        sum_mask += o.abs_mask;
         if (empty) {           // (no list entry touches the pixel: the backward does not read its gradient)
             if (skip.zero_empty) { dpred[p] = 0.f; dpred[(size_t)HW + p] = 0.f; dpred[2 * (size_t)HW + p] = 0.f; dpred[3 * (size_t)HW + p] = 0.f; }
             continue;
         }
-        dpred[p] = s0 * s * m;
-        dpred[(size_t)HW + p] = s1 * s * m;
-        dpred[2 * (size_t)HW + p] = s2 * s * m;
-        dpred[3 * (size_t)HW + p] = s0 * (a0 * s - b0) + s1 * (a1 * s - b1) + s2 * (a2 * s - b2) + sgn(rm) * k_mask;
-        if (dshade) dshade[p] = (s0 * a0 + s1 * a1 + s2 * a2) * m;
+        dpred[p] = o.d0;
+        dpred[(size_t)HW + p] = o.d1;
+        dpred[2 * (size_t)HW + p] = o.d2;
+        dpred[3 * (size_t)HW + p] = o.d3;
+        if (dshade) dshade[p] = o.dshade;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -72,6 +69,7 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
     if (threadIdx.x == 0) {
         partials[2 * blockIdx.x] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
         partials[2 * blockIdx.x + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+        for (int j = (int)blockIdx.x + GOM_LOSS_BLOCKS; j < slots; j += GOM_LOSS_BLOCKS) { partials[2 * j] = 0.f; partials[2 * j + 1] = 0.f; }   // (a frame step's row: one slot per tile for the riders)
     }
 }
 
@@ -79,14 +77,14 @@ __global__ void __launch_bounds__(256) k_l1_loss(int HW, const float *__restrict
 
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
-                      float *loss_partials, void *stream, const GomLossSkip *skip) {
+                      float *loss_partials, void *stream, const GomLossSkip *skip, int slots) {
     if (H <= 0 || W <= 0) { gom_set_error("gom_l1_loss: bad image size"); return -1; }
     if (!pred || !gt_rgb || !gt_mask || !bg || !dL_dpred || !loss_partials) { gom_set_error("gom_l1_loss: null pointer"); return -1; }
     const int HW = H * W;
     const float k_rgb = grad_scale * c_rgb / (3.0f * (float)HW);
     const float k_mask = grad_scale * c_mask / (float)HW;
     hipLaunchKernelGGL(k_l1_loss, dim3(GOM_LOSS_BLOCKS, B), dim3(256), 0, (hipStream_t)stream, HW, pred, shade, gt_rgb, gt_mask, bg,
-                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials, skip ? *skip : GomLossSkip{});
+                       k_rgb, k_mask, dL_dpred, dL_dshade, loss_partials, skip ? *skip : GomLossSkip{}, slots);
     GOM_LAUNCH_CHECK();
     return 0;
 }

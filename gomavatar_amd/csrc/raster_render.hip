@@ -51,6 +51,7 @@
 #include "bwd_order.hpp"
 #include "sort_util.hpp"
 #include "entry_record.hpp"
+#include "l1_pixel.hpp"
 #include <cstdlib>
 
 #ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3 | 4): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2), k_seg_fwd (3): scripts/wg_timeline_T.py; of k_combine_fwd (4): scripts/combine_timeline.py
@@ -1018,8 +1019,9 @@ __device__ __forceinline__ void combine_tile(const int tile, int H, int W, int g
                                                      uint32_t *__restrict__ tile_nmax, uint4 *__restrict__ seg_qmax,
                                                      const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
-                                                     uint32_t *__restrict__ tile_qlim, int skip_empty) {
+                                                     uint32_t *__restrict__ tile_qlim, int skip_empty, const GomLossRider &lr) {
     __shared__ uint32_t s_nmax[4], s_qmax[4];
+    __shared__ float s_lsum[2][4];
     const int tx = tile % gx, fr = (tile / gx) / gy, ty = (tile / gx) % gy;  // fr: frame of a batched launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -1043,11 +1045,24 @@ __device__ __forceinline__ void combine_tile(const int tile, int H, int W, int g
             final_T[pix] = nanv;
             n_contrib[pix] = 0;
         }
-        if (threadIdx.x == 0) { tile_nmax[tile] = 0; if (rank_of) tile_qlim[tile] = 0; }
+        if (threadIdx.x == 0) {
+            tile_nmax[tile] = 0;
+            if (rank_of) tile_qlim[tile] = 0;
+            if (C == 4 && lr.gt_rgb) *reinterpret_cast<float2 *>(lr.partials + 2 * ((size_t)fr * lr.slots + (tile - fr * gx * gy))) = make_float2(__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u));
+        }
         return;
     }
     const uint32_t sb = seg_base[tile], nseg = seg_base[tile + 1] - sb;
     if (nseg == 0 && skip_empty) return;   // this forward's k_emit painted the tile (background, T = 1, no contributor; tile_nmax zeroed by the scan)
+    // GomLossRider: the pixel's targets, loaded here -- in the shadow of the walk over the segments -- for the loss at the end
+    float3 lr_g = make_float3(0.f, 0.f, 0.f);
+    float lr_gm = 0.f, lr_b[3] = {0.f, 0.f, 0.f};
+    if (C == 4 && lr.gt_rgb && inside) {
+        const size_t fp = (size_t)fr * HW + pix;
+        lr_g = *reinterpret_cast<const float3 *>(lr.gt_rgb + 3 * fp);
+        lr_gm = lr.gt_mask[fp];
+        lr_b[0] = lr.bgcolor[3 * fr]; lr_b[1] = lr.bgcolor[3 * fr + 1]; lr_b[2] = lr.bgcolor[3 * fr + 2];
+    }
     float T = 1.f, acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
@@ -1140,22 +1155,109 @@ __device__ __forceinline__ void combine_tile(const int tile, int H, int W, int g
             }
         }
     }
+    float l_rgb = 0.f, l_mask = 0.f;   // GomLossRider: this pixel's |residuals|
     if (inside) {
         final_T[pix] = T;
         n_contrib[pix] = last;
+        float v[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = acc[ch] + T * bg[ch];
+        for (int ch = 0; ch < C; ch++) { v[ch] = acc[ch] + T * bg[ch]; out_color[ch * HW + pix] = v[ch]; }
+        if (C == 4 && lr.gt_rgb) {   // the frame step's loss on the pixel just assembled: its gradient goes out next to the image (l1_pixel.hpp)
+            const GomL1Px o = gom_l1_pixel(v[0], v[1], v[2], v[C - 1], 1.f, lr_b[0], lr_b[1], lr_b[2], lr_g.x, lr_g.y, lr_g.z, lr_gm, lr.k_rgb, lr.k_mask);
+            float *dp = lr.dpred + (size_t)fr * 4 * HW + pix;
+            dp[0] = o.d0; dp[HW] = o.d1; dp[2 * HW] = o.d2; dp[3 * HW] = o.d3;
+            l_rgb = o.abs_rgb; l_mask = o.abs_mask;
+        }
     }
     const uint32_t wmax = wave_max_u32(inside ? last : 0u);
     const uint32_t wq = rank_of ? wave_max_u32(qrank) : 0u;
-    if (lane == 0) { s_nmax[wave] = wmax; s_qmax[wave] = wq; }
+    if (C == 4 && lr.gt_rgb) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { l_rgb += __shfl_xor(l_rgb, d, 64); l_mask += __shfl_xor(l_mask, d, 64); }
+    }
+    if (lane == 0) { s_nmax[wave] = wmax; s_qmax[wave] = wq; s_lsum[0][wave] = l_rgb; s_lsum[1][wave] = l_mask; }
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_nmax[tile] = max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3]));
         if (rank_of) tile_qlim[tile] = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
+        if (C == 4 && lr.gt_rgb) *reinterpret_cast<float2 *>(lr.partials + 2 * ((size_t)fr * lr.slots + (tile - fr * gx * gy))) = make_float2((s_lsum[0][0] + s_lsum[0][1]) + (s_lsum[0][2] + s_lsum[0][3]), (s_lsum[1][0] + s_lsum[1][1]) + (s_lsum[1][2] + s_lsum[1][3]));
     }
     // the four quadrant maxima once per SEGMENT of the tile: the backward finds them with the segment index alone
     for (uint32_t i = threadIdx.x; i < nseg; i += 256) seg_qmax[sb + i] = make_uint4(s_nmax[0], s_nmax[1], s_nmax[2], s_nmax[3]);
+}
+
+// GomLossRider, empty tiles: rider workgroups of k_combine_fwd stride over the tiles in groups of four; an empty tile's prediction is the
+// background k_emit painted, so its loss needs the targets alone.  All loads of a group are issued before the sums (one latency per group).
+#define GOM_LOSS_RIDER_BLOCKS 2048
+__device__ __forceinline__ void loss_empty_tiles_rider(const GomLossRider &lr, const uint32_t rid, const uint32_t n_rid, int H, int W, int gx, int gy, int n_tiles,
+                                                       float bg0, float bg1, float bg2, float bg3, const GomCamera *__restrict__ cams,
+                                                       const uint32_t *__restrict__ seg_base) {
+    __shared__ float s_fill[4][4][2];
+    const int per = gx * gy;
+    const size_t HW = (size_t)H * W;
+    for (int t0 = (int)rid * 4; t0 < n_tiles; t0 += (int)n_rid * 4) {
+        bool emp[4], ins[4];
+        size_t pixs[4];
+        int frs[4];
+        float3 g[4];
+        float gm[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = t0 + k;
+            emp[k] = false; ins[k] = false; pixs[k] = 0; frs[k] = 0; g[k] = make_float3(0.f, 0.f, 0.f); gm[k] = 0.f;
+            if (t < n_tiles) {
+                emp[k] = seg_base[t + 1] == seg_base[t];
+                const int fr = t / per, tl = t - fr * per;
+                const int px = (tl % gx) * 16 + (threadIdx.x & 15), py = (tl / gx) * 16 + (threadIdx.x >> 4);
+                ins[k] = px < W && py < H;
+                frs[k] = fr;
+                pixs[k] = (size_t)fr * HW + (size_t)py * W + px;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (emp[k] && ins[k]) { g[k] = *reinterpret_cast<const float3 *>(lr.gt_rgb + 3 * pixs[k]); gm[k] = lr.gt_mask[pixs[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!emp[k]) continue;   // (uniform over the workgroup)
+            float sr = 0.f, sm = 0.f;
+            if (ins[k]) {
+                const int fr = frs[k];
+                float bg[4] = {bg0, bg1, bg2, bg3};
+                if (cams) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++) bg[ch] = cams[fr].bg[ch];
+                }
+                const GomL1Px o = gom_l1_pixel(bg[0], bg[1], bg[2], bg[3], 1.f, lr.bgcolor[3 * fr], lr.bgcolor[3 * fr + 1], lr.bgcolor[3 * fr + 2], g[k].x, g[k].y, g[k].z, gm[k],
+                                               lr.k_rgb, lr.k_mask);
+                sr = o.abs_rgb; sm = o.abs_mask;
+                if (lr.zero_empty) {   // (split frame call: the caller reads the gradient image itself)
+                    const size_t pix = pixs[k] - (size_t)fr * HW;
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++) lr.dpred[((size_t)fr * 4 + ch) * HW + pix] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sr += __shfl_xor(sr, d, 64); sm += __shfl_xor(sm, d, 64); }
+            if ((threadIdx.x & 63) == 0) { s_fill[k][threadIdx.x >> 6][0] = sr; s_fill[k][threadIdx.x >> 6][1] = sm; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 && t0 + (int)threadIdx.x < n_tiles && seg_base[t0 + threadIdx.x + 1] == seg_base[t0 + threadIdx.x]) {
+            const int t = t0 + (int)threadIdx.x, fr = t / per;
+            *reinterpret_cast<float2 *>(lr.partials + 2 * ((size_t)fr * lr.slots + (t - fr * per))) =
+                make_float2((s_fill[threadIdx.x][0][0] + s_fill[threadIdx.x][1][0]) + (s_fill[threadIdx.x][2][0] + s_fill[threadIdx.x][3][0]),
+                            (s_fill[threadIdx.x][0][1] + s_fill[threadIdx.x][1][1]) + (s_fill[threadIdx.x][2][1] + s_fill[threadIdx.x][3][1]));
+        }
+        __syncthreads();
+    }
+    // (a frame of fewer tiles than slots: the slots behind its tiles are zero)
+    if (rid == 0 && per < lr.slots) {
+        const int B = n_tiles / per;
+        for (int i = (int)threadIdx.x; i < B * (lr.slots - per); i += 256) {
+            const int fr = i / (lr.slots - per), j = per + i % (lr.slots - per);
+            *reinterpret_cast<float2 *>(lr.partials + 2 * ((size_t)fr * lr.slots + j)) = make_float2(0.f, 0.f);
+        }
+    }
 }
 
 // One workgroup per tile -- or, when this forward's k_emit has painted the empty tiles (five in six on a body) and the scan kernel has
@@ -1172,7 +1274,7 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      const GomDevStatus *__restrict__ status, const uint32_t *__restrict__ tile_base,
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
                                                      uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles,
-                                                     GomBwdOrderRider rider) {
+                                                     GomBwdOrderRider rider, GomLossRider lr, int n_loss_riders) {
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 4   // (development: lifetime of every workgroup of this launch, riders first; scripts/combine_timeline.py)
     struct PhRec {
         unsigned long long w0;
@@ -1182,20 +1284,26 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
     // (frame step, batched) the first eight workgroups order the backward's task queue: bwd_order.hpp
     const uint32_t n_rid = rider.status ? 8u : 0u;
     if (blockIdx.x < n_rid) { gom_bwd_order_rider(rider, blockIdx.x); return; }
-    const uint32_t bx = blockIdx.x - n_rid, nbx = gridDim.x - n_rid;
-#define GOM_COMBINE_TILE(T) combine_tile<C>((T), H, W, gx, gy, bg0, bg1, bg2, bg3, cams, seg_base, seg_C, seg_last, seg_Tend, seg_Sbehind, out_color, final_T, \
-                                            n_contrib, tile_nmax, seg_qmax, status, tile_base, point_list, rank_of, tile_qlim, skip_empty)
-    if (!work) { GOM_COMBINE_TILE((int)bx); return; }
-    if (status->overflow) {   // (no work items then: every tile is poisoned)
-        for (int tile = (int)bx; tile < n_tiles; tile += (int)nbx) { GOM_COMBINE_TILE(tile); __syncthreads(); }
+    // (frame step) the LAST workgroups sum the loss of the empty tiles (GomLossRider): bandwidth work in the slots the tiles' latency chains leave free
+    const uint32_t n_lr = (C == 4 && lr.gt_rgb) ? (uint32_t)n_loss_riders : 0u;
+    if (blockIdx.x >= gridDim.x - n_lr) {
+        if (!status->overflow) loss_empty_tiles_rider(lr, blockIdx.x - (gridDim.x - n_lr), n_lr, H, W, gx, gy, n_tiles, bg0, bg1, bg2, bg3, cams, seg_base);
         return;
     }
-    const uint32_t n_work = status->n_work_items;
-    for (uint32_t wi = bx; wi < n_work; wi += nbx) {
-        const uint32_t item = work[wi];
-        if (item >> 24) continue;   // (further windows of a long list: the tile has been taken with window 0)
-        GOM_COMBINE_TILE((int)(item & 0xffffffu));
-        __syncthreads();            // s_nmax / s_qmax of this tile have been read
+    const uint32_t bx = blockIdx.x - n_rid, nbx = gridDim.x - n_rid - n_lr;
+#define GOM_COMBINE_TILE(T) combine_tile<C>((T), H, W, gx, gy, bg0, bg1, bg2, bg3, cams, seg_base, seg_C, seg_last, seg_Tend, seg_Sbehind, out_color, final_T, \
+                                            n_contrib, tile_nmax, seg_qmax, status, tile_base, point_list, rank_of, tile_qlim, skip_empty, lr)
+    if (!work) { GOM_COMBINE_TILE((int)bx); }
+    else if (status->overflow) {   // (no work items then: every tile is poisoned)
+        for (int tile = (int)bx; tile < n_tiles; tile += (int)nbx) { GOM_COMBINE_TILE(tile); __syncthreads(); }
+    } else {
+        const uint32_t n_work = status->n_work_items;
+        for (uint32_t wi = bx; wi < n_work; wi += nbx) {
+            const uint32_t item = work[wi];
+            if (item >> 24) continue;   // (further windows of a long list: the tile has been taken with window 0)
+            GOM_COMBINE_TILE((int)(item & 0xffffffu));
+            __syncthreads();            // s_nmax / s_qmax of this tile have been read
+        }
     }
 #undef GOM_COMBINE_TILE
 }
@@ -1674,10 +1782,13 @@ int gom_launch_render_forward(GomState *s, const GomCamera &cam, int C, const fl
         const bool ride = s->rideBwdOrder && s->rankSort && s->B > 1;
         const bool listed = s->emptyFilled && s->rankSort;   // the non-empty tiles are listed (work items of the tile pass) and the others painted
 #define GOM_CF(CC)                                                                                                        \
-    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3((listed ? (n_tiles < 2048 ? n_tiles : 2048) : n_tiles) + (ride ? 8 : 0)), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
+    hipLaunchKernelGGL((k_combine_fwd<CC>), dim3((listed ? (n_tiles < 2048 ? n_tiles : 2048) : n_tiles) + (ride ? 8 : 0) + n_lr), dim3(256), 0, st, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_base, s->seg_C, s->seg_last, s->seg_Tend, s->seg_Sbehind, out_color, s->final_T,        \
                        s->n_contrib, s->tile_nmax, s->seg_qmax, s->status, s->tile_base, s->point_list, s->rankSort ? s->rank_of : nullptr, s->tile_qlim, s->emptyFilled ? 1 : 0, \
-                       listed ? s->work_items : nullptr, n_tiles, ride ? GomBwdOrderRider{s->status, s->seg_cost, s->bwd_order} : GomBwdOrderRider{})
+                       listed ? s->work_items : nullptr, n_tiles, ride ? GomBwdOrderRider{s->status, s->seg_cost, s->bwd_order} : GomBwdOrderRider{}, lr, n_lr)
+        GomLossRider lr{};   // the frame step's loss rides here
+        if (s->lossRider.gt_rgb && C == 4) lr = s->lossRider;
+        const int n_lr = lr.gt_rgb ? ((n_tiles + 3) / 4 < GOM_LOSS_RIDER_BLOCKS ? (n_tiles + 3) / 4 : GOM_LOSS_RIDER_BLOCKS) : 0;   // a group of four tiles each, up to a chip's worth
         if (C == 3) GOM_CF(3); else GOM_CF(4);
 #undef GOM_CF
     }

@@ -55,7 +55,8 @@ class RenderStep:
         self.opacity = torch.ones(lead + (F,), **f32)      # model.py:242
         self.image = torch.empty(lead + (4, H, W), **f32)  # albedo rgb + mask, CHW
         self.radii = torch.empty(lead + (F,), dtype=torch.int32, device=dev)
-        self.loss_partials = torch.zeros(lead + (_lib.GOM_LOSS_BLOCKS, 2), **f32)
+        # one slot per 16x16 tile (at least GOM_LOSS_BLOCKS): with GOM_OPT_FUSE_LOSS the loss rides in the forward and tile t fills slot t
+        self.loss_partials = torch.zeros(lead + (_lib.load().gom_frame_loss_slots(H, W), 2), **f32)
         # backward intermediates
         self.d_image = torch.zeros(lead + (4, H, W), **f32)   # (the loss kernel leaves the pixels of empty tiles alone: finite from the start)
         self.d_xyz = torch.empty(lead + (F, 3), **f32)

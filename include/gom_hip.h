@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 8
+#define GOM_ABI_VERSION 9
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -102,10 +102,15 @@ enum {
     GOM_OPT_SORT_MODE = 5,     /* how the tile lists get their (depth, index) order: 0 = auto, 1 = merge sort per tile, 2 = rank the
                                   frame's Gaussians by depth once, then a linear bitmap pass per tile (auto picks it when the
                                   bitmap of one frame fits comfortably in LDS: up to 2^18 Gaussians per frame).  Bit-identical results. */
-    GOM_OPT_FUSE_FACE = 7      /* frame step (gom_frame_forward_backward / gom_batch_forward_backward) only: 1 (default) = the per-face
+    GOM_OPT_FUSE_FACE = 7,     /* frame step (gom_frame_forward_backward / gom_batch_forward_backward) only: 1 (default) = the per-face
                                   Gaussian frame and its backward run inside the rasterizer's per-Gaussian kernels and the kinematic chain
                                   inside the skinning launch (three launches and a round trip of the means / covariances / their gradients
                                   through HBM less); 0 = separate kernels.  Bit-identical results. */
+    GOM_OPT_FUSE_LOSS = 8      /* frame step only: 1 (default) = the photometric L1 losses and dL/d(image) are computed inside the forward's
+                                  own launches (the workgroup that assembles a tile has its pixels in registers; the workgroups that paint
+                                  the empty tiles sum their loss), tile t leaving its sums in slot t of the frame's loss_partials row: one launch
+                                  and one read of the image less.  0 = the stand-alone loss kernel (gom_l1_loss's).  The same bits for the
+                                  image gradient; the loss VALUE is summed in another order (per tile instead of per strided block). */
 };
 
 /* kernel ids for gom_state_kernel_times */
@@ -411,7 +416,7 @@ typedef struct GomFrame {
     const float *gt_rgb, *gt_mask, *bgcolor;            /* [H][W][3] [H][W] [3]                                 */
     /* outputs */
     float *image;                       /* [4][H][W] albedo rgb + alpha                                         */
-    float *loss_partials;               /* [GOM_LOSS_BLOCKS][2]                                                 */
+    float *loss_partials;               /* [gom_frame_loss_slots(H, W)][2]: the caller sums the slots (ABI 9)   */
     float *g_vertices, *g_so3, *g_scale, *g_appearance; /* gradients, same layouts as the parameters            */
     /* scratch */
     float *work_RT, *work_fk;           /* [24][12], [24][32]                                                   */
@@ -432,6 +437,10 @@ typedef struct GomFrame {
                                        hipGraph on first use and replay it afterwards: one submission instead of 12.  A recording is
                                        dropped (and made again at its next use) when a buffer of the state is re-allocated -- a larger
                                        frame through the same state -- or one of its options changes */
+/* Slots (pairs of floats) per frame of GomFrame.loss_partials: max(GOM_LOSS_BLOCKS, 16x16 tiles of the image).  With GOM_OPT_FUSE_LOSS the
+ * loss rides in the forward's launches and tile t leaves its sums in slot t; the stand-alone kernel fills the first GOM_LOSS_BLOCKS slots
+ * and zeroes the rest.  Either way the loss value is the sum over a frame's slots. */
+int gom_frame_loss_slots(int H, int W);
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
 
 /* B frames in ONE launch sequence (the same 12 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound

@@ -274,9 +274,12 @@ def test_face_frame_inside_the_per_gaussian_kernels_matches_the_separate_face_ke
 
 @pytest.mark.parametrize("B", [1, 3])
 def test_development_switches_do_not_change_results(B, monkeypatch):
-    """GOM_LOSS_SKIP=0 (the loss kernel reads and writes the pixels of empty tiles too) and GOM_BWD_ORDER=0 (the backward's tasks in list
-    order) are A/B switches: image, loss sums and every gradient must be BITWISE those of the default path -- the skipped pixels hold
-    the background and no list entry reads their gradient; the order of the tasks is not the order of any sum."""
+    """GOM_LOSS_SKIP=0 (the loss kernel reads and writes the pixels of empty tiles too), GOM_BWD_ORDER=0 (the backward's tasks in list
+    order) and GOM_FUSE_LOSS=0 (GOM_OPT_FUSE_LOSS: the loss as a launch of its own instead of riding in k_emit / k_combine_fwd) are A/B
+    switches: image and every gradient must be BITWISE those of the default path -- the skipped pixels hold the background and no list
+    entry reads their gradient; the order of the tasks is not the order of any sum; the loss kernel and the riders share one per-pixel
+    function with every rounding spelled out (l1_pixel.hpp).  The loss SUMS are bitwise too where the launch sequence is the same
+    (GOM_BWD_ORDER) and agree to fp32 summation order where the stand-alone kernel sums strided blocks and the riders sum tiles."""
     from gomavatar_amd.pipeline import RenderStep
     img = 128
     faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
@@ -298,11 +301,17 @@ def test_development_switches_do_not_change_results(B, monkeypatch):
 
     ref_img, ref_loss, ref_grads = run()
     assert float(ref_img[..., 3, :, :].max()) > 0.5 and all(float(g.abs().max()) > 0 for g in ref_grads.values())
-    for name in ("GOM_LOSS_SKIP", "GOM_BWD_ORDER"):
+    for name in ("GOM_LOSS_SKIP", "GOM_BWD_ORDER", "GOM_FUSE_LOSS"):
         monkeypatch.setenv(name, "0")
         im, lo, gr = run()
         monkeypatch.delenv(name)
-        assert torch.equal(im, ref_img) and torch.equal(lo, ref_loss), name
+        assert torch.equal(im, ref_img), name
+        if name == "GOM_BWD_ORDER":
+            assert torch.equal(lo, ref_loss), name
+        else:   # (GOM_LOSS_SKIP=0 also takes the stand-alone kernel)
+            a, b = lo.double().sum(-2), ref_loss.double().sum(-2)
+            print(f"\n[{name}=0, B={B}] loss sums {a.flatten().tolist()} vs riders {b.flatten().tolist()}")
+            assert float(b.abs().min()) > 0 and float(((a - b).abs() / b.abs()).max()) < 2e-6, name
         for k in ref_grads:
             assert torch.equal(gr[k], ref_grads[k]), (name, k)
 
