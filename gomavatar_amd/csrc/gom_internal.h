@@ -387,6 +387,7 @@ int gom_lpips_prepare_planes(int B, int H, int W, const float *rgb, void *out32,
 int gom_lpips_prepare_im2col_planes(int B, int H, int W, const float *rgb, void *out32, size_t out_lo, void *stream);
 int gom_lpips_unprepare_col2im_planes(int B, int H, int W, const void *d_col, float *d_rgb, size_t in_lo, void *stream);
 int gom_conv1_1_image_planes(int B, int H, int W, const float *rgb, const void *wt, const float *bias, void *out, size_t out_lo, void *stream);
+int gom_conv1_1_bwd_image_planes(int B, int H, int W, const void *g, const void *wt, float *d_rgb, size_t in_lo, void *stream);
 int gom_conv1x1_planes(size_t npix, int Cin, int Cout, const void *in, const void *wt, const float *bias, void *out, int relu, size_t in_lo, size_t out_lo, void *stream);
 int gom_lpips_unprepare_planes(int B, int H, int W, int Cpad, const void *d_in, float *d_rgb, size_t in_lo, void *stream);
 int gom_lpips_layer_forward_planes(int B, int C, int HW, const void *f0, const void *f1, const float *w, float *partials, size_t f_lo, void *stream);

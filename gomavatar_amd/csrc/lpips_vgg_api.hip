@@ -256,6 +256,8 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
     }
     const void *g = nullptr;
     int pp = 0, head_blocks[5] = {0, 0, 0, 0, 0};
+    const char *benv = getenv("GOM_LPIPS_FIRST_LAYER_BWD_FUSED");   // (development switch, read per call: 0 = conv1_1's backward as a 1 x 1 convolution + the col2im kernel)
+    const bool first_bwd_fused = !(benv && benv[0] == '0');
     for (int i = 12; i >= 0; i--) {
         const int hh = hs[i], ww = wsz[i], t = kTapIndex[i];
         if (t >= 0) {
@@ -269,6 +271,10 @@ static int lp_enqueue(GomLpipsVgg *h, int B, int H, int W, const float *pred, co
         const void *mask = (i > 0 && !kPoolBefore[i]) ? h->act[0][i - 1] : nullptr;
         void *dst = h->grad[pp];
         pp ^= 1;
+        if (i == 0 && im2col && first_bwd_fused && h->cout[0] == 64) {   // the same two steps in one kernel, the im2col gradient rows in LDS (k_conv1_1_bwd_image)
+            if ((rc = gom_lpips_fold_values(B, h->head_sums, head_blocks, value_partials, stream))) return rc;
+            return gom_conv1_1_bwd_image_planes(B, H, W, g, h->w1_bwd, d_pred, h->lo_g, stream);
+        }
         if (i == 0 && im2col) {   // d(im2col rows) = W^T dY as a 1 x 1 convolution 64 -> 32; the col2im gather rides in the unprepare kernel
             if ((rc = gom_conv1x1_planes((size_t)B * hh * ww, h->cout[0], 32, g, h->w1_bwd, nullptr, dst, 0, h->lo_g, h->lo_g, stream))) return rc;
             if ((rc = gom_lpips_fold_values(B, h->head_sums, head_blocks, value_partials, stream))) return rc;

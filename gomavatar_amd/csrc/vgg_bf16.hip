@@ -887,6 +887,70 @@ __global__ void __launch_bounds__(256) k_conv1_1_image(int B, int H, int W, cons
     }
 }
 
+// conv1_1's backward-data pass straight to the image gradient (round 5): k_conv1x1_bf16<false, 2> (d(im2col rows) = W^T dY, 64 -> 32 columns) and
+// k_lpips_unprepare_col2im in ONE kernel.  A workgroup owns a 16 x 16 pixel tile: the im2col gradient rows of its 18 x 18 halo pixels come off the matrix
+// cores (the fragments and the MFMA order of the 1 x 1 kernel: (g_hi, w_hi), (g_lo, w_hi), (g_hi, w_lo) per 32 channels) and stay in LDS as fp32 -- the
+// two-kernel form rounded them to two bf16 planes in between -- and every pixel gathers column 3 t + c from the neighbour that has it as tap t, in the
+// col2im kernel's order.  70 us of two HBM streams (67 MB read, 34 MB written and read back) become one pass over the 64-channel gradient.
+template <bool X3>
+__global__ void __launch_bounds__(256) k_conv1_1_bwd_image(int B, int H, int W, const bf16_t *__restrict__ g, const bf16_t *__restrict__ wt, float *__restrict__ d_rgb,
+                                                           size_t in_lo) {
+    constexpr int NT = 2, Cout = 32, Cin = 64, PW = 18, NP = PW * PW, STR = 33;   // (33 words per halo pixel: the gather's 16 consecutive pixels hit 16 banks)
+    __shared__ float s_col[NP * STR];
+    const float scale[3] = {0.458f, 0.448f, 0.450f};
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int tx = (int)(blockIdx.x % (uint32_t)tiles_x), ty = (int)((blockIdx.x / (uint32_t)tiles_x) % (uint32_t)tiles_y), b = (int)(blockIdx.x / (uint32_t)(tiles_x * tiles_y));
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4, wave = threadIdx.x >> 6;
+    const int x0 = tx * 16 - 1, y0 = ty * 16 - 1;
+    constexpr int nsrc = Cin / 32, nchunk = X3 ? 3 * nsrc : nsrc;
+    bf16x8 afrag[nchunk][NT];   // the weights: a few KB, the same for every tile
+#pragma unroll
+    for (int cc = 0; cc < nchunk; cc++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) afrag[cc][n] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)cc * Cout + tile_row_channel<NT>(n * 16 + l15)) * 32 + kg * 8);
+    for (int t = wave; t < (NP + 15) / 16; t += 4) {
+        const int j = t * 16 + l15, ly = j / PW, lx = j - ly * PW, gy = y0 + ly, gx = x0 + lx;
+        const bool in = j < NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bf16_t *src = g + (((size_t)b * H + (in ? gy : 0)) * W + (in ? gx : 0)) * Cin + kg * 8;
+        bf16x8 hi[nsrc], lo[nsrc];
+#pragma unroll
+        for (int sc = 0; sc < nsrc; sc++) {
+            hi[sc] = in ? *reinterpret_cast<const bf16x8 *>(src + sc * 32) : bf16x8{};
+            lo[sc] = (X3 && in) ? *reinterpret_cast<const bf16x8 *>(src + in_lo + sc * 32) : bf16x8{};
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < nchunk; cc++) {
+            const int sc = X3 ? cc / 3 : cc;
+            const bf16x8 bfrag = (X3 && cc % 3 == 1) ? lo[sc] : hi[sc];
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[cc][n], bfrag, acc[n], 0, 0, 0);
+        }
+        if (j < NP) {   // the lane holds columns 8 kg + 4 n + r of halo pixel j (tile_row_channel<2>)
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_col[j * STR + 8 * kg + 4 * n + r] = acc[n][r];
+        }
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 15, py = threadIdx.x >> 4, gx = tx * 16 + px, gy = ty * 16 + py;
+    float gs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {   // pixel q = p - offset(tap) has p as its tap `tap` (an outside q left zeros: its fragments were zero)
+        const float *row = s_col + ((py + 2 - tap / 3) * PW + (px + 2 - tap % 3)) * STR + 3 * tap;
+#pragma unroll
+        for (int c = 0; c < 3; c++) gs[c] += row[c];
+    }
+    if (gx < W && gy < H) {
+        float *dst = d_rgb + 3 * (((size_t)b * H + gy) * W + gx);
+#pragma unroll
+        for (int c = 0; c < 3; c++) dst[c] = gs[c] * (2.f / scale[c]);
+    }
+}
+
 // ---- LPIPS head on NHWC bf16 taps: 16 lanes per pixel, each lane strides over the channels 8 at a time ----------------
 constexpr float kEps = 1e-10f;
 __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a DPP row
@@ -1237,6 +1301,15 @@ int gom_conv1x1_planes(size_t npix, int Cin, int Cout, const void *in, const voi
     if (Cout == 64) { if (relu) GOM_C1(true, 4); else GOM_C1(false, 4); }
     else { if (relu) GOM_C1(true, 2); else GOM_C1(false, 2); }
 #undef GOM_C1
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
+
+int gom_conv1_1_bwd_image_planes(int B, int H, int W, const void *g, const void *wt, float *d_rgb, size_t in_lo, void *stream) {
+    if (!g || !wt || !d_rgb || B <= 0 || H <= 0 || W <= 0) { gom_set_error("gom_conv1_1_bwd_image: bad arguments"); return -1; }
+    const unsigned grid = (unsigned)B * (unsigned)((H + 15) / 16) * (unsigned)((W + 15) / 16);
+    if (in_lo) hipLaunchKernelGGL((k_conv1_1_bwd_image<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, W, (const bf16_t *)g, (const bf16_t *)wt, d_rgb, in_lo);
+    else hipLaunchKernelGGL((k_conv1_1_bwd_image<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, W, (const bf16_t *)g, (const bf16_t *)wt, d_rgb, in_lo);
     GOM_LAUNCH_CHECK();
     return 0;
 }

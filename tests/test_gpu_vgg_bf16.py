@@ -223,6 +223,38 @@ def test_first_layer_from_the_image_is_bitwise_the_two_kernel_form(precision):
     assert none is None and abs(float(v_only) - res["1"][0]) <= 2e-6 * res["1"][0], (float(v_only), res["1"][0])
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 48, 80), (1, 256, 256)])
+def test_first_layer_backward_in_one_kernel_matches_the_two_kernel_form(precision, shape):
+    """k_conv1_1_bwd_image: conv1_1's backward-data pass (1 x 1 convolution 64 -> 32 im2col columns) and the col2im gather in one kernel, the
+    im2col gradient rows kept in LDS as fp32.  GOM_LPIPS_FIRST_LAYER_BWD_FUSED=0 is the two-kernel form, which rounds those rows to the
+    storage planes in between (two bf16 planes = 16 mantissa bits; one plane = 8 in the plain mode): same fragments, same MFMA order, so the
+    image gradient differs by that rounding alone -- relative L2 <= 2e-5 (bf16x3) / 6e-3 (bf16) -- and the value not at all."""
+    import os
+    from gomavatar_amd.lpips import LPIPSMatrixCore
+    B, H, W = shape
+    g = torch.Generator().manual_seed(37)
+    pred = torch.rand(B, H, W, 3, generator=g).cuda()
+    gt = (pred.cpu() + 0.2 * torch.randn(B, H, W, 3, generator=g)).clamp(0, 1).cuda()
+    mc = LPIPSMatrixCore(trunk_seed=7, precision=precision)
+    res = {}
+    try:
+        for fused in ("1", "0"):
+            os.environ["GOM_LPIPS_FIRST_LAYER_BWD_FUSED"] = fused
+            v, gr = mc.value_and_grad(pred, gt)
+            res[fused] = (float(v), gr.clone())
+    finally:
+        os.environ.pop("GOM_LPIPS_FIRST_LAYER_BWD_FUSED", None)
+    assert res["1"][0] == res["0"][0] and res["1"][0] > 0
+    a, b = res["1"][1].double(), res["0"][1].double()
+    rel = float((a - b).norm() / b.norm())
+    worst = float((a - b).abs().max() / b.abs().max())
+    print(f"\n[conv1_1 backward in one kernel, {precision}, {shape}] gradient rel L2 {rel:.2e}, worst element / max |g| {worst:.2e}")
+    assert float(b.norm()) > 0 and rel <= (2e-5 if precision == "bf16x3" else 6e-3), rel
+    v2, gr2 = mc.value_and_grad(pred, gt)
+    assert float(v2) == res["1"][0] and torch.equal(gr2, res["1"][1])   # reproducible
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512)])
 def test_pooling_inside_the_convolutions_is_bitwise_the_pool_kernel(shape):
     """The four max-pools of the trunk ride in the epilogue of the convolution in front of them (conv_store: a lane's two rows and its neighbour lane;
