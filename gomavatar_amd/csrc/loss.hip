@@ -283,3 +283,59 @@ extern "C" int gom_unpack_backward(int B, int H, int W, const float *rgb, const 
     GOM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- the tail of compute_loss (train.py:98-163): every term's partial sums -> the vector of terms, its scaled copy and the total, ONE launch ----
+// The terms leave per-workgroup partial sums (or, the L1 terms, their folded values as rows of one element); torch summed each with a launch of
+// its own, concatenated, multiplied by the coefficients and summed again: nine launches of ~4.5 us with ~2.5 us between them on a chain of ~150.
+namespace {
+#define GOM_TAIL_MAX_INPUTS 8
+struct LossTailArgs {
+    int n_inputs;
+    const float *ptr[GOM_TAIL_MAX_INPUTS];   // input i: rows[i] x cols[i] floats, row-major; its first used[i] rows are terms
+    int rows[GOM_TAIL_MAX_INPUTS], cols[GOM_TAIL_MAX_INPUTS], used[GOM_TAIL_MAX_INPUTS];
+    float pre[GOM_TAIL_MAX_INPUTS];          // term = pre * sum(row)
+};
+__global__ void __launch_bounds__(1024) k_loss_tail(LossTailArgs a, const float *__restrict__ coeffs, float *__restrict__ vec, float *__restrict__ scaled, float *__restrict__ total) {
+    __shared__ float s_scaled[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int k = 0;
+    for (int i = 0; i < a.n_inputs; i++) {
+        for (int r = 0; r < a.used[i]; r++, k++) {
+            if ((k & 15) != wave) continue;   // a wave per term, terms dealt round robin
+            const float *row = a.ptr[i] + (size_t)r * a.cols[i];
+            float acc = 0.f;
+            for (int c = lane; c < a.cols[i]; c += 64) acc += row[c];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            const float v = acc * a.pre[i];
+            if (lane == 0) { vec[k] = v; const float sc = v * coeffs[k]; scaled[k] = sc; s_scaled[k] = sc; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int j = 0; j < k; j++) t += s_scaled[j];   // in term order
+        *total = t;
+    }
+}
+}  // namespace
+
+extern "C" int gom_loss_tail(int n_inputs, const float *const *ptrs, const int32_t *rows, const int32_t *cols, const int32_t *used, const float *pre,
+                             const float *coeffs, float *vec, float *scaled, float *total, void *stream) {
+    if (n_inputs < 1 || n_inputs > GOM_TAIL_MAX_INPUTS || !ptrs || !rows || !cols || !used || !pre || !coeffs || !vec || !scaled || !total) {
+        gom_set_error("gom_loss_tail: 1..%d inputs, no null pointers", GOM_TAIL_MAX_INPUTS);
+        return -1;
+    }
+    LossTailArgs a{};
+    a.n_inputs = n_inputs;
+    int K = 0;
+    for (int i = 0; i < n_inputs; i++) {
+        if (!ptrs[i] || rows[i] < 1 || cols[i] < 1 || used[i] < 0 || used[i] > rows[i]) { gom_set_error("gom_loss_tail: bad input %d", i); return -1; }
+        a.ptr[i] = ptrs[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.used[i] = used[i]; a.pre[i] = pre[i];
+        K += used[i];
+    }
+    if (K < 1 || K > 64) { gom_set_error("gom_loss_tail: 1..64 terms"); return -1; }
+    hipLaunchKernelGGL(k_loss_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, coeffs, vec, scaled, total);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

@@ -168,3 +168,59 @@ class _Unpack(torch.autograd.Function):
 def unpack_fused(rgbs, masks, bgcolors):
     """train.py:53-55 as one kernel each way: rgbs (B,H,W,3), masks (B,H,W), bgcolors (B,3)."""
     return _Unpack.apply(rgbs, masks, bgcolors)
+
+
+class _LossTail(torch.autograd.Function):
+    """compute_loss's tail (train.py:98-163) as ONE launch each way (csrc/loss.hip gom_loss_tail): the terms' partial sums -> (vector of terms,
+    vector * coefficients, total).  inputs: 2-D fp32 tensors of partial sums; the first used[i] rows of input i are terms, term = pre[i] * row sum.
+    Backward: d input_i[r, :] = pre[i] * (g_vec + coeff * (g_scaled + g_total)) of its term, as expanded views of one small vector."""
+
+    @staticmethod
+    def forward(ctx, coeffs, used, pre, *inputs):
+        import ctypes
+        lib = _lib.load()
+        n = len(inputs)
+        keep = [x.float().contiguous() for x in inputs]
+        assert all(x.dim() == 2 for x in keep) and len(used) == n and len(pre) == n
+        K = int(sum(used))
+        dev = keep[0].device
+        vec, scaled = torch.empty(K, dtype=torch.float32, device=dev), torch.empty(K, dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in keep])
+        rows = (ctypes.c_int32 * n)(*[x.shape[0] for x in keep])
+        cols = (ctypes.c_int32 * n)(*[x.shape[1] for x in keep])
+        usd = (ctypes.c_int32 * n)(*[int(u) for u in used])
+        pr = (ctypes.c_float * n)(*[float(p) for p in pre])
+        _lib.check(lib.gom_loss_tail(n, ptrs, rows, cols, usd, pr, _lib.ptr(coeffs), _lib.ptr(vec), _lib.ptr(scaled), _lib.ptr(total), _lib.stream_ptr()))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(coeffs)
+        ctx.meta = ([tuple(x.shape) for x in keep], tuple(int(u) for u in used), tuple(float(p) for p in pre), [x.dtype for x in inputs])
+        return vec, scaled, total
+
+    @staticmethod
+    def backward(ctx, g_vec, g_scaled, g_total):
+        (coeffs,) = ctx.saved_tensors
+        shapes, used, pre, dtypes = ctx.meta
+        g = None                                        # d L / d term, per term
+        if g_total is not None:
+            g = coeffs * g_total
+        if g_scaled is not None:
+            g = coeffs * g_scaled if g is None else g + coeffs * g_scaled
+        if g_vec is not None:
+            g = g_vec if g is None else g + g_vec
+        out, k = [], 0
+        for shp, u, p, dt in zip(shapes, used, pre, dtypes):
+            if g is None:
+                out.append(None)
+            else:
+                gi = g[k:k + u] if p == 1.0 else g[k:k + u] * p
+                if u < shp[0]:                           # (rows that are no terms)
+                    gi = torch.cat([gi, gi.new_zeros(shp[0] - u)])
+                out.append(gi.unsqueeze(1).expand(shp).to(dt))
+            k += u
+        return (None, None, None, *out)
+
+
+def loss_tail(coeffs: torch.Tensor, inputs, used, pre):
+    """-> (terms (K,), terms * coeffs (K,), total ()), differentiable w.r.t. the partial-sum matrices `inputs`."""
+    return _LossTail.apply(coeffs, tuple(used), tuple(pre), *inputs)

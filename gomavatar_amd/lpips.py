@@ -290,7 +290,7 @@ class LPIPSMatrixCore:
         torch.cuda.current_stream(gt.device).wait_event(t[1])
         return True
 
-    def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True, out=None):
+    def value_and_grad(self, pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True, out=None, reduce: bool = True):
         """(mean_b LPIPS_b, d/d pred of it): ~75 kernel launches from one `gom_lpips_vgg_value_and_grad` call.
         `out=(partials, d_pred)` persistent buffers + contiguous fp32 `pred`/`gt` at stable addresses on a non-default
         stream make the call replay a captured hipGraph."""
@@ -305,22 +305,28 @@ class LPIPSMatrixCore:
         flags = (1 if (out is not None and _lib.stream_ptr() != 0) else 0) | (2 if self._target_ready(gt) else 0)
         _lib.check(self.lib.gom_lpips_vgg_value_and_grad(self._handle(), B, H, W, _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(partials), 1.0 / B,
                                                          _lib.ptr(d_pred), flags, _lib.stream_ptr()))
+        if not reduce:                                                                 # (the caller sums: value = sum(partials) / B)
+            return partials.view(1, -1), d_pred
         return (partials.sum() if B == 1 else partials.sum() * (1.0 / B)), d_pred      # mean_b of (sum over layers and blocks): one reduction
 
-    def loss(self, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor) -> torch.Tensor:
-        """Differentiable `lpips_loss` (train.py:113-117) for autograd callers."""
-        return _LpipsMC.apply(rgb_pred, rgb_gt, self)
+    def loss(self, rgb_pred: torch.Tensor, rgb_gt: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+        """Differentiable `lpips_loss` (train.py:113-117) for autograd callers.  reduce=False: the (1, 5 B GOM_LOSS_BLOCKS) partial sums,
+        value = their sum / B (train_util.compute_loss folds every term's partial sums in one launch: losses.loss_tail)."""
+        return _LpipsMC.apply(rgb_pred, rgb_gt, self, reduce)
 
 
 class _LpipsMC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, gt, model):
-        value, d_pred = model.value_and_grad(pred, gt, want_grad=pred.requires_grad)
+    def forward(ctx, pred, gt, model, reduce=True):
+        value, d_pred = model.value_and_grad(pred, gt, want_grad=pred.requires_grad, reduce=reduce)
         ctx.save_for_backward(d_pred)
-        ctx.dtype = pred.dtype
+        ctx.dtype, ctx.scale = pred.dtype, (1.0 if reduce else float(pred.shape[0]))
         return value
 
     @staticmethod
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
-        return (d_pred * g).to(ctx.dtype), None, None
+        g0 = g.reshape(-1)[0]      # (a scalar, or the expanded gradient of the partial sums: every element is dL/d sum = dL/d value / B)
+        if ctx.scale != 1.0:       # d_pred is d value / d pred
+            g0 = g0 * ctx.scale
+        return (d_pred * g0).to(ctx.dtype), None, None, None

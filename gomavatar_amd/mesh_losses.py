@@ -44,7 +44,7 @@ class MeshLossTopology:
 
 class _Laplacian(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, lt: MeshLossTopology):
+    def forward(ctx, verts, lt: MeshLossTopology, reduce=True):
         lib = _lib.load()
         v = verts.float().contiguous()
         dirs = torch.empty_like(v)
@@ -52,21 +52,21 @@ class _Laplacian(torch.autograd.Function):
         _lib.check(lib.gom_mesh_laplacian(v.shape[0], _lib.ptr(v), _lib.ptr(lt.nbr_off), _lib.ptr(lt.nbr_idx), _lib.ptr(dirs), _lib.ptr(partials), _lib.stream_ptr()))
         ctx.save_for_backward(dirs)
         ctx.lt = lt
-        return partials.sum()
+        return partials.sum() if reduce else partials.view(1, -1)   # (reduce=False: the caller sums -- train_util.compute_loss folds every term in one launch)
 
     @staticmethod
     def backward(ctx, g):
         (dirs,) = ctx.saved_tensors
         lt, lib = ctx.lt, _lib.load()
-        go = g.float().reshape(1).contiguous()
+        go = g.reshape(-1)[:1].float().contiguous()   # (a scalar, or the expanded gradient of the partial sums: every element is dL/d loss)
         d = torch.empty_like(dirs)
         _lib.check(lib.gom_mesh_laplacian_backward(dirs.shape[0], _lib.ptr(dirs), _lib.ptr(lt.nbr_off), _lib.ptr(lt.nbr_idx), _lib.ptr(go), _lib.ptr(d), _lib.stream_ptr()))
-        return d, None
+        return d, None, None
 
 
 class _NormalConsistency(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, topo, lt: MeshLossTopology):
+    def forward(ctx, verts, topo, lt: MeshLossTopology, reduce=True):
         lib = _lib.load()
         v = verts.float().contiguous()
         pg = torch.empty((max(lt.n_npairs, 1), 2, 3), dtype=torch.float32, device=v.device)
@@ -74,24 +74,24 @@ class _NormalConsistency(torch.autograd.Function):
         _lib.check(lib.gom_mesh_normal_consistency(lt.n_npairs, _lib.ptr(lt.npairs), _lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(pg), _lib.ptr(partials), _lib.stream_ptr()))
         ctx.save_for_backward(v, pg)
         ctx.topo, ctx.lt = topo, lt
-        return partials.sum()
+        return partials.sum() if reduce else partials.view(1, -1)
 
     @staticmethod
     def backward(ctx, g):
         v, pg = ctx.saved_tensors
         topo, lt, lib = ctx.topo, ctx.lt, _lib.load()
-        go = g.float().reshape(1).contiguous()
+        go = g.reshape(-1)[:1].float().contiguous()   # (a scalar, or the expanded gradient of the partial sums: every element is dL/d loss)
         scratch = torch.empty((topo.n_faces, 9), dtype=torch.float32, device=v.device)
         d = torch.empty_like(v)
         _lib.check(lib.gom_mesh_normal_consistency_backward(v.shape[0], topo.n_faces, lt.n_npairs, _lib.ptr(lt.nfp_off), _lib.ptr(lt.nfp_idx), _lib.ptr(pg), _lib.ptr(v),
                                                             _lib.ptr(topo.faces), _lib.ptr(topo.csr_off), _lib.ptr(topo.csr_idx), _lib.ptr(go), _lib.ptr(scratch),
                                                             _lib.ptr(d), _lib.stream_ptr()))
-        return d, None, None
+        return d, None, None, None
 
 
 class _ColorConsistency(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, colors_3F, lt: MeshLossTopology):
+    def forward(ctx, colors_3F, lt: MeshLossTopology, reduce=True):
         lib = _lib.load()
         c = colors_3F.float().contiguous()
         F = c.shape[1]
@@ -100,27 +100,28 @@ class _ColorConsistency(torch.autograd.Function):
         _lib.check(lib.gom_mesh_color_consistency(lt.n_pairs, F, _lib.ptr(lt.pairs), _lib.ptr(c), _lib.ptr(sign), _lib.ptr(partials), _lib.stream_ptr()))
         ctx.save_for_backward(sign)
         ctx.lt, ctx.F = lt, F
-        return partials.sum()
+        return partials.sum() if reduce else partials.view(1, -1)
 
     @staticmethod
     def backward(ctx, g):
         (sign,) = ctx.saved_tensors
         lt, lib = ctx.lt, _lib.load()
-        go = g.float().reshape(1).contiguous()
+        go = g.reshape(-1)[:1].float().contiguous()   # (a scalar, or the expanded gradient of the partial sums: every element is dL/d loss)
         d = torch.empty((3, ctx.F), dtype=torch.float32, device=sign.device)
         _lib.check(lib.gom_mesh_color_consistency_backward(ctx.F, lt.n_pairs, _lib.ptr(lt.fp_off), _lib.ptr(lt.fp_idx), _lib.ptr(sign), _lib.ptr(go), _lib.ptr(d),
                                                            _lib.stream_ptr()))
-        return d, None
+        return d, None, None
 
 
-def laplacian_smoothing(verts_N3: torch.Tensor, lt: MeshLossTopology) -> torch.Tensor:
-    return _Laplacian.apply(verts_N3, lt)
+def laplacian_smoothing(verts_N3: torch.Tensor, lt: MeshLossTopology, reduce: bool = True) -> torch.Tensor:
+    """reduce=False: the (1, GOM_LOSS_BLOCKS) partial sums whose sum is the loss (for losses.loss_tail)."""
+    return _Laplacian.apply(verts_N3, lt, reduce)
 
 
-def normal_consistency(verts_N3: torch.Tensor, topo, lt: MeshLossTopology) -> torch.Tensor:
-    return _NormalConsistency.apply(verts_N3, topo, lt)
+def normal_consistency(verts_N3: torch.Tensor, topo, lt: MeshLossTopology, reduce: bool = True) -> torch.Tensor:
+    return _NormalConsistency.apply(verts_N3, topo, lt, reduce)
 
 
-def color_consistency(colors_3F: torch.Tensor, lt: MeshLossTopology) -> torch.Tensor:
+def color_consistency(colors_3F: torch.Tensor, lt: MeshLossTopology, reduce: bool = True) -> torch.Tensor:
     """colors in the (3, F) parameter layout (appearance_module.py:14)."""
-    return _ColorConsistency.apply(colors_3F, lt)
+    return _ColorConsistency.apply(colors_3F, lt, reduce)

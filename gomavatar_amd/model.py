@@ -337,6 +337,7 @@ class Model(nn.Module):
         # rendering (no autograd) only: mesh branch and splat rasterizer on two streams.  Shortens a frame's latency inside a
         # captured graph (0.71 -> 0.62 ms at 55k faces, 1.39 -> 1.09 ms at 220k); costs host time when launched eagerly: off by default
         self.overlap_branches = False
+        self.overlap_branches_train = os.environ.get("GOM_OVERLAP_BRANCHES_TRAIN", "0") == "1"   # (experiment) the same under autograd: the backward follows the forward's streams
         self._ones = None
         self._side_stream = None
         # the shading of the pixels under the mesh as one native op (csrc/mlp.hip: gom_shade_*); False: the torch selection around the MLP kernels
@@ -490,7 +491,7 @@ class Model(nn.Module):
         # The mesh branch (vertex normals -> normal map + silhouette -> shadow MLP) and the splat rasterizer only share their
         # input; without autograd (rendering) they are issued on two streams: both are chains of single-frame kernels that leave
         # most of the GPU idle, and side by side the frame costs the longer chain instead of the sum.
-        overlap = self.overlap_branches and not torch.is_grad_enabled() and xyz.is_cuda
+        overlap = xyz.is_cuda and (self.overlap_branches_train if torch.is_grad_enabled() else self.overlap_branches)
         if overlap:
             cur = torch.cuda.current_stream()
             if self._side_stream is None:

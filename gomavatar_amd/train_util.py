@@ -3,6 +3,7 @@ the three mesh regularisers it calls (PyTorch3D `mesh_laplacian_smoothing(method
 `mesh_normal_consistency`, utils/network_util.py `mesh_color_consistency`) written against `model.SimpleMesh`."""
 from __future__ import annotations
 
+import os
 import torch
 import torch.nn.functional as F
 
@@ -17,13 +18,13 @@ def unpack(rgbs, masks, bgcolors):
     return rgbs * masks.unsqueeze(-1) + bgcolors[:, None, None, :] * (1 - masks).unsqueeze(-1)
 
 
-def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
+def mesh_laplacian_smoothing(mesh, reduce: bool = True) -> torch.Tensor:
     """utils/network_util.py:669-792 (uniform): mean over vertices of || (1/deg) sum_neighbours v_j - v_i ||^2
     (`loss.norm(dim=1) ** 2` then the un-weighted mean, :789-792); no gradient through the Laplacian matrix."""
     v, e = mesh.verts_packed(), mesh.edges_packed()
     if v.is_cuda and getattr(mesh, "loss_topo", None) is not None:
         from .mesh_losses import laplacian_smoothing
-        return laplacian_smoothing(v, mesh.loss_topo)
+        return laplacian_smoothing(v, mesh.loss_topo, reduce)
     N = v.shape[0]
     deg = torch.zeros(N, device=v.device, dtype=v.dtype).index_add(0, e[:, 0], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
     deg = deg.index_add(0, e[:, 1], torch.ones(e.shape[0], device=v.device, dtype=v.dtype))
@@ -32,14 +33,14 @@ def mesh_laplacian_smoothing(mesh) -> torch.Tensor:
     return (lap.norm(dim=1) ** 2).mean()
 
 
-def mesh_normal_consistency(mesh, face_connectivity=None) -> torch.Tensor:
+def mesh_normal_consistency(mesh, face_connectivity=None, reduce: bool = True) -> torch.Tensor:
     """PyTorch3D mesh_normal_consistency(mesh) as called at train.py:149: 1 - cos between the normals of EVERY pair of faces
     sharing an edge (cosine_similarity eps 1e-8), averaged over the pairs.  `face_connectivity` (optional, host path only)
     overrides the pair list; the default is every edge-adjacent pair of the mesh (`mesh.normal_pairs`)."""
     v, f = mesh.verts_packed(), mesh.faces_packed()
     if v.is_cuda and getattr(mesh, "loss_topo", None) is not None and face_connectivity is None:
         from .mesh_losses import normal_consistency
-        return normal_consistency(v, mesh.topo, mesh.loss_topo)
+        return normal_consistency(v, mesh.topo, mesh.loss_topo, reduce)
     pairs = face_connectivity if face_connectivity is not None else mesh.normal_pairs
     n = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
     a, b = n[pairs[:, 0]], n[pairs[:, 1]]
@@ -47,11 +48,11 @@ def mesh_normal_consistency(mesh, face_connectivity=None) -> torch.Tensor:
     return (1.0 - (a * b).sum(1) / torch.sqrt(w.clamp_min(1e-16))).mean()
 
 
-def mesh_color_consistency(colors, face_connectivity, loss_topo=None) -> torch.Tensor:
+def mesh_color_consistency(colors, face_connectivity, loss_topo=None, reduce: bool = True) -> torch.Tensor:
     """network_util.py:795-799: mean absolute colour difference of edge-adjacent faces."""
     if colors.is_cuda and loss_topo is not None:
         from .mesh_losses import color_consistency
-        return color_consistency(colors.T, loss_topo)      # (F,3) view of the (3,F) parameter -> its own layout
+        return color_consistency(colors.T, loss_topo, reduce)      # (F,3) view of the (3,F) parameter -> its own layout
     return (colors[face_connectivity[:, 0]] - colors[face_connectivity[:, 1]]).abs().mean()
 
 
@@ -84,37 +85,59 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
         else:
             dil = F.max_pool2d(mask_gt.unsqueeze(1), kernel_size=k, stride=1, padding=k // 2).squeeze(1)
             put("normal_mask", torch.mean(torch.abs(outputs["normal_mask"] - dil)), loss_cfg.normal.coeff_mask)
+    # fused: every term hands over its PARTIAL sums ((1, n) matrices; reduce=False) and ONE launch folds them all (losses.loss_tail) instead of a
+    # reduction per term, a concatenation, a multiply and a final sum (nine launches of ~4.5 us + ~2.5 us between launches, and their backward)
+    tail = fused and os.environ.get("GOM_LOSS_TAIL", "1") != "0"   # (development switch: 0 = a reduction per term + cat + multiply + sum)
+    mats = {}        # name -> (matrix of partial sums, factor in front of its sum)
+
+    def term(name, fn, coeff, pre=1.0):
+        v = fn(not tail)
+        if tail and torch.is_tensor(v) and v.dim() == 2:
+            mats[name] = (v, pre)
+            v = None
+        put(name, v, coeff)
     if lpips_func is not None and _get(loss_cfg, "lpips.coeff", 1.0) > 0:
         if hasattr(lpips_func, "loss"):
-            lp = lpips_func.loss(rgb_pred, rgb_gt)
+            term("lpips", lambda r: lpips_func.loss(rgb_pred, rgb_gt, reduce=r), _get(loss_cfg, "lpips.coeff", 1.0), 1.0 / rgb_pred.shape[0])
         else:
-            lp = torch.mean(lpips_func(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1))
-        put("lpips", lp, _get(loss_cfg, "lpips.coeff", 1.0))
+            put("lpips", torch.mean(lpips_func(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1)), _get(loss_cfg, "lpips.coeff", 1.0))
     if _get(loss_cfg, "laplacian.coeff_canonical", 0.0) > 0:
-        put("laplacian_canoincal", mesh_laplacian_smoothing(outputs["mesh_canonical"]), loss_cfg.laplacian.coeff_canonical)
+        term("laplacian_canoincal", lambda r: mesh_laplacian_smoothing(outputs["mesh_canonical"], reduce=r), loss_cfg.laplacian.coeff_canonical)
     if _get(loss_cfg, "laplacian.coeff_observation", 0.0) > 0:
-        put("laplacian_observation", mesh_laplacian_smoothing(outputs["mesh"]), loss_cfg.laplacian.coeff_observation)
+        term("laplacian_observation", lambda r: mesh_laplacian_smoothing(outputs["mesh"], reduce=r), loss_cfg.laplacian.coeff_observation)
     if _get(loss_cfg, "normal.coeff_consist", 0.0) > 0:
-        put("normal_consist", mesh_normal_consistency(outputs["mesh"]), loss_cfg.normal.coeff_consist)      # train.py:149: all edge-adjacent pairs
+        term("normal_consist", lambda r: mesh_normal_consistency(outputs["mesh"], reduce=r), loss_cfg.normal.coeff_consist)      # train.py:149: all edge-adjacent pairs
     if _get(loss_cfg, "color_consist.coeff", 0.0) > 0:
-        put("color_consist", mesh_color_consistency(outputs["colors"], outputs["face_connectivity"], getattr(outputs.get("mesh"), "loss_topo", None)),
-            loss_cfg.color_consist.coeff)
+        term("color_consist", lambda r: mesh_color_consistency(outputs["colors"], outputs["face_connectivity"], getattr(outputs.get("mesh"), "loss_topo", None), reduce=r),
+             loss_cfg.color_consist.coeff)
     if not fused:
         order = sorted(range(len(names)), key=lambda i: _REF_ORDER.index(names[i]))
         losses = {names[i]: {"unscaled": values[i], "scaled": values[i] * coeffs[i]} for i in order}
         return sum(item["scaled"] for item in losses.values()), losses
-    # One vector of all terms: total = (vector * coefficients).sum() is three launches instead of a multiply and an add per term
-    # (and as many again backward); the dict entries are views into it, still differentiable.
-    rest = [v.reshape(1) for v in values if v is not None]
-    vec = torch.cat([l1[:3 if want_nm else 2]] + rest) if rest else l1[:3 if want_nm else 2]
-    key = (tuple(coeffs), vec.device)
+    key = (tuple(coeffs), rgb_pred.device)
     cvec = _COEFF_CACHE.get(key)
     if cvec is None:
         if len(_COEFF_CACHE) > 64:
             _COEFF_CACHE.clear()
-        cvec = _COEFF_CACHE[key] = torch.tensor(coeffs, dtype=vec.dtype, device=vec.device)
-    scaled = vec * cvec
+        cvec = _COEFF_CACHE[key] = torch.tensor(coeffs, dtype=torch.float32, device=rgb_pred.device)
     order = sorted(range(len(names)), key=lambda i: _REF_ORDER.index(names[i]))      # the reference's dict order
+    n_l1 = 3 if want_nm else 2                                                        # (the L1 terms are the first entries of `names`)
+    if all(v is None for v in values):
+        from .losses import loss_tail
+        rest = [mats[n] for n in names[n_l1:]]
+        vec, scaled, total = loss_tail(cvec, [l1.unsqueeze(1)] + [m for m, _ in rest], [n_l1] + [1] * len(rest), [1.0] + [p for _, p in rest])
+        losses = {names[i]: {"unscaled": vec[i], "scaled": scaled[i]} for i in order}
+        return total, losses
+    # a term came as a scalar (a host path, a callable LPIPS): one vector of all terms, total = (vector * coefficients).sum() -- three launches
+    # instead of a multiply and an add per term (and as many again backward); the dict entries are views into it, still differentiable
+    rest = []
+    for n, v in zip(names[n_l1:], values[n_l1:]):
+        if v is None:
+            m, p = mats[n]
+            v = m.sum() if p == 1.0 else m.sum() * p
+        rest.append(v.reshape(1))
+    vec = torch.cat([l1[:n_l1]] + rest) if rest else l1[:n_l1]
+    scaled = vec * cvec
     losses = {names[i]: {"unscaled": vec[i], "scaled": scaled[i]} for i in order}
     return scaled.sum(), losses
 
@@ -128,6 +151,18 @@ def update_lr(optimizer, iter_step, train_cfg) -> None:
         param_group["lr"] = getattr(train_cfg.lr, param_group["name"]) * decay_value
 
 
+_ONES = {}
+
+
+def backward_from(loss: torch.Tensor) -> None:
+    """loss.backward() with the seed gradient (a 1 of the loss's shape) kept per device instead of filled per iteration (one launch less)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones_like(loss)
+    loss.backward(gradient=one)
+
+
 def forward_backward(model, data, train_cfg, n_iters, lpips_func=None, random_bgcolor: bool = True):
     """train.py:317-338: forward -> unpack -> compute_loss -> backward (gradients accumulate into `.grad`).  Returns (loss, loss_items, rgb, mask)."""
     rgb, mask, outputs = model(data["K"], data["E"], data["cnl_gtfms"], data["dst_Rs"], data["dst_Ts"], dst_posevec=data.get("dst_posevec"),
@@ -135,7 +170,7 @@ def forward_backward(model, data, train_cfg, n_iters, lpips_func=None, random_bg
     if random_bgcolor:
         rgb = unpack(rgb, mask, data["bgcolor"])
     loss, loss_items = compute_loss(rgb, mask, outputs, data["target_rgbs"], data["target_masks"], train_cfg.losses, data, n_iters, lpips_func=lpips_func)
-    loss.backward()
+    backward_from(loss)
     return loss, loss_items, rgb, mask
 
 
@@ -207,7 +242,7 @@ class GraphedTrainStep:
                                       i_iter=self.i_iter)
         total, _ = compute_loss(unpack(rgbs, masks, fr["bgcolor"]), masks, out, fr["target_rgbs"], fr["target_masks"], self.loss_cfg,
                                 i_iter=self.i_iter, lpips_func=self.lpips)
-        total.backward()
+        backward_from(total)
         self.opt.step()
         return total.detach()
 

@@ -207,6 +207,12 @@ int gom_l1_terms_forward(int H, int W, const float *rgb, const float *rgb_gt, co
 int gom_l1_terms_backward(int H, int W, const float *rgb, const float *rgb_gt, const float *mask, const float *mask_gt,
                           const float *normal_mask, int dil_k, const float *g3, float *d_rgb, float *d_mask, float *d_normal_mask, void *stream);
 
+/* The tail of compute_loss (train.py:98-163) in one launch: input i is a rows[i] x cols[i] matrix of partial sums (device, row-major) whose first
+ * used[i] rows are loss terms: term = pre[i] * sum(row).  coeffs (device, one per term, in input order) -> vec[k] = the terms, scaled[k] =
+ * coeffs[k] * vec[k], total = sum of scaled in term order.  Up to 8 inputs, 64 terms; ptrs / rows / cols / used / pre are host arrays. */
+int gom_loss_tail(int n_inputs, const float *const *ptrs, const int32_t *rows, const int32_t *cols, const int32_t *used, const float *pre,
+                  const float *coeffs, float *vec, float *scaled, float *total, void *stream);
+
 /* ---- the shadow MLP at its default shape (shadow_module.py:66-117 with mlp_depth 3: D0 -> H -> H -> H -> 1, ReLU x 3, sigmoid),
  * D0, H <= 128, nn.Linear weight layout [out][in].  forward: x [n][D0] -> h1, h2, h3 [n][H] (post-ReLU, kept for the backward) and
  * out [n].  backward: g [n] = dL/d out -> dz4 [n], dz3, dz2, dz1 [n][H] (the dY of every layer: feed them to gom_linear_wgrad with
