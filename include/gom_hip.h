@@ -404,7 +404,7 @@ int gom_ssim(int H, int W, int C, const float *img0, const float *img1, int win,
  * The per-frame hot path as ONE call: FK -> LBS -> per-face Gaussians -> splat forward (4 channels) -> fused
  * unpack + L1 losses (forward and backward) -> splat backward -> face backward -> vertex gather + LBS backward
  * (reference models/model.py:213-250, renderer/gaussian.py:22-100, train.py:53-55,101-111 and their autograd
- * backward).  12 kernel launches (13 for a batch: + the frame sum; 16 / 17 with GOM_OPT_FUSE_FACE 0) enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
+ * backward).  11 kernel launches (12 for a batch: + the frame sum; one more with GOM_OPT_FUSE_LOSS 0, four more with GOM_OPT_FUSE_FACE 0) enqueued back to back from native code (the kinematic chain runs inside the skinning launch, the
  * per-face frame, the depth histogram and the frame's backward inside the rasterizer's per-Gaussian kernels: GOM_OPT_FUSE_FACE); every pointer is caller-owned device
  * memory, `work_*` are scratch tensors of the stated sizes. */
 typedef struct GomFrame {
@@ -449,7 +449,7 @@ typedef struct GomFrame {
 int gom_frame_loss_slots(int H, int W);
 int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, void *stream);
 
-/* B frames in ONE launch sequence (the same 12 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
+/* B frames in ONE launch sequence (the same 11 kernels, each over all B frames, + one frame sum): the launch-latency- and tail-bound
  * kernels of a single 512x512 frame become B times larger launches, which is what fills 256 CUs.  The reference has
  * batch size 1 (train.py:309-349); a batch here is B frames whose gradients are SUMMED, i.e. one optimizer step on B
  * frames, the same semantics as the frame-parallel all-reduce across GPUs.
