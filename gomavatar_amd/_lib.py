@@ -71,6 +71,7 @@ SIGNATURES = {
     "gom_unpack_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 7),
     "gom_l1_terms_forward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 3),
     "gom_loss_tail": (c_int, [c_int] + [c_void_p] * 10),
+    "gom_camera_update_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "gom_l1_terms_backward": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
     "gom_mlp3_forward": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 14),
     "gom_mlp3_wgrad": (c_int, [c_int64, c_int, c_int] + [c_void_p] * 18),

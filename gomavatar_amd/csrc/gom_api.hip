@@ -615,3 +615,55 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     }
     return 0;
 }
+
+// ---- the camera block of renderer/gaussian.py:28-51 written into a DEVICE GomCamera by one launch -------------------------------------------------
+// K (3,3) and E (4,4) are device tensors in the reference's interface; its forward reads them back with .item() (a stream synchronisation per
+// frame), the package's device-side form was ~40 small tensor launches.  One thread does gomavatar_amd.camera.camera_block's arithmetic in its
+// order and precision -- fp64 for K's entries, tan(atan(.)) in fp64 rounded once to fp32, fp32 products summed in k order without contraction
+// (a row of K_ndc has at most two non-zeros: adding the zero products is exact) -- so the struct is the host path's, bit for bit on the
+// reference's golden camera (tests/test_camera.py).
+namespace {
+__global__ void __launch_bounds__(64) k_camera_update(const float *__restrict__ K, const float *__restrict__ E, int H, int W, double z_a, double z_b,
+                                                      const float *__restrict__ bg, GomCamera *__restrict__ cam) {
+    if (threadIdx.x != 0) return;
+    const double fx = K[0], fy = K[4], px = K[2], py = K[5];
+    cam->H = H; cam->W = W;
+    cam->tanfovx = (float)tan(atan((double)W / (2.0 * fx)));
+    cam->tanfovy = (float)tan(atan((double)H / (2.0 * fy)));
+    float Kn[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) Kn[i][j] = 0.f;
+    Kn[0][0] = (float)(2.0 * fx / (double)W); Kn[0][2] = (float)((2.0 * px - (double)W) / (double)W);
+    Kn[1][1] = (float)(2.0 * fy / (double)H); Kn[1][2] = (float)((2.0 * py - (double)H) / (double)H);
+    Kn[2][2] = (float)z_a; Kn[2][3] = (float)z_b;
+    Kn[3][2] = 1.f;
+    float view[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) view[i][k] = E[4 * k + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float acc = __fmul_rn(view[i][0], Kn[j][0]);
+#pragma unroll
+            for (int k = 1; k < 4; k++) acc = __fadd_rn(acc, __fmul_rn(view[i][k], Kn[j][k]));
+            cam->view[4 * i + j] = view[i][j];
+            cam->proj[4 * i + j] = acc;
+        }
+    if (bg) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) cam->bg[c] = bg[c];
+    }
+}
+}  // namespace
+
+extern "C" int gom_camera_update_device(const float *K, const float *E, int H, int W, double znear, double zfar, const float *bg4, GomCamera *cam_device, void *stream) {
+    if (!K || !E || !cam_device || H <= 0 || W <= 0 || !(zfar > znear)) { gom_set_error("gom_camera_update_device: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_camera_update, dim3(1), dim3(64), 0, (hipStream_t)stream, K, E, H, W, zfar / (zfar - znear), -zfar * znear / (zfar - znear), bg4, cam_device);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}

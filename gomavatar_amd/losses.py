@@ -116,6 +116,7 @@ class _Compose(torch.autograd.Function):
         rgb = torch.empty_like(albedo) if sh is not None else None
         _lib.check(lib.gom_compose_forward(H, W, _lib.ptr(im), _lib.ptr(sh), _lib.ptr(albedo), _lib.ptr(mask), _lib.ptr(rgb), _lib.stream_ptr()))
         ctx.save_for_backward(im, sh)
+        ctx.set_materialize_grads(False)    # (an output nobody differentiates -- the albedo -- arrives as None, not as a zero image filled for it)
         ctx.shade_shape = None if shade is None else shade.shape
         if rgb is None:
             return albedo, mask

@@ -334,6 +334,10 @@ class Model(nn.Module):
         self.capture_safe = False
         self.shadow_capacity = None          # pixels the shadow MLP is evaluated on in capture_safe mode (default H*W/3)
         self._dcam = None
+        # the camera block on the device (one launch, no host read of K / E) whenever K and E are fp32 device tensors; GOM_DEVICE_CAMERA=0: the host
+        # camera (the reference's .item() reads).  The same bits either way (tests/test_camera.py).
+        self.device_camera = os.environ.get("GOM_DEVICE_CAMERA", "1") != "0"
+        self._bg4 = None
         # rendering (no autograd) only: mesh branch and splat rasterizer on two streams.  Shortens a frame's latency inside a
         # captured graph (0.71 -> 0.62 ms at 55k faces, 1.39 -> 1.09 ms at 220k); costs host time when launched eagerly: off by default
         self.overlap_branches = False
@@ -408,10 +412,11 @@ class Model(nn.Module):
         tanfov, view, proj = camera_block(K[0].detach().cpu(), E[0].detach().cpu(), H, W)      # host camera: the reference's own .item() reads
         return _lib.make_camera(H, W, float(tanfov[0]), float(tanfov[1]), view.reshape(-1).numpy(), proj.reshape(-1).numpy(), list(bg4))
 
-    def _mesh_branch(self, vertices_observation, K, E):
-        """model.py:270-282: camera-space vertex normals, normal map + soft silhouette, shading = 2 * shadow_module(normal)."""
+    def _mesh_branch(self, vertices_observation, K, E, vo_T=None):
+        """model.py:270-282: camera-space vertex normals, normal map + soft silhouette, shading = 2 * shadow_module(normal).
+        vo_T: the (N, 3) contiguous copy of the posed vertices when the caller has one (training: the mesh regularisers read the same copy)."""
         # normals, normal map, silhouette (model.py:270-273)
-        vn = vertex_normals(vertices_observation.T, self.topo, rotation=E[0, :3, :3])      # (E[:3,:3] @ vn.T).T inside the kernel
+        vn = vertex_normals(vertices_observation.T if vo_T is None else vo_T, self.topo, rotation=E[0, :3, :3])      # (E[:3,:3] @ vn.T).T inside the kernel
         normal, normal_mask = self.normal_renderer(vertices_observation.unsqueeze(0), vn[None], K, E, faces=self.faces)
         if self.shadow_module is not None:
             Bn, H, W, _ = normal.shape
@@ -486,11 +491,19 @@ class Model(nn.Module):
             if self._dcam is None or (self._dcam.H, self._dcam.W) != (self.img_size[1], self.img_size[0]):
                 self._dcam = DeviceCamera(self.img_size[1], self.img_size[0], xyz.device)
             cam = self._dcam.update(K[0], E[0])               # 160 bytes rewritten on the device
+        elif (self.device_camera and K.is_cuda and K.dtype == torch.float32 and E.dtype == torch.float32 and K[0].is_contiguous() and E[0].is_contiguous()):
+            # the camera block formed ON the device by one launch, into 160 bytes of this call's own: the reference reads K and E back with .item()
+            # (gaussian.py:30-31) -- a stream synchronisation per frame, behind which the device waits for the host to enqueue the frame
+            if self._bg4 is None or self._bg4.device != K.device:
+                self._bg4 = torch.zeros(4, device=K.device)   # bg_col = [bg_feat (zeros), 0] (model.py:243)
+            cam = DeviceCamera.fresh(self.img_size[1], self.img_size[0], K[0], E[0], self._bg4)
         else:
             cam = self._camera(K, E, (0.0, 0.0, 0.0, 0.0))    # bg_col = [bg_feat (zeros), 0] (model.py:243)
         # The mesh branch (vertex normals -> normal map + silhouette -> shadow MLP) and the splat rasterizer only share their
         # input; without autograd (rendering) they are issued on two streams: both are chains of single-frame kernels that leave
         # most of the GPU idle, and side by side the frame costs the longer chain instead of the sum.
+        # ONE contiguous (N, 3) copy of the posed (3, N) vertices for the vertex normals AND the mesh regularisers of compute_loss (each made its own)
+        vo_T = vertices_observation.T.contiguous() if self.training else None
         overlap = xyz.is_cuda and (self.overlap_branches_train if torch.is_grad_enabled() else self.overlap_branches)
         if overlap:
             cur = torch.cuda.current_stream()
@@ -498,7 +511,7 @@ class Model(nn.Module):
                 self._side_stream = torch.cuda.Stream()
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
-                normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E)
+                normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E, vo_T)
         img, _ = rasterize(xyz, cov6, feat, opacity, cam)
         if overlap:
             cur.wait_stream(self._side_stream)
@@ -506,16 +519,16 @@ class Model(nn.Module):
                 if t_ is not None:
                     t_.record_stream(cur)
         else:
-            normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E)
+            normal, normal_mask, shadings = self._mesh_branch(vertices_observation, K, E, vo_T)
         # albedos = img[:3] as (1,H,W,3), masks = img[3], rgbs = albedos * shadings: one kernel each way (csrc/loss.hip)
         albedos, masks, rgbs = compose(img, shadings)
         outputs = {}
         if self.training:
-            vo, vc = vertices_observation.T, vertices_canonical.T
+            vo, vc = vo_T, vertices_canonical.T
             outputs.update(colors=self.appearance.T, face_connectivity=self.face_connectivity,
                            mesh=SimpleMesh(vo, self.faces, self.edges, self.topo, self.loss_topo, self.normal_pairs),
                            mesh_canonical=SimpleMesh(vc, self.faces, self.edges, self.topo, self.loss_topo, self.normal_pairs),
                            target_edge_length=self.target_edge_length,
                            albedo=albedos[0],
-                           normal=normal, normal_mask=normal_mask[..., 0] if normal_mask is not None else None, shadow=shadings)
+                           normal=normal, normal_mask=normal_mask.squeeze(-1) if normal_mask is not None else None, shadow=shadings)   # (squeeze: a view's backward is a view; a select's is a zero fill + a copy)
         return rgbs, masks, outputs

@@ -170,8 +170,29 @@ class DeviceCamera:
         self.data[:2] = torch.tensor([self.H, self.W], dtype=torch.int32).view(torch.float32).to(device)
         self._bg_host = (0.0, 0.0, 0.0, 0.0)     # what data[36:40] currently holds, when it came from a host tuple
 
+    @classmethod
+    def fresh(cls, H: int, W: int, K: torch.Tensor, E: torch.Tensor, bg4: torch.Tensor, znear: float = 0.001, zfar: float = 100.0) -> "DeviceCamera":
+        """A camera of its own for ONE forward / backward pair (a later forward cannot overwrite it under an earlier backward): 160 uninitialised bytes
+        that one launch fills completely (H, W, tanfov, view, proj, bg).  K (3,3), E (4,4), bg4 (4,): contiguous fp32 device tensors."""
+        self = cls.__new__(cls)
+        self.H, self.W = int(H), int(W)
+        self.data = torch.empty(40, dtype=torch.float32, device=K.device)
+        self._bg_host = None
+        _lib.check(_lib.load().gom_camera_update_device(_lib.ptr(K.detach()), _lib.ptr(E.detach()), self.H, self.W, float(znear), float(zfar), _lib.ptr(bg4),
+                                                        _lib.ptr(self.data), _lib.stream_ptr()))
+        return self
+
     def update(self, K: torch.Tensor, E: torch.Tensor, bg=(0.0, 0.0, 0.0, 0.0), znear: float = 0.001, zfar: float = 100.0) -> "DeviceCamera":
         """K (3,3), E (4,4) device tensors -> tanfov, viewmatrix = E^T, projmatrix = E^T K_ndc^T (gaussian.py:28-51)."""
+        if (K.is_cuda and K.dtype == torch.float32 and E.dtype == torch.float32 and K.is_contiguous() and E.is_contiguous() and tuple(K.shape) == (3, 3)
+                and tuple(E.shape) == (4, 4) and (torch.is_tensor(bg) or tuple(float(b) for b in bg) == self._bg_host)):
+            # ONE launch (csrc/gom_api.hip k_camera_update: camera_block's arithmetic in its order and precision) instead of ~40 small tensor launches
+            bgt = bg.detach().float().reshape(-1).contiguous() if torch.is_tensor(bg) else None
+            if bgt is not None:
+                self._bg_host = None
+            _lib.check(_lib.load().gom_camera_update_device(_lib.ptr(K.detach()), _lib.ptr(E.detach()), self.H, self.W, float(znear), float(zfar), _lib.ptr(bgt),
+                                                            _lib.ptr(self.data), _lib.stream_ptr()))
+            return self
         from .camera import camera_block
         tanfov, view, proj = camera_block(K, E, self.H, self.W, znear, zfar)      # the one camera function of the package, on the device
         self.data[2:4] = tanfov
@@ -216,6 +237,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.opac_shape = opacities.shape
         ctx.save_for_backward(means3D_c, colors_c, opac_c, cov_c)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)    # (no zero tensor filled for the radii's "gradient")
         return out, radii
 
     @staticmethod
@@ -223,6 +245,8 @@ class _Rasterize(torch.autograd.Function):
         lib = _lib.load()
         means3D, colors, opac, cov6 = ctx.saved_tensors
         P, C = colors.shape
+        if g_out is None:
+            g_out = torch.zeros((C, ctx.cam.H, ctx.cam.W), dtype=torch.float32, device=means3D.device)
         g = g_out.contiguous()
         d_means = torch.empty_like(means3D)
         d_cov = torch.empty_like(cov6)
@@ -251,8 +275,8 @@ def rasterize(means3D: torch.Tensor, cov6: torch.Tensor, colors: torch.Tensor, o
         raise RuntimeError("gomavatar_amd.rasterize: tensors must be on the HIP device (no CPU fallback)")
     if colors.shape[-1] not in (3, 4):
         raise ValueError("colors must have 3 or 4 channels")
-    if means2D is None:
-        means2D = torch.zeros((means3D.shape[0], 3), dtype=means3D.dtype, device=means3D.device)
+    if means2D is None:   # (a carrier for dL/dmeans2D when the caller wants it; its values are never read: not filled)
+        means2D = torch.empty((means3D.shape[0], 3), dtype=means3D.dtype, device=means3D.device)
     if state is None:
         st = _POOL.acquire(means3D.device)
     else:

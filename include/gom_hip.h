@@ -164,6 +164,10 @@ int gom_raster_backward(GomState *s, const GomCamera *cam, int P, int C,
  * e.g. a whole training iteration) that is replayed for other cameras -- overwrite *cam_device before the replay.
  * H and W are launch geometry and stay host values; cam_device->H / W must hold the same numbers.
  * (The reference reads its camera back to the host with .item() every frame, gaussian.py:30-31.) */
+/* The camera block of renderer/gaussian.py:28-51 from the reference's K (3,3) and E (4,4) DEVICE tensors (fp32, row-major) into *cam_device, one
+ * launch, no host read: tanfov = tan(atan(size / 2f)) in fp64, view = E^T, proj = E^T K_ndc^T (znear / zfar as in the reference: 0.001 / 100);
+ * bg4 (device, 4 floats) or null = leave cam_device->bg as it is.  Bit for bit gomavatar_amd.camera.camera_block's struct. */
+int gom_camera_update_device(const float *K, const float *E, int H, int W, double znear, double zfar, const float *bg4, GomCamera *cam_device, void *stream);
 int gom_raster_forward_dcam(GomState *s, int H, int W, const GomCamera *cam_device, int P, int C,
                             const float *means3D, const float *cov6, const float *colors, const float *opacity,
                             float *out_color, int32_t *radii, uint32_t flags, void *stream);

@@ -81,3 +81,23 @@ def test_camera_block_device_and_every_consumer_match_reference_golden(golden_di
     assert raw[2] == np.float32(g["tanfovx"]) and raw[3] == np.float32(g["tanfovy"])
     np.testing.assert_array_equal(raw[4:20].reshape(4, 4), g["viewmatrix"])
     np.testing.assert_array_equal(raw[20:36].reshape(4, 4), g["projmatrix"])
+    # consumer 4: a camera of ONE forward's own, every byte written by the native launch (gom_camera_update_device: what Model.forward uses for fp32 device K / E)
+    bg4 = torch.tensor([0.1, 0.2, 0.3, 0.0], device="cuda")
+    fc = DeviceCamera.fresh(512, 512, K.cuda(), E.cuda(), bg4)
+    raw = fc.data.cpu().numpy()
+    check_struct(_lib.GomCamera.from_buffer_copy(raw.tobytes()))
+    assert raw[36:40].tolist() == bg4.cpu().numpy().tolist()
+    # ... and over random cameras against the host function (fp64 tan(atan(.)) rounded to fp32, products summed without contraction): the same bits
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        Kr = np.array([[rng.uniform(200, 3000), 0, rng.uniform(100, 900)], [0, rng.uniform(200, 3000), rng.uniform(100, 900)], [0, 0, 1]], np.float32)
+        Er = np.eye(4, dtype=np.float32)
+        Er[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        Er[:3, 3] = rng.normal(size=3).astype(np.float32) * 3
+        Hh, Ww = int(rng.integers(64, 1100)), int(rng.integers(64, 1100))
+        tf, vw, pj = camera_block(torch.from_numpy(Kr), torch.from_numpy(Er), Hh, Ww)
+        raw = DeviceCamera.fresh(Hh, Ww, torch.from_numpy(Kr).cuda(), torch.from_numpy(Er).cuda(), bg4).data.cpu().numpy()
+        assert raw[:2].view(np.int32).tolist() == [Hh, Ww]
+        np.testing.assert_array_equal(raw[2:4], tf.numpy())
+        np.testing.assert_array_equal(raw[4:20].reshape(4, 4), vw.numpy())
+        np.testing.assert_array_equal(raw[20:36].reshape(4, 4), pj.numpy())
