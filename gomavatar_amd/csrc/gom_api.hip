@@ -625,6 +625,7 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
 namespace {
 __global__ void __launch_bounds__(64) k_camera_update(const float *__restrict__ K, const float *__restrict__ E, int H, int W, double z_a, double z_b,
                                                       const float *__restrict__ bg, GomCamera *__restrict__ cam) {
+#pragma clang fp contract(off)   // every product below is rounded on its own (HIP's __fmul_rn / __fadd_rn are inline functions compiled under the command line's contraction mode: fusable)
     if (threadIdx.x != 0) return;
     const double fx = K[0], fy = K[4], px = K[2], py = K[5];
     cam->H = H; cam->W = W;
@@ -648,9 +649,9 @@ __global__ void __launch_bounds__(64) k_camera_update(const float *__restrict__ 
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float acc = __fmul_rn(view[i][0], Kn[j][0]);
+            float acc = view[i][0] * Kn[j][0];
 #pragma unroll
-            for (int k = 1; k < 4; k++) acc = __fadd_rn(acc, __fmul_rn(view[i][k], Kn[j][k]));
+            for (int k = 1; k < 4; k++) acc = acc + view[i][k] * Kn[j][k];   // (plain operators: the pragma above governs them, not the bodies of __fmul_rn / __fadd_rn)
             cam->view[4 * i + j] = view[i][j];
             cam->proj[4 * i + j] = acc;
         }

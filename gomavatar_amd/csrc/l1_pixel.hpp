@@ -1,7 +1,7 @@
 // One pixel of the fused photometric L1 losses (unpack, train.py:53-55, + L1 rgb / L1 mask, train.py:101-111) with its gradient.
 // Shared by the stand-alone loss kernel (loss.hip) and by the riders that carry the frame step's loss inside the rasterizer's forward
-// (k_emit's painters for the empty tiles, k_combine_fwd for the others: GomLossRider) -- every rounding is spelled out (explicit fma /
-// mul / sub), so the three call sites give the same bits whatever the compiler would contract around them.
+// (k_combine_fwd's tile workgroups and its empty-tile riders: GomLossRider) -- every rounding is spelled out (contraction off, the fmas
+// explicit), so the call sites give the same bits whatever the compiler would contract around them.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,21 +16,22 @@ __device__ __forceinline__ float gom_sgn(float x) { return (x > 0.f) ? 1.f : ((x
 // a0..a2, m: the rasterizer's planes; s: shade (1 without); b: background of the unpack; g, gm: targets
 __device__ __forceinline__ GomL1Px gom_l1_pixel(float a0, float a1, float a2, float m, float s, float b0, float b1, float b2, float g0, float g1, float g2,
                                                 float gm, float k_rgb, float k_mask) {
+#pragma clang fp contract(off)   // plain operators below are rounded one by one (HIP's __fmul_rn / __fadd_rn are inline functions the compiler may still fuse); the fmas are explicit
     GomL1Px o;
-    const float t = __fsub_rn(1.f, m);
-    const float as0 = __fmul_rn(a0, s), as1 = __fmul_rn(a1, s), as2 = __fmul_rn(a2, s);
-    const float r0 = __fsub_rn(__fmaf_rn(as0, m, __fmul_rn(b0, t)), g0);
-    const float r1 = __fsub_rn(__fmaf_rn(as1, m, __fmul_rn(b1, t)), g1);
-    const float r2 = __fsub_rn(__fmaf_rn(as2, m, __fmul_rn(b2, t)), g2);
-    const float rm = __fsub_rn(m, gm);
-    o.abs_rgb = __fadd_rn(__fadd_rn(fabsf(r0), fabsf(r1)), fabsf(r2));
+    const float t = 1.f - m;
+    const float as0 = a0 * s, as1 = a1 * s, as2 = a2 * s;
+    const float r0 = __builtin_fmaf(as0, m, b0 * t) - g0;
+    const float r1 = __builtin_fmaf(as1, m, b1 * t) - g1;
+    const float r2 = __builtin_fmaf(as2, m, b2 * t) - g2;
+    const float rm = m - gm;
+    o.abs_rgb = (fabsf(r0) + fabsf(r1)) + fabsf(r2);
     o.abs_mask = fabsf(rm);
-    const float s0 = __fmul_rn(gom_sgn(r0), k_rgb), s1 = __fmul_rn(gom_sgn(r1), k_rgb), s2 = __fmul_rn(gom_sgn(r2), k_rgb);
-    const float sm = __fmul_rn(s, m);
-    o.d0 = __fmul_rn(s0, sm);
-    o.d1 = __fmul_rn(s1, sm);
-    o.d2 = __fmul_rn(s2, sm);
-    o.d3 = __fmaf_rn(s0, __fsub_rn(as0, b0), __fmaf_rn(s1, __fsub_rn(as1, b1), __fmaf_rn(s2, __fsub_rn(as2, b2), __fmul_rn(gom_sgn(rm), k_mask))));
-    o.dshade = __fmul_rn(__fmaf_rn(s0, a0, __fmaf_rn(s1, a1, __fmul_rn(s2, a2))), m);
+    const float s0 = gom_sgn(r0) * k_rgb, s1 = gom_sgn(r1) * k_rgb, s2 = gom_sgn(r2) * k_rgb;
+    const float sm = s * m;
+    o.d0 = s0 * sm;
+    o.d1 = s1 * sm;
+    o.d2 = s2 * sm;
+    o.d3 = __builtin_fmaf(s0, as0 - b0, __builtin_fmaf(s1, as1 - b1, __builtin_fmaf(s2, as2 - b2, gom_sgn(rm) * k_mask)));
+    o.dshade = __builtin_fmaf(s0, a0, __builtin_fmaf(s1, a1, s2 * a2)) * m;
     return o;
 }
