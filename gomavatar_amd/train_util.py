@@ -229,11 +229,24 @@ class GraphedTrainStep:
         self.model, self.opt, self.loss_cfg, self.lpips = model, optimizer, loss_cfg, lpips_func
         self.warmup, self.graph, self.static, self.total, self.i_iter = warmup, None, None, None, 0
         model.capture_safe = True
+        # (experiment, off: the mesh branch and the splat rasterizer as parallel branches of the graph -- autograd replays the backward on the forward's
+        #  streams.  Worth 58 us while the graph still held the camera block's ~40 tensor launches; with one camera launch it LOSES 10-25 us: 2.69 against 2.67 ms)
+        self.overlap_branches = os.environ.get("GOM_GRAPH_OVERLAP_BRANCHES", "0") != "0"
 
     def invalidate(self):
         self.graph = None
 
     def _iteration(self):
+        keep = getattr(self.model, "overlap_branches_train", False)
+        if hasattr(self.model, "overlap_branches_train"):
+            self.model.overlap_branches_train = self.overlap_branches or keep
+        try:
+            return self._iteration_body()
+        finally:
+            if hasattr(self.model, "overlap_branches_train"):
+                self.model.overlap_branches_train = keep
+
+    def _iteration_body(self):
         fr = self.static
         self.opt.zero_grad(set_to_none=True)
         if hasattr(self.lpips, "prefetch_target") and _get(self.loss_cfg, "lpips.coeff", 1.0) > 0:
