@@ -103,3 +103,13 @@ def test_kinematic_level_table_matches_the_parent_table():
         depth[i] = depth[parent[i]] + 1
     assert depth == sorted(depth)
     assert start == [depth.index(d) for d in range(1, max(depth) + 1)] + [len(parent)]
+
+
+def test_frame_loss_slots_is_one_per_tile_and_at_least_the_block_count():
+    """GomFrame.loss_partials (ABI 9): gom_frame_loss_slots(H, W) = max(GOM_LOSS_BLOCKS, 16 x 16 tiles of the image) pairs of floats per frame -- a host
+    function of the library (no device needed)."""
+    from gomavatar_amd import _lib
+    lib = _lib.load()
+    assert lib.gom_frame_loss_slots(512, 512) == 1024 and lib.gom_frame_loss_slots(1024, 1024) == 4096
+    assert lib.gom_frame_loss_slots(128, 128) == _lib.GOM_LOSS_BLOCKS == 256 and lib.gom_frame_loss_slots(540, 540) == 34 * 34
+    assert lib.gom_frame_loss_slots(17, 300) == 256 and lib.gom_frame_loss_slots(16 * 40 + 1, 16 * 30) == 41 * 30

@@ -272,8 +272,8 @@ def test_face_frame_inside_the_per_gaussian_kernels_matches_the_separate_face_ke
         assert float(ga.abs().max()) > 0 and torch.equal(ga, gb)
 
 
-@pytest.mark.parametrize("B", [1, 3])
-def test_development_switches_do_not_change_results(B, monkeypatch):
+@pytest.mark.parametrize("B,img", [(1, 128), (3, 128), (1, 104), (2, 104)])   # (104: six and a half tiles a side -- the loss riders' partial tiles)
+def test_development_switches_do_not_change_results(B, img, monkeypatch):
     """GOM_LOSS_SKIP=0 (the loss kernel reads and writes the pixels of empty tiles too), GOM_BWD_ORDER=0 (the backward's tasks in list
     order) and GOM_FUSE_LOSS=0 (GOM_OPT_FUSE_LOSS: the loss as a launch of its own instead of riding in k_emit / k_combine_fwd) are A/B
     switches: image and every gradient must be BITWISE those of the default path -- the skipped pixels hold the background and no list
@@ -281,7 +281,6 @@ def test_development_switches_do_not_change_results(B, monkeypatch):
     function with every rounding spelled out (l1_pixel.hpp).  The loss SUMS are bitwise too where the launch sequence is the same
     (GOM_BWD_ORDER) and agree to fp32 summation order where the stand-alone kernel sums strided blocks and the riders sum tiles."""
     from gomavatar_amd.pipeline import RenderStep
-    img = 128
     faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
     stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
     fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}

@@ -101,3 +101,37 @@ def test_compose_and_unpack_kernels_match_the_torch_chains(H, W, with_shade):
     assert torch.allclose(ig.grad.cpu(), ic.grad, rtol=1e-5, atol=1e-6)
     if with_shade:
         assert torch.allclose(sg.grad.cpu(), sc.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_loss_tail_is_the_sum_per_term_the_scaling_and_the_total_with_their_gradients():
+    """losses.loss_tail (csrc/loss.hip gom_loss_tail): partial-sum matrices -> (terms, terms * coefficients, total) in one launch, against the
+    torch ops it replaces (a sum per term, cat, multiply, sum) in float64; the gradient of `total` w.r.t. every partial sum is its term's
+    coefficient times the factor in front of the row sum, zero on rows that are no terms."""
+    from gomavatar_amd.losses import loss_tail
+    g = torch.Generator().manual_seed(3)
+    mats = [torch.rand(3, 1, generator=g), torch.rand(1, 1280, generator=g), torch.rand(1, 256, generator=g), torch.rand(2, 77, generator=g)]
+    used, pre = [2, 1, 1, 2], [1.0, 0.5, 1.0, 1.0]
+    coeffs = torch.tensor([1.0, 5.0, 1.0, 10.0, 0.1, 0.05], device="cuda")
+    ins = [m.cuda().requires_grad_(True) for m in mats]
+    vec, scaled, total = loss_tail(coeffs, ins, used, pre)
+    ref_terms = torch.cat([(m.double()[:u].sum(1) * p) for m, u, p in zip(mats, used, pre)])
+    ref_scaled = ref_terms * coeffs.cpu().double()
+    assert vec.shape == (6,) and total.dim() == 0
+    assert float((vec.cpu().double() - ref_terms).abs().max()) <= 1e-6 * float(ref_terms.abs().max())
+    assert float((scaled.cpu().double() - ref_scaled).abs().max()) <= 1e-6 * float(ref_scaled.abs().max())
+    assert abs(float(total) - float(ref_scaled.sum())) <= 1e-6 * float(ref_scaled.sum())
+    total.backward()
+    k = 0
+    for x, m, u, p in zip(ins, mats, used, pre):
+        want = torch.zeros_like(m)
+        for r in range(u):
+            want[r] = float(coeffs[k + r]) * p
+        k += u
+        assert torch.allclose(x.grad.cpu(), want, rtol=1e-6, atol=0), (tuple(m.shape), x.grad.cpu()[:, :2], want[:, :2])
+    # a gradient arriving at the TERMS (somebody differentiates losses[name]["unscaled"]) reaches the partial sums as well
+    ins2 = [m.cuda().requires_grad_(True) for m in mats]
+    vec2, _, total2 = loss_tail(coeffs, ins2, used, pre)
+    (total2 + 3.0 * vec2[3]).backward()
+    assert torch.allclose(ins2[2].grad.cpu(), torch.full((1, 256), 10.0 + 3.0), rtol=1e-6)
+    assert torch.allclose(ins2[1].grad.cpu(), torch.full((1, 1280), 0.5), rtol=1e-6)
