@@ -1364,7 +1364,9 @@ int gom_lpips_layer_backward_value_planes(int B, int C, int HW, const void *f0, 
                                           int *n_blocks, size_t f_lo, size_t d_lo, const void *pool_dy, size_t pool_dy_lo, int W, void *stream) {
     if (C != 64 && C != 128 && C != 256 && C != 512) { gom_set_error("LPIPS head (backward + value): C must be 64, 128, 256 or 512"); return -1; }
     if (B <= 0 || HW <= 0 || !block_sums || !n_blocks) { gom_set_error("LPIPS head (backward + value): bad arguments"); return -1; }
-    const size_t groups = ((size_t)HW + 15) / 16;
+    // a workgroup per 16 pixels -- or, without a pool to route (the last tap: 32 x 32 pixels x 512 channels at 512^2), one PIXEL per group of C / 8 lanes:
+    // 64 workgroups walking four pixels each one behind the other were a 12 us latency chain on a quarter of the CUs
+    const size_t groups = pool_dy ? ((size_t)HW + 15) / 16 : ((size_t)HW * (size_t)(C / 8) + 255) / 256;
     const dim3 gridb((unsigned)(groups < GOM_LPIPS_HEAD_BLOCKS ? groups : GOM_LPIPS_HEAD_BLOCKS), B);
     *n_blocks = (int)gridb.x;
     if (pool_dy && (W <= 0 || (W & 1) || HW % W || ((HW / W) & 1))) { gom_set_error("LPIPS head (backward + value + pool): even image sides"); return -1; }
