@@ -821,12 +821,21 @@ __global__ void __launch_bounds__(256) k_conv1x1_bf16(size_t npix, int Cin, cons
 // channels of ScalingLayer(2x - 1), zero-padded to 32) is built in registers by exactly the lanes that need it as a B fragment (pixel l15, channel
 // group kg: the unit one thread of the prepare kernel writes), so the same values go through the same MFMA sequence -- bitwise the two-kernel
 // result -- without 33 MB of rows written and read back per image and plane.  wt: [chunks][64][32], chunks = 1 (bf16) or 3 (bf16x3: hi, hi, lo).
+#ifndef GOM_CONV1_1_STAGED
+#define GOM_CONV1_1_STAGED 1   // 1: the wave's three scaled, split image rows are built ONCE in a wave-private LDS slab and the im2col fragments gathered from there
+#endif                         // 0: every lane scales / splits its own 16 im2col values (round 4: 35 us per 512^2 image, half of it that arithmetic, nine-fold redundant)
 template <bool X3>
 __global__ void __launch_bounds__(256) k_conv1_1_image(int B, int H, int W, const float *__restrict__ rgb, const bf16_t *__restrict__ wt, const float *__restrict__ bias,
                                                        bf16_t *__restrict__ out, size_t out_lo) {
     constexpr int NT = 4, Cout = 64;
     const float shift[3] = {-0.030f, -0.088f, -0.188f}, scale[3] = {0.458f, 0.448f, 0.450f};
     const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
+#if GOM_CONV1_1_STAGED
+    // S[ky][i]: channel i % 3 of pixel x0 - 1 + i / 3 of image row y + ky - 1, scaled, as (hi | lo << 16); zero outside the image.  The im2col row of pixel x0 + xl
+    // is S[0][3 xl .. 3 xl + 8], S[1][..], S[2][..]: column k = 9 ky + j of it is S[ky][3 xl + j]
+    __shared__ uint32_t s_rows[4][3][104];
+    uint32_t (*S)[104] = s_rows[threadIdx.x >> 6];
+#endif
     // a wave owns 32 consecutive pixels of ONE image row (W is a multiple of 32 here: the launcher checks): 32-bit index arithmetic, once per wave
     const uint32_t wpr = (uint32_t)W / 32u, nrow = (uint32_t)B * (uint32_t)H;
     const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwave = (gridDim.x * 256u) >> 6;
@@ -836,6 +845,44 @@ __global__ void __launch_bounds__(256) k_conv1_1_image(int B, int H, int W, cons
         const size_t p0 = (size_t)row * W + x0;
         const float *img_row = rgb + 3 * ((size_t)row * W);   // pixel (row, 0) of this image row; the rows above / below are +- 3 W floats
         bf16x8 bhi[2], blo[2];
+#if GOM_CONV1_1_STAGED
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int dy = ky - 1;
+            const bool row_in = y + dy >= 0 && y + dy < H;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = lane + 64 * h;
+                if (i < 102) {
+                    const int px = i / 3, c = i - 3 * px, xx = (int)x0 - 1 + px;
+                    float v = 0.f;
+                    if (row_in && xx >= 0 && xx < W) {
+                        const float sh = c == 0 ? shift[0] : (c == 1 ? shift[1] : shift[2]), sc = c == 0 ? scale[0] : (c == 1 ? scale[1] : scale[2]);
+                        v = ((2.f * img_row[3 * ((ptrdiff_t)dy * W + xx) + c] - 1.f) - sh) / sc;
+                    }
+                    bf16_t hh, ll = 0;
+                    if (X3) split_bf(v, hh, ll); else hh = f2bf(v);
+                    S[ky][i] = (uint32_t)hh | ((uint32_t)ll << 16);
+                }
+            }
+        }
+        // (LDS operations of one wave execute in order: no barrier)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int xl = 16 * m + l15;
+            uint32_t w8[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = kg * 8 + r, ky = (k >= 9 ? 1 : 0) + (k >= 18 ? 1 : 0), j = k - 9 * ky;
+                w8[r] = k < 27 ? S[ky][3 * xl + j] : 0u;
+            }
+            const uint4 qh = make_uint4((w8[0] & 0xffffu) | (w8[1] << 16), (w8[2] & 0xffffu) | (w8[3] << 16), (w8[4] & 0xffffu) | (w8[5] << 16), (w8[6] & 0xffffu) | (w8[7] << 16));
+            const uint4 ql = make_uint4((w8[0] >> 16) | (w8[1] & 0xffff0000u), (w8[2] >> 16) | (w8[3] & 0xffff0000u), (w8[4] >> 16) | (w8[5] & 0xffff0000u),
+                                        (w8[6] >> 16) | (w8[7] & 0xffff0000u));
+            bhi[m] = __builtin_bit_cast(bf16x8, qh);
+            blo[m] = __builtin_bit_cast(bf16x8, ql);
+        }
+#else
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             const int x = (int)x0 + 16 * m + l15;
@@ -858,6 +905,7 @@ __global__ void __launch_bounds__(256) k_conv1_1_image(int B, int H, int W, cons
             bhi[m] = __builtin_bit_cast(bf16x8, qh);
             blo[m] = __builtin_bit_cast(bf16x8, ql);
         }
+#endif
         f32x4 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; m++)

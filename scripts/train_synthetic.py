@@ -89,6 +89,7 @@ for it in range(a.iters):
     loss, items, rgb, mask = tu.train_iteration(student, opt, fr, tcfg, n_iters, lpips_func=lp)
     n_seg += 1
     if n_iters <= a.dense or n_iters % a.every == 0 or n_iters == a.iters:
+        torch.cuda.synchronize()                                   # (no host read is left in an iteration: the queue the host ran ahead by is TRAINING time, not logging)
         t_log = time.perf_counter()
         row = {"iter": n_iters, "total": float(loss), "psnr": round(psnr8(rgb.detach()[0], fr["target_rgbs"][0]), 4), "faces": int(student.faces.shape[0]),
                **{k: float(v["unscaled"]) for k, v in items.items()}}
