@@ -107,6 +107,7 @@ struct GomState {
     int wantSegShift = 0;             // GOM_OPT_SEG_SHIFT (0 = auto)
     int taskGridPct = 100;            // GOM_OPT_TASK_GRID_PCT
     bool lossSkip = true;             // the frame step's loss kernel skips loads and stores of empty tiles (GomLossSkip)
+    bool sortSplit = false;           // set by the mesh rasterizer around its per-tile sort: keys are face indices alone (gom_launch_sort)
     bool fuseLoss = true;             // GOM_OPT_FUSE_LOSS: the frame step's loss rides in k_emit (empty tiles) and k_combine_fwd (the others): GomLossRider
     GomLossRider lossRider{};         // set by the frame step around its forward
     bool emptyFilled = false;         // this forward's k_emit has painted the empty tiles of the image k_combine_fwd is about to write

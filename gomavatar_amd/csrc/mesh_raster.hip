@@ -559,7 +559,10 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
                        s->mesh_face, s->depth, s->xy, s->conic_opacity, s->tiles_touched, s->rect, s->radii, s->tile_count, s->pair_off, s->status, lds_hist);
     GOM_LAUNCH_CHECK();
     if (int rc = gom_launch_scan_emit(s, F, st)) return rc;
-    if (int rc = gom_launch_sort(s, st)) return rc;
+    s->sortSplit = true;      // (keys = face indices: the 4-wave sort for every tile, an index bitmap for the few long lists)
+    const int src = gom_launch_sort(s, st);
+    s->sortSplit = false;
+    if (src) return src;
     hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(64 * MESH_FW), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
                        s->seg_T, s->seg_Tend, s->seg_last, s->status);
     GOM_LAUNCH_CHECK();

@@ -290,8 +290,9 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
                                                const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_pos, uint32_t *__restrict__ ent_slot,
                                                const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity,
                                                float2 *__restrict__ ent_geo, uint64_t *__restrict__ scratch,
-                                               const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max, uint32_t seg_shift) {
+                                               const GomDevStatus *__restrict__ status, uint32_t log_chunk, uint32_t small_max, uint32_t seg_shift, uint32_t bitmap_words) {
     __shared__ __attribute__((aligned(16))) uint64_t s_x[8 * NT];
+    __shared__ uint32_t s_wsum[NT / 64];
     if (status->overflow) return;
     const int tile = blockIdx.x;
     const uint32_t base = tile_base[tile];
@@ -353,6 +354,39 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
         return;
     }
     // ---- rare: list longer than one chunk
+    uint64_t *src = keys + base, *dst = scratch + base;
+    if (bitmap_words) {
+        // the keys are INDICES alone (the mesh rasterizer: depth bits zero, a face at most once per tile, bitmap_words x 32 >= the face count): a bitmap of the
+        // indices in LDS and a popcount scan give the sorted list in one pass -- the chunk sorts + merge levels below are a ~50 us chain for the
+        // few 8 x 8-pixel tiles that hold thousands of faces, beside 4 000 tiles that are done in a fraction of that
+        uint32_t *bm = reinterpret_cast<uint32_t *>(s_x);
+        for (uint32_t w = t; w < bitmap_words; w += NT) bm[w] = 0u;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += NT) { const uint32_t g = (uint32_t)keys[base + i]; atomicOr(&bm[g >> 5], 1u << (g & 31u)); }
+        __syncthreads();
+        const uint32_t wpt = (bitmap_words + NT - 1u) / NT, w0 = min(bitmap_words, t * wpt), w1 = min(bitmap_words, w0 + wpt);
+        uint32_t mine = 0;
+        for (uint32_t w = w0; w < w1; w++) mine += __popc(bm[w]);
+        uint32_t incl = mine;
+        const uint32_t lane = t & 63u, wid = t >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += y;
+        }
+        if (lane == 63) s_wsum[wid] = incl;
+        __syncthreads();
+        uint32_t pos = incl - mine;
+        for (uint32_t w = 0; w < wid; w++) pos += s_wsum[w];
+        for (uint32_t w = w0; w < w1; w++) {
+            uint32_t bits = bm[w];
+            while (bits) {
+                const uint32_t bit = __ffs(bits) - 1u;
+                bits &= bits - 1u;
+                src[pos++] = (uint64_t)((w << 5) | bit);   // (every key of the list has been read: the bitmap holds them)
+            }
+        }
+    } else {
     for (uint32_t c0 = 0; c0 < n; c0 += CH) {
         const uint32_t cn = min(CH, n - c0);
         uint64_t x[8];
@@ -362,7 +396,6 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
             if (8 * t + r < cn) keys[base + c0 + 8 * t + r] = x[r];
         __syncthreads();  // s_x is re-used by the next chunk
     }
-    uint64_t *src = keys + base, *dst = scratch + base;
     for (uint32_t L = CH; L < n; L <<= 1) {
         __syncthreads();  // the previous level's (or the chunk sorts') global writes are visible to the block
         for (uint32_t o8 = 8 * t; o8 < n; o8 += 8 * NT) {
@@ -376,6 +409,7 @@ __global__ void __launch_bounds__(NT, 8) k_sort(int gx, const uint32_t *__restri
                 if (o8 + r < n) dst[o8 + r] = y[r];
         }
         uint64_t *tmp = src; src = dst; dst = tmp;
+    }
     }
     __syncthreads();
     for (uint32_t i = t; i < n; i += NT) {
@@ -1687,16 +1721,21 @@ int gom_launch_sort(GomState *s, hipStream_t st) {
     const uint32_t lc = (uint32_t)(31 - __builtin_clz((unsigned)s->sortCap));  // log2 of the chunk (13 unless a test lowered it)
     // A single frame is latency-bound by its longest list: one launch.  A batch is throughput-bound: the short lists
     // (the vast majority) go to 4-wave workgroups that pack 8 per CU.
-    const uint32_t small_max = s->B > 1 ? GOM_SORT_SMALL : 0u;
+    // sortSplit (the mesh rasterizer: 4 096 tiles of 8 x 8 pixels, ~40 faces each, keys = face indices alone): ONE launch of the 4-wave instantiation takes
+    // every tile -- eight workgroups per CU instead of two 16-wave ones -- and the few lists beyond its 2 048-entry chunk are sorted through an index
+    // bitmap in LDS (sort_tile), not through the global-memory merge levels (57 us for the mesh's lists through the 16-wave kernel, 80 through this one's merges)
+    const uint32_t bm_words = s->sortSplit && s->P <= 8 * 256 * 2 * 32 ? ((uint32_t)s->P + 31u) >> 5 : 0u;   // (the bitmap shares s_x: 16 NT words)
+    const uint32_t small_max = bm_words ? 0xffffffffu : (s->B > 1 ? GOM_SORT_SMALL : 0u);
     if (small_max) {
         hipLaunchKernelGGL(k_sort<256>, dim3(n_tiles), dim3(256), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
                            s->rect, s->pair_off, s->pair_pos, s->ent_slot, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial),
-                           s->status, lc < 11u ? lc : 11u, small_max, (uint32_t)s->segShift);
+                           s->status, lc < 11u ? lc : 11u, small_max, (uint32_t)s->segShift, bm_words);
         GOM_LAUNCH_CHECK();
+        if (bm_words) return 0;
     }
     hipLaunchKernelGGL(k_sort<1024>, dim3(n_tiles), dim3(1024), 0, st, s->gx, s->tile_base, s->seg_base, s->keys, s->point_list, s->seg_desc,
                        s->rect, s->pair_off, s->pair_pos, s->ent_slot, s->xy, s->conic_opacity, s->ent_geo, reinterpret_cast<uint64_t *>(s->partial), s->status,
-                       lc, small_max, (uint32_t)s->segShift);
+                       lc, small_max, (uint32_t)s->segShift, 0u);
     GOM_LAUNCH_CHECK();
     return 0;
 }
