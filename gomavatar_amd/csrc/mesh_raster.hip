@@ -249,22 +249,33 @@ __global__ void __launch_bounds__(64 * MESH_FW) k_mesh_forward_seg(MeshGrid g, c
 }
 
 // ---- forward, pass 2: per tile, fold its segments in list order ---------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_mesh_combine(MeshGrid g, const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_Q,
+__global__ void __launch_bounds__(256) k_mesh_combine(MeshGrid g, const uint32_t *__restrict__ seg_base, const float *__restrict__ seg_Q,
                                                      const float *__restrict__ seg_z, const uint32_t *__restrict__ seg_face,
                                                      const int32_t *__restrict__ faces, const float *__restrict__ vnormals,
                                                      float *__restrict__ normal_map, float *__restrict__ alpha, uint32_t *__restrict__ pix_to_face,
                                                      float *__restrict__ prodQ, const GomDevStatus *__restrict__ status) {
-    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // a wave per tile, four tiles per workgroup (4 096 single-wave workgroups were dispatch-bound)
+    if (tile >= g.gx * g.gy) return;
     const int xi = (tile % g.gx) * kMeshTile + (lane & 7), yi = (tile / g.gx) * kMeshTile + (lane >> 3);
     if (xi >= g.W || yi >= g.H) return;
     const uint32_t sb = seg_base[tile], ns = status->overflow ? 0u : seg_base[tile + 1] - sb;
     float best_z = 3.0e38f, Q = 1.f;
     uint32_t best = 0xffffffffu;
-    for (uint32_t k = 0; k < ns; k++) {
-        const size_t o = (size_t)(sb + k) * 64 + lane;
-        Q *= seg_Q[o];
-        const float z = seg_z[o];
-        if (z < best_z) { best_z = z; best = seg_face[o]; }
+    for (uint32_t k0 = 0; k0 < ns; k0 += 8) {   // 8 segments per trip, their loads issued together: a tile of thousands of faces (dozens of segments) was a chain of one
+        float q8[8], z8[8];                      // memory latency per segment, and the launch lasted as long as the longest tile (20 us)
+        uint32_t f8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t o = (size_t)(sb + min(k0 + u, ns - 1)) * 64 + lane;
+            q8[u] = seg_Q[o]; z8[u] = seg_z[o]; f8[u] = seg_face[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (k0 + u < ns) {
+                Q *= q8[u];
+                if (z8[u] < best_z) { best_z = z8[u]; best = f8[u]; }
+            }
+        }
     }
     const size_t p = (size_t)yi * g.W + xi;
     float nx = 0.f, ny = 0.f, nz = 0.f;
@@ -566,7 +577,7 @@ extern "C" int gom_mesh_raster_forward(GomState *s, int N, int F, int H, int W, 
     hipLaunchKernelGGL(k_mesh_forward_seg, dim3(8192), dim3(64 * MESH_FW), 0, st, g, s->seg_desc, s->point_list, s->mesh_face, blur, blur_radius, 1.0f / sigma,
                        s->seg_T, s->seg_Tend, s->seg_last, s->status);
     GOM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mesh_combine, dim3(g.gx * g.gy), dim3(64), 0, st, g, s->seg_base, s->seg_T, s->seg_Tend, s->seg_last, faces, vnormals,
+    hipLaunchKernelGGL(k_mesh_combine, dim3((g.gx * g.gy + 3) / 4), dim3(256), 0, st, g, s->seg_base, s->seg_T, s->seg_Tend, s->seg_last, faces, vnormals,
                        normal_map, alpha, s->n_contrib, s->final_T, s->status);
     GOM_LAUNCH_CHECK();
     s->meshBlurRadius = blur_radius; s->meshSigma = sigma; s->meshForward = true;
