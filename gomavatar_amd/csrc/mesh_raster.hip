@@ -315,17 +315,23 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
         const int tx0 = (tile % g.gx) * kMeshTile, ty0 = (tile / g.gx) * kMeshTile;
         const uint32_t base = sd.y, n = sd.z;   // n <= 256
         __syncthreads();   // the previous segment's readers are done
+        float da_mine = 0.f;
         if (threadIdx.x < 64) {
             const int xi = tx0 + (threadIdx.x & 7), yi = ty0 + (threadIdx.x >> 3);
             const bool in = xi < g.W && yi < g.H;
             const size_t p = in ? (size_t)yi * g.W + xi : 0;
             s_p2f[threadIdx.x] = in ? pix_to_face[p] : 0xffffffffu;
             s_Q[threadIdx.x] = in ? prodQ[p] : 1.f;
-            s_da[threadIdx.x] = (in && d_alpha) ? d_alpha[p] : 0.f;
+            da_mine = (in && d_alpha) ? d_alpha[p] : 0.f;
+            s_da[threadIdx.x] = da_mine;
 #pragma unroll
             for (int c = 0; c < 3; c++) s_dn[threadIdx.x][c] = in ? d_normal[3 * p + c] : 0.f;
         }
-        __syncthreads();
+        // A pixel whose dL/d(alpha) is exactly 0 adds +-0 to every silhouette term below (its factors are finite), and that is most of them: under the
+        // body alpha = 1 - Q rounds to 1.0f (Q < 2^-25 with dozens of faces in reach) and |alpha - target|'s gradient is sign(0) = 0 there (train.py:142) --
+        // only the band around the outline carries a silhouette gradient.  Such pixels skip the per-face evaluation (the same bits: x + (+-0) = x, and the
+        // sums start at +0); a tile without any such pixel does the normal-map bookkeeping alone.  (NaN != 0: a poisoned gradient is still evaluated.)
+        const bool sil = __syncthreads_or(da_mine != 0.f) != 0;   // (also the barrier behind the staging)
         for (uint32_t e = lane; e < n; e += 64) {
             const uint32_t f = point_list[base + e];
             float fg[10];
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                 for (int xi = ixa; xi <= ixb; xi++) {
                     const int lp = (yi - ty0) * kMeshTile + (xi - tx0);
                     if (s_p2f[lp] == f) { gn[0] += s_dn[lp][0]; gn[1] += s_dn[lp][1]; gn[2] += s_dn[lp][2]; }
-                    if (!d_alpha) continue;
+                    if (!sil || s_da[lp] == 0.f) continue;
                     const float px = pix_x(g, xi), py = pix_y(g, yi);
                     const FaceEval r = eval_face(fg, px, py, blur, blur_radius, inv_sigma);
                     if (!r.soft) continue;

@@ -215,3 +215,41 @@ def test_two_forwards_in_flight_keep_their_own_scratch():
     loss(*out0).backward()
     loss(*out3).backward()
     assert torch.equal(v0.grad, refs[0]) and torch.equal(v3.grad, refs[1])
+
+
+def test_silhouette_backward_skips_zero_gradient_pixels_exactly():
+    """k_mesh_backward_entries evaluates a (face, pixel) pair only where dL/d(alpha) != 0 (the band around the outline in training: under the body
+    alpha rounds to 1.0f and |alpha - target|'s gradient is sign(0) = 0, train.py:142) and skips whole 8 x 8 tiles without such a pixel.
+    A zero cotangent adds +-0; standing an infinitesimal in for every zero forces the full evaluation and must give the same gradient:
+    bit for bit wherever the gradient is not itself infinitesimal."""
+    from gomavatar_amd.mesh_renderer import MeshNormalRenderer, vertex_normals
+    img = 128
+    v, faces, K, E = _scene(img, body=syn.make_body(0), frame=2)
+    r = MeshNormalRenderer(img_size=(img, img), sigma=1e-5).cuda().train()
+    vc, fc = v.cuda(), faces.cuda()
+    topo = r.topology(fc, vc.shape[2])
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(img, img, generator=g)
+    blocks = (torch.rand(img // 8, img // 8, generator=g) < 0.5).repeat_interleave(8, 0).repeat_interleave(8, 1)    # whole tiles without a gradient
+    keep = blocks & (torch.rand(img, img, generator=g) < 0.4)                                                     # and most pixels of the others
+    grads = []
+    for fill in (0.0, 1e-30):
+        x = vc.clone().requires_grad_()
+        n, m = r(x, vertex_normals(x[0].T, topo)[None], K.cuda(), E.cuda(), fc)
+        cot = torch.where(keep, w, torch.full_like(w, fill)).cuda()
+        (m[0, ..., 0] * cot).sum().backward()
+        grads.append(x.grad[0].cpu())
+    a, b = grads
+    assert float(a.abs().max()) > 1e-3 and torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 1e-20, float((a - b).abs().max())
+    big = b.abs() > 1e-12
+    assert big.float().mean() > 0.01 and torch.equal(a[big], b[big])
+    # and the masked cotangent against the float64 oracle (the gate itself: a tile wrongly taken for gradient-free would lose its faces' terms)
+    vo = v.double().requires_grad_()
+    ndc_o = om.ndc_T_world(vo, K.double(), E.double(), img, img)[0]
+    _, a_o, _ = om.render_tiled(ndc_o, faces, om.vertex_normals(vo[0].T, faces), img, img, sigma_cfg=1e-5, tile=16)
+    (a_o * torch.where(keep, w, torch.zeros_like(w)).double()).sum().backward()
+    gr = vo.grad[0].numpy()
+    err = np.abs(a.numpy().astype(np.float64) - gr)
+    scale = np.abs(gr).max()
+    assert np.quantile(err, 0.99) <= 3e-3 * scale and np.median(err) <= 1e-5 * scale, (np.quantile(err, 0.99), np.median(err), scale)
