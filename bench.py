@@ -216,6 +216,16 @@ class Runner:
                 st.state.set_option(_lib.OPT_SORT_MODE, args.sort_mode)
             self.slots.append(dict(step=st, fp=fp, opt=opt, params=dict(fp.params.items()), stream=torch.cuda.Stream(device=wl.device)))   # (the legacy NULL stream cannot be graph-captured)
         self.batches = wl.batches(self.slots[0]["step"])
+        if os.environ.get("GOM_DEBUG_ADDRS", "0") != "0":    # (development: which buffer does a faulting address belong to)
+            for k, sl in enumerate(self.slots):
+                for nm, t in [("fp.params.flat", sl["fp"].params.flat), ("fp.grads.flat", sl["fp"].grads.flat)] + [("step.grads." + a, b) for a, b in sl["step"].grads.items()]:
+                    print(f"[gom torch pid {os.getpid()}] slot{k}.{nm} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}", file=sys.stderr)
+            for j, bt in enumerate(self.batches):
+                for nm, t in bt.items():
+                    if hasattr(t, "data_ptr") and t.is_cuda:
+                        print(f"[gom torch pid {os.getpid()}] batch{j}.{nm} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}", file=sys.stderr)
+            for nm, t in wl.params.items():
+                print(f"[gom torch pid {os.getpid()}] wl.params.{nm} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}", file=sys.stderr)
         assert self.batches, "not enough frames for one batch"
         # (Measured and dropped: the whole step -- frame step + Adam -- captured by the caller as ONE torch.cuda.CUDAGraph, to close the ~9 us
         #  between the library's graph and the plain Adam launch behind it: 13.55 k instead of 13.8 k frames/s, 4.61 k instead of 4.83 k at
@@ -800,12 +810,19 @@ def main():
     # (in front of the W warm-up steps of the contract: ~0.3 s of the same steps, untimed -- a fresh box's first launches pay for code-object
     #  loading, graph capture and the clocks' ramp, and W = 5 steps of 0.6 ms do not cover that)
     t_pre, i_pre = time.perf_counter(), 0
-    while (time.perf_counter() - t_pre < 0.3) if world == 1 else (i_pre < 256):   # (N > 1: the same number of collectives on every rank)
+    soak = int(os.environ.get("GOM_BENCH_SOAK_PRERUN", "0"))   # (scripts/soak_two_ranks.sh: this many times the pre-run's steps, then exit -- the hunt for LABBOOK R5.8's fault)
+    while (time.perf_counter() - t_pre < 0.3) if world == 1 and not soak else (i_pre < 256 * max(1, soak)):   # (N > 1: the same number of collectives on every rank)
         for _ in range(8):
-            main_run.run_step(i_pre); i_pre += 1
+            main_run.run_step(i_pre, collective=not os.environ.get("GOM_BENCH_SOAK_LOCAL")); i_pre += 1
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if soak:
+        main_run.check()
+        note(f"soak: {i_pre} steps without a fault")
+        if world > 1:
+            dist.destroy_process_group()
+        return
     note("timed region")
     elapsed, n_steps, regions = main_run.measure(args.steps, args.warmup)
     main_run.check()

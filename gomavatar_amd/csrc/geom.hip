@@ -509,6 +509,13 @@ extern "C" int gom_lbs_forward(int N, int J, const float *xyz, const float *weig
     return gom_lbs_forward_batch(1, N, J, xyz, weights, RT, out, stream);
 }
 
+// get_global_RTs + apply_lbs in ONE launch for a frame (k_fk_lbs_fwd: every workgroup runs the 24-joint chain itself; the bits of gom_fk_forward + gom_lbs_forward)
+extern "C" int gom_fk_lbs_forward(int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights, float *RT,
+                                  float *fk_save, float *out, void *stream) {
+    if (N <= 0) { gom_set_error("gom_fk_lbs_forward: bad size N=%d", N); return -1; }
+    return gom_fk_lbs_forward_batch(1, N, cnl_gtfms, dst_Rs, dst_Ts, xyz, weights, RT, fk_save, out, stream);
+}
+
 int gom_face_forward_batch(int B, int N, int F, const float *verts, const int32_t *faces, const float *so3, const float *scale,
                            float sigma, float *xyz, float *cov6, const float *appearance, float *feat4, void *stream) {
     if (N < 0 || F < 0) { gom_set_error("gom_face_forward: bad sizes"); return -1; }

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "gom_internal.h"
+#include <unistd.h>
 #ifdef GOM_LAB
 #include "gom_hip_lab.h"
 #endif
@@ -29,6 +30,25 @@ static int grow(T **p, size_t count) {
         *p = nullptr;
     }
     GOM_HIP_CHECK(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    // GOM_DEBUG_POISON=1 (development): every new scratch buffer starts as 0xA5 bytes instead of whatever the pages held -- a kernel that reads a word
+    // nobody wrote yet shows itself at once instead of once in a dozen multi-process runs (scripts/soak_two_ranks.sh, LABBOOK R5.9)
+    static const bool addrs = getenv("GOM_DEBUG_ADDRS") && atoi(getenv("GOM_DEBUG_ADDRS")) != 0;   // (development: which buffer does a faulting address belong to)
+    static int n_alloc = 0;
+    if (addrs) fprintf(stderr, "[gom alloc pid %d] #%d %p .. %p (%zu bytes, elements of %zu)\n", (int)getpid(), n_alloc++, (void *)*p, (void *)((char *)*p + (count ? count : 1) * sizeof(T)),
+                       (count ? count : 1) * sizeof(T), sizeof(T));
+    static const bool poison = getenv("GOM_DEBUG_POISON") && atoi(getenv("GOM_DEBUG_POISON")) != 0;
+    if (poison) GOM_HIP_CHECK(hipMemset(*p, 0xA5, (count ? count : 1) * sizeof(T)));
+    return 0;
+}
+
+// Zero a freshly allocated counter array NOW.  hipMemset on device memory is enqueued on the legacy NULL stream and may return before it has run;
+// the caller's kernels go to the caller's stream, and a stream created non-blocking (every torch.cuda.Stream) is NOT ordered behind the NULL stream:
+// the first frame's kernels could meet the counters as the pages were left -- tile counts of garbage, lists of garbage lengths, a wild address.
+// Alone on a device the fill always won that race by tens of microseconds; with a second process' persistent kernels on the same device it lost it
+// about once in ten start-ups (`bench.py --gpus 2` on one GPU: "Memory access fault", LABBOOK R5.9).  Allocation path only: the wait costs nothing.
+static int zero_now(void *p, size_t bytes) {
+    GOM_HIP_CHECK(hipMemset(p, 0, bytes));
+    GOM_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
 
@@ -56,7 +76,8 @@ extern "C" GomState *gom_state_create(void) {
     }
     if (hipMalloc((void **)&s->status, sizeof(GomDevStatus)) != hipSuccess ||
         hipMemset(s->status, 0, sizeof(GomDevStatus)) != hipSuccess ||
-        hipMalloc((void **)&s->task_ctr, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess || hipMemset(s->task_ctr, 0, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&s->task_ctr, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess || hipMemset(s->task_ctr, 0, GOM_TASK_CTR_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {   // (the fills have run before anybody's stream meets the words: see zero_now)
         gom_set_error("hipMalloc(status) failed");
         delete s;
         return nullptr;
@@ -170,8 +191,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         const int64_t nbuck = (int64_t)B << sh;
         if (nbuck > s->capBuckets) {
             if (grow_s(s, &s->bucket_count, (size_t)nbuck) || grow_s(s, &s->bucket_base, (size_t)nbuck + 1) || grow_s(s, &s->bucket_cursor, (size_t)nbuck)) return -2;
-            GOM_HIP_CHECK(hipMemset(s->bucket_count, 0, (size_t)nbuck * sizeof(uint32_t)));
-            GOM_HIP_CHECK(hipMemset(s->bucket_cursor, 0, (size_t)nbuck * sizeof(uint32_t)));
+            if (zero_now(s->bucket_count, (size_t)nbuck * sizeof(uint32_t)) || zero_now(s->bucket_cursor, (size_t)nbuck * sizeof(uint32_t))) return -2;
             s->capBuckets = nbuck;
         }
         const int64_t nmm = (int64_t)B * ((P_frame + 255) / 256);      // one (min, max) pair per preprocess block
@@ -182,14 +202,14 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
     }
     if (B > s->capBigFrames) {
         if (grow_s(s, &s->big_list, (size_t)B * GOM_BIG_CAP) || grow_s(s, &s->big_count, (size_t)2 * B)) return -2;
-        GOM_HIP_CHECK(hipMemset(s->big_count, 0, (size_t)2 * B * sizeof(uint32_t)));
+        if (zero_now(s->big_count, (size_t)2 * B * sizeof(uint32_t))) return -2;
         s->capBigFrames = B;
     }
     if (tiles > s->capTiles) {
         if (grow_s(s, &s->tile_count, tiles) || grow_s(s, &s->tile_base, (size_t)tiles + 1) || grow_s(s, &s->tile_cursor, tiles) ||
             grow_s(s, &s->tile_nmax, tiles) || grow_s(s, &s->seg_base, (size_t)tiles + 1) || grow_s(s, &s->tile_qlim, tiles))
             return -2;
-        GOM_HIP_CHECK(hipMemset(s->tile_count, 0, (size_t)tiles * sizeof(uint32_t)));
+        if (zero_now(s->tile_count, (size_t)tiles * sizeof(uint32_t))) return -2;
         s->capTiles = tiles;
         s->capSegs = 0;  // segment buffers depend on the tile count too
     }

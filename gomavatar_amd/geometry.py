@@ -181,11 +181,12 @@ def face_gaussians(vertices_observation: torch.Tensor, so3: torch.Tensor, scale:
 
 
 class _PosedFaceGaussians(torch.autograd.Function):
-    """FK -> LBS -> per-face frame as one node; backward = face_bwd +
-    vertex_bwd (CSR gather fused with the LBS transpose) [+ fk_bwd]."""
+    """FK -> LBS -> per-face frame as one node: two launches forward (k_fk_lbs_fwd: the 24-joint chain in every workgroup, then k_face_fwd),
+    backward = face_bwd + vertex_bwd (CSR gather fused with the LBS transpose) [+ fk_bwd].  With `appearance` (3, F) the face kernel also
+    leaves the rasterizer's features [r g b 1] (F, 4) (gaussian.py:49's cat) and its backward the (3, F) colour gradient."""
 
     @staticmethod
-    def forward(ctx, vertices, so3, scale, dst_Rs, dst_Ts, cnl_gtfms, lbs_weights, topo, sigma):
+    def forward(ctx, vertices, so3, scale, dst_Rs, dst_Ts, cnl_gtfms, lbs_weights, topo, sigma, appearance):
         lib = _lib.load()
         st = _lib.stream_ptr()
         v, w, s = vertices.contiguous(), so3.contiguous(), scale.contiguous()
@@ -197,17 +198,25 @@ class _PosedFaceGaussians(torch.autograd.Function):
         v_obs = torch.empty_like(v)
         xyz = torch.empty((F, 3), dtype=torch.float32, device=dev)
         cov6 = torch.empty((F, 6), dtype=torch.float32, device=dev)
-        _lib.check(lib.gom_fk_forward(_lib.ptr(cnl), _lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(RT), _lib.ptr(save), st))
-        _lib.check(lib.gom_lbs_forward(N, N_JOINTS, _lib.ptr(v), _lib.ptr(lbs_weights), _lib.ptr(RT), _lib.ptr(v_obs), st))
+        app = feat4 = None
+        if appearance is not None:
+            app = appearance.detach().contiguous().float()
+            assert app.shape == (3, F)
+            feat4 = torch.empty((F, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.gom_fk_lbs_forward(N, _lib.ptr(cnl), _lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(v), _lib.ptr(lbs_weights), _lib.ptr(RT), _lib.ptr(save),
+                                          _lib.ptr(v_obs), st))
         _lib.check(lib.gom_face_forward(N, F, _lib.ptr(v_obs), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), float(sigma),
-                                        _lib.ptr(xyz), _lib.ptr(cov6), 0, 0, st))
+                                        _lib.ptr(xyz), _lib.ptr(cov6), _lib.ptr(app), _lib.ptr(feat4), st))
         ctx.save_for_backward(v, w, s, Rs, Ts, RT, save, v_obs, lbs_weights)
         ctx.topo, ctx.sigma = topo, float(sigma)
         ctx.shapes = (dst_Rs.shape, dst_Ts.shape)
-        return xyz, cov6, v_obs
+        ctx.with_feat = appearance is not None
+        if feat4 is None:
+            return xyz, cov6, v_obs
+        return xyz, cov6, v_obs, feat4
 
     @staticmethod
-    def backward(ctx, g_xyz, g_cov6, g_vobs):
+    def backward(ctx, g_xyz, g_cov6, g_vobs, g_feat=None):
         lib = _lib.load()
         st = _lib.stream_ptr()
         v, w, s, Rs, Ts, RT, save, v_obs, lbs_weights = ctx.saved_tensors
@@ -222,9 +231,15 @@ class _PosedFaceGaussians(torch.autograd.Function):
         if g_cov6 is None:
             g_cov6 = torch.zeros((F, 6), dtype=torch.float32, device=dev)
         g_xyz, g_cov6 = g_xyz.contiguous(), g_cov6.contiguous()
+        d_app = None
+        if ctx.with_feat and ctx.needs_input_grad[9] and g_feat is not None:
+            g_feat = g_feat.contiguous().float()
+            d_app = torch.empty((3, F), dtype=torch.float32, device=dev)
+        else:
+            g_feat = None
         _lib.check(lib.gom_face_backward(N, F, _lib.ptr(v_obs), _lib.ptr(topo.faces), _lib.ptr(w), _lib.ptr(s), ctx.sigma,
                                          _lib.ptr(g_xyz), _lib.ptr(g_cov6), _lib.ptr(d_corner),
-                                         _lib.ptr(d_so3), _lib.ptr(d_scale), 0, 0, st))
+                                         _lib.ptr(d_so3), _lib.ptr(d_scale), _lib.ptr(g_feat), _lib.ptr(d_app), st))
         need_pose = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         d_v = torch.empty_like(v)
         dRT = torch.zeros_like(RT) if need_pose else None
@@ -238,14 +253,16 @@ class _PosedFaceGaussians(torch.autograd.Function):
             dTs = torch.empty_like(Ts)
             _lib.check(lib.gom_fk_backward(_lib.ptr(Rs), _lib.ptr(Ts), _lib.ptr(save), _lib.ptr(dRT), _lib.ptr(dRs), _lib.ptr(dTs), st))
             dRs, dTs = dRs.reshape(ctx.shapes[0]), dTs.reshape(ctx.shapes[1])
-        return d_v, d_so3, d_scale, dRs, dTs, None, None, None, None
+        return d_v, d_so3, d_scale, dRs, dTs, None, None, None, None, d_app
 
 
 def posed_face_gaussians(vertices: torch.Tensor, so3: torch.Tensor, scale: torch.Tensor, dst_Rs: torch.Tensor, dst_Ts: torch.Tensor,
-                         cnl_gtfms: torch.Tensor, lbs_weights: torch.Tensor, topo: MeshTopology, sigma: float = 1e-3):
+                         cnl_gtfms: torch.Tensor, lbs_weights: torch.Tensor, topo: MeshTopology, sigma: float = 1e-3,
+                         appearance: Optional[torch.Tensor] = None):
     """Fused models/model.py:213-234: canonical vertices (3,N) + pose ->
-    (centroids (F,3), cov6 (F,6), posed vertices (3,N))."""
-    _check_dev(vertices, so3, scale, dst_Rs, dst_Ts, cnl_gtfms, lbs_weights)
+    (centroids (F,3), cov6 (F,6), posed vertices (3,N)); with `appearance` (3,F) also the rasterizer's
+    features (F,4) = [appearance.T | 1] (gaussian.py:49), written by the face kernel instead of a cat."""
+    _check_dev(vertices, so3, scale, dst_Rs, dst_Ts, cnl_gtfms, lbs_weights, appearance)
     assert lbs_weights.shape[0] == N_JOINTS + 1 and not lbs_weights.requires_grad
     return _PosedFaceGaussians.apply(vertices, so3, scale, dst_Rs.reshape(N_JOINTS, 3, 3), dst_Ts.reshape(N_JOINTS, 3),
-                                     cnl_gtfms.reshape(N_JOINTS, 4, 4), lbs_weights.contiguous(), topo, sigma)
+                                     cnl_gtfms.reshape(N_JOINTS, 4, 4), lbs_weights.contiguous(), topo, sigma, appearance)

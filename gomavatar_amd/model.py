@@ -469,9 +469,11 @@ class Model(nn.Module):
             vertices_pose = self.non_rigid_module(vertices_canonical.unsqueeze(0), dst_posevec, i_iter, R=None, S=None)[0][0]
         else:
             vertices_pose = vertices_canonical
+        feat = None
         if global_R is None:
-            xyz, cov6, vertices_observation = posed_face_gaussians(vertices_pose, self.so3, self.scale, dst_Rs[0], dst_Ts[0], cnl_gtfms[0],
-                                                                   self.lbs_weights, self.topo, self.sigma)
+            # (the rasterizer's features [appearance.T | 1] come out of the face kernel: no cat forward, no slice + transpose backward)
+            xyz, cov6, vertices_observation, feat = posed_face_gaussians(vertices_pose, self.so3, self.scale, dst_Rs[0], dst_Ts[0], cnl_gtfms[0],
+                                                                         self.lbs_weights, self.topo, self.sigma, appearance=self.appearance)
         else:   # PeopleSnapshot test-time pose optimisation (model.py:218-221): a rigid transform after the skinning
             from .geometry import get_global_RTs as _g
             vertices_observation = apply_lbs(vertices_pose.unsqueeze(0), *_g(cnl_gtfms, dst_Rs, dst_Ts), self.lbs_weights)[0]
@@ -485,7 +487,8 @@ class Model(nn.Module):
         # pseudo albedo + mask: one 4-channel pass (the reference pads to 6 channels and rasterizes twice)
         if self._ones is None or self._ones.shape[0] != F or self._ones.device != xyz.device:
             self._ones = torch.ones(F, 1, device=xyz.device)          # (constants of the topology: not two fill launches per frame)
-        feat = torch.cat([self.appearance.T, self._ones], 1)
+        if feat is None:
+            feat = torch.cat([self.appearance.T, self._ones], 1)
         opacity = self._ones[:, 0]
         if self.capture_safe:
             if self._dcam is None or (self._dcam.H, self._dcam.W) != (self.img_size[1], self.img_size[0]):

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, Optional, Sequence, Tuple
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -202,6 +203,9 @@ class FrameParallel:
         if t.is_cuda and not self._nccl:
             if self._host is None or self._host.numel() < t.numel():
                 self._host = torch.empty(t.numel(), dtype=torch.float32).pin_memory()
+                if os.environ.get("GOM_DEBUG_ADDRS", "0") != "0":
+                    import sys
+                    print(f"[gom torch pid {os.getpid()}] pinned staging {self._host.data_ptr():#x} .. {self._host.data_ptr() + self._host.numel() * 4:#x}", file=sys.stderr)
             h = self._host[:t.numel()].view(t.shape)
             h.copy_(t, non_blocking=False)
             fn(h)

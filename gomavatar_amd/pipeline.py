@@ -18,6 +18,7 @@ dimension, the gradients are the sum over the B frames.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -74,6 +75,18 @@ class RenderStep:
         self.cam = None
         self._frame = None
         self._cams_copied = None
+        if os.environ.get("GOM_DEBUG_ADDRS", "0") != "0":    # (development: which buffer does a faulting address belong to)
+            import sys
+            for nm in ("RT", "fk_save", "v_obs", "xyz", "cov6", "feat", "opacity", "image", "radii", "loss_partials", "d_image", "d_xyz", "d_cov6", "d_feat", "d_opacity",
+                       "d_corner", "cams_dev", "lbs_weights"):
+                t = getattr(self, nm)
+                print(f"[gom torch pid {os.getpid()}] RenderStep.{nm} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}", file=sys.stderr)
+            for nm, t in list(self.grads.items()) + [("topo.faces", self.topo.faces), ("topo.csr_off", self.topo.csr_off), ("topo.csr_idx", self.topo.csr_idx)]:
+                print(f"[gom torch pid {os.getpid()}] RenderStep.{nm} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}", file=sys.stderr)
+        if os.environ.get("GOM_DEBUG_POISON", "0") != "0":   # (development, with the library's switch of the same name: every `torch.empty` above starts as 0xA5 bytes)
+            for t in (self.RT, self.fk_save, self.v_obs, self.xyz, self.cov6, self.image, self.radii, self.d_xyz, self.d_cov6, self.d_feat, self.d_opacity,
+                      self.d_corner, *self.grads.values()):
+                t.view(torch.uint8).fill_(0xA5)
 
     # -- inputs ---------------------------------------------------------------
     def set_cameras(self, Ks, Es, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 9
+#define GOM_ABI_VERSION 10
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -240,6 +240,10 @@ int gom_fk_backward(const float *dst_Rs, const float *dst_Ts, const float *fk_sa
                     float *d_dst_Rs, float *d_dst_Ts, void *stream);
 /* xyz [3][N] channel-first, weights [J+1][N] (row J = background, ignored), RT [J][12] -> out [3][N] */
 int gom_lbs_forward(int N, int J, const float *xyz, const float *weights, const float *RT, float *out, void *stream);
+/* Both of the above for one frame in ONE launch (ABI 10): utils/body_util.py:612-644 as models/model.py:213-216 calls them back to back.
+ * Same bits as gom_fk_forward followed by gom_lbs_forward with J = 24; RT and fk_save are written as by gom_fk_forward (for the backward). */
+int gom_fk_lbs_forward(int N, const float *cnl_gtfms, const float *dst_Rs, const float *dst_Ts, const float *xyz, const float *weights,
+                       float *RT, float *fk_save, float *out, void *stream);
 
 /* ---- per-face Gaussians -----------------------------------------------------
  * verts [3][N], faces [F][3] int32, so3 [3][F], scale [3][F], sigma ->

@@ -34,6 +34,8 @@ frames = []
 for i in range(4):
     fr = {k: torch.from_numpy(v).to(dev) for k, v in wl.frames_np[i].items()}
     fr["target_rgbs"], fr["target_masks"] = wl.frames[i]["gt_rgb"][None], wl.frames[i]["gt_mask"][None]
+    if os.environ.get("BINARY_MASKS"):   # masks of {0, 1} like the data sets' segmentation masks (the synthetic targets are rendered: soft everywhere)
+        fr["target_masks"] = (fr["target_masks"] > 0.5).float()
     frames.append(fr)
 if which == "graph":          # the same iteration as ONE HIP graph (train_util.GraphedTrainStep: Adam capturable, lr frozen at capture)
     opt = GomAdam(groups, betas=(0.9, 0.999), capturable=True)

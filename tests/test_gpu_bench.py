@@ -44,15 +44,10 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_launches_itself_for_two_ranks():
-    try:
-        d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
-    except AssertionError as e:
-        # Two ranks on ONE device over gloo is a stand-in for RCCL (module docstring): once in a few dozen runs a rank's TCP pair is torn
-        # down under the other ("Connection closed by peer", SIGABRT inside gloo).  That is the stand-in's transport, not the code under
-        # test: one more attempt; anything else, or a second failure, fails the test.
-        if "Connection closed by peer" not in str(e) and "connection closed" not in str(e).lower():
-            raise
-        d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
+    # (Until round 5 this test retried once on "Connection closed by peer": a rank aborting under the other.  That was no transport hiccup but a
+    #  race of this library's own -- counters zeroed by hipMemset on the NULL stream, met unzeroed by the first frame's kernels on a non-blocking
+    #  stream when a second process held the device (gom_api.hip: zero_now; LABBOOK R5.9; 0 of 60 start-ups since the fix).  No retry any more.)
+    d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
     # N > 1 defaults to BASELINE configs[3]'s literal operating point: ONE frame per GPU per step, all-reduce + Adam inside the timed loop
     # (the native render step exchanges what it trains -- vertices / so3 / scale / appearance of the metric workload, no padding: 3 * 27 554 + 9 * 55 104)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 and d["config"]["frames_per_gpu_per_step"] == 1 and d["config"]["allreduce_floats"] == 578598

@@ -124,3 +124,14 @@ def test_unfused_mirrors_compose_like_the_reference():
         return float((a - b).abs().max()) / float(b.abs().max())
     assert rel(v.grad, v2.grad) <= 1e-5, rel(v.grad, v2.grad)
     assert rel(dR.grad, dR2.grad) <= 1e-4, rel(dR.grad, dR2.grad)   # (the vertex gradient reaches the two paths in different summation orders)
+    # the rasterizer's features [appearance.T | 1] out of the face kernel (gaussian.py:49's cat) and their gradient back into the (3, F) parameter: copies, bit for bit
+    F = sc["faces"].shape[0]
+    app = torch.rand(3, F, device="cuda").requires_grad_()
+    v3 = _cuda(p["vertices"]).requires_grad_()
+    x3, c3, vo3, feat = G.posed_face_gaussians(v3, _cuda(p["so3"]), _cuda(p["scale"]), _cuda(fr["dst_Rs"]), fr["dst_Ts"].cuda(), fr["cnl_gtfms"].cuda(),
+                                               sc["lbs_weights"].cuda(), topo, appearance=app)
+    assert torch.equal(x3, x2) and torch.equal(c3, c2) and torch.equal(vo3, vo)
+    assert torch.equal(feat, torch.cat([app.detach().T, torch.ones(F, 1, device="cuda")], 1))
+    wf = torch.randn(F, 4, device="cuda")
+    ((feat * wf).sum() + x3.sum() + c3.sum() * 100).backward()
+    assert torch.equal(app.grad, wf[:, :3].T.contiguous()) and torch.equal(v3.grad, v2.grad)
