@@ -421,6 +421,7 @@ def extra_figures(torch, wl):
                 mc = LPIPSMatrixCore(trunk_seed=0, device=dev, precision=prec)
                 hook = st.lpips_hook(mc, bt["gt_rgb"], bt["bg"], coeff=1.0)
                 pv = dict(fp.params.items())
+                torch.cuda.synchronize()   # (what was set up on the default stream is there before a non-blocking stream reads it)
                 stream = torch.cuda.Stream(device=dev)
 
                 def native():
@@ -506,6 +507,7 @@ def lpips_roofline(torch, wl):
         mc = LPIPSMatrixCore(trunk_seed=0, device=wl.device, precision=prec)
         gt = wl.frames[0]["gt_rgb"][None].contiguous()
         pred = (gt * 0.9 + 0.05).contiguous()
+        torch.cuda.synchronize()   # (what was set up on the default stream is there before a non-blocking stream reads it)
         stream = torch.cuda.Stream(device=wl.device)
         import torch as _t
         from gomavatar_amd import _lib as _l
@@ -572,6 +574,7 @@ def render_only_modes(torch, wl):
         try:
             st = wl.step(b_)
             bts = wl.batches(st)
+            torch.cuda.synchronize()   # (what was set up on the default stream is there before a non-blocking stream reads it)
             stream = torch.cuda.Stream(device=wl.device)
             j = [0]
 
