@@ -90,9 +90,16 @@ __device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py
     float t0, t1, t2;
     bool g0, g1, g2;
     const float d0 = seg_dist2(px, py, x0, y0, x1, y1, t0, g0), d1 = seg_dist2(px, py, x1, y1, x2, y2, t1, g1), d2 = seg_dist2(px, py, x2, y2, x0, y0, t2, g2);
-    float d = d0; r.edge = 0; r.t = t0; r.degenerate = g0;
-    if (d1 < d) { d = d1; r.edge = 1; r.t = t1; r.degenerate = g1; }
-    if (d2 < d) { d = d2; r.edge = 2; r.t = t2; r.degenerate = g2; }
+    // (selects on values: written as assignments under `if`, the compiler kept t0..t2 / g0..g2 in a scratch-memory array and indexed it with the edge --
+    //  12 scratch stores and 2 loads per evaluation in k_mesh_backward_entries, the only consumer of t and degenerate)
+    const bool u1 = d1 < d0;
+    const float da = u1 ? d1 : d0, ta = u1 ? t1 : t0;
+    const int ga = u1 ? (int)g1 : (int)g0;
+    const bool u2 = d2 < da;
+    const float d = u2 ? d2 : da;
+    r.edge = u2 ? 2 : (u1 ? 1 : 0);
+    r.t = u2 ? t2 : ta;
+    r.degenerate = (u2 ? (int)g2 : ga) != 0;
     if (!r.inside && !(d < blur_radius)) return r;
     r.soft = true;
     const float sd = r.inside ? -d : d;
@@ -356,17 +363,25 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                     const float others = qdiv(s_Q[lp], fmaxf(1.f - r.prob, 1e-30f));
                     float gd = -s_da[lp] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
                     if (r.inside) gd = -gd;                                                    // sd = -dist inside
-                    const int ia = r.edge, ib = (r.edge + 1) % 3;
-                    const float ax = fg[3 * ia], ay = fg[3 * ia + 1], bx = fg[3 * ib], by = fg[3 * ib + 1];
+                    // (corner a = r.edge, b = the next one, picked by selects: an index known only at run time would put fg[] and gv[] into scratch memory)
+                    const int ia = r.edge, ib = ia == 2 ? 0 : ia + 1;
+                    const float ax = ia == 0 ? fg[0] : (ia == 1 ? fg[3] : fg[6]), ay = ia == 0 ? fg[1] : (ia == 1 ? fg[4] : fg[7]);
+                    const float bx = ib == 0 ? fg[0] : (ib == 1 ? fg[3] : fg[6]), by = ib == 0 ? fg[1] : (ib == 1 ? fg[4] : fg[7]);
+                    float cax = 0.f, cay = 0.f, cbx, cby;
                     if (r.degenerate) {
-                        gv[2 * ib] += gd * -2.f * (px - bx); gv[2 * ib + 1] += gd * -2.f * (py - by);
+                        cbx = gd * -2.f * (px - bx); cby = gd * -2.f * (py - by);
                     } else {
                         const float qx = ax + r.t * (bx - ax), qy = ay + r.t * (by - ay);
                         const float rx = px - qx, ry = py - qy;
                         // dist = |p - q|^2, q = a + t (b - a): for 0 < t < 1 the residual is normal to the edge, so only q's
                         // explicit dependence on a, b counts; at the clamps q is the end point itself
-                        gv[2 * ia] += gd * -2.f * rx * (1.f - r.t); gv[2 * ia + 1] += gd * -2.f * ry * (1.f - r.t);
-                        gv[2 * ib] += gd * -2.f * rx * r.t;         gv[2 * ib + 1] += gd * -2.f * ry * r.t;
+                        cax = gd * -2.f * rx * (1.f - r.t); cay = gd * -2.f * ry * (1.f - r.t);
+                        cbx = gd * -2.f * rx * r.t;         cby = gd * -2.f * ry * r.t;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {   // corner a first, then corner b (a != b): the sums of the indexed form, bit for bit
+                        if (!r.degenerate && k == ia) { gv[2 * k] += cax; gv[2 * k + 1] += cay; }
+                        if (k == ib) { gv[2 * k] += cbx; gv[2 * k + 1] += cby; }
                     }
                 }
 #pragma unroll
