@@ -471,6 +471,17 @@ def extra_figures(torch, wl):
             optm = GomAdam(model.get_param_groups(tcfg), betas=(0.9, 0.999))
             it_[0] = 0
             out[f"model_train_iteration_lpips_{prec}_b1_ips"] = round(timeit(torch, train_it, warm=10, chunk=5, windows=3), 1)
+            if prec == "bf16x3":
+                # The data sets' target masks are segmentation masks of {0, 1} (dataset/train.py:240-258); the synthetic targets above are RENDERED masks, soft
+                # everywhere.  With {0, 1} targets |normal_mask - target|'s gradient is exactly 0 under the body (alpha rounds to 1.0f there) and the mesh
+                # rasterizer's backward evaluates the outline's band alone (mesh_raster.hip: k_mesh_backward_entries) -- the same iteration on such targets:
+                soft = [f_["target_masks"] for f_ in frames]
+                for f_ in frames:
+                    f_["target_masks"] = (f_["target_masks"] > 0.5).float()
+                torch.cuda.synchronize()
+                out["model_train_iteration_lpips_bf16x3_binary_target_masks_b1_ips"] = round(timeit(torch, train_it, warm=6, chunk=5, windows=3), 1)
+                for f_, m_ in zip(frames, soft):
+                    f_["target_masks"] = m_
             if prec == "bf16x3":   # the same iteration captured once in a HIP graph and replayed per frame (train_util.GraphedTrainStep; Adam capturable, lr frozen at capture)
                 model_g = Model(cfg, wl.body).train()
                 opt_g = GomAdam(model_g.get_param_groups(tcfg), betas=(0.9, 0.999), capturable=True)
