@@ -28,7 +28,7 @@ for j in range(n0):
         r = seqs[0][j]
         short = nm.replace("(anonymous namespace)::", "").replace("void ", "")[:64]
         print(f"{j:4d} {short:64s} grid {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):6d} x {int(r['Grid_Size_Y']):3d} x {int(r['Grid_Size_Z']):3d}  wg {r['Workgroup_Size_X']:>4s}  {d:8.1f} us")
-print("LPIPS launches total: %.1f us" % tot)
+print(("ALL launches" if os.environ.get("ALL") else "LPIPS launches") + " total: %.1f us" % tot)
 # the summary bench.py's roofline_lpips cites (profiles/<tag>_lpips_launches.json): launches and the convolutions' share of one LPIPS evaluation
 import json
 lp = [j for j in range(n0) if any(k in seqs[0][j]["Kernel_Name"] for k in keys)]
