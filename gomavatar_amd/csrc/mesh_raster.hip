@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                     const float others = qdiv(s_Q[lp], fmaxf(1.f - r.prob, 1e-30f));
                     float gd = -s_da[lp] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
                     if (r.inside) gd = -gd;                                                    // sd = -dist inside
-                    // (corner a = r.edge, b = the next one, picked by selects: an index known only at run time would put fg[] and gv[] into scratch memory)
+                    // (corner a = r.edge, b = the next one, spelled as selects -- what the compiler made of fg[3 * ia] / gv[2 * ia] as well; the kernel's scratch memory
+                    //  came from eval_face's (t, degenerate), see there)
                     const int ia = r.edge, ib = ia == 2 ? 0 : ia + 1;
                     const float ax = ia == 0 ? fg[0] : (ia == 1 ? fg[3] : fg[6]), ay = ia == 0 ? fg[1] : (ia == 1 ? fg[4] : fg[7]);
                     const float bx = ib == 0 ? fg[0] : (ib == 1 ? fg[3] : fg[6]), by = ib == 0 ? fg[1] : (ib == 1 ? fg[4] : fg[7]);
