@@ -46,7 +46,7 @@ def test_bench_line_contract_single_gpu():
 def test_bench_launches_itself_for_two_ranks():
     # (Until round 5 this test retried once on "Connection closed by peer": a rank aborting under the other.  That was no transport hiccup but a
     #  race of this library's own -- counters zeroed by hipMemset on the NULL stream, met unzeroed by the first frame's kernels on a non-blocking
-    #  stream when a second process held the device (gom_api.hip: zero_now; LABBOOK R5.9; 0 of 60 start-ups since the fix).  No retry any more.)
+    #  stream when a second process held the device (gom_api.hip: zero_now; LABBOOK R5.9; 0 of 100 start-ups since the fix).  No retry any more.)
     d = _run("--gpus", "2", "--steps", "6", "--warmup", "2")
     # N > 1 defaults to BASELINE configs[3]'s literal operating point: ONE frame per GPU per step, all-reduce + Adam inside the timed loop
     # (the native render step exchanges what it trains -- vertices / so3 / scale / appearance of the metric workload, no padding: 3 * 27 554 + 9 * 55 104)
