@@ -91,7 +91,7 @@ __device__ __forceinline__ FaceEval eval_face(const float *f, float px, float py
     bool g0, g1, g2;
     const float d0 = seg_dist2(px, py, x0, y0, x1, y1, t0, g0), d1 = seg_dist2(px, py, x1, y1, x2, y2, t1, g1), d2 = seg_dist2(px, py, x2, y2, x0, y0, t2, g2);
     // (selects on values: written as assignments under `if`, the compiler kept t0..t2 / g0..g2 in a scratch-memory array and indexed it with the edge --
-    //  12 scratch stores and 2 loads per evaluation in k_mesh_backward_entries, the only consumer of t and degenerate)
+    //  12 scratch stores and 2 loads per evaluation in k_mesh_backward_entries, the only consumer of t and degenerate: 110 -> 103 us)
     const bool u1 = d1 < d0;
     const float da = u1 ? d1 : d0, ta = u1 ? t1 : t0;
     const int ga = u1 ? (int)g1 : (int)g0;
@@ -363,8 +363,9 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                     const float others = qdiv(s_Q[lp], fmaxf(1.f - r.prob, 1e-30f));
                     float gd = -s_da[lp] * others * r.prob * (1.f - r.prob) * inv_sigma;   // d L / d sd
                     if (r.inside) gd = -gd;                                                    // sd = -dist inside
-                    // (corner a = r.edge, b = the next one, spelled as selects -- what the compiler made of fg[3 * ia] / gv[2 * ia] as well; the kernel's scratch memory
-                    //  came from eval_face's (t, degenerate), see there)
+                    // (corner a = r.edge, b = the next one, spelled as selects and a static loop: as fg[3 * ia] / gv[2 * ia] -- register arrays indexed by a value known
+                    //  only at run time -- this block cost a third of the kernel: 103 -> 70 us.  Same arithmetic; the compiler contracts other multiply-adds now, so the
+                    //  four terms move in their last bit: LABBOOK R5.10)
                     const int ia = r.edge, ib = ia == 2 ? 0 : ia + 1;
                     const float ax = ia == 0 ? fg[0] : (ia == 1 ? fg[3] : fg[6]), ay = ia == 0 ? fg[1] : (ia == 1 ? fg[4] : fg[7]);
                     const float bx = ib == 0 ? fg[0] : (ib == 1 ? fg[3] : fg[6]), by = ib == 0 ? fg[1] : (ib == 1 ? fg[4] : fg[7]);
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256) k_mesh_backward_entries(MeshGrid g, const
                         cbx = gd * -2.f * rx * r.t;         cby = gd * -2.f * ry * r.t;
                     }
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {   // corner a first, then corner b (a != b): the sums of the indexed form, bit for bit
+                    for (int k = 0; k < 3; k++) {   // corner a first, then corner b (a != b): the order of the indexed form
                         if (!r.degenerate && k == ia) { gv[2 * k] += cax; gv[2 * k + 1] += cay; }
                         if (k == ib) { gv[2 * k] += cbx; gv[2 * k + 1] += cby; }
                     }
