@@ -475,13 +475,10 @@ class Model(nn.Module):
             xyz, cov6, vertices_observation, feat = posed_face_gaussians(vertices_pose, self.so3, self.scale, dst_Rs[0], dst_Ts[0], cnl_gtfms[0],
                                                                          self.lbs_weights, self.topo, self.sigma, appearance=self.appearance)
         else:   # PeopleSnapshot test-time pose optimisation (model.py:218-221): a rigid transform after the skinning
-            from .geometry import get_global_RTs as _g
-            vertices_observation = apply_lbs(vertices_pose.unsqueeze(0), *_g(cnl_gtfms, dst_Rs, dst_Ts), self.lbs_weights)[0]
-            th = global_R.norm().clamp_min(1e-8)
-            k = global_R / th
-            Kx = torch.zeros(3, 3, device=k.device, dtype=k.dtype)
-            Kx[0, 1], Kx[0, 2], Kx[1, 0], Kx[1, 2], Kx[2, 0], Kx[2, 1] = -k[2], k[1], k[2], -k[0], -k[1], k[0]
-            Rg = torch.eye(3, device=k.device) + torch.sin(th) * Kx + (1 - torch.cos(th)) * (Kx @ Kx)
+            from .modules import rodrigues
+            vertices_observation = apply_lbs(vertices_pose.unsqueeze(0), *get_global_RTs(cnl_gtfms, dst_Rs, dst_Ts), self.lbs_weights)[0]
+            # RodriguesModule's own arithmetic (utils/network_util.py:64-92): theta = sqrt(1e-5 + |r|^2), "axis" r / theta (NOT a unit vector)
+            Rg = rodrigues(global_R.unsqueeze(0))[0]
             vertices_observation = Rg @ vertices_observation + global_T[:, None]
             xyz, cov6 = face_gaussians(vertices_observation, self.so3, self.scale, self.topo, self.sigma)
         # pseudo albedo + mask: one 4-channel pass (the reference pads to 6 channels and rasterizes twice)

@@ -60,6 +60,19 @@ def so3_exp(v: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
     return f1[..., None, None] * K + f2[..., None, None] * (K @ K) + eye
 
 
+def rodrigues_module(rvec: torch.Tensor) -> torch.Tensor:
+    """utils/network_util.py:64-92 RodriguesModule, (B,3) -> (B,3,3): theta = sqrt(1e-5 + |r|^2), k = r / theta (shorter than a unit
+    vector near zero), R = k k^T + (I - diag(k^2))-style cos terms + sin [k]x exactly as the reference writes them.  Used by
+    models/model.py:218-221 (global_R) and train_pose.py.  PINNED: tests/golden/pose_modules.npz rod_* (tests/test_oracle_geometry.py)."""
+    theta = torch.sqrt(1e-5 + torch.sum(rvec ** 2, dim=1))
+    k = rvec / theta[:, None]
+    c, s = torch.cos(theta), torch.sin(theta)
+    kx, ky, kz = k[:, 0], k[:, 1], k[:, 2]
+    return torch.stack((kx ** 2 + (1. - kx ** 2) * c, kx * ky * (1. - c) - kz * s, kx * kz * (1. - c) + ky * s,
+                        kx * ky * (1. - c) + kz * s, ky ** 2 + (1. - ky ** 2) * c, ky * kz * (1. - c) - kx * s,
+                        kx * kz * (1. - c) - ky * s, ky * kz * (1. - c) + kx * s, kz ** 2 + (1. - kz ** 2) * c), dim=1).view(-1, 3, 3)
+
+
 def steiner_frame(tri: torch.Tensor, sigma: float = 1e-3) -> torch.Tensor:
     """models/model.py:27-41.  tri (F,3,3) rows = corners -> A (F,3,3) with
     columns [2 a0 | 2 a1 | sigma n]."""
@@ -150,13 +163,17 @@ def rasterize(cam: dict, means3D, cov6, colors, opacity) -> torch.Tensor:
     return _OracleRaster.apply(cam, means3D, cov6, colors, opacity)
 
 
-def render_path(params: dict, frame: dict, faces: torch.Tensor, lbs_weights: torch.Tensor, img_size: int, sigma: float = 1e-3):
+def render_path(params: dict, frame: dict, faces: torch.Tensor, lbs_weights: torch.Tensor, img_size: int, sigma: float = 1e-3,
+                global_R=None, global_T=None):
     """The whole restated render path for one frame (models/model.py:213-250 +
     gaussian.py:22-100 fused to one 4-channel pass): returns rgb (1,H,W,3),
     mask (1,H,W) and the intermediates.  params: vertices (3,N), so3 (3,F),
-    scale (3,F), appearance (3,F) torch tensors (may require grad)."""
+    scale (3,F), appearance (3,F) torch tensors (may require grad).
+    global_R (3,) axis-angle / global_T (3,): models/model.py:218-221."""
     Rs, Ts = fk_global_RTs(frame["cnl_gtfms"], frame["dst_Rs"], frame["dst_Ts"])
     v_obs = lbs(params["vertices"].unsqueeze(0), Rs, Ts, lbs_weights)[0]
+    if global_R is not None:
+        v_obs = rodrigues_module(global_R.unsqueeze(0))[0] @ v_obs + global_T[:, None]
     xyz, cov = face_gaussians(v_obs, faces, params["so3"], params["scale"], sigma)
     cov6 = pack_cov6(cov)
     F = faces.shape[0]

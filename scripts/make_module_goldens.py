@@ -15,6 +15,7 @@ import make_goldens as mg  # noqa: E402
 mg.install_stubs({"calls": []})
 from models.modules.non_rigid_module import NonRigidModule as RefNR  # noqa: E402
 from models.modules.pose_refinement_module import PoseRefinementModule as RefPR  # noqa: E402
+from utils.network_util import RodriguesModule as RefRod  # noqa: E402
 
 NS = types.SimpleNamespace
 nr_cfg = NS(name="basic", condition_code_size=69, mlp_width=128, mlp_depth=6, skips=[4], multires=6, i_embed=0, kick_in_iter=150000, full_band_iter=200000)
@@ -39,6 +40,13 @@ out["pr_out"] = Rs.detach().numpy()
 out["pr_gpose"] = torch.autograd.grad((Rs * torch.arange(9.0).view(3, 3)).sum(), pose)[0].numpy()
 out.update({"nr_" + k: v.numpy() for k, v in nr.state_dict().items()})
 out.update({"pr_" + k: v.numpy() for k, v in pr.state_dict().items()})
+# RodriguesModule itself (network_util.py:64-92): Model.forward's global_R branch (model.py:218-221) and train_pose.py's Rh.  Eight vectors:
+# generic, large angle, and |r| at / near zero, where theta = sqrt(1e-5 + |r|^2) is NOT |r| and the "axis" r / theta is not a unit vector.
+rv = torch.randn(8, 3, generator=g)
+rv = (rv * torch.tensor([1.0, 0.3, 2.5, 3e-3, 1e-4, 0.0, 1e-2, 0.7])[:, None]).requires_grad_()
+Rm = RefRod()(rv)
+out["rod_rvec"], out["rod_out"] = rv.detach().numpy(), Rm.detach().numpy()
+out["rod_grvec"] = torch.autograd.grad((Rm * torch.arange(1.0, 10.0).view(3, 3)).sum(), rv)[0].numpy()
 out["nr_param_count"], out["pr_param_count"] = np.int64(counts[0]), np.int64(counts[1])
 np.savez_compressed(os.path.join(REPO, "tests", "golden", "pose_modules.npz"), **out)
 print("pose_modules.npz", out["nr_param_count"], out["pr_param_count"])

@@ -388,3 +388,47 @@ def test_graphed_render_and_two_stream_rendering_equal_the_eager_frame():
             assert float(d.mean()) < 1e-6 and float(d.max()) < 1e-3, (overlap, float(d.mean()), float(d.max()))
         m.capture_safe = False
     m.overlap_branches = False
+
+
+@pytest.mark.parametrize("rvec", [(0.21, -0.33, 0.12), (2e-3, -1e-3, 1.5e-3)])
+def test_global_R_T_branch_matches_reference_arithmetic(rvec):
+    """Model.forward(..., global_R=, global_T=): PeopleSnapshot's test-time pose optimisation (/root/reference/models/model.py:218-221,
+    train_pose.py:247-254): vertices_observation = RodriguesModule(global_R) @ LBS(...) + global_T -- RodriguesModule's OWN arithmetic
+    (utils/network_util.py:64-92: theta = sqrt(1e-5 + |r|^2), r / theta not a unit vector; oracle pinned by tests/golden/pose_modules.npz).
+    Held: albedo and mask against the oracle render of the rigidly moved vertices, and the gradients train_pose.py consumes (wrt global_R, global_T)
+    plus the Gaussian parameters' against the fp64 oracle.  The second vector (|r| ~ 3e-3 ~ sqrt(1e-5)) is where a unit-axis Rodrigues formula
+    moves the body by ~1e-3 (25 % of the angle): the check that failed before round 6."""
+    img = 96
+    m = _small_model(img, seed_shadow=False)
+    fr = _frame(4, img)
+    dv = {k: v.cuda() for k, v in fr.items() if torch.is_tensor(v)}
+    gR = torch.tensor(rvec, device="cuda", requires_grad=True)
+    gT = torch.tensor([0.03, -0.02, 0.05], device="cuda", requires_grad=True)
+    rgbs, masks, out = m(dv["K"], dv["E"], dv["cnl_gtfms"], dv["dst_Rs"], dv["dst_Ts"], global_R=gR, global_T=gT)
+    w = torch.linspace(0.5, 1.5, img * img * 3).reshape(1, img, img, 3)
+    m.zero_grad(set_to_none=True)
+    ((out["albedo"][None] * w.cuda()).sum() + 2.0 * masks.sum()).backward()
+    got = dict(vertices=m.vertices.grad, so3=m.so3.grad, scale=m.scale.grad, appearance=m.appearance.grad, global_R=gR.grad, global_T=gT.grad)
+    # ---- oracle: fp32 for the image, fp64 for the gradients ----
+    faces, w25 = m.faces.cpu(), m.lbs_weights.cpu()
+    base = dict(vertices=m.vertices.detach().cpu(), so3=m.so3.detach().cpu(), scale=m.scale.detach().cpu(), appearance=m.appearance.detach().cpu(),
+                global_R=gR.detach().cpu(), global_T=gT.detach().cpu())
+    o_rgb, o_mask, aux = og.render_path(base, fr, faces, w25, img, global_R=base["global_R"], global_T=base["global_T"])
+    for a, b in ((out["albedo"][None], o_rgb), (masks, o_mask)):
+        d = (a.detach().cpu() - b).abs()
+        assert float(d.mean()) <= 2e-6 and float((d > 1e-4).float().mean()) <= 2e-3, (float(d.mean()), float(d.max()))
+    # the moved vertices themselves (the mesh the outputs carry): fp32 round-off of the reference's expression
+    dvert = (out["mesh"].verts_packed().detach().cpu() - aux["v_obs"].T).abs().max()
+    assert float(dvert) <= 2e-6, float(dvert)
+    p64 = {k: v.double().requires_grad_() for k, v in base.items()}
+    fr64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in fr.items()}
+    r64, m64, _ = og.render_path(p64, fr64, faces, w25.double(), img, global_R=p64["global_R"], global_T=p64["global_T"])
+    ((r64 * w.double()).sum() + 2.0 * m64.sum()).backward()
+    for k, g in got.items():
+        ref = p64[k].grad
+        err = float((g.detach().cpu().double() - ref).norm()) / max(float(ref.norm()), 1e-30)
+        assert err <= 5e-3, (k, err, g.detach().cpu().flatten()[:3], ref.flatten()[:3])
+    # and the wrong formula is far outside these bounds at small angles (so this test does pin the choice)
+    if max(abs(x) for x in rvec) < 1e-2:
+        th = base["global_R"].norm()
+        assert abs(float(th) - float(torch.sqrt(1e-5 + th * th))) > 5e-4

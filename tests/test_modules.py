@@ -53,3 +53,17 @@ def test_pose_refinement_matches_reference():
     np.testing.assert_allclose(Rs.detach().numpy(), G["pr_out"], rtol=2e-6, atol=2e-7)
     g = torch.autograd.grad((Rs * torch.arange(9.0).view(3, 3)).sum(), pose)[0]
     np.testing.assert_allclose(g.numpy(), G["pr_gpose"], rtol=2e-5, atol=2e-6)
+
+
+def test_rodrigues_matches_reference_module():
+    """modules.rodrigues == utils/network_util.py:64-92 RodriguesModule (Model.forward's global_R branch, model.py:218-221; train_pose.py's Rh):
+    eight vectors incl. |r| = 0 and |r| ~ 1e-4, where sqrt(1e-5 + |r|^2) differs from |r| and the result is NOT a rotation about a unit axis."""
+    from gomavatar_amd.modules import rodrigues
+    rv = torch.from_numpy(G["rod_rvec"]).requires_grad_()
+    R = rodrigues(rv)
+    np.testing.assert_allclose(R.detach().numpy(), G["rod_out"], rtol=0, atol=1e-7)
+    g = torch.autograd.grad((R * torch.arange(1.0, 10.0).view(3, 3)).sum(), rv)[0]
+    np.testing.assert_allclose(g.numpy(), G["rod_grvec"], rtol=1e-5, atol=2e-6)     # (x * x against x ** 2: another autograd formula, same function)
+    # the unit-axis formula the branch used before round 6 is measurably something else near zero (this is what the golden pins)
+    th = rv.detach().norm(dim=1).clamp_min(1e-8)
+    assert float((th - torch.sqrt(1e-5 + th * th)).abs().max()) > 1e-3

@@ -82,3 +82,15 @@ def test_camera_block_matches_reference(golden_dir):
     feats = torch.cat([torch.from_numpy(g["feats"]), torch.ones(1, g["feats"].shape[1], 1)], -1)
     np.testing.assert_array_equal(feats[0, :, :3].numpy(), g["call0_colors"])
     np.testing.assert_array_equal(torch.cat([feats[0, :, 3:], feats[0, :, :2]], -1).numpy(), g["call1_colors"])
+
+
+def test_rodrigues_module_matches_reference(golden_dir):
+    """oracle.geometry.rodrigues_module against the reference's own RodriguesModule (scripts/make_module_goldens.py): bitwise in fp32
+    (the same torch expression), and the fp64 evaluation within fp32 round-off of it."""
+    g = _g(golden_dir, "pose_modules.npz")
+    rv = torch.from_numpy(g["rod_rvec"]).requires_grad_()
+    R = og.rodrigues_module(rv)
+    assert np.array_equal(R.detach().numpy(), g["rod_out"])
+    gr = torch.autograd.grad((R * torch.arange(1.0, 10.0).view(3, 3)).sum(), rv)[0]
+    np.testing.assert_allclose(gr.numpy(), g["rod_grvec"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(og.rodrigues_module(rv.detach().double()).numpy(), g["rod_out"], rtol=0, atol=2e-7)
