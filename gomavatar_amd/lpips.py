@@ -195,6 +195,7 @@ def pack_first_layer(w: torch.Tensor, x3: bool):
 
 
 class LPIPSMatrixCore:
+    supports_partial_sums = True       # loss(..., reduce=False) -> partial sums for train_util.compute_loss's fused tail
     """LPIPS-VGG value AND gradient w.r.t. the predicted image in one pass (train.py:113-121 semantics:
     `mean_b LPIPS(2*pred-1, 2*gt-1)`), bf16 activations / fp32 accumulation on MFMA.
 

@@ -95,9 +95,12 @@ class GomAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict) -> None:
         """torch.optim.Adam checkpoints load unchanged; a capturable torch checkpoint holds `step` as DEVICE tensors -- moved to the host here (reading
-        them inside step() would synchronise, which a capture forbids) -- and the device counter is re-seeded from the loaded count at the next step."""
+        them inside step() would synchronise, which a capture forbids) -- and the device counter (kept: a captured step holds its address) is re-seeded from the loaded count."""
         super().load_state_dict(state_dict)
         for st in self.state.values():
             if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
                 st["step"] = st["step"].detach().float().cpu()
-        self._step_dev = None
+        if self._step_dev is not None:
+            # a captured step (GraphedTrainStep) has this tensor's address baked into its graph: keep the tensor, re-seed its value from the loaded count
+            steps = {int(float(st["step"])) for st in self.state.values() if "step" in st}
+            self._step_dev.fill_(max(steps) if steps else 0)

@@ -242,18 +242,33 @@ class FrameParallel:
         opt.moments_sharded = False
 
     def recover(self, opt: Optional["FlatAdam"] = None, src: int = 0) -> None:
-        """Collective, on EVERY rank after a timed-out peer exchange (PeerAllReduce.poll / check raised): resets the exchange and re-broadcasts the
-        parameters -- and `opt`'s moments and step count -- from rank `src`, because a timed-out exchange with the optimizer inside it leaves the
-        replicas stepped slice by slice, differently per rank.  (Under ZeRO-1 the moments of `src` are complete only for its own slice: restore a
-        checkpoint instead if the step that timed out matters.)"""
+        """Collective, on EVERY rank after a timed-out peer exchange (PeerAllReduce.poll / check raised): resets the exchange and makes the replicas
+        agree again -- parameters, `opt`'s moments and step count -- because a timed-out exchange with the optimizer inside it leaves the replicas
+        stepped slice by slice, differently per rank.
+        * replicated optimizer (collective / peer): everything is re-broadcast from rank `src`.
+        * ZeRO-1 (`opt.moments_sharded`): a rank holds CURRENT moments for its own slice only, so broadcasting `src`'s would overwrite every other
+          slice's history with stale data (zeros if ZeRO-1 ran from the start: steps ~3x too large for (world-1)/world of the parameters).  Each slice
+          is taken from its OWNER instead -- moments through `gather_optimizer_state`, parameters the same way (the owner stepped them; what the other
+          ranks hold of that slice depends on how far the timed-out gather got) -- and only the step count comes from `src`.
+        The step that timed out may be lost on the slices whose owner gave up before its Adam launch (one step of some slices: restore a checkpoint if
+        that matters)."""
         if self.peer is not None:
             self.peer.reset()
         if self.world <= 1:
             return
-        self.broadcast_params(src)
+        if opt is not None and getattr(opt, "moments_sharded", False):
+            lo, hi = self.zero1_slice()
+            n = self.params.flat.numel()
+            self.params.flat[:min(lo, n)].zero_()
+            self.params.flat[min(hi, n):].zero_()
+            self._staged(self.params.flat, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
+            self.gather_optimizer_state(opt)          # (own slice kept, sum over the ranks; clears moments_sharded until the next ZeRO-1 step)
+        else:
+            self.broadcast_params(src)
+            if opt is not None:
+                for m in (opt.exp_avg, opt.exp_avg_sq):
+                    self._staged(m, lambda x: dist.broadcast(x, src=src, group=self.group))
         if opt is not None:
-            for m in (opt.exp_avg, opt.exp_avg_sq):
-                self._staged(m, lambda x: dist.broadcast(x, src=src, group=self.group))
             got = [opt.t]
             dist.broadcast_object_list(got, src=src, group=self.group)
             opt.t = int(got[0])
@@ -446,6 +461,13 @@ class ModelFrameParallel:
         self.fp, self.opt, self.torch_opt = None, None, None
         self._stream, self._done = None, None
         self.reseat(first=True)
+        # With `overlap` the exchange + Adam of the last step() may still be running on the side stream when train_iteration returns: every
+        # read of the parameters on the main stream waits for it first -- any forward of the model (an eval render between two steps) and
+        # state_dict() (a checkpoint) through these hooks, zero_grad / optimizer_state_dict / reseat / recover / close directly.  Anything else
+        # that reads `p.data` on another stream must call finish() itself.
+        self._hooks = [model.register_forward_pre_hook(lambda *_: self.finish())]
+        if hasattr(model, "register_state_dict_pre_hook"):
+            self._hooks.append(model.register_state_dict_pre_hook(lambda *_: self.finish()))
 
     # -- layout ------------------------------------------------------------------------------------------------------------------
     def _entries(self):
@@ -492,10 +514,10 @@ class ModelFrameParallel:
             self.opt = FlatAdam(self.fp, dict(self.group_lr), betas=self.betas, eps=self.eps, segments=segs)
             self.torch_opt = None
         else:
-            groups = {}
-            for _, gname, _, p, lr in ent:
-                groups.setdefault(gname, {"name": gname, "params": [], "lr": lr})["params"].append(p)
-            self.torch_opt = torch.optim.Adam(list(groups.values()), betas=self.betas, eps=self.eps)
+            # host tensors: the reference's own optimizer over the reference's own groups, UNCHANGED (group 0 = the skinning weights, the two
+            # `canonical_geometry` groups apart, the reference's order): its state_dict() is what optimizer_state_dict() promises and what the
+            # device path writes, so a state saved on either loads on the other (and in the reference)
+            self.torch_opt = torch.optim.Adam(self.model.get_param_groups(self.train_cfg), betas=self.betas, eps=self.eps)
             self.opt = None
         self._joined = {sg[0]: True for sg in segs}
         if self.fp.world > 1:
@@ -505,7 +527,10 @@ class ModelFrameParallel:
     @property
     def param_groups(self):
         """[{name, lr}] of the groups this object steps (update_lr-compatible view; writing `lr` here has no effect: use `decay`)."""
-        return [{"name": nm, "lr": (self.opt.lr[i] if self.opt is not None else self.torch_opt.param_groups[i]["lr"])} for i, (nm, _, _) in enumerate(self.segments)]
+        if self.opt is None:
+            by_name = {g["name"]: g["lr"] for g in self.torch_opt.param_groups}
+            return [{"name": nm, "lr": by_name[nm]} for nm, _, _ in self.segments]
+        return [{"name": nm, "lr": self.opt.lr[i]} for i, (nm, _, _) in enumerate(self.segments)]
 
     # -- the step -----------------------------------------------------------------------------------------------------------------
     def frame_index(self, step: int) -> int:
@@ -542,7 +567,8 @@ class ModelFrameParallel:
                 p.grad = g
             if lr_decay_steps:
                 for grp in self.torch_opt.param_groups:
-                    grp["lr"] = self.group_lr[grp["name"]] * 0.1 ** (i_iter / lr_decay_steps)
+                    if grp["name"] in self.group_lr:      # (group 0, the skinning-weight buffer, has no segment)
+                        grp["lr"] = self.group_lr[grp["name"]] * 0.1 ** (i_iter / lr_decay_steps)
             self.steps += 1
             return
         for nm, a in active.items():
@@ -631,6 +657,10 @@ class ModelFrameParallel:
 
     def close(self) -> None:
         if self.fp is not None:
+            self.finish()
+            for h in getattr(self, "_hooks", []):
+                h.remove()
+            self._hooks = []
             if self._entries_cache and self.fp.peer is not None:
                 torch.cuda.synchronize()
                 with torch.no_grad():      # the parameters outlive the peer region only as views of `params` (own allocation); the gradients move out of it

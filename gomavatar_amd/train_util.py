@@ -98,7 +98,11 @@ def compute_loss(rgb_pred, mask_pred, outputs, rgb_gt, mask_gt, loss_cfg, data=N
         put(name, v, coeff)
     if lpips_func is not None and _get(loss_cfg, "lpips.coeff", 1.0) > 0:
         if hasattr(lpips_func, "loss"):
-            term("lpips", lambda r: lpips_func.loss(rgb_pred, rgb_gt, reduce=r), _get(loss_cfg, "lpips.coeff", 1.0), 1.0 / rgb_pred.shape[0])
+            def _lpips_term(r):
+                if getattr(lpips_func, "supports_partial_sums", False):        # LPIPSMatrixCore: hands its partial sums to the fused tail
+                    return lpips_func.loss(rgb_pred, rgb_gt, reduce=r)
+                return lpips_func.loss(rgb_pred, rgb_gt)                        # a caller's own object with the plain loss(pred, gt) signature: the reduced scalar
+            term("lpips", _lpips_term, _get(loss_cfg, "lpips.coeff", 1.0), 1.0 / rgb_pred.shape[0])
         else:
             put("lpips", torch.mean(lpips_func(2 * rgb_pred.permute(0, 3, 1, 2) - 1, 2 * rgb_gt.permute(0, 3, 1, 2) - 1)), _get(loss_cfg, "lpips.coeff", 1.0))
     if _get(loss_cfg, "laplacian.coeff_canonical", 0.0) > 0:

@@ -82,6 +82,13 @@ def _worker(rank, world, port, out):
         gathered = [torch.zeros_like(res) for _ in range(world)]
         dist.all_gather(gathered, res)
         sd = mfp.optimizer_state_dict()
+        # the host path's state has the REFERENCE optimizer's layout (round-5 advisor finding: it was built from merged, re-ordered groups):
+        # it loads into torch.optim.Adam(model.get_param_groups(cfg)) and a state saved by that optimizer loads back here
+        ref_opt = torch.optim.Adam(StandIn().get_param_groups(TCFG), betas=(0.9, 0.999))
+        assert [g["name"] for g in sd["param_groups"]] == [g["name"] for g in ref_opt.state_dict()["param_groups"]]
+        assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in ref_opt.state_dict()["param_groups"]]
+        ref_opt.load_state_dict(sd)
+        mfp.load_optimizer_state_dict(ref_opt.state_dict())
         if rank == 0:
             assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
             torch.save({"params": gathered[0], "opt": sd}, out)

@@ -50,3 +50,24 @@ def test_compute_loss_keys_order_total_and_gradients_on_host_tensors():
     total.backward()
     for t in (rgb, mask, nm, colors, verts):
         assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0
+
+
+def test_compute_loss_accepts_a_callers_lpips_object_with_the_plain_signature():
+    """Round-5 advisor finding: compute_loss passed `reduce=` to ANY object with a `.loss` attribute; only LPIPSMatrixCore takes it.  A caller's own
+    object with loss(pred, gt) -- and a plain callable (the reference's LPIPS module, train.py:113-117) -- both work; the term lands where the reference puts it."""
+    g = torch.Generator().manual_seed(2)
+    H = W = 8
+    rgb, mask = torch.rand(1, H, W, 3, generator=g).requires_grad_(), torch.rand(1, H, W, generator=g)
+    rgb_gt, mask_gt = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, generator=g)
+    cfg = NS(rgb=NS(coeff=1.0), mask=NS(coeff=5.0), lpips=NS(coeff=2.0))
+
+    class Plain:
+        def loss(self, pred, gt):
+            return ((pred - gt) ** 2).mean()
+    total, losses = compute_loss(rgb, mask, {}, rgb_gt, mask_gt, cfg, lpips_func=Plain())
+    assert torch.allclose(losses["lpips"]["unscaled"], ((rgb - rgb_gt) ** 2).mean()) and torch.allclose(losses["lpips"]["scaled"], 2.0 * ((rgb - rgb_gt) ** 2).mean())
+    fn = lambda a, b: ((a - b) ** 2).mean((1, 2, 3))         # called on 2 x - 1 in NCHW, like the reference's module
+    total2, losses2 = compute_loss(rgb, mask, {}, rgb_gt, mask_gt, cfg, lpips_func=fn)
+    assert torch.allclose(losses2["lpips"]["unscaled"], 4.0 * ((rgb - rgb_gt) ** 2).mean())
+    total.backward()
+    assert torch.isfinite(rgb.grad).all()
