@@ -71,8 +71,12 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def forward(cam: dict, means3D, cov6, colors, opacity, dtype=np.float32) -> dict:
-    """Full forward.  cam: dict(H, W, tanfovx, tanfovy, viewmatrix(4,4) = E^T,
+def forward(cam: dict, means3D, cov6, colors, opacity, dtype=np.float32, form: str = "ref", margin: bool = False) -> dict:
+    """form: "ref" = the reference's alpha expression, "hip" = the HIP path's formulation of the same alpha (pre-scaled conic, fma chain,
+    exp2; raster_oracle.c A.3).  margin=True adds `margin` (H, W): per pixel the smallest relative distance of a branch-deciding quantity to
+    its threshold (alpha vs 1/255, T (1 - alpha) vs 1e-4, the exponent's sign): pixels with a margin far above fp32 round-off take the same
+    branches in any faithful fp32 implementation.
+    Full forward.  cam: dict(H, W, tanfovx, tanfovy, viewmatrix(4,4) = E^T,
     projmatrix(4,4) = (K_ndc E)^T, bg).  Returns every intermediate:
     depth, radii, xy, conic_opacity, tiles_touched, rect, offsets, D,
     keys(u64), point_list(u32), ranges(tiles,2), color(C,H,W), final_T, n_contrib."""
@@ -104,8 +108,11 @@ def forward(cam: dict, means3D, cov6, colors, opacity, dtype=np.float32) -> dict
     color = np.zeros((C, H, W), dtype)
     final_T = np.zeros((H, W), dtype)
     n_contrib = np.zeros((H, W), np.uint32)
-    lib.or_render_fwd(ctypes.byref(c), C, _p(ranges), _p(vals), _p(xy), _p(conic_opacity), _p(colors), _p(color), _p(final_T), _p(n_contrib))
-    return dict(P=P, C=C, H=H, W=W, D=D, depth=depth, radii=radii, xy=xy, conic_opacity=conic_opacity,
+    assert form in ("ref", "hip")
+    mg = np.zeros((H, W), dtype) if margin else None
+    lib.or_render_fwd_ex(ctypes.byref(c), C, _p(ranges), _p(vals), _p(xy), _p(conic_opacity), _p(colors), _p(color), _p(final_T), _p(n_contrib),
+                         ctypes.c_int(1 if form == "hip" else 0), _p(mg) if margin else None)
+    return dict(margin=mg, form=form, P=P, C=C, H=H, W=W, D=D, depth=depth, radii=radii, xy=xy, conic_opacity=conic_opacity,
                 tiles_touched=tiles_touched, rect=rect, offsets=offsets, keys=keys[:D], point_list=vals[:D],
                 ranges=ranges, color=color, final_T=final_T, n_contrib=n_contrib,
                 _inputs=(means3D, cov6, colors, opacity), _cam=cam, _dtype=dtype)
@@ -126,8 +133,9 @@ def backward(fwd: dict, dL_dcolor) -> dict:
     dcon = np.zeros((P, 3), dtype)
     dop = np.zeros(P, dtype)
     vals = np.ascontiguousarray(fwd["point_list"]) if fwd["D"] > 0 else np.zeros(1, np.uint32)
-    lib.or_render_bwd(ctypes.byref(c), C, _p(fwd["ranges"]), _p(vals), _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(colors),
-                      _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(g), _p(dcol), _p(dm2), _p(dcon), _p(dop))
+    lib.or_render_bwd_ex(ctypes.byref(c), C, _p(fwd["ranges"]), _p(vals), _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(colors),
+                         _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(g), _p(dcol), _p(dm2), _p(dcon), _p(dop),
+                         ctypes.c_int(1 if fwd.get("form", "ref") == "hip" else 0))
     dmeans = np.zeros((P, 3), dtype)
     dcov = np.zeros((P, 6), dtype)
     lib.or_preprocess_bwd(ctypes.byref(c), P, _p(means3D), _p(cov6), _p(fwd["radii"]), _p(dcon), _p(dm2), _p(dmeans), _p(dcov))

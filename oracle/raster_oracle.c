@@ -47,10 +47,18 @@
 #define RSQRT sqrtf
 #define RCEIL ceilf
 #define REXP expf
+#define REXP2 exp2f
+#define RLOG2 log2f
+#define RFMA fmaf
+#define RABS fabsf
 #else
 #define RSQRT sqrt
 #define RCEIL ceil
 #define REXP exp
+#define REXP2 exp2
+#define RLOG2 log2
+#define RFMA fma
+#define RABS fabs
 #endif
 
 typedef struct {
@@ -264,10 +272,41 @@ void or_bin(const OrCamera *cam, int P, const REAL *depth, const int32_t *radii,
 }
 
 /* ------------------------------------------------------------------ A.3 */
-/* colors: P*C (C <= 4). out_color: C*H*W (CHW). final_T, n_contrib: H*W. */
-void or_render_fwd(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
-                   const REAL *xy, const REAL *conic_opacity, const REAL *colors,
-                   REAL *out_color, REAL *final_T, uint32_t *n_contrib) {
+/* Two FORMULATIONS of the same alpha (round 6; `form` argument of the *_ex entry points):
+ *   form 0  the reference's expression (App. A.3): power = -0.5 (a dx^2 + c dy^2) - b dx dy, alpha = min(0.99, opacity * exp(power)).
+ *   form 1  the HIP path's (gomavatar_amd/csrc/raster_render.hip alpha_eval, entry_record.hpp): conic and opacity pre-scaled once per
+ *           Gaussian (A = -0.5 log2e a, B = -log2e b, Cq = -0.5 log2e c, lo = log2(opacity)), pw = fma(dx, fma(A, dx, B dy), (Cq dy) dy),
+ *           opacity * G = exp2(pw + lo); in the backward T / (1 - alpha) as T * (1 / (1 - alpha)).  Same function, other rounding.  What this
+ *           build CANNOT reproduce is the last bit of v_exp_f32 / v_log_f32 / v_rcp_f32 themselves (1-ulp hardware approximations against
+ *           glibc's correctly rounded ones) and the association of the segment-parallel transmittance product.
+ * MARGIN (forward, optional): per pixel, the smallest RELATIVE distance of any quantity that decides a branch for that pixel to its
+ * threshold -- |opacity G - 1/255| / (1/255) for every entry evaluated, |T (1 - alpha) - 1e-4| / 1e-4 for every entry that passed the alpha
+ * test, and |power| relative to the magnitude of its terms (the `power > 0` skip).  A pixel whose margin is far above fp32 round-off takes
+ * the same branches in ANY faithful fp32 implementation; a pixel below it is one where implementations may legitimately differ (a "threshold
+ * flip").  tests/ assert: no pixel with a comfortable margin deviates -- so every deviation is a flip, as a test instead of an argument. */
+typedef struct { REAL A, B, Cq, lo; } OrHipRec;
+static inline OrHipRec or_hip_record(const REAL *co) {
+    const REAL log2e = (REAL)1.44269504088896340736;
+    OrHipRec r;
+    r.A = ((REAL)-0.5 * log2e) * co[0];
+    r.B = (-log2e) * co[1];
+    r.Cq = ((REAL)-0.5 * log2e) * co[2];
+    r.lo = co[3] > (REAL)0 ? RLOG2(co[3]) : -(REAL)INFINITY;
+    return r;
+}
+/* -> opacity * G (unclamped) and log2e * power; *skip = the reference's `power > 0` rule */
+static inline REAL or_hip_og(const OrHipRec *r, REAL dx, REAL dy, int *skip) {
+    const REAL t1 = RFMA(r->A, dx, r->B * dy);
+    const REAL pw = RFMA(dx, t1, (r->Cq * dy) * dy);
+    *skip = pw > (REAL)0;
+    return REXP2(pw + r->lo);
+}
+static inline REAL or_rel(REAL v, REAL thr) { return RABS(v - thr) / thr; }
+
+/* colors: P*C (C <= 4). out_color: C*H*W (CHW). final_T, n_contrib: H*W.  margin: H*W or NULL. */
+void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
+                      const REAL *xy, const REAL *conic_opacity, const REAL *colors,
+                      REAL *out_color, REAL *final_T, uint32_t *n_contrib, int form, REAL *margin) {
     const int H = cam->H, W = cam->W;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
@@ -280,17 +319,38 @@ void or_render_fwd(const OrCamera *cam, int C, const uint32_t *ranges, const uin
                 if (px >= W || py >= H) continue;
                 const REAL pfx = (REAL)px, pfy = (REAL)py;
                 REAL T = 1, Cc[4] = {0, 0, 0, 0};
+                REAL mg = (REAL)1e30, tu = 0; /* tu: estimate of T's accumulated relative uncertainty in units of 1e-6 (below) */
                 uint32_t contributor = 0, last = 0;
                 for (uint32_t e = r0; e < r1; e++) {
                     contributor++;
                     const uint32_t g = vals[e];
                     const REAL dx = xy[2 * g] - pfx, dy = xy[2 * g + 1] - pfy;
                     const REAL *co = conic_opacity + 4 * g;
-                    const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > (REAL)0) continue;
-                    const REAL alpha = rmin((REAL)0.99, co[3] * REXP(power));
+                    REAL og;
+                    int skip;
+                    if (form == 1) {
+                        const OrHipRec rec = or_hip_record(co);
+                        og = or_hip_og(&rec, dx, dy, &skip);
+                    } else {
+                        const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        skip = power > (REAL)0;
+                        og = skip ? (REAL)0 : co[3] * REXP(power);
+                    }
+                    if (margin) { /* the sign of the exponent: only an indefinite (or numerically singular) conic brings it near zero away from the centre */
+                        const REAL q0 = (REAL)0.5 * co[0] * dx * dx, q1 = (REAL)0.5 * co[2] * dy * dy, q2 = co[1] * dx * dy;
+                        const REAL mag = RABS(q0) + RABS(q1) + RABS(q2);
+                        if (mag > (REAL)0) mg = rmin(mg, RABS(q0 + q1 + q2) / mag);
+                    }
+                    if (skip) continue;
+                    if (margin) mg = rmin(mg, or_rel(og, (REAL)1 / (REAL)255));
+                    const REAL alpha = rmin((REAL)0.99, og);
                     if (alpha < (REAL)1 / (REAL)255) continue;
                     const REAL test_T = T * ((REAL)1 - alpha);
+                    /* T is a product of (1 - alpha_i): a relative error d in alpha_i (a few ulp of the exponent: ~5e-7) moves it by
+                     * d alpha_i / (1 - alpha_i), a rounding per product adds 6e-8; the distance to the stop threshold is measured in units
+                     * of that accumulated uncertainty once it exceeds 1e-6 (long lists of nearly opaque entries) */
+                    tu += (REAL)0.06 + (REAL)0.5 * alpha / ((REAL)1 - alpha);
+                    if (margin) mg = rmin(mg, or_rel(test_T, (REAL)0.0001) / (tu > (REAL)1 ? tu : (REAL)1));
                     if (test_T < (REAL)0.0001) break;
                     for (int ch = 0; ch < C; ch++) Cc[ch] += colors[(size_t)g * C + ch] * alpha * T;
                     T = test_T;
@@ -299,9 +359,15 @@ void or_render_fwd(const OrCamera *cam, int C, const uint32_t *ranges, const uin
                 const size_t pix = (size_t)py * W + px;
                 final_T[pix] = T;
                 n_contrib[pix] = last;
+                if (margin) margin[pix] = mg;
                 for (int ch = 0; ch < C; ch++) out_color[(size_t)ch * H * W + pix] = Cc[ch] + T * cam->bg[ch];
             }
     }
+}
+void or_render_fwd(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
+                   const REAL *xy, const REAL *conic_opacity, const REAL *colors,
+                   REAL *out_color, REAL *final_T, uint32_t *n_contrib) {
+    or_render_fwd_ex(cam, C, ranges, vals, xy, conic_opacity, colors, out_color, final_T, n_contrib, 0, NULL);
 }
 
 /* ------------------------------------------------------------------ A.4 */
@@ -312,10 +378,10 @@ static inline void atomic_add(REAL *p, REAL v) {
 
 /* dL_dpix: C*H*W.  Accumulates (+=) into dL_dcolors (P*C), dL_dmean2D (P*2),
  * dL_dconic (P*3), dL_dopacity (P); caller zero-initialises. */
-void or_render_bwd(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
-                   const REAL *xy, const REAL *conic_opacity, const REAL *colors,
-                   const REAL *final_T, const uint32_t *n_contrib, const REAL *dL_dpix,
-                   REAL *dL_dcolors, REAL *dL_dmean2D, REAL *dL_dconic, REAL *dL_dopacity) {
+void or_render_bwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
+                      const REAL *xy, const REAL *conic_opacity, const REAL *colors,
+                      const REAL *final_T, const uint32_t *n_contrib, const REAL *dL_dpix,
+                      REAL *dL_dcolors, REAL *dL_dmean2D, REAL *dL_dconic, REAL *dL_dopacity, int form) {
     const int H = cam->H, W = cam->W;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const REAL ddelx_dx = (REAL)0.5 * (REAL)W, ddely_dy = (REAL)0.5 * (REAL)H;
@@ -341,12 +407,24 @@ void or_render_bwd(const OrCamera *cam, int C, const uint32_t *ranges, const uin
                     const uint32_t g = vals[r0 + k];
                     const REAL dx = xy[2 * g] - pfx, dy = xy[2 * g + 1] - pfy;
                     const REAL *co = conic_opacity + 4 * g;
-                    const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > (REAL)0) continue;
-                    const REAL G = REXP(power);
-                    const REAL alpha = rmin((REAL)0.99, co[3] * G);
-                    if (alpha < (REAL)1 / (REAL)255) continue;
-                    T = T / ((REAL)1 - alpha);
+                    REAL G, alpha;
+                    if (form == 1) { /* the HIP path's formulation of the same alpha (see A.3 above) */
+                        const OrHipRec rec = or_hip_record(co);
+                        int skip;
+                        const REAL og = or_hip_og(&rec, dx, dy, &skip);
+                        if (skip) continue;
+                        alpha = rmin((REAL)0.99, og);
+                        if (alpha < (REAL)1 / (REAL)255) continue;
+                        G = og / co[3];
+                        T = T * ((REAL)1 / ((REAL)1 - alpha));
+                    } else {
+                        const REAL power = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > (REAL)0) continue;
+                        G = REXP(power);
+                        alpha = rmin((REAL)0.99, co[3] * G);
+                        if (alpha < (REAL)1 / (REAL)255) continue;
+                        T = T / ((REAL)1 - alpha);
+                    }
                     const REAL dch_dcol = alpha * T;
                     REAL dL_dalpha = 0;
                     for (int ch = 0; ch < C; ch++) {
@@ -372,6 +450,13 @@ void or_render_bwd(const OrCamera *cam, int C, const uint32_t *ranges, const uin
                 }
             }
     }
+}
+
+void or_render_bwd(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
+                   const REAL *xy, const REAL *conic_opacity, const REAL *colors,
+                   const REAL *final_T, const uint32_t *n_contrib, const REAL *dL_dpix,
+                   REAL *dL_dcolors, REAL *dL_dmean2D, REAL *dL_dconic, REAL *dL_dopacity) {
+    or_render_bwd_ex(cam, C, ranges, vals, xy, conic_opacity, colors, final_T, n_contrib, dL_dpix, dL_dcolors, dL_dmean2D, dL_dconic, dL_dopacity, 0);
 }
 
 /* ------------------------------------------------------------------ A.5 */

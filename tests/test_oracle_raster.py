@@ -132,3 +132,49 @@ def test_thread_count_changes_no_bit():
     #  moves by round-off with the thread count -- as it did before)
     for k in ("dL_dmeans3D", "dL_dcov6", "dL_dopacity"):
         assert np.abs(g1[k] - g8[k]).max() <= 2e-5 * np.abs(g1[k]).max(), k
+
+
+MARGIN = 2e-5     # relative distance of a branch-deciding quantity to its threshold above which fp32 implementations take the same branch
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_two_formulations_of_alpha_differ_only_at_threshold_margins(seed):
+    """The oracle's two fp32 FORMULATIONS of the same alpha (form="ref": the reference's expression; form="hip": the HIP path's pre-scaled
+    conic + fma chain + exp2) are two faithful fp32 implementations of App. A.3.  Claim (tests/test_gpu_raster.py relies on it for the HIP
+    path itself): wherever the per-pixel MARGIN is comfortable, they agree to round-off -- same n_contrib, image within 1e-5 --, i.e. every
+    larger deviation sits on a pixel the margin flags as a threshold flip; and flagged pixels are rare."""
+    from helpers import small_scene
+    cam, means, cov6, colors, op = small_scene(seed=seed, P=2500, H=96, W=112, opacity=(0.15, 1.0), C=4)
+    a = orast.forward(cam, means, cov6, colors, op, margin=True)
+    b = orast.forward(cam, means, cov6, colors, op, form="hip")
+    for k in ("radii", "tiles_touched", "keys", "point_list", "ranges"):       # the binning does not depend on the formulation
+        np.testing.assert_array_equal(a[k], b[k])
+    solid = a["margin"] >= MARGIN
+    assert np.count_nonzero(~solid) <= 1e-3 * solid.size + 2, np.count_nonzero(~solid)
+    d = np.abs(a["color"] - b["color"]).max(0)
+    assert d[solid].max() <= 1e-5 and np.array_equal(a["n_contrib"][solid], b["n_contrib"][solid])
+    assert np.abs(a["final_T"] - b["final_T"])[solid].max() <= 1e-5
+    # gradients of the two formulations, away from the flagged pixels' Gaussians: fp32 round-off of sums
+    g = np.random.default_rng(seed).normal(size=a["color"].shape).astype(np.float32)
+    ga, gb = orast.backward(a, g), orast.backward(b, g)
+    for k in ("dL_dcolors", "dL_dmeans2D", "dL_dconic", "dL_dopacity"):
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-5 * np.abs(ga[k]).max(), k
+
+
+def test_margin_flags_a_constructed_threshold_pixel():
+    """One Gaussian whose alpha at a chosen pixel is EXACTLY at 1/255 up to an ulp: the margin of that pixel is ~1e-7, its neighbours' is not."""
+    from oracle import geometry as og
+    K = np.array([[80.0, 0, 16], [0, 80.0, 16], [0, 0, 1]], np.float32)
+    E = np.eye(4, dtype=np.float32); E[2, 3] = 2.0
+    cam = og.camera_from_KE(K, E, 32, 32)
+    means = np.array([[0.0, 0.0, 0.0]], np.float32)
+    cov6 = np.array([[2e-3, 0, 0, 2e-3, 0, 2e-3]], np.float32)
+    col = np.ones((1, 3), np.float32)
+    f = orast.forward(cam, means, cov6, col, np.ones(1, np.float32), margin=True)
+    co, (cx, cy) = f["conic_opacity"][0], f["xy"][0]
+    # choose the opacity so that alpha(20, 16) = 1/255 exactly (in real arithmetic)
+    dx, dy = cx - 20.0, cy - 16.0
+    power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy
+    o = np.float32((1.0 / 255.0) / np.exp(np.float64(power)))
+    f = orast.forward(cam, means, cov6, col, np.array([o], np.float32), margin=True)
+    assert f["margin"][16, 20] < 1e-6 and f["margin"][16, 18] > 1e-3 and f["margin"][14, 20] > 1e-3, (f["margin"][16, 20], f["margin"][16, 18])
