@@ -75,7 +75,8 @@ def forward(cam: dict, means3D, cov6, colors, opacity, dtype=np.float32, form: s
     """form: "ref" = the reference's alpha expression, "hip" = the HIP path's formulation of the same alpha (pre-scaled conic, fma chain,
     exp2; raster_oracle.c A.3).  margin=True adds `margin` (H, W): per pixel the smallest relative distance of a branch-deciding quantity to
     its threshold (alpha vs 1/255, T (1 - alpha) vs 1e-4, the exponent's sign): pixels with a margin far above fp32 round-off take the same
-    branches in any faithful fp32 implementation.
+    branches in any faithful fp32 implementation; and `roundoff` (H, W): the estimate of what one fp32 rounding of every exponent does to the
+    pixel (large only under needle-shaped conics: ill-conditioned in fp32 in any formulation).
     Full forward.  cam: dict(H, W, tanfovx, tanfovy, viewmatrix(4,4) = E^T,
     projmatrix(4,4) = (K_ndc E)^T, bg).  Returns every intermediate:
     depth, radii, xy, conic_opacity, tiles_touched, rect, offsets, D,
@@ -110,9 +111,10 @@ def forward(cam: dict, means3D, cov6, colors, opacity, dtype=np.float32, form: s
     n_contrib = np.zeros((H, W), np.uint32)
     assert form in ("ref", "hip")
     mg = np.zeros((H, W), dtype) if margin else None
+    ro = np.zeros((H, W), dtype) if margin else None
     lib.or_render_fwd_ex(ctypes.byref(c), C, _p(ranges), _p(vals), _p(xy), _p(conic_opacity), _p(colors), _p(color), _p(final_T), _p(n_contrib),
-                         ctypes.c_int(1 if form == "hip" else 0), _p(mg) if margin else None)
-    return dict(margin=mg, form=form, P=P, C=C, H=H, W=W, D=D, depth=depth, radii=radii, xy=xy, conic_opacity=conic_opacity,
+                         ctypes.c_int(1 if form == "hip" else 0), _p(mg) if margin else None, _p(ro) if margin else None)
+    return dict(margin=mg, roundoff=ro, form=form, P=P, C=C, H=H, W=W, D=D, depth=depth, radii=radii, xy=xy, conic_opacity=conic_opacity,
                 tiles_touched=tiles_touched, rect=rect, offsets=offsets, keys=keys[:D], point_list=vals[:D],
                 ranges=ranges, color=color, final_T=final_T, n_contrib=n_contrib,
                 _inputs=(means3D, cov6, colors, opacity), _cam=cam, _dtype=dtype)

@@ -283,7 +283,11 @@ void or_bin(const OrCamera *cam, int P, const REAL *depth, const int32_t *radii,
  * threshold -- |opacity G - 1/255| / (1/255) for every entry evaluated, |T (1 - alpha) - 1e-4| / 1e-4 for every entry that passed the alpha
  * test, and |power| relative to the magnitude of its terms (the `power > 0` skip).  A pixel whose margin is far above fp32 round-off takes
  * the same branches in ANY faithful fp32 implementation; a pixel below it is one where implementations may legitimately differ (a "threshold
- * flip").  tests/ assert: no pixel with a comfortable margin deviates -- so every deviation is a flip, as a test instead of an argument. */
+ * flip").  ROUNDOFF (optional): per pixel, an estimate of what one fp32 rounding of each exponent does to the composited value --
+ * 1.2e-7 * sum_i w_i max(8, mag_i), w_i = alpha_i T_i the blend weight, mag_i the sum of the magnitudes of the exponent's three products:
+ * needle-shaped conics far from their centre (mag ~ 1e4 with power ~ -2) make a pixel ILL-CONDITIONED in fp32 in any formulation, the
+ * reference's included (form 0 against the float64 build shows it).  tests/ assert: no pixel with a comfortable margin and a small round-off
+ * estimate deviates -- every deviation is a threshold flip or bounded by its own conditioning, as a test instead of an argument. */
 typedef struct { REAL A, B, Cq, lo; } OrHipRec;
 static inline OrHipRec or_hip_record(const REAL *co) {
     const REAL log2e = (REAL)1.44269504088896340736;
@@ -306,7 +310,7 @@ static inline REAL or_rel(REAL v, REAL thr) { return RABS(v - thr) / thr; }
 /* colors: P*C (C <= 4). out_color: C*H*W (CHW). final_T, n_contrib: H*W.  margin: H*W or NULL. */
 void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
                       const REAL *xy, const REAL *conic_opacity, const REAL *colors,
-                      REAL *out_color, REAL *final_T, uint32_t *n_contrib, int form, REAL *margin) {
+                      REAL *out_color, REAL *final_T, uint32_t *n_contrib, int form, REAL *margin, REAL *roundoff) {
     const int H = cam->H, W = cam->W;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
@@ -319,7 +323,7 @@ void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const 
                 if (px >= W || py >= H) continue;
                 const REAL pfx = (REAL)px, pfy = (REAL)py;
                 REAL T = 1, Cc[4] = {0, 0, 0, 0};
-                REAL mg = (REAL)1e30, tu = 0; /* tu: estimate of T's accumulated relative uncertainty in units of 1e-6 (below) */
+                REAL mg = (REAL)1e30, ro = 0, tu = 0; /* tu: estimate of T's accumulated relative uncertainty in units of 1e-6 (below) */
                 uint32_t contributor = 0, last = 0;
                 for (uint32_t e = r0; e < r1; e++) {
                     contributor++;
@@ -336,23 +340,33 @@ void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const 
                         skip = power > (REAL)0;
                         og = skip ? (REAL)0 : co[3] * REXP(power);
                     }
-                    if (margin) { /* the sign of the exponent: only an indefinite (or numerically singular) conic brings it near zero away from the centre */
+                    /* conditioning of the exponent: power is a sum of three products that cancel for elongated, correlated conics far from the
+                     * centre; its fp32 error is ~eps * mag, mag = the sum of their magnitudes, whatever the association (the reference's, the
+                     * HIP path's fma chain): distances to the alpha threshold are measured in units of max(1, mag / 8) (at the threshold
+                     * |power| = ln(255 opacity) <= mag, and 8 is where the exponent's own rounding takes over) */
+                    REAL cond = 1, magc = 8;
+                    if (margin) {
                         const REAL q0 = (REAL)0.5 * co[0] * dx * dx, q1 = (REAL)0.5 * co[2] * dy * dy, q2 = co[1] * dx * dy;
                         const REAL mag = RABS(q0) + RABS(q1) + RABS(q2);
+                        if (mag > (REAL)8) { cond = mag / (REAL)8; magc = mag; }
+                        /* the sign of the exponent: only an indefinite (or numerically singular) conic brings it near zero away from the centre */
                         if (mag > (REAL)0) mg = rmin(mg, RABS(q0 + q1 + q2) / mag);
                     }
                     if (skip) continue;
-                    if (margin) mg = rmin(mg, or_rel(og, (REAL)1 / (REAL)255));
+                    if (margin) mg = rmin(mg, or_rel(og, (REAL)1 / (REAL)255) / cond);
                     const REAL alpha = rmin((REAL)0.99, og);
                     if (alpha < (REAL)1 / (REAL)255) continue;
                     const REAL test_T = T * ((REAL)1 - alpha);
-                    /* T is a product of (1 - alpha_i): a relative error d in alpha_i (a few ulp of the exponent: ~5e-7) moves it by
-                     * d alpha_i / (1 - alpha_i), a rounding per product adds 6e-8; the distance to the stop threshold is measured in units
-                     * of that accumulated uncertainty once it exceeds 1e-6 (long lists of nearly opaque entries) */
-                    tu += (REAL)0.06 + (REAL)0.5 * alpha / ((REAL)1 - alpha);
+                    /* T is a product of (1 - alpha_i): a relative error d in alpha_i (a few ulp of the exponent: ~5e-7 * cond) moves it by
+                     * d alpha_i / (1 - alpha_i) (nothing when alpha_i sits at the 0.99 cap), a rounding per product adds 6e-8; the distance to
+                     * the stop threshold is measured in units of that accumulated uncertainty once it exceeds 1e-6 */
+                    tu += (REAL)0.06 + (og < (REAL)0.99 ? (REAL)0.5 * cond * alpha / ((REAL)1 - alpha) : (REAL)0);
                     if (margin) mg = rmin(mg, or_rel(test_T, (REAL)0.0001) / (tu > (REAL)1 ? tu : (REAL)1));
                     if (test_T < (REAL)0.0001) break;
                     for (int ch = 0; ch < C; ch++) Cc[ch] += colors[(size_t)g * C + ch] * alpha * T;
+                    /* ROUND-OFF ESTIMATE of the pixel: one fp32 rounding of the exponent's terms (1.2e-7 * mag, any formulation) is a relative
+                     * error of alpha and moves the pixel by that much of the entry's blend weight (and, through T, by as much again behind it) */
+                    if (og < (REAL)0.99) ro += (REAL)1.2e-7 * magc * alpha * T;
                     T = test_T;
                     last = contributor;
                 }
@@ -360,6 +374,7 @@ void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const 
                 final_T[pix] = T;
                 n_contrib[pix] = last;
                 if (margin) margin[pix] = mg;
+                if (roundoff) roundoff[pix] = ro;
                 for (int ch = 0; ch < C; ch++) out_color[(size_t)ch * H * W + pix] = Cc[ch] + T * cam->bg[ch];
             }
     }
@@ -367,7 +382,7 @@ void or_render_fwd_ex(const OrCamera *cam, int C, const uint32_t *ranges, const 
 void or_render_fwd(const OrCamera *cam, int C, const uint32_t *ranges, const uint32_t *vals,
                    const REAL *xy, const REAL *conic_opacity, const REAL *colors,
                    REAL *out_color, REAL *final_T, uint32_t *n_contrib) {
-    or_render_fwd_ex(cam, C, ranges, vals, xy, conic_opacity, colors, out_color, final_T, n_contrib, 0, NULL);
+    or_render_fwd_ex(cam, C, ranges, vals, xy, conic_opacity, colors, out_color, final_T, n_contrib, 0, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------ A.4 */
