@@ -43,6 +43,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD, SCLK_HZ = 256 * 4, 2.4e9     # 256 CUs x 4 SIMDs at the 2.4 GHz engine clock (MI355X_MICROARCH.md)
+ISSUE_TICKS_PER_VALU = 3.8           # mean issue ticks per wave-level VALU instruction of the segment kernels' mix at 4 waves / SIMD (profiles/r03_valu_rate.txt)
 MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
 MIN_TIMED_S = 0.25
 PROFILE_TAG = "r05"
@@ -64,6 +66,8 @@ def parse():
     ap.add_argument("--subdiv", type=int, default=1, help="0: 13 776, 1: 55 104 (metric), 2: 220 416 Gaussians")
     ap.add_argument("--frames", type=int, default=32, help="distinct synthetic frames cycled through")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU, rendered by one batched launch sequence (0 = 8 at N = 1, 1 at N > 1)")
+    ap.add_argument("--split", type=int, default=0, help="the step's frames as this many CONCURRENT launch sequences forked and joined inside the step "
+                    "(gom_split_forward_backward: same bits, tails filled; 0 = 2 for a step of 8 frames at N = 1, else 1)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent steps in flight per GPU, each on its own HIP stream with its own scratch; "
                          "1 (default) = strictly one step after the other, as an optimizer loop runs")
@@ -184,17 +188,18 @@ class Runner:
     """S steps in flight of B frames each on one GPU: slot k owns a stream, a RenderStep (scratch + intermediates) and a flat
     gradient buffer (the all-reduce payload; the hot path's gradients are views into it)."""
 
-    def __init__(self, wl, B, S, graph, world, args, impl="collective"):
+    def __init__(self, wl, B, S, graph, world, args, impl="collective", split=1):
         import torch
         from gomavatar_amd import _lib
         from gomavatar_amd.parallel import FrameParallel, shapes_for_model
         self.torch, self.wl, self.B, self.S, self.graph, self.world = torch, wl, B, S, graph, world
+        self.split = split if (split > 1 and B % split == 0 and B // split >= 1) else 1
         pad = 0   # the native step exchanges what it trains (vertices / so3 / scale / appearance); the reference model's full 951 023 floats are exchanged by `modes.model_parallel` (ModelFrameParallel: real weights)
         self.slots = []
         self.adam = not args.no_adam
         from gomavatar_amd.parallel import FlatAdam
         for k in range(S):
-            st = wl.step(B)
+            st = wl.step(B, split=self.split)
             fp = FrameParallel(shapes_for_model(wl.N, wl.F), wl.device, pad_to=pad, impl=impl)
             for name in ("vertices", "so3", "scale", "appearance"):
                 st.grads[name] = fp.grads[name]
@@ -818,7 +823,10 @@ def main():
     img, B, S = args.img, max(1, args.batch), max(1, args.inflight)
     wl = MetricWorkload(dev, subdiv=args.subdiv, img=img, n_frames=max(args.frames, B), rank=rank)
     F, N = wl.F, wl.N
-    main_run = Runner(wl, B, S, not args.no_graph, world, args)
+    # the step's B frames as `split` concurrent launch sequences (same bits: tests/test_gpu_batch.py); 2 x 4 is the fastest cut of 8 frames on MI355X
+    split = args.split if args.split > 0 else (2 if (world == 1 and B == 8 and S == 1 and not args.attach_adam) else 1)
+    main_run = Runner(wl, B, S, not args.no_graph, world, args, split=split)
+    split = main_run.split
 
     # ---------------- the timed region(s) ----------------
     # (in front of the W warm-up steps of the contract: ~0.3 s of the same steps, untimed -- a fresh box's first launches pay for code-object
@@ -915,7 +923,8 @@ def main():
 
     # ---------------- per-kernel times, one step in flight (the kernels own the chip) ----------------
     note("per-kernel profile")
-    alone_run = main_run if S == 1 else Runner(wl, B, 1, not args.no_graph, world, args)
+    # (the roofline describes a launch that OWNS the chip: one sequence of B frames, one step in flight -- as in every earlier round)
+    alone_run = main_run if (S == 1 and split == 1) else Runner(wl, B, 1, not args.no_graph, world, args)
     iso, D_avg = alone_run.kernel_profile(12)
     abytes = algorithmic_bytes(F * B, D_avg, img * img * B, 4)   # per launch: B frames (D_avg already counts all B)
     dom = max(iso, key=iso.get)                                   # dominant kernel = the one that costs most when it owns the chip
@@ -939,7 +948,21 @@ def main():
         return {"kernel": "k_" + name, "avg_us": round(us, 2), "algorithmic_bytes": int(abytes[name]), "achieved": round(gbs, 2),
                 "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": tr}
     dr = kernel_row(dom, iso[dom] * 1e3)
-    roofline = {"kernel": dr["kernel"], "bound": "hbm", "achieved": dr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dr["frac"],
+    # The bound that HOLDS for this kernel is VALU instruction issue, not HBM (round-5 review): `achieved / peak / frac` stay
+    # SURVEY.md 8(d)'s HBM figures (algorithmic bytes / launch duration / 8 TB/s: comparable across rounds and with north_star's 60 % target, which
+    # this design does not reach), `issue` says how far the launch is from the bound it really runs against.
+    vrow = (valu_j or {}).get("k_" + dom) or {}
+    n_valu = vrow.get("valu_insts_per_launch")
+    issue = None
+    if n_valu:
+        floor_us = n_valu * ISSUE_TICKS_PER_VALU / (N_SIMD * SCLK_HZ) * 1e6
+        issue = {"valu_wave_insts": int(n_valu), "valu_wave_insts_source": valu_src,
+                 "issue_floor_us": round(floor_us, 1), "frac_of_issue_floor": round(floor_us / dr["avg_us"], 4) if dr["avg_us"] else None,
+                 "how": f"wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed PMC pass: static for a given pair count D) x {ISSUE_TICKS_PER_VALU} issue "
+                        f"ticks per instruction (scripts/ubench/valu_rate.hip at 4 waves per SIMD, this kernel's mix of plain / packed / DPP / transcendental instructions) "
+                        f"/ ({N_SIMD} SIMDs x {SCLK_HZ / 1e9:.1f} GHz); lanes alive per evaluated entry ~13 %: the instruction count, not the byte count, is what a better design must cut"}
+    roofline = {"kernel": dr["kernel"], "bound": "valu_issue", "bound_of_the_figures_below": "hbm (SURVEY.md 8(d) algorithmic bytes over 8 TB/s)", "issue": issue,
+                "achieved": dr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dr["frac"],
                 "traffic": dr["traffic"], "avg_us": dr["avg_us"], "algorithmic_bytes": dr["algorithmic_bytes"], "pairs_D": int(D_avg),
                 "steps_in_flight": 1, "all_kernels_us": {k: round(v * 1e3, 2) for k, v in iso.items()},
                 "all_kernels_note": "HIP-event brackets around every launch of an UN-GRAPHED pass (the library enqueues the step kernel by kernel for this): each reads "
@@ -951,6 +974,22 @@ def main():
                 # These kernels are VALU-issue bound, not bandwidth bound: the second axis, from the SQ counters
                 # of the PMC pass (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES and useful lanes), when profiles/ holds it
                 "valu": (valu_j or {}).get("k_" + dom), "traffic_source": traffic_src, "valu_source": valu_src}
+
+    if split > 1:
+        # the launches of the TIMED configuration (B / split frames each), bracketed one branch after the other (GOM_OPT_PROFILE serialises the
+        # branches: every launch owns the chip): sums over the step's `split` launches per kernel
+        iso_s, D_s = main_run.kernel_profile(12)
+        ab_s = algorithmic_bytes(F * B, D_s, img * img * B, 4)
+        roofline["timed_configuration"] = {
+            "what": f"the timed step runs {split} concurrent launch sequences of {B // split} frames each (gom_split_forward_backward: fork / join inside one hipGraph, one frame "
+                    f"sum over all {B} frames; gradients bitwise those of one {B}-frame sequence).  The figures above are for the one-sequence launch of {B} frames, which owns "
+                    "the chip (comparable with earlier rounds, and with profiles collected with --split 1); below: the timed configuration's own launches, bracketed one "
+                    "branch after the other (alone on the chip), per launch; in the timed loop they overlap, which is the point",
+            "split": split, "frames_per_launch": B // split,
+            "kernel": "k_" + dom, "avg_us_per_launch_alone": round(iso_s[dom] * 1e3 / split, 2), "algorithmic_bytes_per_launch": int(ab_s[dom] / split),
+            "frac_alone": round(ab_s[dom] / (iso_s[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "all_kernels_us_per_step_alone": {k: round(v * 1e3, 2) for k, v in iso_s.items()},
+            "sum_of_kernels_us_alone": round(sum(iso_s.values()) * 1e3, 1), "ms_per_step_timed": round(1e3 * elapsed / n_steps, 4)}
 
     out = {
         "metric": "rendered frames/sec (fwd+bwd) at 512x512, ~50k Gaussians; PSNR vs ref",
@@ -967,10 +1006,11 @@ def main():
         "data": "synthetic",
         "timed_regions": regions,
         "config": {"workload": f"GoMAvatar hot path fwd+bwd, {F} Gaussians / {N} verts, {img}x{img}, {B} frames per GPU per step "
-                               f"(one batched launch sequence), {S} step(s) in flight per GPU"
+                               + ("(one batched launch sequence)" if split == 1 else f"({split} concurrent launch sequences of {B // split} frames, forked and joined inside the step's one hipGraph)")
+                               + f", {S} step(s) in flight per GPU"
                                + (", + all-reduce of the flat grad buffer" if world > 1 else "") + ("" if args.no_adam else ", + Adam"),
                    "gaussians": F, "image": [img, img], "frames_per_step": world * B, "frames_per_gpu_per_step": B,
-                   "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S,
+                   "parallelism": f"frame-dp{world}", "steps_in_flight_per_gpu": S, "launch_sequences_per_step": split,
                    "optimizer": (f"Adam on the flat parameter buffer inside the timed loop (gom_adam_flat, lr {ADAM_LR:g}: the reference's arithmetic, a rate that "
                                  "keeps the synthetic workload fixed)" + ("; the last launch of the frame step's recorded graph" if main_run.attached else "")
                                  if not args.no_adam else None),
@@ -1006,9 +1046,9 @@ def main():
 
     # ---------------- the other operating points (N = 1) ----------------
     if world == 1 and not args.no_modes:
-        modes = {f"b{B}_inflight{S}": round(value, 1)}
+        modes = {f"b{B}_inflight{S}" + (f"_split{split}" if split > 1 else ""): round(value, 1)}
         for (b_, s_) in ((1, 1), (8, 1), (8, 3)):
-            key = f"b{b_}_inflight{s_}"
+            key = f"b{b_}_inflight{s_}"      # (one launch sequence per step: the operating points of rounds 2-5)
             if key in modes:
                 continue
             r_ = Runner(wl, b_, s_, not args.no_graph, 1, args)

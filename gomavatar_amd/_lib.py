@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- imported first so that libgom_hip.so binds to the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOM_HIP_LIB") or os.path.join(_HERE, "libgom_hip.so")  # env override: experiment builds
 
-GOM_ABI_VERSION = 10
+GOM_ABI_VERSION = 11
 GOM_FWD_REUSE_BINNING = 1
 GOM_BWD_RECOMPUTE_FORWARD = 1
 GOM_LOSS_BLOCKS = 256
@@ -121,6 +121,7 @@ SIGNATURES = {
     "gom_frame_loss_slots": (c_int, [c_int, c_int]),
     "gom_frame_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_uint32, c_void_p]),
     "gom_batch_forward_backward": (c_int, [c_void_p, POINTER(GomFrame), c_int32, c_void_p, c_uint32, c_void_p]),
+    "gom_split_forward_backward": (c_int, [POINTER(c_void_p), POINTER(GomFrame), c_int32, POINTER(c_int32), POINTER(c_void_p), c_uint32, c_void_p]),
     "gom_adam_flat": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_float, c_float,
                               c_float, c_float, c_void_p]),
     "gom_adam_flat_graphable": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int64), POINTER(c_float), POINTER(c_int64), c_int64, c_void_p, c_float,

@@ -454,7 +454,47 @@ __global__ void __launch_bounds__(256) k_sum_frames(int B, SumFramesArgs a) {
     }
 }
 
+// ... and over the frames of SEVERAL launch sequences (gom_split_forward_backward): frame b of tensor k at src[k][b].  Same order, same adds.
+struct SumMultiArgs {
+    size_t n[4];
+    const float *src[4][GOM_SPLIT_MAX_FRAMES];
+    float *dst[4];
+};
+__global__ void __launch_bounds__(256) k_sum_frames_multi(int B, SumMultiArgs a) {
+    const size_t total = a.n[0] + a.n[1] + a.n[2] + a.n[3];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t j = i;
+        int k = 0;
+        while (j >= a.n[k]) { j -= a.n[k]; k++; }
+        float acc = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 8) {   // eight frames' loads in flight, added in frame order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = b0 + u < B ? a.src[k][b0 + u][j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (b0 + u < B) acc += v[u];
+        }
+        a.dst[k][j] = acc;
+    }
+}
+
 }  // namespace
+
+int gom_sum_frames_multi(int B, const size_t n[4], const float *const src[4][GOM_SPLIT_MAX_FRAMES], float *const dst[4], void *stream) {
+    if (B < 1 || B > GOM_SPLIT_MAX_FRAMES) { gom_set_error("gom_sum_frames_multi: 1..%d frames", GOM_SPLIT_MAX_FRAMES); return -1; }
+    SumMultiArgs a;
+    size_t total = 0;
+    for (int k = 0; k < 4; k++) {
+        a.n[k] = n[k]; a.dst[k] = dst[k]; total += n[k];
+        for (int b = 0; b < GOM_SPLIT_MAX_FRAMES; b++) a.src[k][b] = b < B ? src[k][b] : nullptr;
+    }
+    if (total == 0) return 0;
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_sum_frames_multi, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, B, a);
+    GOM_LAUNCH_CHECK();
+    return 0;
+}
 
 int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
                     float *d2, size_t n3, const float *s3, float *d3, void *stream) {

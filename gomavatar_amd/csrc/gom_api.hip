@@ -99,6 +99,15 @@ extern "C" void gom_state_destroy(GomState *s) {
         (void)hipGraphExecDestroy(g.exec);
         (void)hipGraphDestroy(g.graph);
     }
+    for (auto &g : s->splitGraphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    for (hipStream_t t : s->splitStreams)
+        if (t) (void)hipStreamDestroy(t);
+    if (s->splitFork) (void)hipEventDestroy(s->splitFork);
+    for (hipEvent_t e : s->splitJoin)
+        if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -446,13 +455,13 @@ extern "C" int gom_state_export(GomState *s, int id, void *dst, int64_t dst_byte
 static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream);
 
 // per-frame slices of the parameter gradients of a batched call: [so3 | scale | appearance : B x 3F each][vertices : B x 3N]
-static int ensure_batch_grads(GomState *s, int B, int N, int F) {
+static int ensure_batch_grads(GomState *s, int B, int N, int F, bool slices_for_one = false) {
     const size_t vneed = (size_t)B * ((N + 255) / 256) * 2;   // vertex depth ranges of the skinning blocks (frame step)
     if (vneed > s->capVdepth) {
         if (grow_s(s, &s->vdepth_minmax, vneed)) return -2;
         s->capVdepth = vneed;
     }
-    const size_t need = B > 1 ? (size_t)B * (9 * (size_t)F + 3 * (size_t)N) : 0;
+    const size_t need = (B > 1 || slices_for_one) ? (size_t)B * (9 * (size_t)F + 3 * (size_t)N) : 0;
     if (need > s->capBatchGrads) {
         if (grow_s(s, &s->batch_grads, need)) return -2;
         s->capBatchGrads = need;
@@ -557,16 +566,159 @@ extern "C" int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_
     return frame_call(s, f, B, cams_device, flags, stream);
 }
 
+// ---- ONE step as K concurrent launch sequences (include/gom_hip.h: gom_split_forward_backward) ------------------------------------------------
+// The segment kernels of a batched launch are resident grids that drain a task queue: the chip idles behind the last workgroups of every one
+// of the ~12 launches of a step (three steps in flight measure +13 %, but train on stale parameters).  Here the B frames of ONE step are cut
+// into K sub-batches, each with its own GomState, enqueued on K streams between a fork and a join -- the tail of one branch's kernel is filled
+// by the other branch's workgroups -- and ONE frame sum over all B frames in frame order closes the step: the gradients are bitwise those of
+// gom_batch_forward_backward on the B frames (a frame's gradients do not depend on the launch it rides in: tests/test_gpu_batch.py).
+static int split_enqueue(GomState *const *states, const GomFrame *frames, int K, const int32_t *Bs, const GomCamera *const *cams, hipStream_t st, bool serial) {
+    GomState *lead = states[0];
+    if (serial) {   // GOM_OPT_PROFILE: one branch after the other on the caller's stream, so that every bracketed launch owns the chip
+        for (int k = 0; k < K; k++)
+            if (int rc = frame_enqueue(states[k], &frames[k], Bs[k], cams[k], GOM_FRAME_NO_SUM, (void *)st)) return rc;
+    } else {
+        GOM_HIP_CHECK(hipEventRecord(lead->splitFork, st));
+        for (int k = 1; k < K; k++) GOM_HIP_CHECK(hipStreamWaitEvent(lead->splitStreams[k], lead->splitFork, 0));
+        for (int k = K - 1; k >= 0; k--) {   // (the lead's own branch last: the side branches are already running while the host enqueues it)
+            hipStream_t bs = k == 0 ? st : lead->splitStreams[k];
+            if (int rc = frame_enqueue(states[k], &frames[k], Bs[k], cams[k], GOM_FRAME_NO_SUM, (void *)bs)) return rc;
+            if (k) GOM_HIP_CHECK(hipEventRecord(lead->splitJoin[k], bs));
+        }
+        for (int k = 1; k < K; k++) GOM_HIP_CHECK(hipStreamWaitEvent(st, lead->splitJoin[k], 0));
+    }
+    // frame-ordered sum over the slices of every branch: frame b of branch k at batch_grads + [tensor offset in ITS B_k-frame layout] + b * n
+    const GomFrame &f0 = frames[0];
+    const size_t F3 = 3 * (size_t)f0.F, N3 = 3 * (size_t)f0.N;
+    const float *src[4][GOM_SPLIT_MAX_FRAMES];
+    int nfr = 0;
+    for (int k = 0; k < K; k++) {
+        const float *bg = states[k]->batch_grads;
+        for (int b = 0; b < Bs[k]; b++, nfr++) {
+            src[0][nfr] = bg + (size_t)b * F3;
+            src[1][nfr] = bg + (size_t)Bs[k] * F3 + (size_t)b * F3;
+            src[2][nfr] = bg + 2 * (size_t)Bs[k] * F3 + (size_t)b * F3;
+            src[3][nfr] = bg + 3 * (size_t)Bs[k] * F3 + (size_t)b * N3;
+        }
+    }
+    const size_t n[4] = {F3, F3, F3, N3};
+    float *dst[4] = {f0.g_so3, f0.g_scale, f0.g_appearance, f0.g_vertices};
+    return gom_sum_frames_multi(nfr, n, src, dst, (void *)st);
+}
+
+extern "C" int gom_split_forward_backward(GomState *const *states, const GomFrame *frames, int32_t K, const int32_t *Bs, const GomCamera *const *cams_device,
+                                          uint32_t flags, void *stream) {
+    if (!states || !frames || !Bs || !cams_device || K < 1 || K > GOM_SPLIT_MAX) { gom_set_error("gom_split_forward_backward: null argument or K outside 1..%d", GOM_SPLIT_MAX); return -1; }
+    if (flags & ~GOM_FRAME_USE_GRAPH) { gom_set_error("gom_split_forward_backward: only GOM_FRAME_USE_GRAPH is accepted (a split step is a whole step)"); return -1; }
+    int total = 0;
+    for (int k = 0; k < K; k++) {
+        if (!states[k]) { gom_set_error("gom_split_forward_backward: null state %d", k); return -1; }
+        for (int j = 0; j < k; j++)
+            if (states[j] == states[k]) { gom_set_error("gom_split_forward_backward: every branch needs its own GomState"); return -1; }
+        const GomFrame &f = frames[k];
+        if (Bs[k] < 1 || !cams_device[k]) { gom_set_error("gom_split_forward_backward: branch %d needs B >= 1 and a device camera array", k); return -1; }
+        if (f.cam.H != f.H || f.cam.W != f.W) { gom_set_error("gom_split_forward_backward: camera/image size mismatch"); return -1; }
+        if (f.N != frames[0].N || f.F != frames[0].F || f.g_so3 != frames[0].g_so3 || f.g_scale != frames[0].g_scale || f.g_appearance != frames[0].g_appearance ||
+            f.g_vertices != frames[0].g_vertices) {
+            gom_set_error("gom_split_forward_backward: the branches must share the topology sizes and the four gradient outputs");
+            return -1;
+        }
+        total += Bs[k];
+    }
+    if (total > GOM_SPLIT_MAX_FRAMES) { gom_set_error("gom_split_forward_backward: at most %d frames per step", GOM_SPLIT_MAX_FRAMES); return -1; }
+    GomState *lead = states[0];
+    hipStream_t st = (hipStream_t)stream;
+    if (!lead->splitFork) {
+        GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitFork, hipEventDisableTiming));
+        for (int k = 1; k < GOM_SPLIT_MAX; k++) {
+            GOM_HIP_CHECK(hipStreamCreateWithFlags(&lead->splitStreams[k], hipStreamNonBlocking));
+            GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitJoin[k], hipEventDisableTiming));
+        }
+    }
+    for (int k = 0; k < K; k++) {   // every allocation happens here, outside any capture
+        if (int rc = ensure_capacity(states[k], frames[k].F, frames[k].H, frames[k].W, Bs[k])) return rc;
+        if (int rc = ensure_batch_grads(states[k], Bs[k], frames[k].N, frames[k].F, true)) return rc;
+    }
+    bool profiling = false;
+    for (int k = 0; k < K; k++) profiling = profiling || states[k]->profile;
+    if (!(flags & GOM_FRAME_USE_GRAPH) || profiling || stream == nullptr) return split_enqueue(states, frames, K, Bs, cams_device, st, profiling);
+    lead->graphClock++;
+    for (size_t i = 0; i < lead->splitGraphs.size();) {   // recordings made before a buffer of one of their states moved
+        GomSplitGraphEntry &g = lead->splitGraphs[i];
+        bool stale = false;
+        for (int k = 0; k < g.K; k++) stale = stale || g.alloc_gen[k] != g.states[k]->allocGen;
+        if (stale) {
+            (void)hipGraphExecDestroy(g.exec);
+            (void)hipGraphDestroy(g.graph);
+            lead->splitGraphs[i] = lead->splitGraphs.back();
+            lead->splitGraphs.pop_back();
+        } else {
+            i++;
+        }
+    }
+    auto restore = [&](const GomSplitGraphEntry &g) {
+        for (int k = 0; k < K; k++) {
+            GomState *s = states[k];
+            s->P = frames[k].F; s->H = frames[k].H; s->W = frames[k].W; s->C = 4; s->B = Bs[k]; s->cams = cams_device[k]; s->haveForward = true;
+            s->gx = g.host[k].gx; s->gy = g.host[k].gy; s->segShift = g.host[k].segShift; s->rankSort = g.host[k].rankSort;
+            s->bwdOrderReady = false; s->recCounts = g.host[k].recCounts; s->recForward = g.host[k].recForward; s->emptyFilled = false;
+        }
+    };
+    for (auto &g : lead->splitGraphs) {
+        if (g.K != K || g.flags != 0u) continue;
+        bool same = true;
+        for (int k = 0; k < K && same; k++)
+            same = g.states[k] == states[k] && g.Bs[k] == Bs[k] && g.cams[k] == cams_device[k] && memcmp(&g.keys[k], &frames[k], sizeof(GomFrame)) == 0;
+        if (!same) continue;
+        g.last_use = lead->graphClock;
+        GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
+        restore(g);
+        return 0;
+    }
+    GomSplitGraphEntry e{};
+    e.K = K; e.flags = 0u; e.last_use = lead->graphClock;
+    for (int k = 0; k < K; k++) {
+        e.states[k] = states[k]; e.Bs[k] = Bs[k]; e.cams[k] = cams_device[k]; e.alloc_gen[k] = states[k]->allocGen;
+        memcpy(&e.keys[k], &frames[k], sizeof(GomFrame));
+    }
+    GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = split_enqueue(states, frames, K, Bs, cams_device, st, false);
+    hipError_t ce = hipStreamEndCapture(st, &e.graph);
+    if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return rc; }
+    if (ce != hipSuccess) { gom_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return -2; }
+    for (int k = 0; k < K; k++) {
+        const GomState *s = states[k];
+        e.host[k] = GomSplitHostState{s->gx, s->gy, s->segShift, s->rankSort, false, s->recCounts, s->recForward};
+    }
+    GOM_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+    if (lead->splitGraphs.size() >= 16) {   // evict the least recently used recording
+        size_t victim = 0;
+        for (size_t i = 1; i < lead->splitGraphs.size(); i++)
+            if (lead->splitGraphs[i].last_use < lead->splitGraphs[victim].last_use) victim = i;
+        (void)hipGraphExecDestroy(lead->splitGraphs[victim].exec);
+        (void)hipGraphDestroy(lead->splitGraphs[victim].graph);
+        lead->splitGraphs[victim] = e;
+    } else {
+        lead->splitGraphs.push_back(e);
+    }
+    GOM_HIP_CHECK(hipGraphLaunch(e.exec, st));
+    restore(e);
+    return 0;
+}
+
 static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera *cams, uint32_t flags, void *stream) {
     const int N = f->N, F = f->F, H = f->H, W = f->W, J = 24;
     int rc;
     if ((flags & GOM_FRAME_FORWARD_ONLY) && (flags & GOM_FRAME_BACKWARD_ONLY)) { gom_set_error("FORWARD_ONLY and BACKWARD_ONLY together"); return -1; }
     // The per-face frame runs inside the rasterizer's per-Gaussian kernels (GomFaceArgs) unless GOM_OPT_FUSE_FACE is 0.
     const size_t F3 = 3 * (size_t)F, N3 = 3 * (size_t)N;
-    float *b_so3 = B > 1 ? s->batch_grads : f->g_so3;   // B > 1: every frame writes its own slice, one more launch sums them in frame order (no atomics: reproducible)
-    float *b_scale = B > 1 ? s->batch_grads + B * F3 : f->g_scale;
-    float *b_app = B > 1 ? s->batch_grads + 2 * B * F3 : f->g_appearance;
-    float *b_vert = B > 1 ? s->batch_grads + 3 * B * F3 : f->g_vertices;
+    const bool no_sum = (flags & GOM_FRAME_NO_SUM) != 0;   // a branch of gom_split_forward_backward: slices even for one frame, the caller sums all branches' frames
+    flags &= ~GOM_FRAME_NO_SUM;
+    const bool slices = B > 1 || no_sum;
+    float *b_so3 = slices ? s->batch_grads : f->g_so3;   // B > 1: every frame writes its own slice, one more launch sums them in frame order (no atomics: reproducible)
+    float *b_scale = slices ? s->batch_grads + B * F3 : f->g_scale;
+    float *b_app = slices ? s->batch_grads + 2 * B * F3 : f->g_appearance;
+    float *b_vert = slices ? s->batch_grads + 3 * B * F3 : f->g_vertices;
     GomFaceArgs fa{};
     fa.N = N; fa.verts = f->work_vobs; fa.faces = f->faces; fa.so3 = f->so3; fa.scale = f->scale; fa.sigma = f->sigma;
     fa.appearance = f->appearance; fa.feat4 = f->work_feat;
@@ -622,6 +774,7 @@ static int frame_enqueue(GomState *s, const GomFrame *f, int B, const GomCamera 
     if ((rc = gom_vertex_backward_batch(B, F, N, J, f->vertices, f->lbs_weights, f->work_RT, f->csr_off, f->csr_idx, f->work_dcorner,
                                         nullptr, nullptr, b_vert, nullptr, stream)))
         return rc;
+    if (no_sum) return 0;
     if (B > 1) {
         if ((rc = gom_sum_frames4(B, F3, b_so3, f->g_so3, F3, b_scale, f->g_scale, F3, b_app, f->g_appearance, N3, b_vert, f->g_vertices,
                                   stream)))

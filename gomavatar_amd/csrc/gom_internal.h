@@ -94,6 +94,25 @@ struct GomGraphEntry {
     bool rankSort, bwdOrderReady, recCounts, recForward;
 };
 
+// gom_split_forward_backward: one recorded graph of K concurrent launch sequences (kept by states[0])
+#define GOM_SPLIT_MAX 4
+#define GOM_SPLIT_MAX_FRAMES 16
+#define GOM_FRAME_NO_SUM 0x40000000u   // (internal) frame_enqueue: per-frame gradient slices even for one frame, no frame sum, no optimizer
+struct GomSplitHostState { int gx, gy, segShift; bool rankSort, bwdOrderReady, recCounts, recForward; };
+struct GomSplitGraphEntry {
+    int K;
+    uint32_t flags;
+    GomState *states[GOM_SPLIT_MAX];
+    GomFrame keys[GOM_SPLIT_MAX];
+    int Bs[GOM_SPLIT_MAX];
+    const GomCamera *cams[GOM_SPLIT_MAX];
+    uint64_t alloc_gen[GOM_SPLIT_MAX];
+    GomSplitHostState host[GOM_SPLIT_MAX];
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    uint64_t last_use;
+};
+
 struct GomState {
     int device = 0;
     // capacities
@@ -225,6 +244,9 @@ struct GomState {
     } adam;
     // captured whole-frame launch sequences (GOM_FRAME_USE_GRAPH), keyed by the exact frame descriptor
     std::vector<GomGraphEntry> graphs;
+    std::vector<GomSplitGraphEntry> splitGraphs;          // recorded split steps this state leads (gom_split_forward_backward)
+    hipStream_t splitStreams[GOM_SPLIT_MAX] = {};         // side streams of the split step's branches 1 .. K-1 (created on first use)
+    hipEvent_t splitFork = nullptr, splitJoin[GOM_SPLIT_MAX] = {};
     uint64_t graphClock = 0;
     uint64_t allocGen = 0;            // bumped whenever a buffer of the state is re-allocated: older recordings are dropped, not replayed
 };
@@ -373,6 +395,7 @@ struct GomLossSkip {
 int gom_l1_loss_batch(int B, int H, int W, const float *pred, const float *shade, const float *gt_rgb, const float *gt_mask,
                       const float *bg, float c_rgb, float c_mask, float grad_scale, float *dL_dpred, float *dL_dshade,
                       float *loss_partials, void *stream, const GomLossSkip *skip = nullptr, int slots = GOM_LOSS_BLOCKS);
+int gom_sum_frames_multi(int B, const size_t n[4], const float *const src[4][GOM_SPLIT_MAX_FRAMES], float *const dst[4], void *stream);
 int gom_sum_frames4(int B, size_t n0, const float *s0, float *d0, size_t n1, const float *s1, float *d1, size_t n2, const float *s2,
                     float *d2, size_t n3, const float *s3, float *d3, void *stream);
 int gom_launch_preprocess_backward(GomState *s, const GomCamera &cam, int P, int C, const float *means3D,

@@ -131,6 +131,20 @@ class RenderStep:
         f.work_dfeat, f.work_dopacity, f.work_dcorner, f.work_radii = P(self.d_feat), P(self.d_opacity), P(self.d_corner), P(self.radii)
         return f
 
+    def _fill_frame(self, params, frame, target_rgb, target_mask, bgcolor) -> "_lib.GomFrame":
+        """The call's GomFrame descriptor (the cached struct with this call's parameter / pose / target / gradient pointers)."""
+        P = _lib.ptr
+        f = self._frame
+        if f is None:
+            f = self._frame = self._frame_struct()
+        f.cam = self.cam
+        f.vertices, f.so3, f.scale, f.appearance = P(params["vertices"]), P(params["so3"]), P(params["scale"]), P(params["appearance"])
+        f.cnl_gtfms, f.dst_Rs, f.dst_Ts = P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"])
+        f.gt_rgb, f.gt_mask, f.bgcolor = P(target_rgb), P(target_mask), P(bgcolor)
+        g = self.grads
+        f.g_vertices, f.g_so3, f.g_scale, f.g_appearance = P(g["vertices"]), P(g["so3"]), P(g["scale"]), P(g["appearance"])
+        return f
+
     def forward_backward(self, params: Dict[str, torch.Tensor], frame: Dict[str, torch.Tensor], target_rgb: torch.Tensor,
                          target_mask: torch.Tensor, bgcolor: torch.Tensor, backward: bool = True, graph: bool = False,
                          image_grad_hook=None) -> None:
@@ -142,15 +156,7 @@ class RenderStep:
         `image_grad_hook(step)`: called between the forward half (image + d(L1)/d(image) in `self.d_image`) and the backward
         half of a split call; it may ADD any other image-space gradient to `self.d_image` ((B,)4,H,W) -- see `lpips_hook`."""
         P = _lib.ptr
-        f = self._frame
-        if f is None:
-            f = self._frame = self._frame_struct()
-        f.cam = self.cam
-        f.vertices, f.so3, f.scale, f.appearance = P(params["vertices"]), P(params["so3"]), P(params["scale"]), P(params["appearance"])
-        f.cnl_gtfms, f.dst_Rs, f.dst_Ts = P(frame["cnl_gtfms"]), P(frame["dst_Rs"]), P(frame["dst_Ts"])
-        f.gt_rgb, f.gt_mask, f.bgcolor = P(target_rgb), P(target_mask), P(bgcolor)
-        g = self.grads
-        f.g_vertices, f.g_so3, f.g_scale, f.g_appearance = P(g["vertices"]), P(g["so3"]), P(g["scale"]), P(g["appearance"])
+        f = self._fill_frame(params, frame, target_rgb, target_mask, bgcolor)
         gflag = _lib.GOM_FRAME_USE_GRAPH if graph else 0
 
         def call(flags):
@@ -193,4 +199,111 @@ class RenderStep:
         gaussian.py:93-100 returns (B = 1 unless batched)."""
         img = self.image if self.B > 1 else self.image[None]
         pred = img.permute(0, 2, 3, 1)
+        return pred[..., :3], pred[..., 3]
+
+
+class _SplitState:
+    """`RenderStep.state`'s interface over the branches' states (options go to all of them, pair counts and kernel times add up)."""
+
+    def __init__(self, states):
+        self.states = list(states)
+
+    def set_option(self, opt: int, value: int) -> None:
+        for st in self.states:
+            st.set_option(opt, value)
+
+    def poll(self):
+        got = [st.poll() for st in self.states]
+        return sum(g[0] for g in got), any(g[1] for g in got)
+
+    def kernel_times_ms(self) -> dict:
+        """Per kernel: the SUM over the branches' launches (profiling enqueues the branches kernel by kernel; they still share the chip)."""
+        out = {}
+        for st in self.states:
+            for k, v in st.kernel_times_ms().items():
+                if v >= 0.0:
+                    out[k] = out.get(k, 0.0) + v
+                else:
+                    out.setdefault(k, -1.0)
+        return out
+
+
+class SplitRenderStep:
+    """ONE step of `batch` frames as `split` CONCURRENT launch sequences (`gom_split_forward_backward`): `split` RenderSteps of
+    batch / split frames each, every one with its own scratch state, forked and joined inside one native call (one hipGraph) and closed by
+    one frame sum over all `batch` frames in frame order.  Why: the resident-grid segment kernels leave the chip idle behind their last
+    workgroups at the end of each of a step's ~12 launches; two sequences side by side fill each other's tails.  Same interface and the same
+    bits as RenderStep(batch=batch): `image`, `radii`, `loss_partials`, `d_image`, `xyz`, `cov6`, `v_obs` are whole-batch tensors whose
+    slices the branches write; `grads` is shared by the branches (the frame sum writes it)."""
+
+    _PER_FRAME = ("RT", "fk_save", "v_obs", "xyz", "cov6", "feat", "opacity", "image", "radii", "loss_partials", "d_image", "d_xyz", "d_cov6", "d_feat",
+                  "d_opacity", "d_corner", "cams_dev")
+
+    def __init__(self, faces: torch.Tensor, n_verts: int, img_hw, lbs_weights: torch.Tensor, sigma: float = 1e-3, c_rgb: float = 1.0,
+                 c_mask: float = 5.0, device: Optional[torch.device] = None, batch: int = 8, split: int = 2):
+        assert split >= 1 and batch % split == 0 and batch // split >= 1, "batch must be a multiple of split"
+        self.B, self.K, self.b = int(batch), int(split), int(batch) // int(split)
+        self.parts = [RenderStep(faces, n_verts, img_hw, lbs_weights, sigma, c_rgb, c_mask, device, batch=self.b) for _ in range(self.K)]
+        p0 = self.parts[0]
+        self.lib, self.device, self.topo, self.N, self.F, self.H, self.W = p0.lib, p0.device, p0.topo, p0.N, p0.F, p0.H, p0.W
+        for name in self._PER_FRAME:            # whole-batch tensors; every branch's tensor becomes a view of its frames
+            t0 = getattr(p0, name)
+            per = t0.shape if self.b == 1 and name != "cams_dev" else t0.shape[1:]
+            whole = torch.zeros((self.B,) + tuple(per), dtype=t0.dtype, device=t0.device)
+            if name in ("feat", "opacity"):
+                whole.fill_(1.0)
+            for k, p in enumerate(self.parts):
+                setattr(p, name, whole[k * self.b:(k + 1) * self.b].view(getattr(p, name).shape))
+            setattr(self, "_whole_" + name if name == "cams_dev" else name, whole)
+        self.grads = p0.grads
+        for p in self.parts[1:]:
+            p.grads = self.grads                  # ONE dict: the caller may re-seat its tensors (bench.py: views of the flat exchange buffer)
+        self.state = _SplitState([p.state for p in self.parts])
+        self.cam = None
+
+    # -- cameras: one device array of B cameras, branch k reads rows [k b, (k + 1) b) ------------------------------------------------
+    @property
+    def cams_dev(self) -> torch.Tensor:
+        return self._whole_cams_dev
+
+    @cams_dev.setter
+    def cams_dev(self, t: torch.Tensor) -> None:
+        assert t.shape == self._whole_cams_dev.shape and t.dtype == torch.uint8
+        self._whole_cams_dev = t
+        for k, p in enumerate(self.parts):
+            p.cams_dev = t[k * self.b:(k + 1) * self.b]
+
+    def set_cameras(self, Ks, Es, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
+        assert len(Ks) == self.B and len(Es) == self.B
+        for k, p in enumerate(self.parts):
+            p.set_cameras(Ks[k * self.b:(k + 1) * self.b], Es[k * self.b:(k + 1) * self.b], bg4)
+        self.cam = self.parts[0].cam
+
+    def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
+        self.set_cameras([K] * self.B, [E] * self.B, bg4)
+
+    def forward_backward(self, params, frame, target_rgb, target_mask, bgcolor, backward: bool = True, graph: bool = False, image_grad_hook=None) -> None:
+        """As RenderStep.forward_backward with a leading dimension `batch` on every per-frame tensor; whole steps only."""
+        if not backward or image_grad_hook is not None:
+            raise NotImplementedError("SplitRenderStep runs whole steps (forward + backward, no hook): use RenderStep for split calls")
+        K, b = self.K, self.b
+        frames = (_lib.GomFrame * K)()
+        for k, p in enumerate(self.parts):
+            sl = slice(k * b, (k + 1) * b)
+            if self.cam is not None:
+                p.cam = self.cam                      # (a batched call reads only H and W from it: the per-frame cameras are the device array)
+            cut = (lambda t: t[sl]) if b > 1 else (lambda t: t[k * b])
+            f = p._fill_frame(params, {n: cut(frame[n]) for n in ("cnl_gtfms", "dst_Rs", "dst_Ts")}, cut(target_rgb), cut(target_mask), cut(bgcolor))
+            ctypes.memmove(ctypes.byref(frames[k]), ctypes.byref(f), ctypes.sizeof(_lib.GomFrame))
+        states = (ctypes.c_void_p * K)(*[p.state.handle for p in self.parts])
+        cams = (ctypes.c_void_p * K)(*[_lib.ptr(p.cams_dev) for p in self.parts])
+        Bs = (ctypes.c_int32 * K)(*([b] * K))
+        _lib.check(self.lib.gom_split_forward_backward(states, frames, K, Bs, cams, _lib.GOM_FRAME_USE_GRAPH if graph else 0, _lib.stream_ptr()))
+
+    def losses(self):
+        s = self.loss_partials.sum(-2)
+        return s[..., 0] / (3.0 * self.H * self.W), s[..., 1] / float(self.H * self.W)
+
+    def rgb_mask(self):
+        pred = self.image.permute(0, 2, 3, 1)
         return pred[..., :3], pred[..., 3]

@@ -54,7 +54,11 @@ class MetricWorkload:
         return dict(vertices=torch.from_numpy(self.body["canonical_vertex"]).T.contiguous(), so3=torch.from_numpy(gp["so3"]),
                     scale=torch.from_numpy(gp["scale"]), appearance=torch.from_numpy(gp["appearance"]))
 
-    def step(self, batch: int = 1) -> RenderStep:
+    def step(self, batch: int = 1, split: int = 1):
+        """split > 1: the step's `batch` frames as `split` concurrent launch sequences (pipeline.SplitRenderStep: same bits, tails filled)."""
+        if split > 1:
+            from .pipeline import SplitRenderStep
+            return SplitRenderStep(self.faces, self.N, (self.img, self.img), self.w25, device=self.device, batch=batch, split=split)
         return RenderStep(self.faces, self.N, (self.img, self.img), self.w25, device=self.device, batch=batch)
 
     def batches(self, step: RenderStep) -> List[Dict[str, torch.Tensor]]:

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GOM_ABI_VERSION 10
+#define GOM_ABI_VERSION 11
 
 /* Camera of one rasterizer call: the 12 fields of GaussianRasterizationSettings
  * that matter on this path (gaussian.py:53-66).  view/proj are the 16 floats of
@@ -468,6 +468,23 @@ int gom_frame_forward_backward(GomState *s, const GomFrame *f, uint32_t flags, v
  *     hipGraph picks up new cameras without re-capture.  f->cam only provides H and W.
  *   - results are bit-identical to B separate gom_frame_forward_backward calls. */
 int gom_batch_forward_backward(GomState *s, const GomFrame *f, int32_t B, const GomCamera *cams_device, uint32_t flags, void *stream);
+
+/* ONE step of B = sum(Bs) frames as K CONCURRENT launch sequences (ABI 11): branch k runs frames[k] (a GomFrame as for
+ * gom_batch_forward_backward, Bs[k] frames, device cameras cams_device[k]) on ITS OWN state states[k]; branch 0 on `stream`, the others
+ * on streams the library owns, between a fork behind everything already enqueued on `stream` and a join; one frame sum over all B
+ * frames in frame order (branch 0's frames first) closes the step on `stream`.  Why: the segment kernels of a batched launch are
+ * resident grids draining a task queue, and the chip idles behind the last workgroups of each of a step's ~12 launches; side by side, one
+ * branch's tails are filled by the other's workgroups (MI355X, 55 104 Gaussians at 512x512, 8 frames: 2 x 4 is the fastest cut).  It stays
+ * ONE step -- nothing of the next step starts before this one's gradients are complete, unlike several steps in flight -- i.e. the
+ * reference's semantics of one optimizer step per batch (train.py:309-349).
+ *   - every branch's g_vertices / g_so3 / g_scale / g_appearance must be the SAME four tensors (the step's gradients: the sum over all B
+ *     frames), N and F equal; everything else of a GomFrame is per branch (inputs, image, loss_partials, work_*: leading dimension Bs[k]);
+ *   - K <= 4, B <= 16; flags: 0 or GOM_FRAME_USE_GRAPH (fork, branches, join and sum recorded as ONE hipGraph, replayed while the K
+ *     descriptors, states and camera arrays stay the same);
+ *   - results: images, losses, radii bitwise those of the frames rendered one by one; gradients bitwise those of
+ *     gom_batch_forward_backward over the same B frames in the same order. */
+int gom_split_forward_backward(GomState *const *states, const GomFrame *frames, int32_t K, const int32_t *Bs, const GomCamera *const *cams_device,
+                               uint32_t flags, void *stream);
 
 /* ---- frame-parallel step, behind the gradient -----------------------------------------------------------------
  * Adam on the FLAT parameter buffer: the reference's torch.optim.Adam(param_groups, betas=(0.9, 0.999)) (train.py:263-267,

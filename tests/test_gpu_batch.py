@@ -351,3 +351,43 @@ def test_recorded_step_survives_a_larger_frame_on_the_same_state():
     assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
     for k in ref[2]:
         assert torch.equal(again[2][k], ref[2][k]), k
+
+
+@pytest.mark.parametrize("B,K,img,graph", [(4, 2, 96, True), (4, 4, 96, False), (6, 2, 128, True), (8, 2, 256, True)])
+def test_split_step_equals_one_launch_sequence_bitwise(B, K, img, graph):
+    """pipeline.SplitRenderStep / gom_split_forward_backward (ABI 11): ONE step of B frames as K CONCURRENT launch sequences of B / K frames,
+    each on its own state and stream between a fork and a join, closed by one frame sum over all B frames in frame order -- against
+    RenderStep(batch=B), the one launch sequence: images, loss partials, radii and all four gradients BITWISE equal (a frame's results do not
+    depend on the launch it rides in; the sum adds the same slices in the same order).  (4, 4): one frame per branch -- the single-frame
+    kernels with per-frame gradient slices.  graph: capture, then replays of the recorded fork / join."""
+    from gomavatar_amd.pipeline import RenderStep, SplitRenderStep
+    faces, N, w25, params, frames, gt_rgb, gt_mask = _scene(img, B)
+    stack = lambda k: torch.from_numpy(np.stack([f[k][0] for f in frames])).contiguous().cuda()
+    fr_b = {k: stack(k) for k in ("cnl_gtfms", "dst_Rs", "dst_Ts")}
+    bg_b = stack("bgcolor")
+    bg4 = (0.1, 0.2, 0.3, 0.0)
+    from gomavatar_amd import _lib
+    one = RenderStep(faces, N, (img, img), w25, batch=B)
+    split = SplitRenderStep(faces, N, (img, img), w25, batch=B, split=K)
+    if B // K == 1:
+        split.state.set_option(_lib.OPT_SEG_SHIFT, 8)     # (a one-frame branch would pick 128-entry segments: bitwise equality needs the batch's 256)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    res = []
+    for st in (one, split):
+        st.set_cameras([f["K"][0] for f in frames], [f["E"][0] for f in frames], bg4)
+        with torch.cuda.stream(stream):
+            for _ in range(3 if graph else 1):
+                st.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b, graph=graph)
+        stream.synchronize()
+        assert st.state.poll()[0] > 0 and not st.state.poll()[1]
+        res.append((st.image.clone(), st.loss_partials.clone(), st.radii.clone(), st.d_image.clone(), {k: v.clone() for k, v in st.grads.items()}))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for k in res[0][4]:
+        assert torch.equal(res[0][4][k], res[1][4][k]), k
+        assert float(res[0][4][k].abs().max()) > 0
+    assert one.state.poll()[0] == split.state.poll()[0]      # the same number of (tile, Gaussian) pairs in all
+    # refusals: loud, not silent
+    with pytest.raises(NotImplementedError):
+        split.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b, backward=False)
