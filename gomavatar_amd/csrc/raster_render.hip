@@ -720,7 +720,11 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
         // pass-through: colours into list order for the compositing / backward kernels (nobody waits on it here)
+#if defined(GOM_KO_T) && GOM_KO_T >= 2   // development knock-outs of this kernel (profiles/r06_forward_ladder.txt): 1 = no alpha loop, 2 = + no entry loads / cull / staging, 3 = + no stores
+        if (false) {
+#else
         if (q == 0 && threadIdx.x < cnt) {
+#endif
             const uint32_t g = point_list[start + threadIdx.x];
             float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
             cl.x = colors[(size_t)g * C]; cl.y = colors[(size_t)g * C + 1]; cl.z = colors[(size_t)g * C + 2];
@@ -730,15 +734,25 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         float T = 1.f;
         uint32_t n_pos = 0;   // (REC) surviving entries with alpha > 0 at this lane's pixel
         {
+#if defined(GOM_KO_T) && GOM_KO_T >= 2
+            EntryRegs<0> r; r.x = r.y = r.a = r.b = r.c = 0.f; r.o = -INFINITY; r.keep = false;
+#else
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
+#endif
             tq.request();
             unsigned long long mask = __ballot(r.keep);
+#if !(defined(GOM_KO_T) && GOM_KO_T >= 3)
             if (lane == 0) cull_masks[((size_t)seg * GOM_NSUB + sub) * 4 + q] = mask;   // for the two passes that follow
+#endif
             GOM_PAIR_STAT(4, __popcll(mask));
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
             ph_lastsurv = __popcll(mask);
 #endif
+#if defined(GOM_KO_T) && GOM_KO_T >= 1
+            const uint32_t n4 = (GOM_KO_T >= 2 || cnt == 0xffffffffu) ? 0u : (stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o), 0u);
+#else
             const uint32_t n4 = stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o);   // (LDS operations of one wave execute in order: no barrier)
+#endif
             for (uint32_t j = 0; j < n4 / 2; j += 2) {
                 const v2f a0 = pair_alpha(load_pair(s_pr[sub], j), pfx, pfy);
                 const v2f a1 = pair_alpha(load_pair(s_pr[sub], j + 1), pfx, pfy);
@@ -753,12 +767,18 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             const uint32_t tot = wave_sum_u32(n_pos);
             if (lane == 0) rec.piece_ub[((size_t)seg * GOM_NSUB + sub) * 4 + q] = tot;
         }
+#if !(defined(GOM_KO_T) && GOM_KO_T >= 3)
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;   // (the last piece's row is never read; leaving it out measured 82 us instead of 76)
+#endif
         float(*sp)[64] = s_P[tq.it & 1];  // double-buffered: the readers of the previous task use the other half
         sp[sub][lane] = T;
         tq.publish(s_task);
         __syncthreads();
+#if defined(GOM_KO_T) && GOM_KO_T >= 3
+        if (sub == 0 && cnt == 0xffffffffu) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
+#else
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
+#endif
 #if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
         { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) { ph_max = ph_last; ph_maxsurv = ph_lastsurv; } }
 #endif
@@ -843,6 +863,7 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
                     T = (Tn >= kStopT * 0.99999f) ? Tn : 0.f;
                 }
             }
+            // (measured, round 6: ending this walk once every pixel of the quadrant has stopped -- a ballot per eight rows -- changes nothing: 108.2 against 107.5 us)
         }
         {
             float p[GOM_NSUB - 1];
@@ -935,6 +956,12 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) ecol[u][ch] = cv[ch];
                 }
+#if defined(GOM_KO_FWD) && GOM_KO_FWD == 3   // development knock-out: the alphas are evaluated, the serial chain is not (results invalid)
+#pragma unroll
+                for (int u = 0; u < GOM_FWD_EPT; u++) acc[0] += al[u] * ecol[u][0];
+                if (acc[0] == 123.456f) wl = 0.f;
+                continue;
+#endif
 #pragma unroll
                 for (int u = 0; u < GOM_FWD_EPT; u++) {  // the serial chain: T -> test_T -> select
                     const float a = al[u] * wl;
