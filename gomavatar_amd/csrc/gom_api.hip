@@ -257,7 +257,7 @@ static int ensure_capacity(GomState *s, int P_frame, int H, int W, int B) {
         s->capSegs = wantSegs;
     }
 #ifdef GOM_LAB
-    if (s->bwdMode == 3) {   // records of the laboratory render backward (rec_bwd.hpp), only for a state that uses it: one per blending (pixel, entry) pair in
+    if (s->bwdMode == 3) {   // records of the laboratory render backward (lab/rec_bwd.hpp), only for a state that uses it: one per blending (pixel, entry) pair in
                              // GOM_REC_SHARDS equal regions (24 bytes x 8 per unit of pair capacity), and the per-piece bookkeeping
         int64_t wantRec = s->capPairs * GOM_REC_PER_PAIR / GOM_REC_SHARDS * GOM_REC_SHARDS;
         if (wantRec > 0xf0000000LL) wantRec = 0xf0000000LL / GOM_REC_SHARDS * GOM_REC_SHARDS;

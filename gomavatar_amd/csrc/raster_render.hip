@@ -54,26 +54,6 @@
 #include "l1_pixel.hpp"
 #include <cstdlib>
 
-#ifdef GOM_PHASE_PROF  // development only (scripts/exp_build.py NAME -DGOM_PHASE_PROF=1 | 2 | 3 | 4): workgroup timeline of k_seg_T (1), k_seg_bwd_pair (2), k_seg_fwd (3): scripts/wg_timeline_T.py; of k_combine_fwd (4): scripts/combine_timeline.py
-__device__ unsigned long long g_phase[16];
-__device__ unsigned long long g_wg_busy[GOM_SEG_GRID * 4];
-extern "C" int gom_debug_phase_counters(unsigned long long *out, unsigned long long *wg, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
-    if (wg) (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_wg_busy), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
-    if (reset) {
-        static unsigned long long z[GOM_SEG_GRID * 4];
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(unsigned long long) * 16);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_busy), z, sizeof(z));
-    }
-    return 0;
-}
-__device__ unsigned long long g_wg_t0[GOM_SEG_GRID * 4], g_wg_t1[GOM_SEG_GRID * 4];
-extern "C" int gom_debug_wg_timeline(unsigned long long *t0, unsigned long long *t1) {
-    (void)hipMemcpyFromSymbol(t0, HIP_SYMBOL(g_wg_t0), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
-    (void)hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_wg_t1), sizeof(unsigned long long) * GOM_SEG_GRID * 4);
-    return 0;
-}
-#endif
 namespace {
 
 constexpr float kStopT = 0.0001f;          // App. A.3: stop when T(1-alpha) < 1e-4
@@ -673,12 +653,6 @@ struct PairQueue {
     }
 };
 
-#ifdef GOM_BLK_STATS
-__device__ unsigned long long g_pair_stats[8];   // development: [0] live (half, wave) pieces, [1] survivors evaluated, [2] of them with a lane alive, [3] lanes alive, [4] survivors k_seg_T evaluates (all pieces, live or not)
-#define GOM_PAIR_STAT(I, V) do { if (lane == 0) atomicAdd(&g_pair_stats[I], (unsigned long long)(V)); } while (0)
-#else
-#define GOM_PAIR_STAT(I, V) do { } while (0)
-#endif
 // ------------------------------------------------- forward, pass A (T only) -
 // prod(1 - alpha) of every 32-entry sub-range (and of the whole segment) for every pixel of the tile, from
 // alpha alone (no colours, no stop rule): lets every later pass know the transmittance at which each piece
@@ -702,10 +676,6 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1   // (scripts/wg_timeline_T.py: lifetime, number of tasks, longest and last task of every workgroup)
-    const unsigned long long ph_w0 = wall_clock64();
-    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64(), ph_lastsurv = 0, ph_maxsurv = 0;
-#endif
     TaskQueue tq;
     for (tq.init(task_ctr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
@@ -720,11 +690,7 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         const float qx1 = qx0 + 7.f, qy1 = qy0 + 7.f;
         const float pfx = qx0 + (float)(lane & 7), pfy = qy0 + (float)(lane >> 3);
         // pass-through: colours into list order for the compositing / backward kernels (nobody waits on it here)
-#if defined(GOM_KO_T) && GOM_KO_T >= 2   // development knock-outs of this kernel (profiles/r06_forward_ladder.txt): 1 = no alpha loop, 2 = + no entry loads / cull / staging, 3 = + no stores
-        if (false) {
-#else
         if (q == 0 && threadIdx.x < cnt) {
-#endif
             const uint32_t g = point_list[start + threadIdx.x];
             float4 cl = make_float4(0.f, 0.f, 0.f, 0.f);
             cl.x = colors[(size_t)g * C]; cl.y = colors[(size_t)g * C + 1]; cl.z = colors[(size_t)g * C + 2];
@@ -734,25 +700,11 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
         float T = 1.f;
         uint32_t n_pos = 0;   // (REC) surviving entries with alpha > 0 at this lane's pixel
         {
-#if defined(GOM_KO_T) && GOM_KO_T >= 2
-            EntryRegs<0> r; r.x = r.y = r.a = r.b = r.c = 0.f; r.o = -INFINITY; r.keep = false;
-#else
             const EntryRegs<0> r = load_sub<0>(ent_geo, nullptr, start, cnt, sub, lane, qx0, qy0, qx1, qy1, sub_sz);
-#endif
             tq.request();
             unsigned long long mask = __ballot(r.keep);
-#if !(defined(GOM_KO_T) && GOM_KO_T >= 3)
             if (lane == 0) cull_masks[((size_t)seg * GOM_NSUB + sub) * 4 + q] = mask;   // for the two passes that follow
-#endif
-            GOM_PAIR_STAT(4, __popcll(mask));
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
-            ph_lastsurv = __popcll(mask);
-#endif
-#if defined(GOM_KO_T) && GOM_KO_T >= 1
-            const uint32_t n4 = (GOM_KO_T >= 2 || cnt == 0xffffffffu) ? 0u : (stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o), 0u);
-#else
             const uint32_t n4 = stage_pairs(s_pr[sub], r.keep, mask, lane, r.x, r.y, r.a, r.b, r.c, r.o);   // (LDS operations of one wave execute in order: no barrier)
-#endif
             for (uint32_t j = 0; j < n4 / 2; j += 2) {
                 const v2f a0 = pair_alpha(load_pair(s_pr[sub], j), pfx, pfy);
                 const v2f a1 = pair_alpha(load_pair(s_pr[sub], j + 1), pfx, pfy);
@@ -767,28 +719,13 @@ __global__ void __launch_bounds__(256) k_seg_T(uint32_t seg_shift, int gx, int g
             const uint32_t tot = wave_sum_u32(n_pos);
             if (lane == 0) rec.piece_ub[((size_t)seg * GOM_NSUB + sub) * 4 + q] = tot;
         }
-#if !(defined(GOM_KO_T) && GOM_KO_T >= 3)
         sub_T[((size_t)seg * GOM_NSUB + sub) * GOM_TPX + pxi] = T;   // (the last piece's row is never read; leaving it out measured 82 us instead of 76)
-#endif
         float(*sp)[64] = s_P[tq.it & 1];  // double-buffered: the readers of the previous task use the other half
         sp[sub][lane] = T;
         tq.publish(s_task);
         __syncthreads();
-#if defined(GOM_KO_T) && GOM_KO_T >= 3
-        if (sub == 0 && cnt == 0xffffffffu) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
-#else
         if (sub == 0) seg_T[(size_t)seg * GOM_TPX + pxi] = ((sp[0][lane] * sp[1][lane]) * sp[2][lane]) * sp[3][lane];
-#endif
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
-        { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) { ph_max = ph_last; ph_maxsurv = ph_lastsurv; } }
-#endif
     }
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 1
-    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
-        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = wall_clock64();
-        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | (ph_maxsurv << 24) | (ph_lastsurv << 16) | ph_tasks;
-    }
-#endif
     tq.finish();
 }
 
@@ -821,18 +758,11 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;  // the 4 waves of a workgroup = the 4 sub-ranges of one (segment, quadrant)
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3   // (scripts/wg_timeline_T.py)
-    const unsigned long long ph_w0 = wall_clock64();
-    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
-#endif
     TaskQueue tq;
     for (tq.init(task_ctr ? task_ctr + GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
         if (task == 0xffffffffu) break;
         const uint32_t seg = task >> 2;
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3
-        { const unsigned long long t = wall_clock64(); if (ph_tasks) { ph_last = t - ph_t; if (ph_last > ph_max) ph_max = ph_last; } ph_t = t; ph_tasks++; }
-#endif
         const int q = (int)(task & 3);
         const int pxi = q * 64 + lane;
         const uint4 d = seg_desc[seg];
@@ -880,11 +810,7 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
         float wl = T > 0.f ? 1.f : 0.f;  // lane still compositing (float mask: no SALU in the chain)
         tq.request();  // (behind every load of this task)
         const bool any_alive = __syncthreads_or(wl != 0.f ? 1 : 0) != 0;  // also fences the LDS of the previous segment
-#if defined(GOM_KO_FWD) && GOM_KO_FWD == 2   // development knock-outs (scripts/exp_build.py NAME -DGOM_KO_FWD=1|2): no compositing loop / every segment treated as dead
-        if (true) {
-#else
         if (!any_alive) {  // every pixel of the quadrant stopped before this segment
-#endif
             if (sub == 0) {   // (the assembly pass needs seg_Tend = 0 only, but loads all three rows of a segment in one batch: with the other two
                               //  left unwritten -- 24 MB of stores less per 8-frame launch -- its loads came from HBM instead of the L2 / MALL: k_combine_fwd 25 -> 29 us)
                 const size_t o = (size_t)seg * GOM_TPX + pxi;
@@ -906,9 +832,6 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
         uint32_t last = 0;
         if (__ballot(wl != 0.f) != 0ull) {
             unsigned long long mask = __ballot(r.keep);
-#if defined(GOM_KO_FWD) && GOM_KO_FWD == 1
-            mask = 0ull;
-#endif
             // (REC) the piece's record region: upper bound from k_seg_T, one dequeue-like atomic per live piece
             const uint32_t piece = ((seg * GOM_NSUB + (uint32_t)sub) << 2) | (uint32_t)q;
             uint32_t rbase = 0, rcur = 0, rub = 0, my_cnt = 0;   // my_cnt: records of entry `lane` of the sub-range (v_writelane, one per entry)
@@ -917,11 +840,7 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
                 rub = __builtin_amdgcn_readfirstlane(rec.piece_ub[piece]);
                 const uint32_t shard = piece % GOM_REC_SHARDS;
                 uint32_t b = 0;
-#if defined(GOM_KO_FWDREC) && (GOM_KO_FWDREC & 2)   // development knock-out: no allocation (a fixed region per piece, results invalid)
-                b = (piece & 1023u) * 4096u;
-#else
                 if (lane == 0 && rub) b = atomicAdd(rec.cursor + 32 * shard, rub);
-#endif
                 b = __builtin_amdgcn_readfirstlane(b);
                 rec_on = rub != 0u && b + rub <= rec.shard_cap;
                 if (rub != 0u && !rec_on && lane == 0) atomicOr(rec.overflow, 1u);
@@ -956,12 +875,6 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
 #pragma unroll
                     for (int ch = 0; ch < C; ch++) ecol[u][ch] = cv[ch];
                 }
-#if defined(GOM_KO_FWD) && GOM_KO_FWD == 3   // development knock-out: the alphas are evaluated, the serial chain is not (results invalid)
-#pragma unroll
-                for (int u = 0; u < GOM_FWD_EPT; u++) acc[0] += al[u] * ecol[u][0];
-                if (acc[0] == 123.456f) wl = 0.f;
-                continue;
-#endif
 #pragma unroll
                 for (int u = 0; u < GOM_FWD_EPT; u++) {  // the serial chain: T -> test_T -> select
                     const float a = al[u] * wl;
@@ -975,11 +888,7 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
                         const bool em = w > 0.f;
                         const unsigned long long bm = __ballot(em);
                         if (bm != 0ull && rec_on) {
-#if defined(GOM_KO_FWDREC) && (GOM_KO_FWDREC & 1)   // development knock-out: no record stores
-                            if (em && T == 123.456f) {
-#else
                             if (em) {
-#endif
                                 const uint32_t idx = rcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
                                 rec.rec_acc[idx] = make_float4(acc[0], C > 1 ? acc[1 % C] : 0.f, C > 2 ? acc[2 % C] : 0.f, C > 3 ? acc[3 % C] : 0.f);
                                 rec.rec_ti[idx] = make_float2(T, __uint_as_float(((uint32_t)kk[u] << 6) | (uint32_t)lane));
@@ -1058,14 +967,6 @@ __global__ void __launch_bounds__(256, REC ? GOM_FWD_WAVES_REC : GOM_FWD_WAVES) 
             st4<C>(seg_C, seg, pxi, tot);
         }
     }
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 3
-    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
-        const unsigned long long t = wall_clock64();
-        ph_last = t - ph_t; if (ph_last > ph_max) ph_max = ph_last;
-        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = t;
-        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | ph_tasks;
-    }
-#endif
     tq.finish();
 }
 
@@ -1336,12 +1237,6 @@ __global__ void __launch_bounds__(256) k_combine_fwd(int H, int W, int gx, int g
                                                      const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ rank_of,
                                                      uint32_t *__restrict__ tile_qlim, int skip_empty, const uint32_t *__restrict__ work, int n_tiles,
                                                      GomBwdOrderRider rider, GomLossRider lr, int n_loss_riders) {
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 4   // (development: lifetime of every workgroup of this launch, riders first; scripts/combine_timeline.py)
-    struct PhRec {
-        unsigned long long w0;
-        __device__ ~PhRec() { if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) { g_wg_t0[blockIdx.x] = w0; g_wg_t1[blockIdx.x] = wall_clock64(); } }
-    } ph_rec{(unsigned long long)wall_clock64()};
-#endif
     // (frame step, batched) the first eight workgroups order the backward's task queue: bwd_order.hpp
     const uint32_t n_rid = rider.status ? 8u : 0u;
     if (blockIdx.x < n_rid) { gom_bwd_order_rider(rider, blockIdx.x); return; }
@@ -1399,9 +1294,6 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
     bool from_n1;
     const int slot20 = wave_sum20_slot(lane, from_n1);   // where this lane's share of a reduced pair goes (or -1)
     const size_t HW = (size_t)H * W;
-#ifdef GOM_PHASE_PROF
-    const unsigned long long ph_k0 = __builtin_readcyclecounter(), ph_w0 = wall_clock64();
-#endif
     TaskQueue tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
@@ -1486,11 +1378,7 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
             const unsigned long long mask = __ballot(r.keep);
             const uint32_t npairs = stage_bwd_pairs<C>(s_slab[q], r, mask, lane);
             const uint32_t pos_limit = survivors_before(mask, my_last > s0 ? my_last - s0 : 0u);
-            done = bwd_replay<C>(s_slab[q], npairs, &s_acc[buf][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1
-#ifdef GOM_BLK_STATS
-                                 , lane
-#endif
-            );
+            done = bwd_replay<C>(s_slab[q], npairs, &s_acc[buf][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1);
             smask = mask;
         }
         if (lane == 0) { s_done[buf][q] = done; s_mask[buf][q] = smask; }
@@ -1516,15 +1404,6 @@ __global__ void __launch_bounds__(256, GOM_BWD_WAVES) k_seg_bwd(uint32_t seg_shi
         }
     }
     tq.finish();
-#ifdef GOM_PHASE_PROF
-    if (threadIdx.x == 0) {
-#ifdef GOM_PHASE_PROF_BWD   // (the arrays are shared with k_seg_T's instrumentation: one kernel at a time)
-        g_wg_busy[blockIdx.x] += __builtin_readcyclecounter() - ph_k0;
-        g_wg_t0[blockIdx.x] = ph_w0;   // timeline of the last launch (100 MHz wall clock, common to all XCDs)
-        g_wg_t1[blockIdx.x] = wall_clock64();
-#endif
-    }
-#endif
 }
 
 // ------------------------------------------- backward, two sub-ranges between barriers -
@@ -1555,10 +1434,6 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     __shared__ unsigned long long s_done[2][4], s_mask[2][4];   // pairs of rows written; the survivors (list order) they belong to
     __shared__ uint32_t s_task[2];
     __shared__ float4 s_slab[4][GOM_BPAIR_F4];       // wave-private pair records of the survivors, geometry and colours
-#ifdef GOM_KO_PAD_LDS   // development: occupancy sensitivity (extra LDS per workgroup, bytes)
-    __shared__ float s_pad[GOM_KO_PAD_LDS / 4];
-    if (seg_shift == 99u) { s_pad[threadIdx.x] = (float)H; __syncthreads(); partial[threadIdx.x] = s_pad[(threadIdx.x * 7) % (GOM_KO_PAD_LDS / 4)]; }
-#endif
     const uint32_t sub_sz = (1u << seg_shift) >> 2;
     if (status->overflow) return;
     const uint32_t nsegs = status->num_segs;
@@ -1566,10 +1441,6 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
     bool from_n1;
     const int slot20 = wave_sum20_slot(lane, from_n1);
     const size_t HW = (size_t)H * W;
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2   // (scripts/wg_timeline_T.py)
-    const unsigned long long ph_w0 = wall_clock64();
-    unsigned long long ph_tasks = 0, ph_max = 0, ph_last = 0, ph_t = wall_clock64();
-#endif
     PairQueue tq;
     for (tq.init(task_ctr ? task_ctr + 2 * GOM_TQ_WORDS : nullptr, nsegs, s_task, task_order);; tq.advance()) {
         const uint32_t task = tq.current(s_task);
@@ -1583,11 +1454,7 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         const uint32_t e0 = d.w << seg_shift;
         const uint32_t tmax = max(max(qm4.x, qm4.y), max(qm4.z, qm4.w));
         const uint32_t s0a = e0 + (uint32_t)sub_a * sub_sz;
-#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 4
-        if (true) {
-#else
         if ((uint32_t)sub_a * sub_sz >= cnt || s0a >= tmax) {
-#endif   // no entries, or every pixel of the tile stopped before the pair: nothing is written
             tq.request();
             tq.publish(s_task);
             __syncthreads();
@@ -1654,18 +1521,9 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
                     R_acc = sd * (T > 0.f ? 1.f / T : 0.f);   // (same operations as k_seg_bwd: the two kernels agree bitwise)
                 }
                 const unsigned long long mask = __ballot(r.keep);
-                GOM_PAIR_STAT(0, 1); GOM_PAIR_STAT(1, __popcll(mask));
-#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 6
-                const uint32_t npairs = 0;
-#else
                 const uint32_t npairs = stage_bwd_pairs<C>(s_slab[wv], r, mask, lane);
-#endif
                 const uint32_t pos_limit = survivors_before(mask, my_last > s0 ? my_last - s0 : 0u);
-                done = bwd_replay<C>(s_slab[wv], npairs, &s_acc[half][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1
-#ifdef GOM_BLK_STATS
-                                     , lane
-#endif
-                );
+                done = bwd_replay<C>(s_slab[wv], npairs, &s_acc[half][q][0][0], dpix, pfx, pfy, T, R_acc, T_final, bg_dot, pos_limit, slot20, from_n1);
                 smask = mask;
             }
             if (lane == 0) { s_done[half][q] = done; s_mask[half][q] = smask; }
@@ -1674,26 +1532,9 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
         if (!requested) tq.request();
         tq.publish(s_task);
         __syncthreads();
-#ifdef GOM_BLK_STATS
-        if (threadIdx.x == 0) {   // development: how even the eight pieces of a task are -- [5] sum of the survivors, [6] the busiest wave as assigned (w, 3 - w), [7] as a largest-first deal would have it
-            uint32_t c[8], tot = 0;
-            for (int i = 0; i < 8; i++) { c[i] = (uint32_t)__popcll(s_mask[i >> 2][i & 3]); tot += c[i]; }
-            uint32_t cur = 0;
-            for (int w = 0; w < 4; w++) cur = max(cur, c[w] + c[4 + 3 - w]);
-            for (int i = 0; i < 8; i++) for (int k = i + 1; k < 8; k++) if (c[k] > c[i]) { const uint32_t t = c[i]; c[i] = c[k]; c[k] = t; }
-            uint32_t ld[4] = {0, 0, 0, 0};
-            for (int i = 0; i < 8; i++) { int m = 0; for (int w = 1; w < 4; w++) if (ld[w] < ld[m]) m = w; ld[m] += c[i]; }
-            const uint32_t lpt = max(max(ld[0], ld[1]), max(ld[2], ld[3]));
-            atomicAdd(&g_pair_stats[5], (unsigned long long)tot); atomicAdd(&g_pair_stats[6], (unsigned long long)cur); atomicAdd(&g_pair_stats[7], (unsigned long long)lpt);
-        }
-#endif
         {   // one 48-byte record per entry of the two sub-ranges (threads 0..127), quadrants summed in a fixed order
             const int half = (threadIdx.x >> 6) & 1, e = threadIdx.x & 63;
-#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 5
-            if (my_rec && cnt == 0xffffffffu) {
-#else
             if (my_rec) {
-#endif
                 const uint32_t slot = ent_slot[start + (uint32_t)(sub_a + half) * sub_sz + (uint32_t)e];
                 float rr[10];
 #pragma unroll
@@ -1713,33 +1554,17 @@ __global__ void __launch_bounds__(256, GOM_BWDP_WAVES) k_seg_bwd_pair(uint32_t s
             }
         }
         __syncthreads();   // the next pair overwrites s_acc / s_done
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2
-        { const unsigned long long t = wall_clock64(); ph_last = t - ph_t; ph_t = t; ph_tasks++; if (ph_last > ph_max) ph_max = ph_last; }
-#endif
     }
-#if defined(GOM_PHASE_PROF) && GOM_PHASE_PROF == 2
-    if (threadIdx.x == 0 && blockIdx.x < GOM_SEG_GRID * 4) {
-        g_wg_t0[blockIdx.x] = ph_w0; g_wg_t1[blockIdx.x] = wall_clock64();
-        g_wg_busy[blockIdx.x] = (ph_max << 48) | (ph_last << 32) | ph_tasks;
-    }
-#endif
     tq.finish();
 }
 
 #ifdef GOM_LAB   // (include/gom_hip_lab.h: built, measured, not adopted)
-#include "seg_bwd_blk.hpp"
-#include "rec_bwd.hpp"
+#include "lab/seg_bwd_blk.hpp"
+#include "lab/rec_bwd.hpp"
 #endif
 
 }  // namespace
 
-#ifdef GOM_BLK_STATS
-extern "C" int gom_debug_blk_stats(unsigned long long *out, int reset) {
-    if (out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_stats), sizeof(unsigned long long) * 8); (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_pair_stats), sizeof(unsigned long long) * 8); }
-    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stats), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), z, sizeof(z)); }
-    return 0;
-}
-#endif
 
 int gom_launch_sort(GomState *s, hipStream_t st) {
     const int n_tiles = s->gx * s->gy * s->B;
@@ -1869,7 +1694,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
     if (n_tiles == 0) return 0;
     GomKernelTimer timer(s, GOM_K_SEG_BWD, st);
 #ifdef GOM_LAB
-    if (s->recForward) {   // the forward left records: a lane per blending (pixel, entry) pair (rec_bwd.hpp)
+    if (s->recForward) {   // the forward left records: a lane per blending (pixel, entry) pair (lab/rec_bwd.hpp)
         const GomRecArgs ra = rec_args(s);
 #define GOM_RB(CC)                                                                                                        \
     hipLaunchKernelGGL((k_rec_bwd<CC>), dim3(GOM_RESIDENT(k_rec_bwd<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
@@ -1880,7 +1705,7 @@ int gom_launch_render_backward(GomState *s, const GomCamera &cam, int C, const f
         GOM_LAUNCH_CHECK();
         return 0;
     }
-    if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (seg_bwd_blk.hpp)
+    if (s->bwdMode == 2) {   // (sub-range, 4 x 4 block) items, one per DPP row (lab/seg_bwd_blk.hpp)
 #define GOM_SBB(CC)                                                                                                       \
     hipLaunchKernelGGL((k_seg_bwd_blk<CC>), dim3(GOM_RESIDENT(k_seg_bwd_blk<CC>)), dim3(256), 0, st, (uint32_t)s->segShift, s->H, s->W, s->gx, s->gy, cam.bg[0], cam.bg[1], cam.bg[2], \
                        cam.bg[3], s->cams, s->seg_desc, s->seg_qmax, s->ent_geo, s->ent_col, s->final_T, s->n_contrib, dL_dcolor,           \

@@ -101,9 +101,6 @@ __device__ __forceinline__ int wave_sum20_slot(int lane, bool &from_n1) {
 template <int C>
 __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uint32_t npairs, float *acc, const float (&dpix)[C], float pfx, float pfy,
                                                          float T, float R_acc, float T_final, float bg_dot, uint32_t pos_limit, int slot20, bool from_n1
-#ifdef GOM_BLK_STATS
-                                                         , int lane
-#endif
 ) {
 #pragma clang fp contract(off)
     unsigned long long done = 0ull;
@@ -113,9 +110,6 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
     const v2f lim = {(float)pos_limit, (float)pos_limit};
     v2f pos = {(float)(2u * npairs), (float)(2u * npairs + 1u)};
     const float ntf = -T_final;
-#ifdef GOM_KO_REPLAY   // development knock-outs (scripts/exp_build.py NAME -DGOM_KO_REPLAY=1|2|3): no replay / alphas only / no reduction
-    if (GOM_KO_REPLAY == 1 || GOM_KO_REPLAY >= 4) npairs = 0;
-#endif
     for (int j = (int)npairs - 1; j >= 0; j--) {
         const float4 *p = slab + 5 * j;
         const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
@@ -124,13 +118,7 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         pos = pos - v2f{2.f, 2.f};   // (2 j, 2 j + 1) as floats, carried: there is no scalar int -> float on gfx950
         const AlphaEval<v2f> e = alpha_eval_lim(v2f{p0.x, p0.y}, v2f{p0.z, p0.w}, v2f{p1.x, p1.y}, v2f{p1.z, p1.w}, v2f{p2.x, p2.y}, v2f{p2.z, p2.w}, px, py, lim, pos);
         const v2f mm = e.mm, al = e.al, dx = e.dx, dy = e.dy;
-#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 2
-        if (__ballot(fmaxf(al.x, al.y) > 1.f) == 0ull) continue;
-#endif
         if (__ballot(fmaxf(al.x, al.y) > 0.f) == 0ull) continue;     // wave-uniform: nobody blends either entry (their rows are not written)
-#ifdef GOM_BLK_STATS
-        { GOM_PAIR_STAT(2, 1); const unsigned long long a0_ = __ballot(al.x > 0.f), a1_ = __ballot(al.y > 0.f); GOM_PAIR_STAT(3, __popcll(a0_) + __popcll(a1_)); }
-#endif
         // An entry with alpha == 0 is replayed as a zero-alpha layer: the recurrences leave T / accum_rec exactly as skipping would.
         const v2f oma = one - al;
         const v2f inv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};   // v_rcp_f32 (1 ulp), shared by both divisions
@@ -166,11 +154,7 @@ __device__ __forceinline__ unsigned long long bwd_replay(const float4 *slab, uin
         z[8] = z[5] * dy;
         z[9] = z[6] * dy;
         float n0, n1;
-#if defined(GOM_KO_REPLAY) && GOM_KO_REPLAY == 3
-        { v2f t_ = z[0]; for (int i = 1; i < 10; i++) t_ += z[i]; n0 = t_.x; n1 = t_.y; }
-#else
         wave_sum20_banks(z, n0, n1);
-#endif
         done |= 1ull << j;
         if (slot20 >= 0) acc[20 * j + slot20] = from_n1 ? n1 : n0;
     }

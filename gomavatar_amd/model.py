@@ -199,10 +199,13 @@ class _ShadeUnderMesh(torch.autograd.Function):
     The workspace (block counts, gather partials, the ROW COUNT, a counter) is allocated per forward call and saved for that call's backward:
     a second forward before the first backward (gradient accumulation over frames, a second Model, a render in between, another stream)
     must not overwrite the row count the first backward reads."""
-    # GOM_MLP_MATRIX_CORES=1: the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes).  Measured: forward 49 -> 22 us,
-    # backward 63 -> 37 us (+ 8 us of weight packing) per frame, and the shading moves by 6e-6 relative (three chained layers of dropped lo x lo
-    # terms) where the fp32 VALU layers are exact fp32: 45 us of a 3.3 ms iteration is not worth the digit -- opt-in.
-    matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "0") != "0"
+    # The layers on the bf16 matrix cores at fp32 grade (csrc/mlp_mc.hip: every operand as hi / lo bf16 planes, three MFMA passes per product, fp32
+    # accumulation: "bf16x3", as the LPIPS trunk).  Measured: forward 49 -> 22 us, backward 63 -> 37 us (+ 8 us of weight packing) per frame; the shading
+    # moves by 6e-6 relative against the fp32 VALU layers (three chained layers without the lo x lo terms), gradients by 1e-5 .. 8e-4 of their norm on
+    # untrained layers.  DEFAULT since round 6: every training-parity test holds its bounds unchanged with it (teacher-forced gradients of
+    # test_gpu_train_loop.py, the reference-recorded goldens of test_gpu_train_golden.py, the M-body step with LPIPS against the float64 oracle:
+    # 24 tests, run with the switch on and off).  GOM_MLP_MATRIX_CORES=0: the fp32 VALU layers (csrc/mlp.hip).
+    matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "1") != "0"
 
     @staticmethod
     def forward(ctx, flat, L, W1, b1, W2, b2, W3, b3, W4, b4):

@@ -3,8 +3,8 @@
  * nor exports them, and include/gom_hip.h -- the product ABI -- does not declare them.
  *   - gom_state_set_frame_optimizer: the Adam launch as the last launch of the frame step's recorded graph (measured slower than a plain
  *     launch behind the graph: 13.96 k against 14.09 k frames/s);
- *   - GOM_OPT_BWD_MODE 2: the (sub-range, 4 x 4 block) render backward, one item per DPP row (csrc/seg_bwd_blk.hpp: 200 us against 152);
- *   - GOM_OPT_BWD_MODE 3: the records render backward (csrc/rec_bwd.hpp + the REC = true instantiations of k_seg_T / k_seg_fwd): the forward leaves
+ *   - GOM_OPT_BWD_MODE 2: the (sub-range, 4 x 4 block) render backward, one item per DPP row (csrc/lab/seg_bwd_blk.hpp: 200 us against 152);
+ *   - GOM_OPT_BWD_MODE 3: the records render backward (csrc/lab/rec_bwd.hpp + the REC = true instantiations of k_seg_T / k_seg_fwd): the forward leaves
  *     one record per blending (pixel, entry) pair, the backward walks a lane per entry over its records instead of replaying the list (set it
  *     BEFORE the forward; 298 us + 55 us of forward overhead against the replay's 153: profiles/r04_records_backward.txt).  Its record buffers
  *     (24 bytes x 8 per unit of pair capacity) are allocated for a state in that mode only. */

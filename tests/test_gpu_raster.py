@@ -562,12 +562,12 @@ def test_backward_task_shapes_agree(seg_shift):
             assert np.quantile(err, 0.999) <= 2e-4 * scale and np.median(err) <= 1e-6 * scale, (mode, name, np.quantile(err, 0.999), np.median(err), scale)
     for a, b in zip(got[0], got[1]):
         np.testing.assert_array_equal(a, b)
-    # mode 2 -- (sub-range, 4x4 block) items, one per DPP row (csrc/seg_bwd_blk.hpp) -- sums a Gaussian's pixels block by block instead of
+    # mode 2 -- (sub-range, 4x4 block) items, one per DPP row (csrc/lab/seg_bwd_blk.hpp) -- sums a Gaussian's pixels block by block instead of
     # quadrant by quadrant: fp32 round-off away from the other two (both are held to the fp64 oracle above), bitwise equal to itself
     for a, b, c in zip(got[0], got[2], got[3]):
         np.testing.assert_array_equal(b, c)
         assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
-    # mode 3 -- a lane per (pixel, entry) record the forward left (csrc/rec_bwd.hpp): the suffix colour comes from a difference of the piece's
+    # mode 3 -- a lane per (pixel, entry) record the forward left (csrc/lab/rec_bwd.hpp): the suffix colour comes from a difference of the piece's
     # totals instead of the replay's recurrence: round-off away from the replay kernels, bitwise equal to itself (one summation order per entry)
     for a, b, c in zip(got[0], got[4], got[5]):
         np.testing.assert_array_equal(b, c)
