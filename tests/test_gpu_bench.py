@@ -35,6 +35,14 @@ def test_bench_line_contract_single_gpu():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
     assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # round 6: the bound that holds is named (VALU issue), the HBM figures stay SURVEY 8(d)'s; the timed step is two concurrent 4-frame launch
+    # sequences (gom_split_forward_backward), the roofline describes the one-sequence 8-frame launch and carries the timed configuration's own launches
+    assert r["bound"] == "valu_issue" and "hbm" in r["bound_of_the_figures_below"]
+    assert r["issue"] is None or (r["issue"]["issue_floor_us"] > 0 and 0 < r["issue"]["frac_of_issue_floor"] <= 1.0)
+    assert d["config"]["launch_sequences_per_step"] == 2 and "2 concurrent launch sequences of 4 frames" in d["config"]["workload"]
+    tc = r["timed_configuration"]
+    assert tc["split"] == 2 and tc["frames_per_launch"] == 4 and tc["avg_us_per_launch_alone"] > 0 and 0 < tc["frac_alone"] < 1
+    assert tc["sum_of_kernels_us_alone"] > 1e3 * tc["ms_per_step_timed"]          # the launches overlap in the timed loop: that is the point
     assert r["traffic_source"] is None or (r["traffic_source"]["measured_in_this_run"] is False and len(r["traffic_source"]["sha256_16"]) == 16)
     assert d["config"]["optimizer"]
     c = d["cpu_baseline"]
