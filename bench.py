@@ -47,7 +47,7 @@ N_SIMD, SCLK_HZ = 256 * 4, 2.4e9     # 256 CUs x 4 SIMDs at the 2.4 GHz engine c
 ISSUE_TICKS_PER_VALU = 3.8           # mean issue ticks per wave-level VALU instruction of the segment kernels' mix at 4 waves / SIMD (profiles/r03_valu_rate.txt)
 MODEL_PARAMS_M = 951_023  # reference model at 55 104 Gaussians: all-reduce payload
 MIN_TIMED_S = 0.25
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 ADAM_LR = 1e-9   # the reference's Adam arithmetic and traffic at a rate that leaves the synthetic workload the parity tests check unchanged over 10^4 timed steps
 
 
