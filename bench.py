@@ -1115,6 +1115,16 @@ def main():
                 both = [(r_["iter"], hip[r_["iter"]], r_["psnr"]) for r_ in orc["log"] if r_["iter"] in hip]
                 row["vs_oracle_trained"] = {"iterations_compared": len(both), "max_abs_psnr_difference_db": round(max(abs(a - b) for _, a, b in both), 3) if both else None,
                                             "mean_abs_psnr_difference_db": round(sum(abs(a - b) for _, a, b in both) / max(len(both), 1), 4), "source": osrc}
+            # ... and the oracle CONTINUING this run from its saved state across the subdivision (round 6: scripts/train_curve_oracle.py --from-state)
+            orc2, osrc2 = read_profile_json("train_curve_oracle_from_hip_state")
+            if orc2:
+                hip = {r_["iter"]: r_ for r_ in curve["log"]}
+                both = [(r_["iter"], hip[r_["iter"]]["psnr"], r_["psnr"], hip[r_["iter"]]["faces"]) for r_ in orc2["log"] if r_["iter"] in hip and hip[r_["iter"]].get("faces") == r_.get("faces")]
+                after = [b for b in both if b[0] > orc2.get("subdivide_at", 1000)]
+                stat = lambda rows: {"iterations_compared": len(rows), "max_abs_psnr_difference_db": round(max(abs(a - b) for _, a, b, _ in rows), 3) if rows else None,
+                                     "mean_abs_psnr_difference_db": round(sum(abs(a - b) for _, a, b, _ in rows) / max(len(rows), 1), 4)}
+                row["vs_oracle_continuing_from_hip_state"] = {"from_iterations_done": orc2.get("start_iterations_done"), "subdivide_at": orc2.get("subdivide_at"), **stat(both),
+                                                              "after_the_subdivision": stat(after), "source": osrc2}
             row["source"] = src
             out["modes"]["cfg2_train_curve"] = row
 

@@ -22,9 +22,13 @@ from gomavatar_amd.optim import GomAdam
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000); ap.add_argument("--subdivide-at", type=int, default=1000)
 ap.add_argument("--dense", type=int, default=200, help="log every iteration up to here (the span the oracle-trained curve covers)")
-ap.add_argument("--every", type=int, default=50); ap.add_argument("--tag", default="r05"); ap.add_argument("--no-lpips", action="store_true")
+ap.add_argument("--every", type=int, default=50); ap.add_argument("--tag", default="r06"); ap.add_argument("--no-lpips", action="store_true")
 ap.add_argument("--precision", default="bf16x3"); ap.add_argument("--out", default=None)
+ap.add_argument("--save-state-at", type=int, default=-1, help="after this many iterations: parameters + Adam state -> --state-out (the start of scripts/train_curve_oracle.py --from-state)")
+ap.add_argument("--state-out", default=None)
+ap.add_argument("--dense-range", default="", help="A:B -- also log every iteration with A < n_iters <= B (the span an oracle run from a saved state covers)")
 a = ap.parse_args()
+dense_lo, dense_hi = (int(x) for x in a.dense_range.split(":")) if a.dense_range else (0, 0)
 dev = "cuda"
 mcfg, tcfg = zju_cfg(C.IMG, lr_decay_steps=C.LR_DECAY_STEPS)
 if a.no_lpips:
@@ -85,10 +89,22 @@ for it in range(a.iters):
         seg_name, t_seg, n_seg = "after_subdivision", None, 0
     if t_seg is None and (it >= 20 if seg_name == "before_subdivision" else it >= a.subdivide_at + 20):   # steady state: lazy loading, allocator growth behind us
         torch.cuda.synchronize(); t_seg, n_seg = time.perf_counter(), 0
+    if it == a.save_state_at:                                     # the state BEFORE iteration it + 1: what the CPU oracle continues from
+        import numpy as np
+        torch.cuda.synchronize()
+        named = [("vertices", student.vertices), ("so3", student.so3), ("scale", student.scale), ("appearance", student.appearance)]
+        named += [(f"shadow{i}", p_) for i, p_ in enumerate(l_ for lyr in student.shadow_module.block_mlps if isinstance(lyr, torch.nn.Linear) for l_ in (lyr.weight, lyr.bias))]
+        opt._sync_steps() if hasattr(opt, "_sync_steps") else None
+        st = {"iterations_done": np.int64(it)}
+        for nm, p_ in named:
+            s_ = opt.state[p_]
+            st[nm] = p_.detach().cpu().numpy(); st[nm + ".exp_avg"] = s_["exp_avg"].cpu().numpy(); st[nm + ".exp_avg_sq"] = s_["exp_avg_sq"].cpu().numpy()
+            st[nm + ".step"] = np.float64(float(s_["step"]))
+        np.savez_compressed(a.state_out or os.path.join(ROOT, "profiles", f"{a.tag}_hip_state_iter{it}.npz"), **st)
     fr = frames[it % C.N_VIEWS]
     loss, items, rgb, mask = tu.train_iteration(student, opt, fr, tcfg, n_iters, lpips_func=lp)
     n_seg += 1
-    if n_iters <= a.dense or n_iters % a.every == 0 or n_iters == a.iters:
+    if n_iters <= a.dense or n_iters % a.every == 0 or n_iters == a.iters or dense_lo < n_iters <= dense_hi:
         torch.cuda.synchronize()                                   # (no host read is left in an iteration: the queue the host ran ahead by is TRAINING time, not logging)
         t_log = time.perf_counter()
         row = {"iter": n_iters, "total": float(loss), "psnr": round(psnr8(rgb.detach()[0], fr["target_rgbs"][0]), 4), "faces": int(student.faces.shape[0]),
