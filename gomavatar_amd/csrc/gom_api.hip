@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "gom_internal.h"
+#include <atomic>
 #include <unistd.h>
 #ifdef GOM_LAB
 #include "gom_hip_lab.h"
@@ -82,6 +83,8 @@ extern "C" GomState *gom_state_create(void) {
         delete s;
         return nullptr;
     }
+    static std::atomic<uint64_t> next_uid{1};
+    s->uid = next_uid.fetch_add(1);
     return s;
 }
 
@@ -645,8 +648,12 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
     lead->graphClock++;
     for (size_t i = 0; i < lead->splitGraphs.size();) {   // recordings made before a buffer of one of their states moved
         GomSplitGraphEntry &g = lead->splitGraphs[i];
+        // (only the states of THIS call are known to be alive: a recording that names other states -- possibly destroyed since -- is left alone
+        //  here, never matched below, and ages out of the 16 slots)
         bool stale = false;
-        for (int k = 0; k < g.K; k++) stale = stale || g.alloc_gen[k] != g.states[k]->allocGen;
+        for (int k = 0; k < g.K; k++)
+            for (int c = 0; c < K; c++)
+                if (g.states[k] == states[c]) stale = stale || g.uids[k] != states[c]->uid || g.alloc_gen[k] != states[c]->allocGen;
         if (stale) {
             (void)hipGraphExecDestroy(g.exec);
             (void)hipGraphDestroy(g.graph);
@@ -668,7 +675,8 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
         if (g.K != K || g.flags != 0u) continue;
         bool same = true;
         for (int k = 0; k < K && same; k++)
-            same = g.states[k] == states[k] && g.Bs[k] == Bs[k] && g.cams[k] == cams_device[k] && memcmp(&g.keys[k], &frames[k], sizeof(GomFrame)) == 0;
+            same = g.states[k] == states[k] && g.uids[k] == states[k]->uid && g.alloc_gen[k] == states[k]->allocGen && g.Bs[k] == Bs[k] && g.cams[k] == cams_device[k] &&
+                   memcmp(&g.keys[k], &frames[k], sizeof(GomFrame)) == 0;
         if (!same) continue;
         g.last_use = lead->graphClock;
         GOM_HIP_CHECK(hipGraphLaunch(g.exec, st));
@@ -678,7 +686,7 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
     GomSplitGraphEntry e{};
     e.K = K; e.flags = 0u; e.last_use = lead->graphClock;
     for (int k = 0; k < K; k++) {
-        e.states[k] = states[k]; e.Bs[k] = Bs[k]; e.cams[k] = cams_device[k]; e.alloc_gen[k] = states[k]->allocGen;
+        e.states[k] = states[k]; e.uids[k] = states[k]->uid; e.Bs[k] = Bs[k]; e.cams[k] = cams_device[k]; e.alloc_gen[k] = states[k]->allocGen;
         memcpy(&e.keys[k], &frames[k], sizeof(GomFrame));
     }
     GOM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));

@@ -103,6 +103,7 @@ struct GomSplitGraphEntry {
     int K;
     uint32_t flags;
     GomState *states[GOM_SPLIT_MAX];
+    uint64_t uids[GOM_SPLIT_MAX];      // GomState::uid of the branch states at capture: a destroyed state's address may be handed out again
     GomFrame keys[GOM_SPLIT_MAX];
     int Bs[GOM_SPLIT_MAX];
     const GomCamera *cams[GOM_SPLIT_MAX];
@@ -115,6 +116,7 @@ struct GomSplitGraphEntry {
 
 struct GomState {
     int device = 0;
+    uint64_t uid = 0;                 // unique per created state (gom_state_create): what a recording made with OTHER states remembers them by
     // capacities
     int capP = 0, capTiles = 0, capPix = 0;
     int64_t capPairs = 0;

@@ -388,6 +388,25 @@ def test_split_step_equals_one_launch_sequence_bitwise(B, K, img, graph):
         assert torch.equal(res[0][4][k], res[1][4][k]), k
         assert float(res[0][4][k].abs().max()) > 0
     assert one.state.poll()[0] == split.state.poll()[0]      # the same number of (tile, Gaussian) pairs in all
+    # a branch state replaced (the old one destroyed, its address possibly handed out again): the lead's recording that names it is neither replayed nor
+    # dereferenced (recordings remember their states by uid), the step is recorded anew and gives the same bits
+    if graph:
+        from gomavatar_amd.rasterizer import RasterState
+        old_state = split.parts[-1].state
+        split.parts[-1].state = RasterState()
+        if B // K == 1:
+            split.parts[-1].state.set_option(_lib.OPT_SEG_SHIFT, 8)
+        split.state.states[-1] = split.parts[-1].state
+        del old_state
+        for v in split.grads.values():
+            v.zero_()
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                split.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b, graph=True)
+        stream.synchronize()
+        assert torch.equal(split.image, res[0][0])
+        for k in res[0][4]:
+            assert torch.equal(split.grads[k], res[0][4][k]), k
     # refusals: loud, not silent
     with pytest.raises(NotImplementedError):
         split.forward_backward(params, fr_b, gt_rgb, gt_mask, bg_b, backward=False)
