@@ -585,3 +585,51 @@ def test_zz_flip_census(capsys):
               f" beyond 1e-4 or other n_contrib: {dev}, of which {dev_ill} bounded by their conditioning, the rest on flagged pixels; largest deviation of a solid pixel {max(r[6] for r in FLIP_LOG):.1e};"
               f" beyond 1e-4 against the oracle in the HIP formulation: {sum(h[1] for h in hip)} (reference formulation, same comparisons: {sum(h[0] for h in hip)})")
     assert dev <= frag + dev_ill
+
+
+def gaussians_under_flagged_pixels(f, flagged, n_contrib_other=None):
+    """Gaussians that reach (alpha >= half the 1/255 threshold, within the list positions either side blended) a pixel of the boolean map `flagged`:
+    the ones whose gradients a threshold flip or an ill-conditioned exponent at that pixel can move."""
+    H, W = flagged.shape
+    gx = (W + 15) // 16
+    bad = np.zeros(f["xy"].shape[0], bool)
+    for y_, x_ in zip(*np.nonzero(flagged)):
+        t_ = (int(y_) // 16) * gx + int(x_) // 16
+        lst = f["point_list"][f["ranges"][t_, 0]:f["ranges"][t_, 1]].astype(np.int64)
+        last = int(f["n_contrib"][y_, x_]) if n_contrib_other is None else int(max(f["n_contrib"][y_, x_], n_contrib_other[y_, x_]))
+        lst = lst[:last + 2]
+        dx, dy = f["xy"][lst, 0].astype(np.float64) - x_, f["xy"][lst, 1].astype(np.float64) - y_
+        co = f["conic_opacity"][lst].astype(np.float64)
+        power = -0.5 * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy
+        bad[lst[(power <= 1e-6) & (co[:, 3] * np.exp(np.minimum(power, 0.0)) >= 0.5 / 255.0)]] = True
+    return bad
+
+
+@pytest.mark.parametrize("seed,P,shape,opacity", [(51, 1500, (96, 112), (0.3, 1.0)), (52, 4000, (128, 128), (0.05, 0.6)), (53, 800, (64, 64), 1.0)])
+def test_raster_boundary_gradients_are_round_off_away_from_flagged_pixels(seed, P, shape, opacity):
+    """The render backward's OWN outputs -- dL/dcolors, dL/dopacity, dL/dmeans2D: plain sums over a Gaussian's pixels, in front of the ill-conditioned
+    conic -> covariance step -- against the float64 oracle, FLIP-AWARE (round-5 review): the Gaussians that blend into a pixel whose branch margin is below
+    MARGIN, whose round-off estimate is above 2e-5, or that did deviate are set aside; every other element agrees to 1e-5 of the tensor's largest gradient
+    (the review's bound; measured below) -- round-off, with ZERO exceptions.  The gradients behind the covariance step (means3D, cov6) keep the quantile bounds of
+    test_backward_matches_oracle: their tail is conditioning, which the fp32 build of the oracle shares (tests/test_gpu_metric_workload.py)."""
+    from gpu_util import hip_forward, export_state
+    H, W = shape
+    cam, means, cov6, colors, op = small_scene(seed=seed, P=P, H=H, W=W, opacity=opacity, scale=0.05, C=4)
+    cam["bg"] = np.array([0.2, 0.5, 0.1, 0.4], np.float32)
+    wimg = np.random.default_rng(seed).normal(size=(4, H, W)).astype(np.float32)
+    out, radii, st, t = hip_forward(cam, means, cov6, colors, op, requires_grad=True, means2D=True)
+    (out * torch.from_numpy(wimg).cuda()).sum().backward()
+    e = export_state(st, P, H, W)
+    f32 = orast.forward(cam, means, cov6, colors, op, margin=True)
+    f64 = orast.forward(cam, means, cov6, colors, op, dtype=np.float64, margin=True)
+    g = orast.backward(f64, wimg.astype(np.float64))
+    img = out.detach().cpu().numpy()
+    flagged = (f32["margin"] < MARGIN) | (f64["margin"] < MARGIN) | (f32["roundoff"] > 2e-5) | (np.abs(img - f64["color"]).max(axis=0) > IMG_TOL) | (e["n_contrib"] != f64["n_contrib"])
+    aside = gaussians_under_flagged_pixels(f64, flagged, e["n_contrib"])
+    assert flagged.mean() <= 5e-2 and aside.mean() <= 0.5, (float(flagged.mean()), float(aside.mean()))      # (not vacuous: most Gaussians are held to the tight bound)
+    for name, got, ref in (("colors", t[2].grad, g["dL_dcolors"]), ("opacity", t[3].grad, g["dL_dopacity"]), ("means2D", t[4].grad[:, :2], g["dL_dmeans2D"])):
+        got = got.cpu().numpy().astype(np.float64).reshape(ref.shape)
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref)[~aside]
+        print(f"[boundary gradients, seed {seed}] d{name}: max |err| / max|g| away from the flagged pixels' Gaussians {float(err.max()) / scale:.1e} ({int(aside.sum())} of {P} set aside, {int(flagged.sum())} pixels flagged)")
+        assert scale > 0 and err.size > 0.5 * P and float(err.max()) <= 1e-5 * scale, (name, float(err.max()) / scale, int(aside.sum()), int(flagged.sum()))
