@@ -241,19 +241,23 @@ class SplitRenderStep:
 
     def __init__(self, faces: torch.Tensor, n_verts: int, img_hw, lbs_weights: torch.Tensor, sigma: float = 1e-3, c_rgb: float = 1.0,
                  c_mask: float = 5.0, device: Optional[torch.device] = None, batch: int = 8, split: int = 2):
-        assert split >= 1 and batch % split == 0 and batch // split >= 1, "batch must be a multiple of split"
-        self.B, self.K, self.b = int(batch), int(split), int(batch) // int(split)
-        self.parts = [RenderStep(faces, n_verts, img_hw, lbs_weights, sigma, c_rgb, c_mask, device, batch=self.b) for _ in range(self.K)]
+        # split: the number of equal sequences, or the list of their sizes (e.g. (3, 3, 2))
+        sizes = [int(batch) // int(split)] * int(split) if isinstance(split, int) else [int(x) for x in split]
+        assert len(sizes) >= 1 and all(x >= 1 for x in sizes) and sum(sizes) == int(batch), "the sequences' sizes must add up to the batch"
+        self.B, self.K, self.sizes = int(batch), len(sizes), sizes
+        self.offs = [sum(sizes[:k]) for k in range(self.K + 1)]
+        self.b = sizes[0]
+        self.parts = [RenderStep(faces, n_verts, img_hw, lbs_weights, sigma, c_rgb, c_mask, device, batch=x) for x in sizes]
         p0 = self.parts[0]
         self.lib, self.device, self.topo, self.N, self.F, self.H, self.W = p0.lib, p0.device, p0.topo, p0.N, p0.F, p0.H, p0.W
         for name in self._PER_FRAME:            # whole-batch tensors; every branch's tensor becomes a view of its frames
             t0 = getattr(p0, name)
-            per = t0.shape if self.b == 1 and name != "cams_dev" else t0.shape[1:]
+            per = t0.shape if sizes[0] == 1 and name != "cams_dev" else t0.shape[1:]
             whole = torch.zeros((self.B,) + tuple(per), dtype=t0.dtype, device=t0.device)
             if name in ("feat", "opacity"):
                 whole.fill_(1.0)
             for k, p in enumerate(self.parts):
-                setattr(p, name, whole[k * self.b:(k + 1) * self.b].view(getattr(p, name).shape))
+                setattr(p, name, whole[self.offs[k]:self.offs[k + 1]].view(getattr(p, name).shape))
             setattr(self, "_whole_" + name if name == "cams_dev" else name, whole)
         self.grads = p0.grads
         for p in self.parts[1:]:
@@ -271,12 +275,12 @@ class SplitRenderStep:
         assert t.shape == self._whole_cams_dev.shape and t.dtype == torch.uint8
         self._whole_cams_dev = t
         for k, p in enumerate(self.parts):
-            p.cams_dev = t[k * self.b:(k + 1) * self.b]
+            p.cams_dev = t[self.offs[k]:self.offs[k + 1]]
 
     def set_cameras(self, Ks, Es, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
         assert len(Ks) == self.B and len(Es) == self.B
         for k, p in enumerate(self.parts):
-            p.set_cameras(Ks[k * self.b:(k + 1) * self.b], Es[k * self.b:(k + 1) * self.b], bg4)
+            p.set_cameras(Ks[self.offs[k]:self.offs[k + 1]], Es[self.offs[k]:self.offs[k + 1]], bg4)
         self.cam = self.parts[0].cam
 
     def set_camera(self, K, E, bg4=(0.0, 0.0, 0.0, 0.0)) -> None:
@@ -286,18 +290,18 @@ class SplitRenderStep:
         """As RenderStep.forward_backward with a leading dimension `batch` on every per-frame tensor; whole steps only."""
         if not backward or image_grad_hook is not None:
             raise NotImplementedError("SplitRenderStep runs whole steps (forward + backward, no hook): use RenderStep for split calls")
-        K, b = self.K, self.b
+        K = self.K
         frames = (_lib.GomFrame * K)()
         for k, p in enumerate(self.parts):
-            sl = slice(k * b, (k + 1) * b)
+            sl = slice(self.offs[k], self.offs[k + 1])
             if self.cam is not None:
                 p.cam = self.cam                      # (a batched call reads only H and W from it: the per-frame cameras are the device array)
-            cut = (lambda t: t[sl]) if b > 1 else (lambda t: t[k * b])
+            cut = (lambda t, sl=sl: t[sl]) if self.sizes[k] > 1 else (lambda t, i=self.offs[k]: t[i])
             f = p._fill_frame(params, {n: cut(frame[n]) for n in ("cnl_gtfms", "dst_Rs", "dst_Ts")}, cut(target_rgb), cut(target_mask), cut(bgcolor))
             ctypes.memmove(ctypes.byref(frames[k]), ctypes.byref(f), ctypes.sizeof(_lib.GomFrame))
         states = (ctypes.c_void_p * K)(*[p.state.handle for p in self.parts])
         cams = (ctypes.c_void_p * K)(*[_lib.ptr(p.cams_dev) for p in self.parts])
-        Bs = (ctypes.c_int32 * K)(*([b] * K))
+        Bs = (ctypes.c_int32 * K)(*self.sizes)
         _lib.check(self.lib.gom_split_forward_backward(states, frames, K, Bs, cams, _lib.GOM_FRAME_USE_GRAPH if graph else 0, _lib.stream_ptr()))
 
     def losses(self):

@@ -56,7 +56,7 @@ class MetricWorkload:
 
     def step(self, batch: int = 1, split: int = 1):
         """split > 1: the step's `batch` frames as `split` concurrent launch sequences (pipeline.SplitRenderStep: same bits, tails filled)."""
-        if split > 1:
+        if not isinstance(split, int) or split > 1:
             from .pipeline import SplitRenderStep
             return SplitRenderStep(self.faces, self.N, (self.img, self.img), self.w25, device=self.device, batch=batch, split=split)
         return RenderStep(self.faces, self.N, (self.img, self.img), self.w25, device=self.device, batch=batch)

@@ -43,7 +43,7 @@ def rate(step, n=1500, warm=60):
 
 # bitwise: gradients, images, losses, radii of the split step against the single launch sequence (no Adam: same parameters)
 ref = None
-for K in (1, 2, 4):
+for K in (1, 2, 4, (3, 3, 2), (5, 3), (2, 2, 2, 2)):
     step, st, fp = make(K, adam=False)
     for _ in range(3): step()
     torch.cuda.synchronize()
@@ -52,7 +52,7 @@ for K in (1, 2, 4):
         ref = got
     else:
         print(f"K={K}: bitwise equal to one launch sequence:", [bool(torch.equal(a, b)) for a, b in zip(ref, got)], flush=True)
-for K, pct in ((1, 0), (2, 0), (2, 75), (2, 60), (2, 50), (2, 40), (4, 50), (4, 30), (1, 0), (2, 0), (2, 60), (2, 50)):
+for K, pct in ((1, 0), (2, 0), ((3, 3, 2), 0), ((5, 3), 0), ((6, 2), 0), ((4, 2, 2), 0), (1, 0), (2, 0), ((3, 3, 2), 0), ((5, 3), 0)):
     step, st, fp = make(K, pct=pct)
     r = rate(step)
     print(f"K={K} grid {pct or 100} %: {r:.1f} steps/s = {r * B / 1e3:.2f} k frames/s ({1e3 / r:.4f} ms per 8-frame step)", flush=True)

@@ -353,10 +353,10 @@ def test_recorded_step_survives_a_larger_frame_on_the_same_state():
         assert torch.equal(again[2][k], ref[2][k]), k
 
 
-@pytest.mark.parametrize("B,K,img,graph", [(4, 2, 96, True), (4, 4, 96, False), (6, 2, 128, True), (8, 2, 256, True)])
+@pytest.mark.parametrize("B,K,img,graph", [(4, 2, 96, True), (4, 4, 96, False), (6, 2, 128, True), (8, 2, 256, True), (8, (3, 3, 2), 128, True), (5, (4, 1), 96, False)])
 def test_split_step_equals_one_launch_sequence_bitwise(B, K, img, graph):
     """pipeline.SplitRenderStep / gom_split_forward_backward (ABI 11): ONE step of B frames as K CONCURRENT launch sequences of B / K frames,
-    each on its own state and stream between a fork and a join, closed by one frame sum over all B frames in frame order -- against
+    (K a tuple: sequences of those sizes) each on its own state and stream between a fork and a join, closed by one frame sum over all B frames in frame order -- against
     RenderStep(batch=B), the one launch sequence: images, loss partials, radii and all four gradients BITWISE equal (a frame's results do not
     depend on the launch it rides in; the sum adds the same slices in the same order).  (4, 4): one frame per branch -- the single-frame
     kernels with per-frame gradient slices.  graph: capture, then replays of the recorded fork / join."""
@@ -369,7 +369,7 @@ def test_split_step_equals_one_launch_sequence_bitwise(B, K, img, graph):
     from gomavatar_amd import _lib
     one = RenderStep(faces, N, (img, img), w25, batch=B)
     split = SplitRenderStep(faces, N, (img, img), w25, batch=B, split=K)
-    if B // K == 1:
+    if 1 in split.sizes:
         split.state.set_option(_lib.OPT_SEG_SHIFT, 8)     # (a one-frame branch would pick 128-entry segments: bitwise equality needs the batch's 256)
     stream = torch.cuda.Stream()
     stream.wait_stream(torch.cuda.current_stream())
@@ -394,7 +394,7 @@ def test_split_step_equals_one_launch_sequence_bitwise(B, K, img, graph):
         from gomavatar_amd.rasterizer import RasterState
         old_state = split.parts[-1].state
         split.parts[-1].state = RasterState()
-        if B // K == 1:
+        if 1 in split.sizes:
             split.parts[-1].state.set_option(_lib.OPT_SEG_SHIFT, 8)
         split.state.states[-1] = split.parts[-1].state
         del old_state
