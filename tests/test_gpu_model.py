@@ -157,7 +157,8 @@ def test_fused_shading_equals_the_torch_selection_around_the_mlp():
     another order: round-off).  With the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes per product) the
     shading agrees to 2e-5 (measured 6e-6: each operand keeps 16 mantissa bits) and the gradients to 2e-3 of their norm (measured 1e-5 .. 8e-4 over
     unseeded random layers: the vertex gradient through 32 x-frequency encodings of an untrained MLP is a sum with heavy cancellation); bitwise
-    repeatable run to run.  The default since round 6 (all training-parity tests hold their bounds with it); GOM_MLP_MATRIX_CORES=0 = the fp32 VALU layers."""
+    repeatable run to run IN THIS TEST.  Opt-in: GOM_MLP_MATRIX_CORES=1 (round 6 made it the default for half a day and found it not repeatable in every context:
+    the three-step training goldens and the 8-rank bitwise comparison turned intermittent -- model.py)."""
     from gomavatar_amd.model import _ShadeUnderMesh
     img = 128
     torch.manual_seed(11)                                                         # (the layers' default initialisation)
@@ -174,7 +175,7 @@ def test_fused_shading_equals_the_torch_selection_around_the_mlp():
             res.append((rgbs.detach().clone(), out["shadow"].detach().clone(),
                         [p.grad.detach().clone() for p in (m.vertices, m.so3, m.scale, m.appearance)] + [p.grad.detach().clone() for p in m.shadow_module.parameters()]))
     finally:
-        _ShadeUnderMesh.matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "1") != "0"
+        _ShadeUnderMesh.matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "0") != "0"
     assert float(res[0][1].min()) != float(res[0][1].max())                      # the shading really varies under the mesh
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
