@@ -631,13 +631,19 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
     if (total > GOM_SPLIT_MAX_FRAMES) { gom_set_error("gom_split_forward_backward: at most %d frames per step", GOM_SPLIT_MAX_FRAMES); return -1; }
     GomState *lead = states[0];
     hipStream_t st = (hipStream_t)stream;
-    if (!lead->splitFork) {
+    if (!lead->splitFork) {   // the branches' streams and events live on the LEAD state's device (a process may drive several devices)
+        int cur = lead->device;
+        (void)hipGetDevice(&cur);
+        if (cur != lead->device) GOM_HIP_CHECK(hipSetDevice(lead->device));
         GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitFork, hipEventDisableTiming));
         for (int k = 1; k < GOM_SPLIT_MAX; k++) {
             GOM_HIP_CHECK(hipStreamCreateWithFlags(&lead->splitStreams[k], hipStreamNonBlocking));
             GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitJoin[k], hipEventDisableTiming));
         }
+        if (cur != lead->device) GOM_HIP_CHECK(hipSetDevice(cur));
     }
+    for (int k = 1; k < K; k++)
+        if (states[k]->device != lead->device) { gom_set_error("gom_split_forward_backward: every branch state must live on the lead state's device"); return -1; }
     for (int k = 0; k < K; k++) {   // every allocation happens here, outside any capture
         if (int rc = ensure_capacity(states[k], frames[k].F, frames[k].H, frames[k].W, Bs[k])) return rc;
         if (int rc = ensure_batch_grads(states[k], Bs[k], frames[k].N, frames[k].F, true)) return rc;
