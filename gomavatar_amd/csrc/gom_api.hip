@@ -631,12 +631,13 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
     if (total > GOM_SPLIT_MAX_FRAMES) { gom_set_error("gom_split_forward_backward: at most %d frames per step", GOM_SPLIT_MAX_FRAMES); return -1; }
     GomState *lead = states[0];
     hipStream_t st = (hipStream_t)stream;
-    if (!lead->splitFork) {   // the branches' streams and events live on the LEAD state's device (a process may drive several devices)
+    if (!lead->splitFork || (K > 1 && !lead->splitStreams[K - 1])) {   // the branches' streams and events live on the LEAD state's device (a process may drive several devices)
         int cur = lead->device;
         (void)hipGetDevice(&cur);
         if (cur != lead->device) GOM_HIP_CHECK(hipSetDevice(lead->device));
-        GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitFork, hipEventDisableTiming));
-        for (int k = 1; k < GOM_SPLIT_MAX; k++) {
+        if (!lead->splitFork) GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitFork, hipEventDisableTiming));
+        for (int k = 1; k < K; k++) {   // only as many as this call's K needs: every live stream costs the process's OTHER launches a little (bench.py's eager Model iteration: 394 -> 367 it/s with three of them alive)
+            if (lead->splitStreams[k]) continue;
             // (measured, round 6: a side stream created with hipStreamCreateWithPriority -- highest OR lowest -- makes the step 0.79 ms instead of 0.51:
             //  the two sequences no longer overlap.  Default priority on both.)
             GOM_HIP_CHECK(hipStreamCreateWithFlags(&lead->splitStreams[k], hipStreamNonBlocking));

@@ -234,7 +234,9 @@ class SplitRenderStep:
     one frame sum over all `batch` frames in frame order.  Why: the resident-grid segment kernels leave the chip idle behind their last
     workgroups at the end of each of a step's ~12 launches; two sequences side by side fill each other's tails.  Same interface and the same
     bits as RenderStep(batch=batch): `image`, `radii`, `loss_partials`, `d_image`, `xyz`, `cov6`, `v_obs` are whole-batch tensors whose
-    slices the branches write; `grads` is shared by the branches (the frame sum writes it)."""
+    slices the branches write; `grads` is shared by the branches (the frame sum writes it).
+    A side note measured in bench.py: the side branch's stream is the library's own and lives as long as the lead state; a live extra stream costs the process's
+    OTHER launches ~1 us each (an eager, launch-bound torch loop next to it: 394 -> 367 it/s) -- drop the object when the split steps are over."""
 
     _PER_FRAME = ("RT", "fk_save", "v_obs", "xyz", "cov6", "feat", "opacity", "image", "radii", "loss_partials", "d_image", "d_xyz", "d_cov6", "d_feat",
                   "d_opacity", "d_corner", "cams_dev")
