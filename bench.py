@@ -1036,9 +1036,9 @@ def main():
         "roofline": roofline,
     }
 
-    # The headline's runners go before the other operating points are measured: their states hold streams of the library's own (the split step's side
-    # branch), and every live stream costs the process's OTHER launches a little -- the eager `Model` iteration below read 367 it/s with them alive
-    # against 394 without (same box, same process order otherwise).  The closing PSNR check builds a fresh step.
+    # The headline's runners go before the other operating points are measured: with them alive (three states, their recorded graphs, the library's side streams)
+    # the eager `Model` iteration below read 367 it/s against 394 without (same box, A/B; mechanism not pinned down: LABBOOK R6.5).  The closing PSNR check
+    # builds a fresh step.
     import gc
     main_run.slots, alone_run = [], None
     gc.collect(); torch.cuda.empty_cache()

@@ -636,7 +636,7 @@ extern "C" int gom_split_forward_backward(GomState *const *states, const GomFram
         (void)hipGetDevice(&cur);
         if (cur != lead->device) GOM_HIP_CHECK(hipSetDevice(lead->device));
         if (!lead->splitFork) GOM_HIP_CHECK(hipEventCreateWithFlags(&lead->splitFork, hipEventDisableTiming));
-        for (int k = 1; k < K; k++) {   // only as many as this call's K needs: every live stream costs the process's OTHER launches a little (bench.py's eager Model iteration: 394 -> 367 it/s with three of them alive)
+        for (int k = 1; k < K; k++) {   // only as many as this call's K needs
             if (lead->splitStreams[k]) continue;
             // (measured, round 6: a side stream created with hipStreamCreateWithPriority -- highest OR lowest -- makes the step 0.79 ms instead of 0.51:
             //  the two sequences no longer overlap.  Default priority on both.)

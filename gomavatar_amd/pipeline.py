@@ -235,8 +235,8 @@ class SplitRenderStep:
     workgroups at the end of each of a step's ~12 launches; two sequences side by side fill each other's tails.  Same interface and the same
     bits as RenderStep(batch=batch): `image`, `radii`, `loss_partials`, `d_image`, `xyz`, `cov6`, `v_obs` are whole-batch tensors whose
     slices the branches write; `grads` is shared by the branches (the frame sum writes it).
-    A side note measured in bench.py: the side branch's stream is the library's own and lives as long as the lead state; a live extra stream costs the process's
-    OTHER launches ~1 us each (an eager, launch-bound torch loop next to it: 394 -> 367 it/s) -- drop the object when the split steps are over."""
+    (bench.py releases its split runners before it measures eager torch loops: with the round's first version of the library -- three side streams per lead state -- such a loop
+    read 7 % slower next to a live split runner; not reproduced with the one stream a two-way split creates now.  LABBOOK R6.5.)"""
 
     _PER_FRAME = ("RT", "fk_save", "v_obs", "xyz", "cov6", "feat", "opacity", "image", "radii", "loss_partials", "d_image", "d_xyz", "d_cov6", "d_feat",
                   "d_opacity", "d_corner", "cams_dev")
