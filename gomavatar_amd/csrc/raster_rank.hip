@@ -204,7 +204,8 @@ int gom_launch_tile_rank(GomState *s, hipStream_t st) {
     // One frame: 16-wave workgroups.  A single frame's tile pass is the latency chain of its longest list (5 000 entries on a body: every work item of the tile rebuilds the
     // tile's whole bitmap), and four times the threads walk it in a quarter of the trips: 26.7 -> 16.1 us, 197 -> 186 us per frame (5.07 -> 5.37 k frames/s at B = 1; round 6).
     // A batched launch has items to spare and keeps 4-wave workgroups (8 frames: 256 / 512 / 1024 threads = 0.512 / 0.515 / 0.530 ms per step).
-    if (s->B == 1) {
+    static const bool wide_b1 = !(getenv("GOM_RANK_NT_B1") && atoi(getenv("GOM_RANK_NT_B1")) == 256);   // (development switch: 256 = the 4-wave workgroups for one frame too)
+    if (s->B == 1 && wide_b1) {
         hipLaunchKernelGGL((k_tile_rank<1024>), dim3(grid), dim3(1024), lds, st, s->gx, s->gy, nb, s->tile_base, s->seg_base, s->work_items, &s->status->n_work_items,
                            s->keys32, s->bucket_base, s->order, s->rec_g, s->point_list, s->seg_desc, s->ent_slot, s->ent_geo, s->status, (uint32_t)s->segShift, bm_words, s->seg_cost, s->rank_of);
         GOM_LAUNCH_CHECK();
