@@ -501,14 +501,29 @@ extern "C" int gom_peer_reduce_handle(GomPeerReduce *h, void *handle64) {
     if (!h || !handle64) { gom_set_error("gom_peer_reduce_handle: null argument"); return -1; }
     // (seen once in ~25 multi-process runs on one device: `invalid argument` while several processes export their regions at the same moment;
     //  the same call succeeds a few milliseconds later)
+    // Round 6: with EIGHT processes on one device the failure was seen to PERSIST for a region (six attempts over 1.3 s, one run in six): after three
+    // attempts the region is allocated anew (the old one is freed only behind the new allocation, so the new one lies elsewhere) -- nobody holds its
+    // address yet (peers map it from this handle, the caller asks for gom_peer_reduce_buffer after the exchange of the handles).
     hipError_t e = hipSuccess;
-    for (int attempt = 0; attempt < 6; attempt++) {
-        e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), h->local);
-        if (e == hipSuccess) return 0;
-        (void)hipGetLastError();
-        usleep(20000 << attempt);
+    for (int round = 0; round < 4; round++) {
+        for (int attempt = 0; attempt < 3; attempt++) {
+            e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle64), h->local);
+            if (e == hipSuccess) return 0;
+            (void)hipGetLastError();
+            usleep(20000 << attempt);
+        }
+        unsigned char *fresh = nullptr;
+        if (hipExtMallocWithFlags((void **)&fresh, h->bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(fresh, 0, h->bytes) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            if (fresh) (void)hipFree(fresh);
+            break;
+        }
+        (void)hipFree(h->local);
+        h->local = fresh;
+        h->peer[h->rank] = h->local;
     }
-    gom_set_error("hipIpcGetMemHandle failed after 6 attempts: %s", hipGetErrorString(e));
+    gom_set_error("hipIpcGetMemHandle failed after 12 attempts on 4 regions: %s", hipGetErrorString(e));
     return -2;
 }
 

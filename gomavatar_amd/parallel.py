@@ -64,37 +64,52 @@ class PeerAllReduce:
         self.numel = int(numel)
         torch.cuda.set_device(device)
         # Every step that can fail (allocation, IPC export, IPC mapping) is followed by an exchange of its outcome, so that ALL ranks
-        # raise together instead of one leaving the others inside a collective.
-        self._h, mine, err = None, None, None
-        try:
-            self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
-            if not self._h:
-                _lib.check(-1)
-            if timeout_s is not None:
-                _lib.check(self.lib.gom_peer_reduce_set_timeout(self._h, float(timeout_s)))
-            buf = (ctypes.c_ubyte * 64)()
-            _lib.check(self.lib.gom_peer_reduce_handle(self._h, buf))
-            mine = bytes(buf)
-        except Exception as e:
-            err = f"rank {self.rank}: {type(e).__name__}: {e}"
-        got = [None] * self.world
-        dist.all_gather_object(got, (err, mine), group=group)
-        self._raise_together([g[0] for g in got])
-        try:
-            blob = (ctypes.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(g[1] for g in got))
-            _lib.check(self.lib.gom_peer_reduce_connect(self._h, blob))
-            self.buffer = torch.as_tensor(_DevicePtr(self.lib.gom_peer_reduce_buffer(self._h), self.numel), device=torch.device(device))
-        except Exception as e:
-            err = f"rank {self.rank}: {type(e).__name__}: {e}"
-        got = [None] * self.world
-        dist.all_gather_object(got, err, group=group)   # (also the barrier: every rank has mapped every region before anyone raises a flag in it)
-        self._raise_together(got)
+        # raise together instead of one leaving the others inside a collective -- and so that all of them can TRY AGAIN together: with many
+        # processes on one device the IPC export fails now and then (`invalid argument`, one set-up in six with eight processes; round 6),
+        # a fresh region a moment later works.  Three collective attempts, then the error.
+        for attempt in range(3):
+            self._h, mine, err = None, None, None
+            try:
+                self._h = self.lib.gom_peer_reduce_create(self.rank, self.world, self.numel)
+                if not self._h:
+                    _lib.check(-1)
+                if timeout_s is not None:
+                    _lib.check(self.lib.gom_peer_reduce_set_timeout(self._h, float(timeout_s)))
+                buf = (ctypes.c_ubyte * 64)()
+                _lib.check(self.lib.gom_peer_reduce_handle(self._h, buf))
+                mine = bytes(buf)
+                if attempt == 0 and self.rank == self.world - 1 and os.environ.get("GOM_DEBUG_FAIL_FIRST_PEER_SETUP", "0") != "0":
+                    raise RuntimeError("injected failure of the first set-up attempt (GOM_DEBUG_FAIL_FIRST_PEER_SETUP: tests/test_gpu_peer_allreduce.py)")
+            except Exception as e:
+                err = f"rank {self.rank}: {type(e).__name__}: {e}"
+            got = [None] * self.world
+            dist.all_gather_object(got, (err, mine), group=group)
+            if self._failed_together([g[0] for g in got], last=attempt == 2):
+                continue
+            try:
+                blob = (ctypes.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(g[1] for g in got))
+                _lib.check(self.lib.gom_peer_reduce_connect(self._h, blob))
+                self.buffer = torch.as_tensor(_DevicePtr(self.lib.gom_peer_reduce_buffer(self._h), self.numel), device=torch.device(device))
+            except Exception as e:
+                err = f"rank {self.rank}: {type(e).__name__}: {e}"
+            got = [None] * self.world
+            dist.all_gather_object(got, err, group=group)   # (also the barrier: every rank has mapped every region before anyone raises a flag in it)
+            if self._failed_together(got, last=attempt == 2):
+                continue
+            break
 
-    def _raise_together(self, errs) -> None:
+    def _failed_together(self, errs, last: bool) -> bool:
+        """Every rank sees the same list: all of them release what they have and either try again (-> True) or raise (the last attempt)."""
         bad = [e for e in errs if e]
-        if bad:
-            self.close(collective=False)   # (nobody has raised a flag in anybody's region yet)
+        if not bad:
+            return False
+        self.buffer = None
+        self.close(collective=False)   # (nobody has raised a flag in anybody's region yet)
+        if last:
             raise RuntimeError("peer all-reduce unavailable (" + bad[0] + ")")
+        import time
+        time.sleep(0.2)
+        return True
 
     def poll(self) -> None:
         """Every step, before the exchange is enqueued: raises if a wait of an EARLIER exchange gave up (the kernel that times out writes a

@@ -145,13 +145,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n", [(2, 951023), (4, 951023), (8, 951023), (3, 951023), (2, 1030), (8, 1030)])
-def test_peer_allreduce_equals_rank_order_sum_bitwise(world, n, tmp_path, capsys):
+@pytest.mark.parametrize("world,n,inject", [(2, 951023, False), (4, 951023, False), (8, 951023, False), (3, 951023, False), (2, 1030, False), (8, 1030, False), (4, 1030, True)])
+def test_peer_allreduce_equals_rank_order_sum_bitwise(world, n, inject, tmp_path, capsys):
+    """inject: the LAST rank's first set-up attempt fails (GOM_DEBUG_FAIL_FIRST_PEER_SETUP) -- what `hipIpcGetMemHandle: invalid argument` did to one set-up in six with eight
+    processes on one device (round 6): every rank sees the failure in the exchange of outcomes, releases its region and all of them set up again together."""
     import json
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if inject:
+        env["GOM_DEBUG_FAIL_FIRST_PEER_SETUP"] = "1"
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env={**env, "RANK": str(r), "LOCAL_RANK": str(r)}, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
