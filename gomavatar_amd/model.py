@@ -200,10 +200,11 @@ class _ShadeUnderMesh(torch.autograd.Function):
     a second forward before the first backward (gradient accumulation over frames, a second Model, a render in between, another stream)
     must not overwrite the row count the first backward reads."""
     # GOM_MLP_MATRIX_CORES=1: the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes).  Measured: forward 49 -> 22 us,
-    # backward 63 -> 37 us (+ 8 us of weight packing) per frame (Model iteration 377 -> 383 it/s), the shading moves by 6e-6 relative.  OPT-IN, and round 6 says why
-    # twice: made the default for half a day, it turned two tests intermittent -- the three-step training goldens (step 2's rgb term 1.4e-3 off on some runs, within
-    # 1e-4 on others) and the 8-rank bitwise comparison (4.6e-7 once in three runs) -- i.e. the path is not repeatable run to run in every context, where the fp32
-    # VALU layers are bitwise (LABBOOK R6.6).  Until that is found it stays a development switch.
+    # backward 63 -> 37 us (+ 8 us of weight packing) per frame (Model iteration 377 -> 383 it/s), the shading moves by 6e-6 relative.  OPT-IN, for a reason that is
+    # not in this path's own results (bitwise repeatable, every buffer): while its waves are resident, a `v_pk_fma_f32 ... op_sel:[0,1,0]` of ANY OTHER kernel on the
+    # same SIMD -- another stream, another process on the device -- can lose a term in lanes 48..63 (LABBOOK R6.8, scripts/ubench/pkfma_beside_mfma.hip: MFMAs fed
+    # straight from LDS reads beside packed fp32; profiles/r06_coresidency/).  Made the default for half a day in round 6, it turned the eight-process bitwise test
+    # intermittent through the fp32 weight-gradient kernel next door.  The LPIPS trunk's kernels were measured NOT to do this; these do.  Never beside other work.
     matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "0") != "0"
 
     @staticmethod
