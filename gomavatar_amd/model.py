@@ -204,7 +204,9 @@ class _ShadeUnderMesh(torch.autograd.Function):
     # not in this path's own results (bitwise repeatable, every buffer): while its waves are resident, a `v_pk_fma_f32 ... op_sel:[0,1,0]` of ANY OTHER kernel on the
     # same SIMD -- another stream, another process on the device -- can lose a term in lanes 48..63 (LABBOOK R6.8, scripts/ubench/pkfma_beside_mfma.hip: MFMAs fed
     # straight from LDS reads beside packed fp32; profiles/r06_coresidency/).  Made the default for half a day in round 6, it turned the eight-process bitwise test
-    # intermittent through the fp32 weight-gradient kernel next door.  The LPIPS trunk's kernels were measured NOT to do this; these do.  Never beside other work.
+    # intermittent through the fp32 weight-gradient kernel next door.  The trigger is an MFMA consuming a register an LDS read has only just written; the kernels now
+    # request their fragments a k-step ahead like the LPIPS trunk's (which were measured NOT to do this) and the fault is down from 1e8 to 0-96 wrong results per loop of
+    # the strongest victim, the neighbouring kernels of the library bitwise again -- but not to zero, so: still opt-in, still not beside other work.
     matrix_cores = os.environ.get("GOM_MLP_MATRIX_CORES", "0") != "0"
 
     @staticmethod

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything LABBOOK R6.8 quotes, on one box -> gpurun_out/coresidency/
-O=gpurun_out/coresidency; mkdir -p $O
-(cd scripts/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/pk pkfma_beside_mfma.hip 2>/dev/null && timeout 300 /tmp/pk) > $O/pkfma_beside_mfma.txt 2>&1
+O=${O:-gpurun_out/coresidency}; mkdir -p $O
+(cd scripts/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/pk pkfma_beside_mfma.hip 2>/dev/null && PK_MORE=1 timeout 300 /tmp/pk) > $O/pkfma_beside_mfma.txt 2>&1
 {
   echo "# scripts/mc_forensics.py: victim = the weight-gradient kernels of the shadow MLP (fp32 VALU, csrc/mlp.hip) alone in its process; three aggressor PROCESSES beside it"
   bash scripts/mc_forensics.sh 2>&1 | grep -v amdgpu.ids

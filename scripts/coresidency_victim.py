@@ -19,10 +19,10 @@ sm_params = [p for m in sm.block_mlps if isinstance(m, torch.nn.Linear) for p in
 def aggressor(kind, img):
     if kind == "none":
         return lambda: None
-    if kind == "mc":
+    if kind in ("mc", "valu_mlp"):
         nrm = torch.nn.functional.normalize(torch.randn(img * img, 3, device=dev), dim=-1)
         def f():
-            _ShadeUnderMesh.matrix_cores = True
+            _ShadeUnderMesh.matrix_cores = kind == "mc"
             x = nrm.clone().requires_grad_()
             _ShadeUnderMesh.apply(x, sm.multires, *sm_params).sum().backward()
             _ShadeUnderMesh.matrix_cores = False
@@ -34,7 +34,7 @@ def aggressor(kind, img):
         lp.loss(x, b).sum().backward()
     return f
 
-for kind, img in (("none", 0), ("bf16x3", 512), ("bf16x3", 256), ("bf16", 512), ("mc", 256)):
+for kind, img in (("none", 0), ("bf16x3", 512), ("bf16x3", 256), ("bf16", 512), ("valu_mlp", 256), ("mc", 256)):
     f = aggressor(kind, img)
     for with_lds in (1, 0):
         hist = torch.zeros(24, dtype=torch.int32, device=dev)
@@ -42,12 +42,12 @@ for kind, img in (("none", 0), ("bf16x3", 512), ("bf16x3", 256), ("bf16", 512), 
         t0 = time.time(); launches = 0; evals = 0
         while time.time() - t0 < secs:
             with torch.cuda.stream(side):
-                for _ in range(3 if kind != "mc" else 30):
+                for _ in range(3 if kind not in ("mc", "valu_mlp") else 30):
                     f(); evals += 1
             for _ in range(40):
                 vlib.pk_victim_launch(with_lds, 1024, 512, hist.data_ptr(), torch.cuda.current_stream().cuda_stream); launches += 1
             torch.cuda.synchronize()
         h = hist.cpu().reshape(6, 4)
-        name = {"none": "no aggressor", "mc": "matrix-core shadow MLP (mlp_mc.hip, opt-in)"}.get(kind, f"LPIPS trunk {kind}, {img}^2 (vgg_bf16.hip), forward + backward")
+        name = {"none": "no aggressor", "mc": "matrix-core shadow MLP (mlp_mc.hip, opt-in)", "valu_mlp": "fp32 VALU shadow MLP (mlp.hip, the default), forward + backward"}.get(kind, f"LPIPS trunk {kind}, {img}^2 (vgg_bf16.hip), forward + backward")
         print(f"{name:75s} victim {'with 16 KB LDS' if with_lds else 'without LDS   '}: {launches} launches beside {evals} aggressor calls; wrong results "
               f"(op_sel:[0,1,0] low half, lanes 48-63): {int(h[0, 3])}; anywhere else: {int(h.sum() - h[0, 3])}", flush=True)

@@ -124,19 +124,27 @@ __global__ void __launch_bounds__(512, MINB) k_aggr_shape(int iters, float *out)
 #pragma unroll
         for (int j = 0; j < 4; j++) b[j] = *reinterpret_cast<const bf16x8 *>(dl + ((it & 3) * 4096) + ((j * 16 + (lane & 15)) * 64 + (lane >> 4) * 16) % 4096);
     };
-    bf16x8 a[2][2], b[2][4];
-    if (PIPE) load(0, a[0], b[0]);
-    for (int it = 0; it < iters; it++) {
-        const int cur = PIPE ? (it & 1) : 0;
-        if (PIPE) {      // the next trip's fragments are requested BEFORE this trip's MFMAs (what the product's trunk kernels do with counted waits): no MFMA waits on an LDS return
-            load(it + 1, a[cur ^ 1], b[cur ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        } else load(it, a[0], b[0]);
+    bf16x8 a0[2], b0[4], a1[2], b1[4];
+    auto mm = [&](bf16x8 (&a)[2], bf16x8 (&b)[4]) {
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int n = 0; n < 2; n++) acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][n], b[cur][m], acc[m * 2 + n], 0, 0, 0);
-        if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < 2; n++) acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], b[m], acc[m * 2 + n], 0, 0, 0);
+    };
+    if (PIPE) {      // register double buffer, unrolled by two: a trip's fragments are requested BEFORE the previous trip's MFMAs issue (the structure of the product's trunk kernels)
+        load(0, a0, b0);
+        for (int it = 0; it < iters; it += 2) {
+            load(it + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(it + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int it = 0; it < iters; it++) { load(it, a0, b0); mm(a0, b0); }
     }
     float s = 0.f;
 #pragma unroll
@@ -162,7 +170,7 @@ int main() {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_aggr_shape<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_aggr_shape<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const char *forms[3] = {"op_sel:[0,1,0]   ", "op_sel_hi:[1,0,1]", "plain            "};
-    for (int k = -1; k < (getenv("PK_MORE") ? 19 : 16); k++) {   // PK_MORE=1: three more shapes of the 157 KB aggressor (reads a trip ahead -- slow: the double buffer lives in scratch --, a clobbered v200): both still corrupt
+    for (int k = -1; k < (getenv("PK_MORE") ? 19 : 16); k++) {   // PK_MORE=1: three more shapes of the 157 KB aggressor (reads a trip ahead in a register double buffer, a clobbered v200)
         CK(hipMemset(hist, 0, 24 * 4)); CK(hipMemset(sample, 0, 12 * 4)); CK(hipDeviceSynchronize());
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, sa));
