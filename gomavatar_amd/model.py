@@ -510,6 +510,8 @@ class Model(nn.Module):
         # ONE contiguous (N, 3) copy of the posed (3, N) vertices for the vertex normals AND the mesh regularisers of compute_loss (each made its own)
         vo_T = vertices_observation.T.contiguous() if self.training else None
         overlap = xyz.is_cuda and (self.overlap_branches_train if torch.is_grad_enabled() else self.overlap_branches)
+        if _ShadeUnderMesh.matrix_cores:
+            overlap = False     # the matrix-core shading kernels never run beside the rasterizer's (LABBOOK R6.8: their waves can corrupt a neighbour's packed-fp32 FMA)
         if overlap:
             cur = torch.cuda.current_stream()
             if self._side_stream is None:
