@@ -1122,6 +1122,14 @@ def main():
                 both = [(r_["iter"], hip[r_["iter"]], r_["psnr"]) for r_ in orc["log"] if r_["iter"] in hip]
                 row["vs_oracle_trained"] = {"iterations_compared": len(both), "max_abs_psnr_difference_db": round(max(abs(a - b) for _, a, b in both), 3) if both else None,
                                             "mean_abs_psnr_difference_db": round(sum(abs(a - b) for _, a, b in both) / max(len(both), 1), 4), "source": osrc}
+                # the float64 oracle against ITSELF: an earlier run of the same script (thread scheduling = summation order differs) -- the chaos floor the comparison above sits on
+                orc0, osrc0 = read_profile_json("train_curve_oracle_first_run")
+                if orc0:
+                    o1 = {r_["iter"]: r_["psnr"] for r_ in orc["log"]}
+                    two = [(r_["iter"], r_["psnr"], o1[r_["iter"]]) for r_ in orc0["log"] if r_["iter"] in o1]
+                    if two:
+                        row["vs_oracle_trained"]["oracle_against_its_own_earlier_run"] = {"iterations_compared": len(two), "max_abs_psnr_difference_db": round(max(abs(a - b) for _, a, b in two), 3),
+                                                                                          "mean_abs_psnr_difference_db": round(sum(abs(a - b) for _, a, b in two) / len(two), 4), "source": osrc0}
             # ... and the oracle CONTINUING this run from its saved state across the subdivision (round 6: scripts/train_curve_oracle.py --from-state)
             orc2, osrc2 = read_profile_json("train_curve_oracle_from_hip_state")
             if orc2:
