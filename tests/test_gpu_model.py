@@ -157,8 +157,8 @@ def test_fused_shading_equals_the_torch_selection_around_the_mlp():
     another order: round-off).  With the layers on the bf16 matrix cores (csrc/mlp_mc.hip: hi / lo planes, three MFMA passes per product) the
     shading agrees to 2e-5 (measured 6e-6: each operand keeps 16 mantissa bits) and the gradients to 2e-3 of their norm (measured 1e-5 .. 8e-4 over
     unseeded random layers: the vertex gradient through 32 x-frequency encodings of an untrained MLP is a sum with heavy cancellation); bitwise
-    repeatable run to run IN THIS TEST.  Opt-in: GOM_MLP_MATRIX_CORES=1 (round 6 made it the default for half a day and found it not repeatable in every context:
-    the three-step training goldens and the 8-rank bitwise comparison turned intermittent -- model.py)."""
+    repeatable run to run.  Opt-in: GOM_MLP_MATRIX_CORES=1 (round 6 made it the default for half a day: the 8-rank bitwise comparison turned intermittent -- not through
+    this path's results but through a packed-fp32 FMA of the kernel NEXT to its waves, LABBOOK R6.8 -- and the three-step training goldens bimodal -- model.py)."""
     from gomavatar_amd.model import _ShadeUnderMesh
     img = 128
     torch.manual_seed(11)                                                         # (the layers' default initialisation)
